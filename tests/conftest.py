@@ -1,0 +1,32 @@
+"""Shared pytest configuration.
+
+* ``gpu`` marker: tests that need a real MI355X (run with ``-m gpu`` on the GPU box).
+* ``sys.path``: the repo root (for ``oracle``) and ``tiny-llm_amd`` + ``tiny-llm_amd/extensions_hip``
+  (the source roots, like the reference's ``pythonpath = ["src", "."]``, pyproject.toml:63-65).
+* Nothing here reads /root/reference: it does not exist on the GPU box.
+"""
+
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+for extra in (ROOT, ROOT / "tiny-llm_amd", ROOT / "tiny-llm_amd" / "extensions_hip"):
+    if str(extra) not in sys.path:
+        sys.path.insert(0, str(extra))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (pytest -m gpu)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this process")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

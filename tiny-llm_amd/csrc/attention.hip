@@ -1,0 +1,679 @@
+// Attention kernels for gfx950: dense decode attention, paged-KV scatter,
+// split-context paged decode attention (+merge) and paged FlashAttention on
+// bf16 MFMA.  Reference: week2_kernels.metal:119-235, paged_attention.metal:82-506,
+// host dispatch week2_kernels.cpp:176-211 and paged_attention.cpp:129-225.
+#include "common.h"
+
+namespace tl {
+
+constexpr float LOG2E = 1.44269504089f;
+
+// ---------------------------------------------------------------------------
+// Dense decode attention (any dtype, D <= 256).  One workgroup per query row;
+// 16 groups of 16 lanes each walk the context with their own online softmax,
+// then merge through LDS.  Same visibility rule as the reference kernel
+// (position > S - L + query_position is skipped, week2_kernels.metal:165).
+// ---------------------------------------------------------------------------
+template <typename TT>
+__global__ __launch_bounds__(256) void decode_attention_kernel(const typename TT::storage *__restrict__ q,
+                                                               const typename TT::storage *__restrict__ k,
+                                                               const typename TT::storage *__restrict__ v,
+                                                               const float *__restrict__ mask,
+                                                               typename TT::storage *__restrict__ out, int q_rows,
+                                                               int L, int S, int D, int num_heads, int num_kv_heads,
+                                                               float scale, int is_causal, int has_mask) {
+    constexpr int MAXV = 16;  // D <= 256
+    extern __shared__ __attribute__((aligned(16))) float dsm[];  // [16][D] acc + [16] m + [16] l
+    const int query_index = blockIdx.x;
+    const int query_row = query_index / L;
+    const int qp = query_index - query_row * L;
+    const int batch = query_row / num_heads;
+    const int qh = query_row - batch * num_heads;
+    const int kvh = qh / (num_heads / num_kv_heads);
+    const long kv_row = (long)batch * num_kv_heads + kvh;
+    const int g = threadIdx.x >> 4;
+    const int t = threadIdx.x & 15;
+    const int nv = (D + 15) >> 4;
+
+    float qv[MAXV], acc[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int d = t + 16 * i;
+        qv[i] = (i < nv && d < D) ? TT::to_float(q[(long)query_index * D + d]) * scale : 0.f;
+        acc[i] = 0.f;
+    }
+    float m = -1e30f, l = 0.f;
+    const int last_visible = is_causal ? (S - L + qp) : (S - 1);
+    for (int pos = g; pos < S; pos += 16) {
+        if (pos > last_visible) break;
+        const typename TT::storage *kp = k + (kv_row * S + pos) * D;
+        const typename TT::storage *vp = v + (kv_row * S + pos) * D;
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int d = t + 16 * i;
+            if (i < nv && d < D) part += qv[i] * TT::to_float(kp[d]);
+        }
+        float score = group16_sum(part);
+        if (has_mask) score += mask[(long)query_index * S + pos];
+        const float nm = fmaxf(m, score);
+        const float of = __expf(m - nm);
+        const float sf = __expf(score - nm);
+        l = l * of + sf;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int d = t + 16 * i;
+            if (i < nv && d < D) acc[i] = acc[i] * of + sf * TT::to_float(vp[d]);
+        }
+        m = nm;
+    }
+    float *pacc = dsm;
+    float *pm = dsm + 16 * D;
+    float *pl = pm + 16;
+    if (t == 0) {
+        pm[g] = m;
+        pl[g] = l;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int d = t + 16 * i;
+        if (i < nv && d < D) pacc[g * D + d] = acc[i];
+    }
+    __syncthreads();
+    float gm = -1e30f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gm = fmaxf(gm, pm[j]);
+    float gl = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gl += pl[j] * __expf(pm[j] - gm);
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float vs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) vs += pacc[j * D + d] * __expf(pm[j] - gm);
+        out[(long)query_index * D + d] = TT::from_float(gl == 0.f ? 0.f : vs / gl);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Paged KV scatter: values [1,H,len,D] -> pages[page_id,h,start+t,:], 16 B per
+// thread.  reference: paged_attention.metal:82-106 (in-place on `pages`).
+// ---------------------------------------------------------------------------
+template <int BYTES>
+__global__ __launch_bounds__(256) void paged_cache_update_kernel(const char *__restrict__ values,
+                                                                 char *__restrict__ pages, int heads, int length,
+                                                                 long row_bytes, int page_size, int page_id,
+                                                                 int start) {
+    // one "row" = one token's D elements for one head = row_bytes bytes
+    const long vec_per_row = row_bytes / BYTES;
+    const long total = (long)heads * length * vec_per_row;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long rowi = idx / vec_per_row;
+    const long within = idx - rowi * vec_per_row;
+    const int head = (int)(rowi / length);
+    const int token = (int)(rowi - (long)head * length);
+    const long dst = (((long)page_id * heads + head) * page_size + start + token) * row_bytes + within * BYTES;
+    const long src = rowi * row_bytes + within * BYTES;
+    if constexpr (BYTES == 16) {
+        *reinterpret_cast<uint4 *>(pages + dst) = *reinterpret_cast<const uint4 *>(values + src);
+    } else if constexpr (BYTES == 4) {
+        *reinterpret_cast<uint32_t *>(pages + dst) = *reinterpret_cast<const uint32_t *>(values + src);
+    } else {
+        *reinterpret_cast<uint16_t *>(pages + dst) = *reinterpret_cast<const uint16_t *>(values + src);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Paged decode attention, split over the context (flash-decoding).
+//   grid = (n_splits * n_row_chunks, Hkv, B); workgroup = 16 groups x 16 lanes.
+//   A workgroup owns one KV head, RQ=4 query rows of that head's GQA group
+//   (row r -> q head r / L, query position r % L) and one slice of the context,
+//   so every K/V byte is fetched once per 4 query heads (the reference fetches
+//   it once per query head, paged_attention.metal:108-248).  A 16-lane group
+//   reads one token's K (and V) row as 16 x 16 B = fully coalesced 256 B.
+//   Result: either final output (n_splits == 1) or (m, l, acc) partials that
+//   paged_merge_kernel combines.
+// ---------------------------------------------------------------------------
+constexpr int PD_RQ = 4;
+
+template <typename TT, int VD, bool VEC>
+__global__ __launch_bounds__(256) void paged_decode_kernel(
+    const typename TT::storage *__restrict__ q, const typename TT::storage *__restrict__ key_pages,
+    const typename TT::storage *__restrict__ value_pages, const int32_t *__restrict__ block_table,
+    const int32_t *__restrict__ context_lens, typename TT::storage *__restrict__ out, float *__restrict__ ws, int L,
+    int D, int page_size, int max_pages, int num_heads, int num_kv_heads, float scale, int is_causal, int n_splits,
+    int n_row_chunks) {
+    using S = typename TT::storage;
+    extern __shared__ __attribute__((aligned(16))) float psm[];  // [16][RQ][D+2]
+    const int split = blockIdx.x % n_splits;
+    const int chunk = blockIdx.x / n_splits;
+    const int kvh = blockIdx.y;
+    const int b = blockIdx.z;
+    const int rep = num_heads / num_kv_heads;
+    const int R = rep * L;
+    const int g = threadIdx.x >> 4;
+    const int t = threadIdx.x & 15;
+    const int ctx = context_lens[b];
+    const float scale_log2 = scale * LOG2E;
+    const int stride = D + 2;
+
+    // query rows of this chunk
+    int rq_n[PD_RQ], rq_qp[PD_RQ], rq_vis[PD_RQ];
+    bool rq_ok[PD_RQ];
+    float qv[PD_RQ][VD], acc[PD_RQ][VD], m[PD_RQ], l[PD_RQ];
+    int max_vis = 0;
+#pragma unroll
+    for (int r = 0; r < PD_RQ; ++r) {
+        const int rr = chunk * PD_RQ + r;
+        rq_ok[r] = rr < R;
+        const int hq = rq_ok[r] ? rr / L : 0;
+        rq_qp[r] = rq_ok[r] ? rr - hq * L : 0;
+        rq_n[r] = b * num_heads + kvh * rep + hq;
+        int vis = is_causal ? min(max(ctx - L + rq_qp[r] + 1, 0), ctx) : ctx;
+        rq_vis[r] = rq_ok[r] ? vis : 0;
+        max_vis = max(max_vis, rq_vis[r]);
+        m[r] = -1e30f;
+        l[r] = 0.f;
+        const S *qp = q + ((long)rq_n[r] * L + rq_qp[r]) * D;
+#pragma unroll
+        for (int i = 0; i < VD; ++i) {
+            const int d = VEC ? t * VD + i : t + 16 * i;
+            qv[r][i] = (rq_ok[r] && d < D) ? TT::to_float(qp[d]) * scale_log2 : 0.f;
+            acc[r][i] = 0.f;
+        }
+    }
+    // context slice of this split (multiples of 16 tokens so groups stay aligned)
+    const int per = ((max_vis + n_splits - 1) / n_splits + 15) & ~15;
+    const int t_begin = split * per;
+    const int t_end = min(t_begin + per, max_vis);
+
+    for (int tok = t_begin + g; tok < t_end; tok += 16) {
+        const int lp = tok / page_size;
+        const int slot = tok - lp * page_size;
+        const int page_id = lp < max_pages ? block_table[(long)b * max_pages + lp] : -1;
+        if (page_id < 0) continue;
+        const long off = (((long)page_id * num_kv_heads + kvh) * page_size + slot) * D;
+        float kf[VD], vf[VD];
+        if constexpr (VEC) {
+            S kr[VD], vr[VD];
+            constexpr int BYTES = VD * sizeof(S);
+            if constexpr (BYTES == 16) {
+                *reinterpret_cast<uint4 *>(kr) = *reinterpret_cast<const uint4 *>(key_pages + off + t * VD);
+                *reinterpret_cast<uint4 *>(vr) = *reinterpret_cast<const uint4 *>(value_pages + off + t * VD);
+            } else if constexpr (BYTES == 32) {
+                reinterpret_cast<uint4 *>(kr)[0] = reinterpret_cast<const uint4 *>(key_pages + off + t * VD)[0];
+                reinterpret_cast<uint4 *>(kr)[1] = reinterpret_cast<const uint4 *>(key_pages + off + t * VD)[1];
+                reinterpret_cast<uint4 *>(vr)[0] = reinterpret_cast<const uint4 *>(value_pages + off + t * VD)[0];
+                reinterpret_cast<uint4 *>(vr)[1] = reinterpret_cast<const uint4 *>(value_pages + off + t * VD)[1];
+            } else {
+                *reinterpret_cast<uint2 *>(kr) = *reinterpret_cast<const uint2 *>(key_pages + off + t * VD);
+                *reinterpret_cast<uint2 *>(vr) = *reinterpret_cast<const uint2 *>(value_pages + off + t * VD);
+            }
+#pragma unroll
+            for (int i = 0; i < VD; ++i) {
+                kf[i] = TT::to_float(kr[i]);
+                vf[i] = TT::to_float(vr[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VD; ++i) {
+                const int d = t + 16 * i;
+                kf[i] = d < D ? TT::to_float(key_pages[off + d]) : 0.f;
+                vf[i] = d < D ? TT::to_float(value_pages[off + d]) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PD_RQ; ++r) {
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < VD; ++i) part += qv[r][i] * kf[i];
+            const float score = group16_sum(part);
+            if (tok < rq_vis[r]) {
+                const float nm = fmaxf(m[r], score);
+                const float of = exp2f(m[r] - nm);
+                const float sf = exp2f(score - nm);
+                l[r] = l[r] * of + sf;
+#pragma unroll
+                for (int i = 0; i < VD; ++i) acc[r][i] = acc[r][i] * of + sf * vf[i];
+                m[r] = nm;
+            }
+        }
+    }
+
+    // merge the 16 groups
+#pragma unroll
+    for (int r = 0; r < PD_RQ; ++r) {
+        float *dst = psm + ((long)g * PD_RQ + r) * stride;
+#pragma unroll
+        for (int i = 0; i < VD; ++i) {
+            const int d = VEC ? t * VD + i : t + 16 * i;
+            if (d < D) dst[d] = acc[r][i];
+        }
+        if (t == 0) {
+            dst[D] = m[r];
+            dst[D + 1] = l[r];
+        }
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < PD_RQ * D; item += 256) {
+        const int r = item / D;
+        const int d = item - r * D;
+        const int rr = chunk * PD_RQ + r;
+        if (rr >= R) continue;
+        const int hq_o = rr / L;
+        const int qp_o = rr - hq_o * L;
+        float gm = -1e30f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gm = fmaxf(gm, psm[((long)j * PD_RQ + r) * stride + D]);
+        float gl = 0.f, vs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float *src = psm + ((long)j * PD_RQ + r) * stride;
+            const float f = exp2f(src[D] - gm);
+            gl += src[D + 1] * f;
+            vs += src[d] * f;
+        }
+        const long orow = ((long)b * num_heads + kvh * rep + hq_o) * L + qp_o;
+        if (n_splits == 1) {
+            out[orow * D + d] = TT::from_float(gl == 0.f ? 0.f : vs / gl);
+        } else {
+            float *w = ws + (orow * n_splits + split) * stride;
+            w[d] = vs;
+            if (d == 0) {
+                w[D] = gm;
+                w[D + 1] = gl;
+            }
+        }
+    }
+}
+
+template <typename TT>
+__global__ __launch_bounds__(128) void paged_merge_kernel(const float *__restrict__ ws,
+                                                          typename TT::storage *__restrict__ out, int D,
+                                                          int n_splits) {
+    const long orow = blockIdx.x;
+    const int stride = D + 2;
+    const float *base = ws + orow * n_splits * stride;
+    float gm = -1e30f;
+    for (int s = 0; s < n_splits; ++s) gm = fmaxf(gm, base[s * stride + D]);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float gl = 0.f, vs = 0.f;
+        for (int s = 0; s < n_splits; ++s) {
+            const float f = exp2f(base[s * stride + D] - gm);
+            gl += base[s * stride + D + 1] * f;
+            vs += base[s * stride + d] * f;
+        }
+        out[orow * D + d] = TT::from_float(gl == 0.f ? 0.f : vs / gl);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Paged FlashAttention-2 on bf16 MFMA (D = 128, L > 8).
+//   reference: paged_attention_mma_bf16_d128 (paged_attention.metal:250-506),
+//   BQ=64/BK=32 with 8x8 simdgroup MMA.  gfx950 design:
+//   * workgroup = 4 waves; each wave owns a 32-row query block of ONE query
+//     head; the 4 waves of a workgroup are 4 (head, q-block) items of the same
+//     KV head, so a K/V tile staged in LDS is shared by the whole GQA group.
+//   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16: a lane then holds 16 scores of
+//     ONE query row, so the softmax row reduction is in-register plus a single
+//     cross-half exchange, and P^T is already in B-operand layout for
+//     O^T = V^T P^T (the k index of that product is permuted consistently:
+//     k = 16s + 4h + (j&3) + 8(j>>2)).
+//   * K tile row-major + XOR swizzle (ds_read_b128 conflict-free), V tile
+//     stored transposed [dim][token] with a 36-element row so the A fragment is
+//     two ds_read_b64.
+//   * next tile's global loads are issued before the current tile's MFMAs.
+//   fp32 scores/softmax, P rounded to bf16 before PV, causal tile skipping and
+//   zero output for empty rows, as the reference.
+// ---------------------------------------------------------------------------
+constexpr int FA_LDV = 36;
+
+__global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
+    const uint16_t *__restrict__ q, const uint16_t *__restrict__ key_pages, const uint16_t *__restrict__ value_pages,
+    const int32_t *__restrict__ block_table, const int32_t *__restrict__ context_lens, uint16_t *__restrict__ out,
+    int L, int page_size, int max_pages, int num_heads, int num_kv_heads, float scale, int is_causal) {
+    constexpr int D = 128;
+    __shared__ __attribute__((aligned(16))) uint16_t ks[32 * D];        // [token][dim] swizzled
+    __shared__ __attribute__((aligned(16))) uint16_t vt[D * FA_LDV];     // [dim][token]
+    __shared__ int tile_page[2][32];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int l32 = lane & 31;
+    const int h = lane >> 5;
+    const int kvh = blockIdx.y;
+    const int b = blockIdx.z;
+    const int rep = num_heads / num_kv_heads;
+    const int QB = (L + 31) / 32;
+    const int items = rep * QB;
+    const int item = blockIdx.x * 4 + wave;
+    const bool wave_live = item < items;
+    const int hq = wave_live ? item % rep : 0;
+    const int qb = wave_live ? item / rep : 0;
+    const int n = b * num_heads + kvh * rep + hq;
+    const int ctx = context_lens[b];
+    const float scale_log2 = scale * LOG2E;
+    const int qrow = qb * 32 + l32;
+    const bool q_valid = wave_live && qrow < L;
+
+    // Q^T fragments (B operand): lane (qrow, half h), step s -> dims 16s + 8h .. +8
+    u32x4 qf[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (q_valid) {
+            qf[s] = *reinterpret_cast<const u32x4 *>(q + ((long)n * L + qrow) * D + 16 * s + 8 * h);
+        } else {
+            qf[s] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float run_max = -INFINITY, run_sum = 0.f;
+
+    // tile range: block-level limit = max over this block's items
+    const int total_tiles = (ctx + 31) / 32;
+    int my_tiles = total_tiles;
+    if (is_causal) {
+        const int last_query = min((qb + 1) * 32, L) - 1;
+        const int last_key = last_query + (ctx - L);
+        my_tiles = min(max((last_key + 1 + 31) / 32, 0), total_tiles);
+    }
+    if (!wave_live) my_tiles = 0;
+    int blk_tiles;
+    {
+        // items of a block differ at most in q-block; the last wave_live item has the largest limit
+        const int last_item = min(blockIdx.x * 4 + 3, items - 1);
+        const int last_qb = last_item / rep;
+        if (is_causal) {
+            const int lq = min((last_qb + 1) * 32, L) - 1;
+            const int lk = lq + (ctx - L);
+            blk_tiles = min(max((lk + 1 + 31) / 32, 0), total_tiles);
+        } else {
+            blk_tiles = total_tiles;
+        }
+    }
+
+    // staging: thread -> (token = c/16, chunk = c%16) for c = tid, tid+256
+    u32x4 kreg[2], vreg[2];
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * 256;
+            const int tok_in = c >> 4;
+            const int ch = c & 15;
+            const int tok = tile * 32 + tok_in;
+            const int lp = tok / page_size;
+            const int slot = tok - lp * page_size;
+            int page_id = -1;
+            if (tok < ctx && lp < max_pages) page_id = block_table[(long)b * max_pages + lp];
+            if (page_id >= 0) {
+                const long off = (((long)page_id * num_kv_heads + kvh) * page_size + slot) * D + ch * 8;
+                kreg[i] = *reinterpret_cast<const u32x4 *>(key_pages + off);
+                vreg[i] = *reinterpret_cast<const u32x4 *>(value_pages + off);
+            } else {
+                kreg[i] = u32x4{0u, 0u, 0u, 0u};
+                vreg[i] = u32x4{0u, 0u, 0u, 0u};
+            }
+            if (ch == 0) tile_page[tile & 1][tok_in] = page_id;  // read one iteration later, after two barriers
+        }
+    };
+
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * 256;
+            const int tok_in = c >> 4;
+            const int ch = c & 15;
+            *reinterpret_cast<u32x4 *>(&ks[tok_in * D + ((ch ^ (tok_in & 15)) * 8)]) = kreg[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vt[(ch * 8 + 2 * e) * FA_LDV + tok_in] = (uint16_t)(vreg[i][e] & 0xffffu);
+                vt[(ch * 8 + 2 * e + 1) * FA_LDV + tok_in] = (uint16_t)(vreg[i][e] >> 16);
+            }
+        }
+    };
+
+    for (int tile = 0; tile < blk_tiles; ++tile) {
+        if (tile == 0) stage_load(0);
+        __syncthreads();  // previous tile's LDS reads are complete
+        stage_store();
+        __syncthreads();
+        if (tile + 1 < blk_tiles) stage_load(tile + 1);
+        if (tile >= my_tiles) continue;  // wave-uniform: this wave's rows see nothing here (still hits barriers)
+
+        // S^T = K Q^T
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int ch = (2 * s + h) ^ (l32 & 15);
+            const u32x4 kf = *reinterpret_cast<const u32x4 *>(&ks[l32 * D + ch * 8]);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                           __builtin_bit_cast(bf16x8_t, qf[s]), sacc, 0, 0, 0);
+        }
+        // mask + scale ; lane holds tokens (r&3)+8(r>>2)+4h of query row qrow
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tok = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            bool valid = q_valid && tok < ctx && tile_page[tile & 1][(r & 3) + 8 * (r >> 2) + 4 * h] >= 0;
+            if (is_causal) valid = valid && tok <= qrow + (ctx - L);
+            sacc[r] = valid ? sacc[r] * scale_log2 : -INFINITY;
+            tmax = fmaxf(tmax, sacc[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float new_max = fmaxf(run_max, tmax);
+        const bool finite_row = q_valid && new_max != -INFINITY;
+        const float prev_scale = (run_max == -INFINITY || !finite_row) ? 0.f : exp2f(run_max - new_max);
+        float tsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = (sacc[r] == -INFINITY || !finite_row) ? 0.f : exp2f(sacc[r] - new_max);
+            sacc[r] = p;
+            tsum += p;
+        }
+        tsum += __shfl_xor(tsum, 32, 64);
+        run_max = new_max;
+        run_sum = prev_scale * run_sum + tsum;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= prev_scale;
+
+        // P^T fragments (B operand), step s uses regs 8s..8s+7
+        u32x4 pf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pf[s][e] = BF16::pack2(sacc[8 * s + 2 * e], sacc[8 * s + 2 * e + 1]);
+
+        // O^T += V^T P^T
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int d = db * 32 + l32;
+                const u32x2 lo = *reinterpret_cast<const u32x2 *>(&vt[d * FA_LDV + 16 * s + 4 * h]);
+                const u32x2 hi = *reinterpret_cast<const u32x2 *>(&vt[d * FA_LDV + 16 * s + 4 * h + 8]);
+                const u32x4 vf = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
+                                                                __builtin_bit_cast(bf16x8_t, pf[s]), o[db], 0, 0, 0);
+            }
+        }
+    }
+
+    if (!q_valid) return;
+    uint16_t *orow = out + ((long)n * L + qrow) * D;
+    const float inv = run_sum == 0.f ? 0.f : 1.0f / run_sum;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            // regs 4rg..4rg+3 -> dims db*32 + 8rg + 4h + 0..3
+            u32x2 pk;
+            pk[0] = BF16::pack2(o[db][4 * rg + 0] * inv, o[db][4 * rg + 1] * inv);
+            pk[1] = BF16::pack2(o[db][4 * rg + 2] * inv, o[db][4 * rg + 3] * inv);
+            *reinterpret_cast<u32x2 *>(orow + db * 32 + 8 * rg + 4 * h) = pk;
+        }
+    }
+}
+
+static int pick_splits(int B, int Hkv, int row_chunks, int max_ctx) {
+    const int base = std::max(1, B * Hkv * row_chunks);
+    int s = (512 + base - 1) / base;
+    const int by_len = std::max(1, max_ctx / 64);
+    s = std::min(s, by_len);
+    s = std::min(s, 64);
+    return std::max(s, 1);
+}
+
+}  // namespace tl
+
+using namespace tl;
+
+extern "C" int tl_decode_attention(const void *q, const void *k, const void *v, const float *mask, void *out,
+                                   int q_rows, int L, int S, int D, int num_heads, int num_kv_heads, float scale,
+                                   int is_causal, int has_mask, tl_dtype dtype, void *stream) {
+    TL_REQUIRE(q && k && v && out, "decode_attention: null pointer");
+    TL_REQUIRE(D > 0 && D <= 256 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0 &&
+                   q_rows % num_heads == 0,
+               "decode_attention: incompatible attention shapes");
+    TL_REQUIRE(!has_mask || mask, "decode_attention: mask must have shape [B*Hq,L,S]");
+    if (q_rows == 0 || L == 0) return TL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(16 * D + 32) * sizeof(float);
+    const dim3 grid(q_rows * L), block(256);
+#define DA_LAUNCH(TT)                                                                                            \
+    hipLaunchKernelGGL((decode_attention_kernel<TT>), grid, block, lds, st, (const typename TT::storage *)q,     \
+                       (const typename TT::storage *)k, (const typename TT::storage *)v, mask,                   \
+                       (typename TT::storage *)out, q_rows, L, S, D, num_heads, num_kv_heads, scale, is_causal, \
+                       has_mask)
+    switch (dtype) {
+        case TL_F32: DA_LAUNCH(F32); break;
+        case TL_F16: DA_LAUNCH(F16); break;
+        case TL_BF16: DA_LAUNCH(BF16); break;
+        default: return fail(TL_ERR_INVALID, "decode_attention: expected float32, float16, or bfloat16");
+    }
+#undef DA_LAUNCH
+    TL_CHECK_LAUNCH("decode_attention");
+    return TL_OK;
+}
+
+extern "C" int tl_paged_cache_update(void *pages, const void *values, int num_pages, int heads, int page_size,
+                                     int head_dim, int length, int page_id, int start, tl_dtype dtype, void *stream) {
+    TL_REQUIRE(dtype == TL_F32 || dtype == TL_BF16,
+               "paged_cache_update: pages and values must have the same float32 or bfloat16 dtype");
+    TL_REQUIRE(pages && values, "paged_cache_update: null pointer");
+    TL_REQUIRE(heads > 0 && page_size > 0 && head_dim > 0 && length >= 0,
+               "paged_cache_update: expected pages [P, H, page_size, D] and values [1, H, length, D]");
+    TL_REQUIRE(page_id >= 0 && page_id < num_pages && start >= 0 && start + length <= page_size,
+               "paged_cache_update: destination slice is outside page storage");
+    if (length == 0) return TL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long esz = dtype == TL_F32 ? 4 : 2;
+    const long row_bytes = (long)head_dim * esz;
+    const bool a16 = row_bytes % 16 == 0 && ((uintptr_t)pages % 16 == 0) && ((uintptr_t)values % 16 == 0);
+    if (a16) {
+        const long total = (long)heads * length * (row_bytes / 16);
+        hipLaunchKernelGGL((paged_cache_update_kernel<16>), dim3(ceil_div(total, 256)), dim3(256), 0, st,
+                           (const char *)values, (char *)pages, heads, length, row_bytes, page_size, page_id, start);
+    } else if (esz == 4) {
+        const long total = (long)heads * length * (row_bytes / 4);
+        hipLaunchKernelGGL((paged_cache_update_kernel<4>), dim3(ceil_div(total, 256)), dim3(256), 0, st,
+                           (const char *)values, (char *)pages, heads, length, row_bytes, page_size, page_id, start);
+    } else {
+        const long total = (long)heads * length * (row_bytes / 2);
+        hipLaunchKernelGGL((paged_cache_update_kernel<2>), dim3(ceil_div(total, 256)), dim3(256), 0, st,
+                           (const char *)values, (char *)pages, heads, length, row_bytes, page_size, page_id, start);
+    }
+    TL_CHECK_LAUNCH("paged_cache_update");
+    return TL_OK;
+}
+
+static bool paged_uses_fa(int L, int D, tl_dtype dtype) { return L > 8 && dtype == TL_BF16 && D == 128; }
+
+extern "C" size_t tl_paged_attention_workspace_bytes(int N, int L, int D, int page_size, int max_pages, int num_heads,
+                                                     int num_kv_heads, int max_context_hint) {
+    if (N <= 0 || L <= 0 || num_heads <= 0 || num_kv_heads <= 0) return 0;
+    const int B = N / num_heads;
+    const int rep = num_heads / num_kv_heads;
+    const int row_chunks = (rep * L + PD_RQ - 1) / PD_RQ;
+    const int max_ctx = max_context_hint > 0 ? max_context_hint : max_pages * page_size;
+    const int splits = pick_splits(B, num_kv_heads, row_chunks, max_ctx);
+    if (splits <= 1) return 0;
+    return (size_t)N * L * splits * (D + 2) * sizeof(float);
+}
+
+extern "C" int tl_paged_attention(const void *q, const void *key_pages, const void *value_pages,
+                                  const int32_t *block_table, const int32_t *context_lens, void *out, int N, int L,
+                                  int D, int num_pages, int page_size, int max_pages, int num_heads, int num_kv_heads,
+                                  float scale, int is_causal, int max_context_hint, tl_dtype dtype, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+    TL_REQUIRE(dtype == TL_F32 || dtype == TL_BF16,
+               "paged_attention: q, key_pages, and value_pages must have the same float32 or bfloat16 dtype");
+    TL_REQUIRE(q && key_pages && value_pages && block_table && context_lens && out, "paged_attention: null pointer");
+    TL_REQUIRE(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
+               "paged_attention: num_heads must be divisible by num_kv_heads");
+    TL_REQUIRE(N % num_heads == 0, "paged_attention: q.shape[0] must be divisible by num_heads");
+    TL_REQUIRE(page_size > 0 && max_pages > 0 && num_pages > 0 && L > 0,
+               "paged_attention: page tensors must be 4D [P, H_kv, page_size, D]");
+    TL_REQUIRE(D > 0 && D <= 128, "paged_attention: head dimension must be at most 128");
+    if (N == 0) return TL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = N / num_heads;
+    const int rep = num_heads / num_kv_heads;
+
+    if (L > 8 && dtype == TL_BF16) {
+        if (D != 128) return fail(TL_ERR_UNSUPPORTED, "paged_attention: bfloat16 prefill requires head dimension 128");
+        const int items = rep * ((L + 31) / 32);
+        const dim3 grid((items + 3) / 4, num_kv_heads, B);
+        hipLaunchKernelGGL(paged_fa_bf16_d128_kernel, grid, dim3(256), 0, st, (const uint16_t *)q,
+                           (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,
+                           (uint16_t *)out, L, page_size, max_pages, num_heads, num_kv_heads, scale, is_causal);
+        TL_CHECK_LAUNCH("paged_attention(prefill)");
+        return TL_OK;
+    }
+
+    // decode (L <= 8) and the fp32 prefill fallback share the split-context kernel
+    const int row_chunks = (rep * L + PD_RQ - 1) / PD_RQ;
+    const int max_ctx = max_context_hint > 0 ? max_context_hint : max_pages * page_size;
+    const int splits = pick_splits(B, num_kv_heads, row_chunks, max_ctx);
+    const size_t need = splits > 1 ? (size_t)N * L * splits * (D + 2) * sizeof(float) : 0;
+    if (need > 0 && (!workspace || workspace_bytes < need))
+        return fail(TL_ERR_INVALID, "paged_attention: workspace is missing or too small");
+    const dim3 grid(splits * row_chunks, num_kv_heads, B), block(256);
+    const size_t lds = (size_t)16 * PD_RQ * (D + 2) * sizeof(float);
+    float *ws = (float *)workspace;
+#define PD_LAUNCH(TT, VDv, VECv)                                                                                    \
+    hipLaunchKernelGGL((paged_decode_kernel<TT, VDv, VECv>), grid, block, lds, st, (const typename TT::storage *)q, \
+                       (const typename TT::storage *)key_pages, (const typename TT::storage *)value_pages,         \
+                       block_table, context_lens, (typename TT::storage *)out, ws, L, D, page_size, max_pages,     \
+                       num_heads, num_kv_heads, scale, is_causal, splits, row_chunks)
+    if (dtype == TL_BF16) {
+        if (D == 128) PD_LAUNCH(BF16, 8, true);
+        else if (D == 64) PD_LAUNCH(BF16, 4, true);
+        else PD_LAUNCH(BF16, 8, false);
+    } else {
+        if (D == 128) PD_LAUNCH(F32, 8, true);
+        else if (D == 64) PD_LAUNCH(F32, 4, true);
+        else PD_LAUNCH(F32, 8, false);
+    }
+#undef PD_LAUNCH
+    TL_CHECK_LAUNCH("paged_attention(decode)");
+    if (splits > 1) {
+        if (dtype == TL_BF16) {
+            hipLaunchKernelGGL((paged_merge_kernel<BF16>), dim3(N * L), dim3(128), 0, st, ws, (uint16_t *)out, D, splits);
+        } else {
+            hipLaunchKernelGGL((paged_merge_kernel<F32>), dim3(N * L), dim3(128), 0, st, ws, (float *)out, D, splits);
+        }
+        TL_CHECK_LAUNCH("paged_attention(merge)");
+    }
+    (void)paged_uses_fa;
+    return TL_OK;
+}

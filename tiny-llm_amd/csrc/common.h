@@ -1,0 +1,98 @@
+// Shared device/host helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/tinyllm_hip.h"
+
+namespace tl {
+
+// ---- error plumbing ---------------------------------------------------------
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define TL_REQUIRE(cond, msg)                                 \
+    do {                                                      \
+        if (!(cond)) return ::tl::fail(TL_ERR_INVALID, msg);  \
+    } while (0)
+
+#define TL_CHECK_LAUNCH(name)                                                               \
+    do {                                                                                    \
+        hipError_t e__ = hipGetLastError();                                                 \
+        if (e__ != hipSuccess)                                                              \
+            return ::tl::fail(TL_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+// ---- scalar type traits -----------------------------------------------------
+// Storage types are raw 16-bit words for f16/bf16 so that vector loads are
+// plain integer loads; conversion is explicit.
+struct BF16 {
+    using storage = uint16_t;
+    static constexpr tl_dtype tag = TL_BF16;
+    __device__ __forceinline__ static float to_float(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+    // round-to-nearest-even, NaN preserved (matches static_cast<bfloat16_t>(float))
+    // (lowers to v_cvt_pk_bf16_f32 on gfx950)
+    __device__ __forceinline__ static uint16_t from_float(float f) {
+        return __builtin_bit_cast(uint16_t, (__bf16)f);
+    }
+    __device__ __forceinline__ static uint32_t pack2(float lo, float hi) {
+        typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+        v2 r;
+        r[0] = (__bf16)lo;
+        r[1] = (__bf16)hi;
+        return __builtin_bit_cast(uint32_t, r);
+    }
+};
+struct F16 {
+    using storage = uint16_t;
+    static constexpr tl_dtype tag = TL_F16;
+    __device__ __forceinline__ static float to_float(uint16_t v) { return __half2float(__ushort_as_half(v)); }
+    __device__ __forceinline__ static uint16_t from_float(float f) { return __half_as_ushort(__float2half_rn(f)); }
+    __device__ __forceinline__ static uint32_t pack2(float lo, float hi) {
+        return (uint32_t)from_float(lo) | ((uint32_t)from_float(hi) << 16);
+    }
+};
+struct F32 {
+    using storage = float;
+    static constexpr tl_dtype tag = TL_F32;
+    __device__ __forceinline__ static float to_float(float v) { return v; }
+    __device__ __forceinline__ static float from_float(float f) { return f; }
+};
+
+__device__ __forceinline__ float bf16_round(float f) { return BF16::to_float(BF16::from_float(f)); }
+
+// ---- wave helpers -----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce over aligned groups of 16 lanes
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace tl

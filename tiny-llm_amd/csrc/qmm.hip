@@ -1,0 +1,335 @@
+// W4A16 (group 128) matmul operator: dispatch + the non-GEMV kernels.
+//   reference dispatch: quantized_matmul.cpp:111-240
+//   * use_simdgroup && M<=8        -> qmv_kernel (qmv.h)                       [decode]
+//   * use_simdgroup (&& split-K)   -> qmm_mfma_kernel (bf16/f16 MFMA 32x32x16) [prefill]
+//   * otherwise                    -> qmm_vanilla_kernel (semantic definition)
+#include "common.h"
+#include "qmv.h"
+
+namespace tl {
+
+// ---------------------------------------------------------------------------
+// One thread per output element, the reference's order of operations
+// (quantized_matmul.metal:8-56): sum += (q*scale + bias) * a, fp32, one cast.
+// ---------------------------------------------------------------------------
+template <typename TT>
+__global__ __launch_bounds__(256) void qmm_vanilla_kernel(const uint16_t *__restrict__ scales,
+                                                          const uint16_t *__restrict__ biases,
+                                                          const uint16_t *__restrict__ a,
+                                                          const uint32_t *__restrict__ b, uint16_t *__restrict__ out,
+                                                          int M, int N, int K) {
+    // x = output column k (fast, so weight rows differ per lane and activations broadcast)
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= M || k >= K) return;
+    const int G = N / 128;
+    const uint32_t *bw = b + (size_t)k * (N / 8);
+    const uint16_t *ar = a + (size_t)i * N;
+    float sum = 0.f;
+    for (int g = 0; g < G; ++g) {
+        const float scale = TT::to_float(scales[(size_t)k * G + g]);
+        const float bias = TT::to_float(biases[(size_t)k * G + g]);
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t packed = bw[g * 16 + w];
+            const uint4 av = *reinterpret_cast<const uint4 *>(ar + g * 128 + w * 8);
+            const uint32_t aw[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float q = (float)((packed >> (4 * e)) & 0xfu);
+                const uint16_t ae = (uint16_t)((aw[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                sum += (q * scale + bias) * TT::to_float(ae);
+            }
+        }
+    }
+    out[(size_t)i * K + k] = TT::from_float(sum);
+}
+
+// ---------------------------------------------------------------------------
+// Prefill GEMM on MFMA.  Semantics follow the reference tile kernel
+// (quantized_matmul.metal:96-249): weights are dequantised to T (one rounding),
+// multiplied on the matrix unit with fp32 accumulation, output cast to T.
+//
+// gfx950 mapping (v_mfma_f32_32x32x16_{bf16,f16}):
+//   workgroup = 4 waves; tile = (32*MT activation rows) x (128 output features);
+//   wave w owns output features [32w, 32w+32) for all MT row tiles.
+//   B operand (W^T): a lane's fragment is 8 consecutive reduction elements of
+//   ONE weight row = exactly one packed uint32, so weights go global -> VGPR ->
+//   dequant -> MFMA with no LDS round trip.  A lane pulls 16 B (4 words) per
+//   64-wide super-step; the reduction index inside a super-step is permuted
+//   (n = 64j + 32h + 8s + i for lane-half h, step s) so those 4 words are
+//   contiguous -- the activation fragment uses the same permutation.
+//   A operand (activations): staged once per workgroup into a double-buffered,
+//   XOR-swizzled LDS tile and read back with ds_read_b128.
+// ---------------------------------------------------------------------------
+template <typename TT>
+struct Mfma;
+template <>
+struct Mfma<BF16> {
+    __device__ __forceinline__ static f32x16 mma(const u32x4 &a, const u32x4 &b, const f32x16 &c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                       c, 0, 0, 0);
+    }
+};
+template <>
+struct Mfma<F16> {
+    __device__ __forceinline__ static f32x16 mma(const u32x4 &a, const u32x4 &b, const f32x16 &c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b),
+                                                      c, 0, 0, 0);
+    }
+};
+
+template <typename TT>
+__device__ __forceinline__ u32x4 dequant_word(uint32_t w, float s, float beta) {
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float lo = (float)((w >> (8 * e)) & 0xfu) * s + beta;
+        const float hi = (float)((w >> (8 * e + 4)) & 0xfu) * s + beta;
+        r[e] = TT::pack2(lo, hi);
+    }
+    return r;
+}
+
+template <typename TT, int MT>
+__global__ __launch_bounds__(256) void qmm_mfma_kernel(const uint16_t *__restrict__ scales,
+                                                       const uint16_t *__restrict__ biases,
+                                                       const uint16_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                       uint16_t *__restrict__ out, int M, int N, int K,
+                                                       int partition_size, size_t partition_stride) {
+    constexpr int BM = 32 * MT;
+    __shared__ __attribute__((aligned(16))) uint16_t atile[2][BM * 64];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int l32 = lane & 31;
+    const int h = lane >> 5;
+    const int bn0 = blockIdx.x * 128;
+    const int bm0 = blockIdx.y * BM;
+    const int red0 = blockIdx.z * partition_size;
+    const int j0 = red0 >> 6;
+    const int j1 = (red0 + partition_size) >> 6;
+    const int G = N >> 7;
+    const int words = N >> 3;
+
+    const int wrow = bn0 + wave * 32 + l32;  // weight row (= output feature) of this lane
+    const bool wok = wrow < K;
+    const uint32_t *wsrc = b + (size_t)(wok ? wrow : 0) * words;
+    const uint16_t *ssrc = scales + (size_t)(wok ? wrow : 0) * G;
+    const uint16_t *bsrc = biases + (size_t)(wok ? wrow : 0) * G;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    u32x4 areg[MT];
+    auto load_a = [&](int j) {
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            const int c = tid + q * 256;
+            const int r = c >> 3;
+            const int ch = c & 7;
+            const int gr = bm0 + r;
+            if (gr < M) {
+                areg[q] = *reinterpret_cast<const u32x4 *>(a + (size_t)gr * N + j * 64 + ch * 8);
+            } else {
+                areg[q] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            const int c = tid + q * 256;
+            const int r = c >> 3;
+            const int ch = c & 7;
+            const int sw = ch ^ ((r >> 1) & 7);
+            *reinterpret_cast<u32x4 *>(&atile[buf][r * 64 + sw * 8]) = areg[q];
+        }
+    };
+
+    u32x4 wcur = u32x4{0u, 0u, 0u, 0u}, wnext = wcur;
+    float sc = 0.f, be = 0.f;
+    load_a(j0);
+    if (wok) wcur = *reinterpret_cast<const u32x4 *>(wsrc + j0 * 8 + h * 4);
+    int buf = 0;
+    for (int j = j0; j < j1; ++j) {
+        store_a(buf);
+        __syncthreads();
+        if (j + 1 < j1) {
+            load_a(j + 1);
+            if (wok) wnext = *reinterpret_cast<const u32x4 *>(wsrc + (j + 1) * 8 + h * 4);
+        }
+        if (((j & 1) == 0 || j == j0) && wok) {
+            sc = TT::to_float(ssrc[j >> 1]);
+            be = TT::to_float(bsrc[j >> 1]);
+        }
+        u32x4 bf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bf[s] = dequant_word<TT>(wcur[s], sc, be);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = mt * 32 + l32;
+                const int ch = (4 * h + s) ^ ((r >> 1) & 7);
+                const u32x4 af = *reinterpret_cast<const u32x4 *>(&atile[buf][r * 64 + ch * 8]);
+                acc[mt] = Mfma<TT>::mma(af, bf[s], acc[mt]);
+            }
+        }
+        buf ^= 1;
+        wcur = wnext;
+    }
+
+    if (!wok) return;
+    uint16_t *dst = out + (size_t)blockIdx.z * partition_stride;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = bm0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < M) dst[(size_t)m * K + wrow] = TT::from_float(acc[mt][r]);
+        }
+    }
+}
+
+// partials [split_k][M*K] in T -> fp32 sum -> T   (quantized_matmul.metal:277-293)
+template <typename TT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const uint16_t *__restrict__ partials,
+                                                            uint16_t *__restrict__ out, size_t elements, int split_k) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= elements) return;
+    float sum = 0.f;
+    for (int p = 0; p < split_k; ++p) sum += TT::to_float(partials[(size_t)p * elements + i]);
+    out[i] = TT::from_float(sum);
+}
+
+static int mfma_mt(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
+
+// Split-K policy.  Reference (quantized_matmul.cpp:138-151) targets 320
+// threadgroups of 32x32 on an M4 Pro; here a tile is (32*MT)x128 and the
+// target is two workgroups per CU on 256 CUs.
+static int split_k_policy(int M, int N, int K) {
+    const int mt = mfma_mt(M);
+    const int tiles = ceil_div(M, 32 * mt) * ceil_div(K, 128);
+    constexpr int target = 512;
+    constexpr int max_split = 16;
+    int s = std::min(std::min(max_split, std::max(1, target / std::max(tiles, 1))), N / 128);
+    while (s > 1 && N % (s * 128) != 0) --s;
+    return std::max(s, 1);
+}
+
+template <typename TT>
+static int launch_qmv(const QmvArgs &args, hipStream_t st) {
+    const QmvPlan pl = qmv_plan(args.M, args.N, args.K);
+    if (pl.lds > 150 * 1024) return -1;  // caller splits M
+    const dim3 grid(pl.blocks), block(256);
+#define QMV_CASE(MRv, WNv, RPLv)                                                                            \
+    if (pl.MR == MRv && pl.WN == WNv && pl.RPL == RPLv) {                                                   \
+        auto kern = qmv_kernel<TT, MRv, WNv, RPLv, PRO_NONE, EPI_STORE>;                                    \
+        if (pl.lds > 64 * 1024)                                                                             \
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
+        hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                            \
+        return 0;                                                                                           \
+    }
+#define QMV_MR(MRv) QMV_CASE(MRv, 1, 2) QMV_CASE(MRv, 1, 1) QMV_CASE(MRv, 2, 1) QMV_CASE(MRv, 4, 1)
+    QMV_MR(1) QMV_MR(2) QMV_MR(4) QMV_MR(8)
+#undef QMV_MR
+#undef QMV_CASE
+    return -2;
+}
+
+template <typename TT>
+static int run_qmm(const void *scales, const void *biases, const void *a, const uint32_t *b, void *out, int M, int N,
+                   int K, int use_simdgroup, int use_split_k, void *workspace, size_t workspace_bytes,
+                   hipStream_t st) {
+    auto S = (const uint16_t *)scales;
+    auto Bi = (const uint16_t *)biases;
+    auto A = (const uint16_t *)a;
+    auto O = (uint16_t *)out;
+    if (use_simdgroup && M <= 8) {
+        // GEMV; if the activation tile would not fit in LDS, process the rows in halves.
+        int m0 = 0;
+        int step = M;
+        while (qmv_plan(step, N, K).lds > 150 * 1024 && step > 1) step = (step + 1) / 2;
+        for (; m0 < M; m0 += step) {
+            QmvArgs args{};
+            args.scales = S; args.biases = Bi; args.b = b;
+            args.a = A + (size_t)m0 * N;
+            args.out = O + (size_t)m0 * K;
+            args.M = std::min(step, M - m0); args.N = N; args.K = K;
+            const int rc = launch_qmv<TT>(args, st);
+            if (rc != 0) return fail(TL_ERR_UNSUPPORTED, "quantized_matmul: no GEMV configuration for this shape");
+        }
+        return TL_OK;
+    }
+    if (use_simdgroup) {
+        const int mt = mfma_mt(M);
+        const int split = use_split_k ? split_k_policy(M, N, K) : 1;
+        const dim3 grid(ceil_div(K, 128), ceil_div(M, 32 * mt), split), block(256);
+        uint16_t *dst = O;
+        if (split > 1) {
+            const size_t need = (size_t)split * M * K * 2;
+            if (!workspace || workspace_bytes < need)
+                return fail(TL_ERR_INVALID, "quantized_matmul: split-K workspace is missing or too small");
+            dst = (uint16_t *)workspace;
+        }
+        const int psize = N / split;
+        const size_t pstride = (size_t)M * K;
+        switch (mt) {
+            case 1: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 1>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
+            case 2: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 2>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
+            default: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 4>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
+        }
+        if (split > 1) {
+            const size_t elements = (size_t)M * K;
+            hipLaunchKernelGGL((splitk_reduce_kernel<TT>), dim3(ceil_div(elements, 256)), dim3(256), 0, st,
+                               (const uint16_t *)workspace, O, elements, split);
+        }
+        return TL_OK;
+    }
+    hipLaunchKernelGGL((qmm_vanilla_kernel<TT>), dim3(ceil_div(K, 64), ceil_div(M, 4)), dim3(256), 0, st, S, Bi, A, b, O,
+                       M, N, K);
+    return TL_OK;
+}
+
+}  // namespace tl
+
+using namespace tl;
+
+extern "C" int tl_quantized_matmul_split_k(int M, int N, int K, int use_simdgroup, int use_split_k) {
+    if (!use_simdgroup || !use_split_k || M <= 8 || N < 128) return 1;
+    return split_k_policy(M, N, K);
+}
+
+extern "C" size_t tl_quantized_matmul_workspace_bytes(int M, int N, int K, tl_dtype dtype, int use_simdgroup,
+                                                      int use_split_k) {
+    (void)dtype;
+    const int s = tl_quantized_matmul_split_k(M, N, K, use_simdgroup, use_split_k);
+    return s > 1 ? (size_t)s * M * K * 2 : 0;
+}
+
+extern "C" int tl_quantized_matmul(const void *scales, const void *biases, const void *a, const uint32_t *b,
+                                   void *out, int M, int N, int K, int group_size, int bits, tl_dtype dtype,
+                                   int use_simdgroup, int use_split_k, void *workspace, size_t workspace_bytes,
+                                   void *stream) {
+    TL_REQUIRE(dtype == TL_F16 || dtype == TL_BF16, "quantized_matmul: scales must be float16 or bfloat16");
+    TL_REQUIRE(bits == 4, "quantized_matmul: bits must be 4");
+    TL_REQUIRE(group_size == 128, "quantized_matmul: group_size must be 128");
+    TL_REQUIRE(scales && biases && a && b && out, "quantized_matmul: null pointer");
+    TL_REQUIRE(M >= 0 && K >= 0 && N > 0, "quantized_matmul: a must be a 2D array");
+    TL_REQUIRE(N % 128 == 0, "quantized_matmul: N must be divisible by group_size");
+    TL_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0), "quantized_matmul: a must be contiguous");
+    if (M == 0 || K == 0) return TL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (dtype == TL_F16) {
+        rc = run_qmm<F16>(scales, biases, a, b, out, M, N, K, use_simdgroup, use_split_k, workspace, workspace_bytes, st);
+    } else {
+        rc = run_qmm<BF16>(scales, biases, a, b, out, M, N, K, use_simdgroup, use_split_k, workspace, workspace_bytes, st);
+    }
+    if (rc != TL_OK) return rc;
+    TL_CHECK_LAUNCH("quantized_matmul");
+    return TL_OK;
+}

@@ -1,0 +1,428 @@
+"""ctypes binding of ``libtinyllm_hip.so`` with the reference extension's Python surface.
+
+Mirrors the nanobind module ``tiny_llm_ext_ref._ext``
+(reference: src/extensions_ref/bindings.cpp:11-65): same function names, keyword
+names and defaults, but the arrays are PyTorch-ROCm tensors and the kernels are
+hand-written gfx950 HIP behind the C ABI declared in ``include/tinyllm_hip.h``.
+
+Like the reference, the extension is GPU-only: every op raises ``RuntimeError``
+for host tensors (reference ``eval_cpu`` throws, quantized_matmul.cpp:103-109),
+and importing this module fails loudly when the shared library is missing.
+There is no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import torch
+
+_LIB_NAME = "libtinyllm_hip.so"
+_LIB_PATH = Path(__file__).resolve().parent / _LIB_NAME
+
+if not _LIB_PATH.exists():
+    raise ImportError(
+        f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C tiny-llm_amd/csrc` (hipcc, gfx950). There is no CPU fallback."
+    )
+
+_lib = ctypes.CDLL(str(_LIB_PATH), mode=os.RTLD_LOCAL if hasattr(os, "RTLD_LOCAL") else 0)
+
+_c_void_p = ctypes.c_void_p
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_c_size_t = ctypes.c_size_t
+
+TL_F32, TL_F16, TL_BF16 = 0, 1, 2
+_DTYPES = {torch.float32: TL_F32, torch.float16: TL_F16, torch.bfloat16: TL_BF16}
+
+# name -> (restype, argtypes); every symbol declared in include/tinyllm_hip.h and
+# include/tinyllm_engine.h must appear here (tests/test_abi.py checks the headers).
+_SIGNATURES = {
+    "tl_last_error": (ctypes.c_char_p, []),
+    "tl_abi_version": (_c_int, []),
+    "tl_load_library": (_c_int, [ctypes.c_char_p]),
+    "tl_quantized_matmul": (
+        _c_int,
+        [_c_void_p] * 5 + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p],
+    ),
+    "tl_quantized_matmul_workspace_bytes": (_c_size_t, [_c_int] * 6),
+    "tl_quantized_matmul_split_k": (_c_int, [_c_int] * 5),
+    "tl_quantized_embedding": (_c_int, [_c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
+    "tl_rms_norm": (_c_int, [_c_void_p] * 3 + [_c_int, _c_int, _c_float, _c_int, _c_void_p]),
+    "tl_rope": (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_float, _c_int, _c_int, _c_void_p]),
+    "tl_swiglu": (_c_int, [_c_void_p] * 3 + [_c_size_t, _c_int, _c_void_p]),
+    "tl_decode_attention": (_c_int, [_c_void_p] * 5 + [_c_int] * 6 + [_c_float, _c_int, _c_int, _c_int, _c_void_p]),
+    "tl_paged_cache_update": (_c_int, [_c_void_p] * 2 + [_c_int] * 8 + [_c_void_p]),
+    "tl_paged_attention": (
+        _c_int,
+        [_c_void_p] * 6 + [_c_int] * 8 + [_c_float, _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p],
+    ),
+    "tl_paged_attention_workspace_bytes": (_c_size_t, [_c_int] * 8),
+}
+
+for _name, (_res, _args) in _SIGNATURES.items():
+    _fn = getattr(_lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def _bind_optional(name: str, restype, argtypes) -> bool:
+    fn = getattr(_lib, name, None)
+    if fn is None:
+        return False
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return True
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded shared library (used by the decode engine binding)."""
+    return _lib
+
+
+def library_path() -> str:
+    return str(_LIB_PATH)
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        message = _lib.tl_last_error()
+        raise RuntimeError(message.decode() if message else f"tinyllm_hip error {status}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(op: str, *tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(f"{op}: the course extension is GPU-only")
+
+
+def _ptr(t: torch.Tensor) -> int:
+    return t.data_ptr()
+
+
+_workspaces: dict[tuple[int, int], torch.Tensor] = {}
+
+
+def _workspace(nbytes: int, device: torch.device) -> torch.Tensor | None:
+    """Per-(device, stream) scratch buffer; grows geometrically, reused across calls."""
+    if nbytes <= 0:
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def load_library(path: str) -> None:
+    """reference: load_library(path) registers the metallib (utils.cpp:9-14). Here: verify a gfx950 device."""
+    _check(_lib.tl_load_library(str(path).encode()))
+
+
+def quantized_matmul(
+    scales: torch.Tensor,
+    biases: torch.Tensor,
+    group_size: int,
+    bits: int,
+    a: torch.Tensor,
+    b: torch.Tensor,
+    transpose_b: bool = False,
+    use_simdgroup: bool = True,
+    use_split_k: bool = False,
+    stream=None,
+) -> torch.Tensor:
+    """W4A16 ``a[M,N] @ dequant(b[K,N/8]).T`` (reference quantized_matmul.cpp:14-80 for the checks)."""
+    if scales.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("quantized_matmul: scales must be float16 or bfloat16")
+    if scales.dtype != biases.dtype:
+        raise RuntimeError("quantized_matmul: scales and biases must be the same dtype")
+    if b.dtype not in (torch.uint32, torch.int32):
+        raise RuntimeError("quantized_matmul: b must be uint32")
+    if a.dtype != scales.dtype:
+        raise RuntimeError("quantized_matmul: a must be the same dtype as scales")
+    if a.dim() != 2:
+        raise RuntimeError("quantized_matmul: a must be a 2D array")
+    if b.dim() != 2:
+        raise RuntimeError("quantized_matmul: b must be a 2D array")
+    if bits != 4:
+        raise RuntimeError("quantized_matmul: bits must be 4")
+    if group_size != 128:
+        raise RuntimeError("quantized_matmul: group_size must be 128")
+    if not transpose_b:
+        raise RuntimeError("quantized_matmul: b must be transposed")
+    if scales.shape != biases.shape:
+        raise RuntimeError("quantized_matmul: scales and biases must have the same shape")
+    if b.shape[0] != scales.shape[0]:
+        raise RuntimeError("quantized_matmul: b must have the same number of rows as scales")
+    M, N = a.shape
+    K = b.shape[0]
+    if N % group_size != 0:
+        raise RuntimeError("quantized_matmul: a columns must be divisible by group_size")
+    if scales.dim() != 2 or scales.shape[1] != N // group_size:
+        raise RuntimeError("quantized_matmul: scales must have one column per input group")
+    if b.shape[1] != N // 8:
+        raise RuntimeError("quantized_matmul: a must have the same number of columns as b")
+    _require_gpu("quantized_matmul", scales, biases, a, b)
+    if not a.is_contiguous():
+        raise RuntimeError("quantized_matmul: a must be contiguous")
+    if not b.is_contiguous():
+        raise RuntimeError("quantized_matmul: b must be contiguous")
+    scales = scales.contiguous()
+    biases = biases.contiguous()
+    dt = _DTYPES[a.dtype]
+    out = torch.empty((M, K), dtype=a.dtype, device=a.device)
+    ws_bytes = _lib.tl_quantized_matmul_workspace_bytes(M, N, K, dt, int(use_simdgroup), int(use_split_k))
+    ws = _workspace(ws_bytes, a.device)
+    _check(
+        _lib.tl_quantized_matmul(
+            _ptr(scales), _ptr(biases), _ptr(a), _ptr(b), _ptr(out), M, N, K, group_size, bits, dt,
+            int(use_simdgroup), int(use_split_k), _ptr(ws) if ws is not None else None,
+            ws.numel() if ws is not None else 0, _stream(),
+        )
+    )
+    return out
+
+
+def quantized_embedding(
+    indices: torch.Tensor,
+    scales: torch.Tensor,
+    biases: torch.Tensor,
+    weight: torch.Tensor,
+    group_size: int,
+    bits: int,
+    stream=None,
+) -> torch.Tensor:
+    """Gather + dequantize rows of a packed table (reference quantized_matmul.cpp:82-101)."""
+    if indices.dtype not in (torch.int32, torch.uint32) or weight.dtype not in (torch.uint32, torch.int32):
+        raise RuntimeError("quantized_embedding: indices and weight must use 32-bit integers")
+    if scales.dtype != biases.dtype or scales.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("quantized_embedding: scales and biases must have the same 16-bit dtype")
+    if group_size != 128 or bits != 4 or scales.shape != biases.shape:
+        raise RuntimeError("quantized_embedding: expected 4-bit weights with group size 128")
+    dim = weight.shape[1] * 8
+    if scales.shape[0] != weight.shape[0] or scales.shape[1] != dim // group_size:
+        raise RuntimeError("quantized_embedding: incompatible parameter shapes")
+    _require_gpu("quantized_embedding", indices, scales, biases, weight)
+    indices = indices.contiguous()
+    out = torch.empty((*indices.shape, dim), dtype=scales.dtype, device=scales.device)
+    _check(
+        _lib.tl_quantized_embedding(
+            _ptr(indices), int(indices.dtype == torch.uint32), _ptr(scales.contiguous()), _ptr(biases.contiguous()),
+            _ptr(weight.contiguous()), _ptr(out), indices.numel(), dim, weight.shape[0], group_size, bits,
+            _DTYPES[scales.dtype], _stream(),
+        )
+    )
+    return out
+
+
+def _require_float(x: torch.Tensor, name: str) -> None:
+    if x.dtype not in _DTYPES:
+        raise RuntimeError(f"{name}: expected float32, float16, or bfloat16")
+
+
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float, stream=None) -> torch.Tensor:
+    """Fused RMSNorm over the last dim (reference week2_kernels.cpp:36-42)."""
+    _require_float(x, "rms_norm")
+    if x.dtype != weight.dtype or weight.dim() != 1 or weight.shape[0] != x.shape[-1]:
+        raise RuntimeError("rms_norm: weight must match the input dtype and final dimension")
+    _require_gpu("rms_norm", x, weight)
+    x = x.contiguous()
+    weight = weight.contiguous()
+    out = torch.empty_like(x)
+    dim = x.shape[-1]
+    rows = x.numel() // dim if dim else 0
+    _check(_lib.tl_rms_norm(_ptr(x), _ptr(weight), _ptr(out), rows, dim, float(eps), _DTYPES[x.dtype], _stream()))
+    return out
+
+
+def rope(
+    x: torch.Tensor, offsets: torch.Tensor, dims: int, base: float, traditional: bool = False, stream=None
+) -> torch.Tensor:
+    """Fused RoPE, x=[B,L,H,D], one int32 offset per batch row (reference week2_kernels.cpp:44-55)."""
+    _require_float(x, "rope")
+    if x.dim() != 4 or offsets.dtype != torch.int32 or offsets.dim() != 1 or offsets.shape[0] != x.shape[0]:
+        raise RuntimeError("rope: expected x=[B,L,H,D] and one int32 offset per batch row")
+    if dims <= 0 or dims > x.shape[3] or dims % 2 != 0:
+        raise RuntimeError("rope: dims must be positive, even, and no larger than the head dimension")
+    _require_gpu("rope", x, offsets)
+    x = x.contiguous()
+    offsets = offsets.contiguous()
+    out = torch.empty_like(x)
+    B, L, H, D = x.shape
+    _check(
+        _lib.tl_rope(_ptr(x), _ptr(offsets), _ptr(out), B, L, H, D, int(dims), float(base), int(bool(traditional)),
+                     _DTYPES[x.dtype], _stream())
+    )
+    return out
+
+
+def swiglu(gate: torch.Tensor, up: torch.Tensor, stream=None) -> torch.Tensor:
+    """``silu(gate) * up`` (reference week2_kernels.cpp:57-63)."""
+    _require_float(gate, "swiglu")
+    if gate.dtype != up.dtype or gate.shape != up.shape:
+        raise RuntimeError("swiglu: gate and up must have the same shape and dtype")
+    _require_gpu("swiglu", gate, up)
+    gate = gate.contiguous()
+    up = up.contiguous()
+    out = torch.empty_like(gate)
+    _check(_lib.tl_swiglu(_ptr(gate), _ptr(up), _ptr(out), gate.numel(), _DTYPES[gate.dtype], _stream()))
+    return out
+
+
+def decode_attention(
+    query: torch.Tensor,
+    key: torch.Tensor,
+    value: torch.Tensor,
+    mask: torch.Tensor,
+    scale: float,
+    is_causal: bool,
+    has_mask: bool,
+    num_heads: int,
+    num_kv_heads: int,
+    stream=None,
+) -> torch.Tensor:
+    """Dense-KV online-softmax GQA attention (reference week2_kernels.cpp:65-84)."""
+    _require_float(query, "decode_attention")
+    if query.dtype != key.dtype or query.dtype != value.dtype or mask.dtype != torch.float32:
+        raise RuntimeError("decode_attention: q, k, and v dtypes must match; mask must be float32")
+    if (
+        query.dim() != 3 or key.dim() != 3 or value.dim() != 3 or query.shape[2] > 256
+        or query.shape[2] != key.shape[2] or query.shape[2] != value.shape[2] or key.shape != value.shape
+        or num_heads % num_kv_heads != 0
+    ):
+        raise RuntimeError("decode_attention: incompatible attention shapes")
+    if has_mask and (
+        mask.dim() != 3 or mask.shape[0] != query.shape[0] or mask.shape[1] != query.shape[1]
+        or mask.shape[2] != key.shape[1]
+    ):
+        raise RuntimeError("decode_attention: mask must have shape [B*Hq,L,S]")
+    _require_gpu("decode_attention", query, key, value)
+    if has_mask:
+        _require_gpu("decode_attention", mask)
+    query, key, value, mask = query.contiguous(), key.contiguous(), value.contiguous(), mask.contiguous()
+    out = torch.empty_like(query)
+    q_rows, L, D = query.shape
+    S = key.shape[1]
+    _check(
+        _lib.tl_decode_attention(
+            _ptr(query), _ptr(key), _ptr(value), _ptr(mask) if has_mask else None, _ptr(out), q_rows, L, S, D,
+            int(num_heads), int(num_kv_heads), float(scale), int(bool(is_causal)), int(bool(has_mask)),
+            _DTYPES[query.dtype], _stream(),
+        )
+    )
+    return out
+
+
+def paged_cache_update(pages: torch.Tensor, values: torch.Tensor, page_id: int, start: int, stream=None) -> torch.Tensor:
+    """In-place write of ``values[1,H,len,D]`` into ``pages[P,H,page,D]``; returns ``pages`` itself
+    (the reference output aliases the input buffer, paged_attention.cpp:46-49)."""
+    if pages.dtype not in (torch.float32, torch.bfloat16) or values.dtype != pages.dtype:
+        raise RuntimeError("paged_cache_update: pages and values must have the same float32 or bfloat16 dtype")
+    if pages.dim() != 4 or values.dim() != 4 or values.shape[0] != 1:
+        raise RuntimeError("paged_cache_update: expected pages [P, H, page_size, D] and values [1, H, length, D]")
+    if values.shape[1] != pages.shape[1] or values.shape[3] != pages.shape[3]:
+        raise RuntimeError("paged_cache_update: values must match the page head count and head dimension")
+    if page_id < 0 or page_id >= pages.shape[0] or start < 0 or start + values.shape[2] > pages.shape[2]:
+        raise RuntimeError("paged_cache_update: destination slice is outside page storage")
+    _require_gpu("paged_cache_update", pages, values)
+    if not pages.is_contiguous() or not values.is_contiguous():
+        raise RuntimeError("paged_cache_update: pages and values must be contiguous")
+    P, H, page_size, D = pages.shape
+    _check(
+        _lib.tl_paged_cache_update(_ptr(pages), _ptr(values), P, H, page_size, D, values.shape[2], int(page_id),
+                                   int(start), _DTYPES[pages.dtype], _stream())
+    )
+    return pages
+
+
+def paged_attention(
+    query: torch.Tensor,
+    key_pages: torch.Tensor,
+    value_pages: torch.Tensor,
+    block_table: torch.Tensor,
+    context_lens: torch.Tensor,
+    scale: float = 1.0,
+    is_causal: bool = False,
+    *,
+    num_kv_heads: int,
+    num_heads: int,
+    stream=None,
+    max_context_hint: int = 0,
+) -> torch.Tensor:
+    """Block-table attention over paged K/V (reference paged_attention.cpp:77-122 for the checks).
+
+    ``max_context_hint`` (extension of the reference signature) is a host-known upper
+    bound of ``context_lens`` used only to size the context split of the decode kernel.
+    """
+    if query.dtype not in (torch.float32, torch.bfloat16) or key_pages.dtype != query.dtype \
+            or value_pages.dtype != query.dtype:
+        raise RuntimeError(
+            "paged_attention: q, key_pages, and value_pages must have the same float32 or bfloat16 dtype")
+    if block_table.dtype != torch.int32 or context_lens.dtype != torch.int32:
+        raise RuntimeError("paged_attention: block_table and context_lens must be int32")
+    if query.dim() != 3:
+        raise RuntimeError("paged_attention: q must be 3D [B * H_q, L, D]")
+    if key_pages.dim() != 4 or value_pages.dim() != 4:
+        raise RuntimeError("paged_attention: page tensors must be 4D [P, H_kv, page_size, D]")
+    if block_table.dim() != 2 or context_lens.dim() != 1:
+        raise RuntimeError("paged_attention: block_table must be 2D and context_lens must be 1D")
+    if num_heads % num_kv_heads != 0:
+        raise RuntimeError("paged_attention: num_heads must be divisible by num_kv_heads")
+    if query.shape[0] % num_heads != 0:
+        raise RuntimeError("paged_attention: q.shape[0] must be divisible by num_heads")
+    if key_pages.shape != value_pages.shape:
+        raise RuntimeError("paged_attention: key_pages and value_pages must have the same shape")
+    if key_pages.shape[1] != num_kv_heads:
+        raise RuntimeError("paged_attention: page tensor head count must equal num_kv_heads")
+    if query.shape[2] != key_pages.shape[3]:
+        raise RuntimeError("paged_attention: q and page tensors must have the same head dimension")
+    if block_table.shape[0] != context_lens.shape[0]:
+        raise RuntimeError("paged_attention: block_table and context_lens batch sizes must match")
+    if query.shape[0] // num_heads != block_table.shape[0]:
+        raise RuntimeError("paged_attention: q batch size must match block_table batch size")
+    _require_gpu("paged_attention", query, key_pages, value_pages, block_table, context_lens)
+    N, L, D = query.shape
+    P, _, page_size, _ = key_pages.shape
+    max_pages = block_table.shape[1]
+    if D > 128:
+        raise RuntimeError("paged_attention: head dimension must be at most 128")
+    if L > 8 and query.dtype == torch.bfloat16 and D != 128:
+        raise RuntimeError("paged_attention: bfloat16 prefill requires head dimension 128")
+    for name, t in (("q", query), ("key_pages", key_pages), ("value_pages", value_pages),
+                    ("block_table", block_table), ("context_lens", context_lens)):
+        if not t.is_contiguous():
+            raise RuntimeError(f"paged_attention: {name} must be contiguous")
+    out = torch.empty_like(query)
+    ws_bytes = _lib.tl_paged_attention_workspace_bytes(N, L, D, page_size, max_pages, num_heads, num_kv_heads,
+                                                       int(max_context_hint))
+    ws = _workspace(ws_bytes, query.device)
+    _check(
+        _lib.tl_paged_attention(
+            _ptr(query), _ptr(key_pages), _ptr(value_pages), _ptr(block_table), _ptr(context_lens), _ptr(out), N, L,
+            D, P, page_size, max_pages, int(num_heads), int(num_kv_heads), float(scale), int(bool(is_causal)),
+            int(max_context_hint), _DTYPES[query.dtype], _ptr(ws) if ws is not None else None,
+            ws.numel() if ws is not None else 0, _stream(),
+        )
+    )
+    return out
+
+
+__all__ = [
+    "load_library",
+    "quantized_matmul",
+    "quantized_embedding",
+    "rms_norm",
+    "rope",
+    "swiglu",
+    "decode_attention",
+    "paged_cache_update",
+    "paged_attention",
+]

@@ -1,0 +1,25 @@
+"""Readable building blocks on torch tensors (reference: src/tiny_llm_ref/basics.py)."""
+
+import torch
+
+
+def softmax(x: torch.Tensor, axis: int) -> torch.Tensor:
+    """Numerically-stable softmax; rows that are entirely -inf come out as zeros instead of NaN."""
+    peak = torch.amax(x, dim=axis, keepdim=True)
+    peak = torch.where(torch.isfinite(peak), peak, torch.zeros_like(peak))
+    e = torch.exp(x - peak)
+    total = e.sum(dim=axis, keepdim=True)
+    return e / torch.where(total == 0, torch.ones_like(total), total)
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """``x @ w.T (+ bias)`` with w stored [out, in] (reference basics.py:10-18)."""
+    y = torch.matmul(x, w.transpose(-1, -2))
+    return y if bias is None else y + bias
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    """x * sigmoid(x), evaluated through exp(-|x|) so large negative inputs do not overflow
+    (reference basics.py:21-26)."""
+    z = torch.exp(-torch.abs(x))
+    return x * torch.where(x < 0, z / (1 + z), 1 / (1 + z))

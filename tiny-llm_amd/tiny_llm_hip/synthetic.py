@@ -1,0 +1,95 @@
+"""Affine W4 quantiser and synthetic Qwen3-shaped checkpoints.
+
+No real checkpoint can be downloaded where this runs, so benches and tests build random-weight models with
+the exact tensor layout ``mlx_lm.load`` would hand the reference models (the attribute tree read by
+qwen3_week2.py:288-350): ``model.args.*`` plus, per linear, ``weight`` (packed uint32 bits held in an
+int32 tensor), ``scales``, ``biases``, ``group_size``, ``bits``.
+"""
+
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+
+QWEN3_CONFIGS = {
+    # public Qwen3 configs (values pinned for 4B in the reference's benchmark JSON)
+    "qwen3-4b": dict(hidden_size=2560, num_hidden_layers=36, num_attention_heads=32, num_key_value_heads=8,
+                     head_dim=128, intermediate_size=9728, vocab_size=151936, rope_theta=1000000,
+                     rms_norm_eps=1e-6, max_position_embeddings=40960, tie_word_embeddings=True),
+    "qwen3-0.6b": dict(hidden_size=1024, num_hidden_layers=28, num_attention_heads=16, num_key_value_heads=8,
+                       head_dim=128, intermediate_size=3072, vocab_size=151936, rope_theta=1000000,
+                       rms_norm_eps=1e-6, max_position_embeddings=40960, tie_word_embeddings=True),
+}
+
+
+def quantize(w: torch.Tensor, group_size: int = 128, bits: int = 4):
+    """Group-wise affine quantisation in the MLX packing: (packed [K, N/8] int32 bits, scales, biases).
+
+    Restates ``mx.quantize`` (mlx 0.32): per group, scale = (max-min)/15 signed towards the larger-magnitude
+    edge, that edge becomes the bias after snapping it to a multiple of the scale; codes are packed eight
+    per 32-bit word with element 8j+i in bits [4i, 4i+4) (reference quantize.py:113-115)."""
+    if bits != 4:
+        raise ValueError("only 4-bit quantisation is supported")
+    K, N = w.shape
+    if N % group_size:
+        raise ValueError("last dimension must be divisible by group_size")
+    dtype = w.dtype
+    g = w.to(torch.float32).reshape(K, N // group_size, group_size)
+    hi = g.amax(dim=-1)
+    lo = g.amin(dim=-1)
+    scale = torch.clamp((hi - lo) / 15.0, min=1e-7)
+    lower_side = lo.abs() > hi.abs()
+    scale = torch.where(lower_side, scale, -scale)
+    edge = torch.where(lower_side, lo, hi)
+    q0 = torch.round(edge / scale)
+    snap = q0 != 0
+    scale = torch.where(snap, edge / torch.where(snap, q0, torch.ones_like(q0)), scale)
+    bias = torch.where(snap, edge, torch.zeros_like(edge))
+    scale = scale.to(dtype)
+    bias = bias.to(dtype)
+    s32 = scale.to(torch.float32)
+    safe = torch.where(s32 == 0, torch.ones_like(s32), s32)
+    codes = torch.clamp(torch.round((g - bias.to(torch.float32)[..., None]) / safe[..., None]), 0, 15)
+    codes = codes.to(torch.int64).reshape(K, N // 8, 8)
+    shifts = torch.arange(0, 32, 4, dtype=torch.int64, device=w.device)
+    words = (codes << shifts).sum(dim=-1)  # < 2^32
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+    return words, scale, bias
+
+
+def _qlayer(weight: torch.Tensor) -> SimpleNamespace:
+    packed, scales, biases = quantize(weight)
+    return SimpleNamespace(weight=packed, scales=scales, biases=biases, group_size=128, bits=4)
+
+
+def synthetic_qwen3(config: dict | str, seed: int = 0, sigma: float = 0.02, device: str = "cuda",
+                    norm_jitter: float = 0.05) -> SimpleNamespace:
+    """Random-weight Qwen3 in the mlx_lm object shape.  w ~ N(0, sigma) in bf16 -> W4 g128."""
+    cfg = dict(QWEN3_CONFIGS[config]) if isinstance(config, str) else dict(config)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+
+    def linear(out_dim: int, in_dim: int) -> SimpleNamespace:
+        w = (torch.randn((out_dim, in_dim), generator=gen, device=device, dtype=torch.float32) * sigma)
+        return _qlayer(w.to(torch.bfloat16))
+
+    def norm(n: int) -> SimpleNamespace:
+        w = 1.0 + norm_jitter * torch.randn((n,), generator=gen, device=device, dtype=torch.float32)
+        return SimpleNamespace(weight=w.to(torch.bfloat16))
+
+    hs, inter = cfg["hidden_size"], cfg["intermediate_size"]
+    hq, hkv, hd = cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"]
+    layers = []
+    for _ in range(cfg["num_hidden_layers"]):
+        layers.append(SimpleNamespace(
+            self_attn=SimpleNamespace(
+                q_proj=linear(hq * hd, hs), k_proj=linear(hkv * hd, hs), v_proj=linear(hkv * hd, hs),
+                o_proj=linear(hs, hq * hd), q_norm=norm(hd), k_norm=norm(hd)),
+            mlp=SimpleNamespace(gate_proj=linear(inter, hs), up_proj=linear(inter, hs), down_proj=linear(hs, inter)),
+            input_layernorm=norm(hs), post_attention_layernorm=norm(hs)))
+    model = SimpleNamespace(embed_tokens=linear(cfg["vocab_size"], hs), layers=layers, norm=norm(hs))
+    out = SimpleNamespace(args=SimpleNamespace(**cfg), model=model)
+    if not cfg.get("tie_word_embeddings", True):
+        out.lm_head = linear(cfg["vocab_size"], hs)
+    return out
