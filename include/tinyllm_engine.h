@@ -1,4 +1,159 @@
-/* placeholder: filled in with the fused decode engine ABI */
+/*
+ * tinyllm_engine.h — C ABI of the fused Qwen3 W4A16 forward ("decode engine").
+ *
+ * The reference runs one token through ~690 separately dispatched MLX primitives
+ * (layer loop: src/tiny_llm_ref/qwen3_week2.py:357-392, qwen3_week3.py:320-338;
+ * per-layer ops: qwen3_week3.py:55-121,141-147,181-187).  On an MI355X the whole
+ * 382 us/token budget would be spent in launch gaps, so the same arithmetic is
+ * issued here as 5 kernels per layer, captured once in a hipGraph and replayed:
+ *
+ *   1. RMSNorm -> fused QKV W4 GEMV                 (input_layernorm + wq|wk|wv)
+ *   2. q/k-RMSNorm + RoPE + paged KV append + split-context GQA attention
+ *      (+ a merge kernel only when the context is split)
+ *   3. wo W4 GEMV + residual add
+ *   4. RMSNorm -> gate|up W4 GEMV -> SwiGLU         (post_attention_layernorm + MLP in)
+ *   5. w_down W4 GEMV + residual add
+ *   final: RMSNorm -> lm_head W4 GEMV -> argmax -> next-token embedding gather.
+ *
+ * Every reference op boundary is kept as a bf16 rounding point inside the fused
+ * kernels, so logits track the op-by-op path (tests/test_engine_gpu.py).
+ *
+ * State that changes every token (token ids, context lengths, step counter) lives
+ * in device memory and is advanced by the last kernel of the step, so a captured
+ * step replays without host involvement; the host only appends a page id to a
+ * block-table row when a sequence crosses a page boundary.
+ *
+ * The multi-token path (chunked prefill, reference Request.try_prefill
+ * src/tiny_llm_ref/batch.py:48-76) uses the MFMA W4 GEMM and the paged
+ * FlashAttention kernel of tinyllm_hip.h with the same fused weight layout.
+ *
+ * KV storage is the reference's paged layout, one pool per layer:
+ * key/value pages [P, Hkv, page_size, D] bf16 (paged_kv_cache.py:21-242), block
+ * table [max_batch, max_pages_per_seq] int32 (-1 = unused), context_lens
+ * [max_batch] int32 (kv_cache.py:210-224).  Pools are owned by the engine and
+ * sized once at creation (288 GB of HBM: no growth path on the hot loop).
+ *
+ * All functions return 0 / negative tl_status; message via tl_last_error().
+ * Pointers named *_dev are device pointers; everything else is host memory.
+ */
 #ifndef TINYLLM_ENGINE_H
 #define TINYLLM_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
 #endif
+
+typedef struct tl_engine tl_engine;
+
+/* One W4 (group 128) linear: packed [rows, in/8] uint32, scales/biases [rows, in/128] bf16. */
+typedef struct tl_w4 {
+    const uint32_t *weight_dev;
+    const void *scales_dev;
+    const void *biases_dev;
+    int rows; /* out features */
+    int cols; /* in features  */
+} tl_w4;
+
+/* Per-layer weights in the engine's fused layout (built by the host mirror,
+ * tiny_llm_hip/engine.py, from the mlx_lm-shaped checkpoint object):
+ *   wqkv  rows = [q (Hq*D) | k (Hkv*D) | v (Hkv*D)]                      cols = hidden
+ *   wo    rows = hidden                                                  cols = Hq*D
+ *   wgu   rows interleaved: 2i = gate_proj row i, 2i+1 = up_proj row i   cols = hidden
+ *   wdown rows = hidden                                                  cols = intermediate */
+typedef struct tl_layer_weights {
+    tl_w4 wqkv, wo, wgu, wdown;
+    const void *input_norm_dev; /* [hidden] bf16 */
+    const void *post_norm_dev;  /* [hidden] bf16 */
+    const void *q_norm_dev;     /* [D] bf16 */
+    const void *k_norm_dev;     /* [D] bf16 */
+} tl_layer_weights;
+
+typedef struct tl_engine_config {
+    int hidden_size, num_layers, num_heads, num_kv_heads, head_dim, intermediate_size, vocab_size;
+    float rope_theta, rms_norm_eps;
+    int page_size;         /* tokens per KV page (reference default 128, qwen3_week3.py:222) */
+    int num_pages;         /* physical pages per layer pool */
+    int max_batch;         /* sequence slots */
+    int max_pages_per_seq; /* block-table width */
+    int max_prefill_rows;  /* largest prefill chunk (rows of the activation workspace) */
+} tl_engine_config;
+
+/* Counters mirroring the pool statistics the reference serving bench prints
+ * (paged_kv_cache.py:36-40, benches/bench.py:546-556). */
+typedef struct tl_engine_stats {
+    int pages_in_use, pages_free, peak_pages_in_use;
+    long page_allocations, reused_page_allocations;
+    long decode_steps, graph_captures, graph_replays, prefill_tokens;
+    size_t kv_bytes, workspace_bytes;
+} tl_engine_stats;
+
+/* embed: the quantized embedding table [vocab, hidden]; lm_head: NULL for tied
+ * embeddings (reference qwen3_week3.py:314-318).  Weight memory is borrowed and
+ * must outlive the engine.  `stream` is the hipStream_t all work is issued on;
+ * NULL makes the engine create and own a non-blocking stream (the legacy default
+ * stream cannot be graph-captured) after a device-wide synchronise. */
+int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weights *layers, const tl_w4 *embed,
+                     const void *final_norm_dev, const tl_w4 *lm_head, void *stream, tl_engine **out);
+void tl_engine_destroy(tl_engine *e);
+/* Block the host until everything enqueued on the engine stream has finished. */
+int tl_engine_synchronize(tl_engine *e);
+
+/* Sequence slots ------------------------------------------------------------
+ * begin: claim slot (must be free), context 0.  Fails with TL_ERR_INVALID when
+ *        the slot is live.
+ * reserve: make sure pages exist for `total_tokens` tokens of context (allocates
+ *        from the free list, appends to the slot's block-table row); fails
+ *        without side effects when the pool or the table width is exhausted
+ *        (transactional like TinyKvPagedCache._append_chunk, paged_kv_cache.py:271-312).
+ * release: return the slot's pages to the free list, context 0, row = -1.
+ * rewind: drop the last n tokens of the slot (reference rewind(), paged_kv_cache.py:414-434). */
+int tl_engine_begin(tl_engine *e, int slot);
+int tl_engine_reserve(tl_engine *e, int slot, int total_tokens);
+int tl_engine_release(tl_engine *e, int slot);
+int tl_engine_rewind(tl_engine *e, int slot, int n);
+int tl_engine_context_len(const tl_engine *e, int slot);  /* host mirror, <0 if slot free */
+
+/* Chunked prefill of ONE slot: runs `n` tokens (host int32 ids) at positions
+ * [context, context+n) through the multi-token path, appends their K/V, and, when
+ * want_logits != 0, computes the last row's logits + greedy token which becomes
+ * the slot's pending input token for the next decode step.  n <= max_prefill_rows. */
+int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, int n, int want_logits);
+
+/* Set the pending input token of a slot explicitly (e.g. sampled on the host). */
+int tl_engine_set_token(tl_engine *e, int slot, int32_t token);
+
+/* Run `steps` greedy decode steps over the live slots [0, batch): each step feeds
+ * every slot's pending token at position context_len, appends K/V, and leaves the
+ * argmax token as the next pending token.  Generated ids are appended to an
+ * on-device ring [capacity, max_batch] readable via tl_engine_read_tokens.
+ * The step is captured in a hipGraph on first use (re-captured when the
+ * attention split bucket or batch changes); use_graph = 0 launches eagerly.
+ * Pages are reserved on demand (TL_ERR_INVALID if the pool is exhausted).
+ * Does not synchronise. */
+int tl_engine_decode(tl_engine *e, int batch, int steps, int use_graph);
+
+/* Copy the ids produced by the last `count` decode steps for `slot` to host
+ * (synchronises the stream). */
+int tl_engine_read_tokens(tl_engine *e, int slot, int count, int32_t *out);
+
+/* Device pointer to the most recent logits, [rows, vocab] bf16 (decode: rows =
+ * batch of the last step; prefill with want_logits: 1 row). */
+const void *tl_engine_logits_dev(const tl_engine *e);
+/* Stream-ordered device-to-device copy of the first `rows` logits rows into dst_dev ([rows, vocab] bf16). */
+int tl_engine_copy_logits(tl_engine *e, void *dst_dev, int rows);
+/* Device pointer to the pending token ids [max_batch] int32. */
+const int32_t *tl_engine_tokens_dev(const tl_engine *e);
+
+int tl_engine_get_stats(const tl_engine *e, tl_engine_stats *out);
+
+/* Algorithmic HBM bytes of ONE decode step at the current state: all W4 weights
+ * streamed once + K/V of every live context. */
+size_t tl_engine_step_bytes(const tl_engine *e, int batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYLLM_ENGINE_H */

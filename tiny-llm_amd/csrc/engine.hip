@@ -1,0 +1,706 @@
+// Decode engine: host side of include/tinyllm_engine.h.
+//   * page allocator + slot table (host mirrors of block_table / context_lens), transactional reserve
+//     (reference semantics: TinyKvPagedPool / TinyKvPagedCache, src/tiny_llm_ref/paged_kv_cache.py:21-443)
+//   * one fused decode step = 5 launches per layer (+ merge when the context is split) + 2 at the end,
+//     captured into a hipGraph per (batch, n_splits) and replayed
+//   * multi-token prefill on the MFMA W4 GEMM + paged FlashAttention operators of tinyllm_hip.h
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tinyllm_engine.h"
+#include "common.h"
+#include "engine_kernels.h"
+#include "qmv.h"
+
+namespace tl {
+
+#define TL_TRY(expr)                  \
+    do {                              \
+        const int rc__ = (expr);      \
+        if (rc__ != TL_OK) return rc__; \
+    } while (0)
+
+#define TL_HIP(expr)                                                                           \
+    do {                                                                                       \
+        const hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess) return fail(TL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace tl
+
+using namespace tl;
+
+struct tl_engine {
+    tl_engine_config cfg{};
+    std::vector<tl_layer_weights> layers;
+    tl_w4 embed{}, lm_head{};
+    const void *final_norm = nullptr;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+
+    // device memory (one arena for state + activations, one for KV)
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    uint16_t *kpool = nullptr, *vpool = nullptr;  // [layers][P, Hkv, page, D]
+    size_t layer_pool_elems = 0, kv_bytes = 0;
+    void *splitk_ws = nullptr;
+    size_t splitk_ws_bytes = 0;
+
+    int32_t *block_table = nullptr, *context_lens = nullptr, *tokens = nullptr, *live = nullptr, *produced = nullptr,
+            *ring = nullptr, *scratch_ctx = nullptr, *prefill_tokens = nullptr;
+    uint16_t *x = nullptr, *h = nullptr, *xn = nullptr, *qkv = nullptr, *q_t = nullptr, *attn_t = nullptr,
+             *attn = nullptr, *gu = nullptr, *act = nullptr, *tmp = nullptr, *logits = nullptr;
+    float *attn_ws = nullptr;
+    size_t attn_ws_bytes = 0;
+    int rows_cap = 0;
+    int ring_cap = 4096;
+
+    // host mirrors
+    std::vector<std::vector<int>> slot_pages;
+    std::vector<int> slot_ctx;
+    std::vector<char> slot_live;
+    std::vector<int> slot_produced;
+    std::vector<int> free_pages;
+    std::vector<char> page_was_used;
+    tl_engine_stats stats{};
+
+    bool warmed = false;
+    std::map<std::pair<int, int>, hipGraphExec_t> graphs;
+    int logits_rows = 0;
+
+    int qkv_dim() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
+    int q_dim() const { return cfg.num_heads * cfg.head_dim; }
+    const tl_w4 &head() const { return lm_head.weight_dev ? lm_head : embed; }
+    uint16_t *layer_k(int l) const { return kpool + (size_t)l * layer_pool_elems; }
+    uint16_t *layer_v(int l) const { return vpool + (size_t)l * layer_pool_elems; }
+};
+
+namespace tl {
+
+// ---- small launch helpers ----------------------------------------------------------------------
+static int poke(tl_engine *e, std::vector<std::pair<int32_t *, int32_t>> &items) {
+    for (size_t i = 0; i < items.size(); i += 8) {
+        PokeArgs a{};
+        a.n = (int)std::min<size_t>(8, items.size() - i);
+        for (int j = 0; j < a.n; ++j) {
+            a.addr[j] = items[i + j].first;
+            a.value[j] = items[i + j].second;
+        }
+        hipLaunchKernelGGL(poke_kernel, dim3(1), dim3(64), 0, e->stream, a);
+    }
+    items.clear();
+    TL_CHECK_LAUNCH("engine poke");
+    return TL_OK;
+}
+
+static int check_w4(const tl_w4 &w, int rows, int cols, const char *name) {
+    if (!w.weight_dev || !w.scales_dev || !w.biases_dev)
+        return fail(TL_ERR_INVALID, std::string("engine: null weight pointer in ") + name);
+    if (w.rows != rows || w.cols != cols)
+        return fail(TL_ERR_INVALID, std::string("engine: unexpected shape for ") + name + " (got " +
+                                        std::to_string(w.rows) + "x" + std::to_string(w.cols) + ", want " +
+                                        std::to_string(rows) + "x" + std::to_string(cols) + ")");
+    if ((uintptr_t)w.weight_dev % 16 != 0)
+        return fail(TL_ERR_INVALID, std::string("engine: weight not 16-byte aligned: ") + name);
+    return TL_OK;
+}
+
+// GEMV with fused prologue/epilogue over M <= 8 rows; splits the rows when the activation tile exceeds LDS.
+static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
+                      const void *norm_w, const uint16_t *residual) {
+    int step = M;
+    while (qmv_plan(step, w.cols, w.rows).lds > 150 * 1024 && step > 1) step = (step + 1) / 2;
+    const int out_cols = epi == EPI_SWIGLU ? w.rows / 2 : w.rows;
+    for (int m0 = 0; m0 < M; m0 += step) {
+        QmvArgs args{};
+        args.scales = (const uint16_t *)w.scales_dev;
+        args.biases = (const uint16_t *)w.biases_dev;
+        args.b = w.weight_dev;
+        args.a = a + (size_t)m0 * w.cols;
+        args.out = out + (size_t)m0 * out_cols;
+        args.norm_w = (const uint16_t *)norm_w;
+        args.residual = residual ? residual + (size_t)m0 * w.rows : nullptr;
+        args.eps = e->cfg.rms_norm_eps;
+        args.M = std::min(step, M - m0);
+        args.N = w.cols;
+        args.K = w.rows;
+        if (launch_qmv_fused_bf16(args, pro, epi, e->stream) != 0)
+            return fail(TL_ERR_UNSUPPORTED, "engine: no GEMV configuration for this shape");
+    }
+    TL_CHECK_LAUNCH("engine gemv");
+    return TL_OK;
+}
+
+static int pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
+    const int rep = e->cfg.num_heads / e->cfg.num_kv_heads;
+    const int chunks = (rep + AD_RQ - 1) / AD_RQ;
+    const int base = std::max(1, batch * e->cfg.num_kv_heads * chunks);
+    int bucket = 64;
+    while (bucket < max_ctx) bucket *= 2;
+    int s = bucket / 64;                        // >= 64 cached tokens per workgroup
+    s = std::min(s, std::max(1, 1024 / base));  // ~4 workgroups per CU is plenty
+    s = std::min(s, 64);
+    return std::max(s, 1);
+}
+
+template <int VD>
+static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t st) {
+    const size_t lds = (size_t)16 * AD_RQ * (16 * VD + 2) * sizeof(float);
+    hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4>), grid, dim3(256), lds, st, a);
+}
+
+// One fused decode step over slots [0, batch).
+static int enqueue_step(tl_engine *e, int batch, int n_splits) {
+    const tl_engine_config &c = e->cfg;
+    const int D = c.head_dim;
+    const int rep = c.num_heads / c.num_kv_heads;
+    const int chunks = (rep + AD_RQ - 1) / AD_RQ;
+    for (int l = 0; l < c.num_layers; ++l) {
+        const tl_layer_weights &w = e->layers[l];
+        TL_TRY(engine_qmv(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr));
+        AttnDecodeArgs a{};
+        a.qkv = e->qkv;
+        a.q_norm_w = (const uint16_t *)w.q_norm_dev;
+        a.k_norm_w = (const uint16_t *)w.k_norm_dev;
+        a.key_pages = e->layer_k(l);
+        a.value_pages = e->layer_v(l);
+        a.block_table = e->block_table;
+        a.context_lens = e->context_lens;
+        a.out = e->attn;
+        a.ws = e->attn_ws;
+        a.page_size = c.page_size;
+        a.max_pages = c.max_pages_per_seq;
+        a.num_heads = c.num_heads;
+        a.num_kv_heads = c.num_kv_heads;
+        a.scale = 1.0f / sqrtf((float)D);
+        a.eps = c.rms_norm_eps;
+        a.rope_base = c.rope_theta;
+        a.n_splits = n_splits;
+        a.n_row_chunks = chunks;
+        const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
+        switch (D) {
+            case 128: launch_attn_decode<8>(a, grid, e->stream); break;
+            case 64: launch_attn_decode<4>(a, grid, e->stream); break;
+            case 32: launch_attn_decode<2>(a, grid, e->stream); break;
+            default: return fail(TL_ERR_UNSUPPORTED, "engine: head_dim must be 32, 64 or 128");
+        }
+        if (n_splits > 1)
+            hipLaunchKernelGGL(attn_merge_kernel, dim3(batch * c.num_heads), dim3(128), 0, e->stream, e->attn_ws,
+                               e->attn, D, n_splits);
+        TL_CHECK_LAUNCH("engine attention");
+        TL_TRY(engine_qmv(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x));
+        TL_TRY(engine_qmv(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr));
+        TL_TRY(engine_qmv(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h));
+    }
+    TL_TRY(engine_qmv(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr));
+    StepEndArgs s{};
+    s.logits = e->logits;
+    s.vocab = c.vocab_size;
+    s.slot0 = 0;
+    s.tokens = e->tokens;
+    s.context_lens = e->context_lens;
+    s.live = e->live;
+    s.produced = e->produced;
+    s.ring = e->ring;
+    s.ring_cap = e->ring_cap;
+    s.advance = 1;
+    s.emb_w = e->embed.weight_dev;
+    s.emb_s = (const uint16_t *)e->embed.scales_dev;
+    s.emb_b = (const uint16_t *)e->embed.biases_dev;
+    s.x = e->x;
+    s.hidden = c.hidden_size;
+    hipLaunchKernelGGL(step_end_kernel, dim3(batch), dim3(1024), 0, e->stream, s);
+    TL_CHECK_LAUNCH("engine step end");
+    return TL_OK;
+}
+
+static int reserve_locked(tl_engine *e, int slot, int total_tokens,
+                          std::vector<std::pair<int32_t *, int32_t>> &pokes) {
+    const tl_engine_config &c = e->cfg;
+    const int need = (total_tokens + c.page_size - 1) / c.page_size;
+    auto &pages = e->slot_pages[slot];
+    const int have = (int)pages.size();
+    if (need <= have) return TL_OK;
+    if (need > c.max_pages_per_seq)
+        return fail(TL_ERR_INVALID, "engine: sequence exceeds max_pages_per_seq * page_size tokens");
+    if (need - have > (int)e->free_pages.size())
+        return fail(TL_ERR_INVALID, "engine: KV page pool exhausted");
+    for (int j = have; j < need; ++j) {
+        const int id = e->free_pages.back();
+        e->free_pages.pop_back();
+        pages.push_back(id);
+        pokes.emplace_back(e->block_table + (size_t)slot * c.max_pages_per_seq + j, id);
+        e->stats.page_allocations++;
+        if (e->page_was_used[id]) e->stats.reused_page_allocations++;
+        e->page_was_used[id] = 1;
+    }
+    e->stats.pages_in_use += need - have;
+    e->stats.peak_pages_in_use = std::max(e->stats.peak_pages_in_use, e->stats.pages_in_use);
+    return TL_OK;
+}
+
+static int slot_check(const tl_engine *e, int slot, bool must_be_live) {
+    if (!e) return fail(TL_ERR_INVALID, "engine: null engine");
+    if (slot < 0 || slot >= e->cfg.max_batch) return fail(TL_ERR_INVALID, "engine: slot out of range");
+    if (must_be_live && !e->slot_live[slot]) return fail(TL_ERR_INVALID, "engine: slot holds no sequence");
+    return TL_OK;
+}
+
+}  // namespace tl
+
+// ================================================================================================
+extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weights *layers, const tl_w4 *embed,
+                                const void *final_norm_dev, const tl_w4 *lm_head, void *stream, tl_engine **out) {
+    TL_REQUIRE(cfg && layers && embed && final_norm_dev && out, "engine_create: null argument");
+    const tl_engine_config &c = *cfg;
+    TL_REQUIRE(c.num_layers > 0 && c.hidden_size > 0 && c.hidden_size % 128 == 0, "engine_create: hidden_size must be a positive multiple of 128");
+    TL_REQUIRE(c.num_heads > 0 && c.num_kv_heads > 0 && c.num_heads % c.num_kv_heads == 0,
+               "engine_create: num_heads must be divisible by num_kv_heads");
+    TL_REQUIRE(c.head_dim == 32 || c.head_dim == 64 || c.head_dim == 128, "engine_create: head_dim must be 32, 64 or 128");
+    TL_REQUIRE((c.num_heads * c.head_dim) % 128 == 0 && c.intermediate_size % 128 == 0,
+               "engine_create: projection widths must be multiples of the quantization group (128)");
+    TL_REQUIRE(c.page_size > 0 && c.num_pages > 0 && c.max_batch > 0 && c.max_batch <= 8 && c.max_pages_per_seq > 0,
+               "engine_create: need page_size, num_pages, max_pages_per_seq > 0 and 1 <= max_batch <= 8");
+    TL_REQUIRE(c.max_prefill_rows > 0, "engine_create: max_prefill_rows must be positive");
+    const int qkv_dim = (c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
+    const int q_dim = c.num_heads * c.head_dim;
+    for (int l = 0; l < c.num_layers; ++l) {
+        TL_TRY(check_w4(layers[l].wqkv, qkv_dim, c.hidden_size, "wqkv"));
+        TL_TRY(check_w4(layers[l].wo, c.hidden_size, q_dim, "wo"));
+        TL_TRY(check_w4(layers[l].wgu, 2 * c.intermediate_size, c.hidden_size, "wgu"));
+        TL_TRY(check_w4(layers[l].wdown, c.hidden_size, c.intermediate_size, "wdown"));
+        TL_REQUIRE(layers[l].input_norm_dev && layers[l].post_norm_dev && layers[l].q_norm_dev && layers[l].k_norm_dev,
+                   "engine_create: null norm weight");
+    }
+    TL_TRY(check_w4(*embed, c.vocab_size, c.hidden_size, "embed_tokens"));
+    if (lm_head) TL_TRY(check_w4(*lm_head, c.vocab_size, c.hidden_size, "lm_head"));
+
+    auto *e = new tl_engine();
+    e->cfg = c;
+    e->layers.assign(layers, layers + c.num_layers);
+    e->embed = *embed;
+    if (lm_head) e->lm_head = *lm_head;
+    e->final_norm = final_norm_dev;
+    e->stream = (hipStream_t)stream;
+    if (!e->stream) {
+        // The legacy default stream cannot be captured into a graph: own a non-blocking stream instead, and
+        // make sure everything the caller enqueued before (weight uploads / re-packing) has finished.
+        if (hipDeviceSynchronize() != hipSuccess ||
+            hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete e;
+            return fail(TL_ERR_HIP, "engine_create: could not create the engine stream");
+        }
+        e->owns_stream = true;
+    }
+    e->rows_cap = std::max(c.max_prefill_rows, c.max_batch);
+
+    // ---- arena layout
+    const size_t R = (size_t)e->rows_cap;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    const size_t o_bt = carve((size_t)c.max_batch * c.max_pages_per_seq * 4);
+    const size_t o_ctx = carve((size_t)c.max_batch * 4);
+    const size_t o_tok = carve((size_t)c.max_batch * 4);
+    const size_t o_live = carve((size_t)c.max_batch * 4);
+    const size_t o_prod = carve((size_t)c.max_batch * 4);
+    const size_t o_ring = carve((size_t)c.max_batch * e->ring_cap * 4);
+    const size_t o_sctx = carve(64);
+    const size_t o_ptok = carve(R * 4);
+    const size_t o_x = carve(R * c.hidden_size * 2);
+    const size_t o_h = carve(R * c.hidden_size * 2);
+    const size_t o_xn = carve(R * c.hidden_size * 2);
+    const size_t o_tmp = carve(R * c.hidden_size * 2);
+    const size_t o_qkv = carve(R * qkv_dim * 2);
+    const size_t o_qt = carve(R * q_dim * 2);
+    const size_t o_at = carve(R * q_dim * 2);
+    const size_t o_attn = carve(R * q_dim * 2);
+    const size_t o_gu = carve(R * 2 * c.intermediate_size * 2);
+    const size_t o_act = carve(R * c.intermediate_size * 2);
+    const size_t o_log = carve((size_t)c.max_batch * c.vocab_size * 2);
+    // attention partials: decode (batch*Hq rows x 64 splits) or the L<=8 operator path during short prefills
+    e->attn_ws_bytes = std::max((size_t)c.max_batch * c.num_heads * 64 * (c.head_dim + 2) * 4,
+                                (size_t)c.num_heads * 8 * 64 * (c.head_dim + 2) * 4);
+    const size_t o_ws = carve(e->attn_ws_bytes);
+    e->arena_bytes = off;
+
+    auto cleanup_fail = [&](const std::string &msg) {
+        if (e->arena) (void)hipFree(e->arena);
+        if (e->kpool) (void)hipFree(e->kpool);
+        if (e->vpool) (void)hipFree(e->vpool);
+        if (e->owns_stream) (void)hipStreamDestroy(e->stream);
+        delete e;
+        return fail(TL_ERR_HIP, msg);
+    };
+    if (hipMalloc((void **)&e->arena, e->arena_bytes) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(arena) failed");
+    e->layer_pool_elems = (size_t)c.num_pages * c.num_kv_heads * c.page_size * c.head_dim;
+    const size_t pool_bytes = e->layer_pool_elems * 2 * c.num_layers;
+    if (hipMalloc((void **)&e->kpool, pool_bytes) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(key pages) failed");
+    if (hipMalloc((void **)&e->vpool, pool_bytes) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(value pages) failed");
+    e->kv_bytes = 2 * pool_bytes;
+
+    char *A = e->arena;
+    e->block_table = (int32_t *)(A + o_bt);
+    e->context_lens = (int32_t *)(A + o_ctx);
+    e->tokens = (int32_t *)(A + o_tok);
+    e->live = (int32_t *)(A + o_live);
+    e->produced = (int32_t *)(A + o_prod);
+    e->ring = (int32_t *)(A + o_ring);
+    e->scratch_ctx = (int32_t *)(A + o_sctx);
+    e->prefill_tokens = (int32_t *)(A + o_ptok);
+    e->x = (uint16_t *)(A + o_x);
+    e->h = (uint16_t *)(A + o_h);
+    e->xn = (uint16_t *)(A + o_xn);
+    e->tmp = (uint16_t *)(A + o_tmp);
+    e->qkv = (uint16_t *)(A + o_qkv);
+    e->q_t = (uint16_t *)(A + o_qt);
+    e->attn_t = (uint16_t *)(A + o_at);
+    e->attn = (uint16_t *)(A + o_attn);
+    e->gu = (uint16_t *)(A + o_gu);
+    e->act = (uint16_t *)(A + o_act);
+    e->logits = (uint16_t *)(A + o_log);
+    e->attn_ws = (float *)(A + o_ws);
+
+    // state words: zero everything up to the activations, then the block table to -1
+    if (hipMemsetAsync(e->arena, 0, o_x, e->stream) != hipSuccess) return cleanup_fail("engine_create: memset failed");
+    const int bt_n = c.max_batch * c.max_pages_per_seq;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(ceil_div(bt_n, 256)), dim3(256), 0, e->stream, e->block_table, -1, bt_n);
+    if (hipGetLastError() != hipSuccess) return cleanup_fail("engine_create: block-table init failed");
+
+    e->slot_pages.assign(c.max_batch, {});
+    e->slot_ctx.assign(c.max_batch, 0);
+    e->slot_live.assign(c.max_batch, 0);
+    e->slot_produced.assign(c.max_batch, 0);
+    e->free_pages.resize(c.num_pages);
+    for (int i = 0; i < c.num_pages; ++i) e->free_pages[i] = c.num_pages - 1 - i;  // pop_back hands out 0,1,2,...
+    e->page_was_used.assign(c.num_pages, 0);
+    e->stats.pages_free = c.num_pages;
+    e->stats.kv_bytes = e->kv_bytes;
+    e->stats.workspace_bytes = e->arena_bytes;
+    *out = e;
+    return TL_OK;
+}
+
+extern "C" void tl_engine_destroy(tl_engine *e) {
+    if (!e) return;
+    (void)hipStreamSynchronize(e->stream);
+    for (auto &kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+    if (e->arena) (void)hipFree(e->arena);
+    if (e->kpool) (void)hipFree(e->kpool);
+    if (e->vpool) (void)hipFree(e->vpool);
+    if (e->splitk_ws) (void)hipFree(e->splitk_ws);
+    if (e->owns_stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int tl_engine_synchronize(tl_engine *e) {
+    TL_REQUIRE(e, "engine_synchronize: null engine");
+    TL_HIP(hipStreamSynchronize(e->stream));
+    return TL_OK;
+}
+
+extern "C" int tl_engine_begin(tl_engine *e, int slot) {
+    TL_TRY(slot_check(e, slot, false));
+    TL_REQUIRE(!e->slot_live[slot], "engine_begin: slot already holds a sequence (release it first)");
+    e->slot_live[slot] = 1;
+    e->slot_ctx[slot] = 0;
+    e->slot_produced[slot] = 0;
+    std::vector<std::pair<int32_t *, int32_t>> pk;
+    pk.emplace_back(e->live + slot, 1);
+    pk.emplace_back(e->context_lens + slot, 0);
+    pk.emplace_back(e->produced + slot, 0);
+    pk.emplace_back(e->tokens + slot, 0);
+    return poke(e, pk);
+}
+
+extern "C" int tl_engine_reserve(tl_engine *e, int slot, int total_tokens) {
+    TL_TRY(slot_check(e, slot, true));
+    TL_REQUIRE(total_tokens >= 0, "engine_reserve: total_tokens must be nonnegative");
+    std::vector<std::pair<int32_t *, int32_t>> pk;
+    TL_TRY(reserve_locked(e, slot, total_tokens, pk));
+    e->stats.pages_free = (int)e->free_pages.size();
+    return poke(e, pk);
+}
+
+extern "C" int tl_engine_release(tl_engine *e, int slot) {
+    TL_TRY(slot_check(e, slot, true));
+    std::vector<std::pair<int32_t *, int32_t>> pk;
+    auto &pages = e->slot_pages[slot];
+    for (size_t j = 0; j < pages.size(); ++j) {
+        e->free_pages.push_back(pages[j]);
+        pk.emplace_back(e->block_table + (size_t)slot * e->cfg.max_pages_per_seq + j, -1);
+    }
+    e->stats.pages_in_use -= (int)pages.size();
+    pages.clear();
+    e->slot_live[slot] = 0;
+    e->slot_ctx[slot] = 0;
+    pk.emplace_back(e->live + slot, 0);
+    pk.emplace_back(e->context_lens + slot, 0);
+    pk.emplace_back(e->tokens + slot, 0);
+    e->stats.pages_free = (int)e->free_pages.size();
+    return poke(e, pk);
+}
+
+extern "C" int tl_engine_rewind(tl_engine *e, int slot, int n) {
+    TL_TRY(slot_check(e, slot, true));
+    TL_REQUIRE(n >= 0 && n <= e->slot_ctx[slot], "engine_rewind: cannot rewind past the start of the sequence");
+    const int ctx = e->slot_ctx[slot] - n;
+    const int keep = (ctx + e->cfg.page_size - 1) / e->cfg.page_size;
+    std::vector<std::pair<int32_t *, int32_t>> pk;
+    auto &pages = e->slot_pages[slot];
+    while ((int)pages.size() > keep) {
+        e->free_pages.push_back(pages.back());
+        pk.emplace_back(e->block_table + (size_t)slot * e->cfg.max_pages_per_seq + (pages.size() - 1), -1);
+        pages.pop_back();
+        e->stats.pages_in_use--;
+    }
+    e->slot_ctx[slot] = ctx;
+    pk.emplace_back(e->context_lens + slot, ctx);
+    e->stats.pages_free = (int)e->free_pages.size();
+    return poke(e, pk);
+}
+
+extern "C" int tl_engine_context_len(const tl_engine *e, int slot) {
+    if (!e || slot < 0 || slot >= e->cfg.max_batch || !e->slot_live[slot]) return -1;
+    return e->slot_ctx[slot];
+}
+
+extern "C" int tl_engine_set_token(tl_engine *e, int slot, int32_t token) {
+    TL_TRY(slot_check(e, slot, true));
+    TL_REQUIRE(token >= 0 && token < e->cfg.vocab_size, "engine_set_token: token id out of range");
+    std::vector<std::pair<int32_t *, int32_t>> pk;
+    pk.emplace_back(e->tokens + slot, token);
+    return poke(e, pk);
+}
+
+static int ensure_splitk(tl_engine *e, size_t bytes) {
+    if (bytes <= e->splitk_ws_bytes) return TL_OK;
+    TL_HIP(hipStreamSynchronize(e->stream));
+    if (e->splitk_ws) (void)hipFree(e->splitk_ws);
+    e->splitk_ws = nullptr;
+    e->splitk_ws_bytes = 0;
+    const size_t want = std::max(bytes, (size_t)64 << 20);
+    TL_HIP(hipMalloc(&e->splitk_ws, want));
+    e->splitk_ws_bytes = want;
+    return TL_OK;
+}
+
+static int engine_qmm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M) {
+    const size_t need = tl_quantized_matmul_workspace_bytes(M, w.cols, w.rows, TL_BF16, 1, 1);
+    TL_TRY(ensure_splitk(e, need));
+    return tl_quantized_matmul(w.scales_dev, w.biases_dev, a, w.weight_dev, out, M, w.cols, w.rows, 128, 4, TL_BF16, 1, 1,
+                               e->splitk_ws, e->splitk_ws_bytes, e->stream);
+}
+
+extern "C" int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, int n, int want_logits) {
+    TL_TRY(slot_check(e, slot, true));
+    TL_REQUIRE(tokens && n > 0, "engine_prefill: need at least one token");
+    TL_REQUIRE(n <= e->cfg.max_prefill_rows, "engine_prefill: chunk exceeds max_prefill_rows");
+    const tl_engine_config &c = e->cfg;
+    TL_REQUIRE(n <= 8 || c.head_dim == 128, "engine_prefill: chunks longer than 8 tokens need head_dim 128 (bf16 FlashAttention)");
+    for (int i = 0; i < n; ++i) TL_REQUIRE(tokens[i] >= 0 && tokens[i] < c.vocab_size, "engine_prefill: token id out of range");
+    const int start = e->slot_ctx[slot];
+    std::vector<std::pair<int32_t *, int32_t>> pk;
+    TL_TRY(reserve_locked(e, slot, start + n, pk));
+    e->stats.pages_free = (int)e->free_pages.size();
+    pk.emplace_back(e->scratch_ctx, start + n);
+    TL_TRY(poke(e, pk));
+    TL_HIP(hipMemcpyAsync(e->prefill_tokens, tokens, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+
+    const int D = c.head_dim, Hq = c.num_heads, Hkv = c.num_kv_heads;
+    const int32_t *block_row = e->block_table + (size_t)slot * c.max_pages_per_seq;
+    TL_TRY(tl_quantized_embedding(e->prefill_tokens, 0, e->embed.scales_dev, e->embed.biases_dev, e->embed.weight_dev, e->x,
+                                  n, c.hidden_size, c.vocab_size, 128, 4, TL_BF16, e->stream));
+    const size_t attn_ws_need = tl_paged_attention_workspace_bytes(Hq, n, D, c.page_size, c.max_pages_per_seq, Hq, Hkv, start + n);
+    TL_REQUIRE(attn_ws_need <= e->attn_ws_bytes, "engine_prefill: attention workspace too small");
+    for (int l = 0; l < c.num_layers; ++l) {
+        const tl_layer_weights &w = e->layers[l];
+        TL_TRY(tl_rms_norm(e->x, w.input_norm_dev, e->xn, n, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
+        TL_TRY(engine_qmm(e, w.wqkv, e->xn, e->qkv, n));
+        QkvPostArgs q{};
+        q.qkv = e->qkv;
+        q.q_norm_w = (const uint16_t *)w.q_norm_dev;
+        q.k_norm_w = (const uint16_t *)w.k_norm_dev;
+        q.q_t = e->q_t;
+        q.key_pages = e->layer_k(l);
+        q.value_pages = e->layer_v(l);
+        q.block_row = block_row;
+        q.T = n;
+        q.start = start;
+        q.page_size = c.page_size;
+        q.max_pages = c.max_pages_per_seq;
+        q.num_heads = Hq;
+        q.num_kv_heads = Hkv;
+        q.eps = c.rms_norm_eps;
+        q.rope_base = c.rope_theta;
+        switch (D) {
+            case 128: hipLaunchKernelGGL((qkv_post_kernel<8>), dim3(n), dim3(256), 0, e->stream, q); break;
+            case 64: hipLaunchKernelGGL((qkv_post_kernel<4>), dim3(n), dim3(256), 0, e->stream, q); break;
+            default: hipLaunchKernelGGL((qkv_post_kernel<2>), dim3(n), dim3(256), 0, e->stream, q); break;
+        }
+        TL_CHECK_LAUNCH("engine qkv_post");
+        TL_TRY(tl_paged_attention(e->q_t, e->layer_k(l), e->layer_v(l), block_row, e->scratch_ctx, e->attn_t, Hq, n, D,
+                                  c.num_pages, c.page_size, c.max_pages_per_seq, Hq, Hkv, 1.0f / sqrtf((float)D), 1, start + n,
+                                  TL_BF16, e->attn_ws, e->attn_ws_bytes, e->stream));
+        {
+            const long total = (long)Hq * n * (D / 8);
+            hipLaunchKernelGGL(heads_to_rows_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, e->stream, e->attn_t, e->attn, Hq, n, D);
+        }
+        TL_TRY(engine_qmm(e, w.wo, e->attn, e->tmp, n));
+        {
+            const long n8 = (long)n * c.hidden_size / 8;
+            hipLaunchKernelGGL(residual_add_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, e->x, e->tmp, e->h, n8);
+        }
+        TL_TRY(tl_rms_norm(e->h, w.post_norm_dev, e->xn, n, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
+        TL_TRY(engine_qmm(e, w.wgu, e->xn, e->gu, n));
+        {
+            const long n4 = (long)n * c.intermediate_size / 4;
+            hipLaunchKernelGGL(swiglu_interleaved_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, e->stream, e->gu, e->act, n4);
+        }
+        TL_TRY(engine_qmm(e, w.wdown, e->act, e->tmp, n));
+        {
+            const long n8 = (long)n * c.hidden_size / 8;
+            hipLaunchKernelGGL(residual_add_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, e->h, e->tmp, e->x, n8);
+        }
+        TL_CHECK_LAUNCH("engine prefill layer");
+    }
+    e->slot_ctx[slot] = start + n;
+    pk.emplace_back(e->context_lens + slot, start + n);
+    TL_TRY(poke(e, pk));
+    e->stats.prefill_tokens += n;
+    if (want_logits) {
+        // logits_to_keep = 1 (reference qwen3_week3.py:331-336): last row only
+        const uint16_t *last = e->x + (size_t)(n - 1) * c.hidden_size;
+        TL_TRY(engine_qmv(e, e->head(), last, e->logits, 1, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr));
+        e->logits_rows = 1;
+        StepEndArgs s{};
+        s.logits = e->logits;
+        s.vocab = c.vocab_size;
+        s.slot0 = slot;
+        s.tokens = e->tokens;
+        s.context_lens = e->context_lens;
+        s.live = e->live;
+        s.produced = e->produced;
+        s.ring = e->ring;
+        s.ring_cap = e->ring_cap;
+        s.advance = 0;
+        s.emb_w = e->embed.weight_dev;
+        s.emb_s = (const uint16_t *)e->embed.scales_dev;
+        s.emb_b = (const uint16_t *)e->embed.biases_dev;
+        s.x = e->h;  // scratch: the prefill activations in x[0..n) must stay intact; decode re-embeds from tokens
+        s.hidden = c.hidden_size;
+        hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(1024), 0, e->stream, s);
+        TL_CHECK_LAUNCH("engine prefill argmax");
+        e->slot_produced[slot] += 1;
+    }
+    return TL_OK;
+}
+
+extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_graph) {
+    TL_REQUIRE(e, "engine_decode: null engine");
+    TL_REQUIRE(batch > 0 && batch <= e->cfg.max_batch, "engine_decode: batch out of range");
+    TL_REQUIRE(steps >= 0, "engine_decode: steps must be nonnegative");
+    if (steps == 0) return TL_OK;
+    const tl_engine_config &c = e->cfg;
+    // input activations of the first step come from the pending token ids
+    hipLaunchKernelGGL(embed_slots_kernel, dim3(batch), dim3(256), 0, e->stream, e->tokens, e->embed.weight_dev,
+                       (const uint16_t *)e->embed.scales_dev, (const uint16_t *)e->embed.biases_dev, e->x, c.hidden_size,
+                       c.vocab_size);
+    TL_CHECK_LAUNCH("engine embed");
+    std::vector<std::pair<int32_t *, int32_t>> pk;
+    for (int s = 0; s < steps; ++s) {
+        int max_ctx = 1;
+        for (int b = 0; b < batch; ++b) {
+            if (!e->slot_live[b]) continue;
+            TL_TRY(reserve_locked(e, b, e->slot_ctx[b] + 1, pk));
+            max_ctx = std::max(max_ctx, e->slot_ctx[b] + 1);
+        }
+        if (!pk.empty()) {
+            e->stats.pages_free = (int)e->free_pages.size();
+            TL_TRY(poke(e, pk));
+        }
+        const int n_splits = pick_decode_splits(e, batch, max_ctx);
+        if (use_graph && e->warmed) {
+            const auto key = std::make_pair(batch, n_splits);
+            auto it = e->graphs.find(key);
+            if (it == e->graphs.end()) {
+                hipGraph_t graph = nullptr;
+                TL_HIP(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+                const int rc = enqueue_step(e, batch, n_splits);
+                const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
+                if (rc != TL_OK) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    return rc;
+                }
+                if (ce != hipSuccess) return fail(TL_ERR_HIP, std::string("engine_decode: graph capture failed: ") + hipGetErrorString(ce));
+                hipGraphExec_t exec = nullptr;
+                const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ie != hipSuccess) return fail(TL_ERR_HIP, std::string("engine_decode: graph instantiate failed: ") + hipGetErrorString(ie));
+                it = e->graphs.emplace(key, exec).first;
+                e->stats.graph_captures++;
+            }
+            TL_HIP(hipGraphLaunch(it->second, e->stream));
+            e->stats.graph_replays++;
+        } else {
+            TL_TRY(enqueue_step(e, batch, n_splits));
+            e->warmed = true;
+        }
+        for (int b = 0; b < batch; ++b) {
+            if (!e->slot_live[b]) continue;
+            e->slot_ctx[b] += 1;
+            e->slot_produced[b] += 1;
+        }
+        e->stats.decode_steps++;
+    }
+    e->logits_rows = batch;
+    return TL_OK;
+}
+
+extern "C" int tl_engine_read_tokens(tl_engine *e, int slot, int count, int32_t *out) {
+    TL_TRY(slot_check(e, slot, false));
+    TL_REQUIRE(out && count >= 0 && count <= e->ring_cap, "engine_read_tokens: bad count");
+    TL_REQUIRE(count <= e->slot_produced[slot], "engine_read_tokens: fewer ids have been produced");
+    TL_HIP(hipStreamSynchronize(e->stream));
+    std::vector<int32_t> ring(e->ring_cap);
+    TL_HIP(hipMemcpy(ring.data(), e->ring + (size_t)slot * e->ring_cap, (size_t)e->ring_cap * 4, hipMemcpyDeviceToHost));
+    const int produced = e->slot_produced[slot];
+    for (int i = 0; i < count; ++i) out[i] = ring[(produced - count + i) % e->ring_cap];
+    return TL_OK;
+}
+
+extern "C" const void *tl_engine_logits_dev(const tl_engine *e) { return e ? e->logits : nullptr; }
+extern "C" int tl_engine_copy_logits(tl_engine *e, void *dst_dev, int rows) {
+    TL_REQUIRE(e && dst_dev, "engine_copy_logits: null argument");
+    TL_REQUIRE(rows > 0 && rows <= e->cfg.max_batch, "engine_copy_logits: rows out of range");
+    TL_HIP(hipMemcpyAsync(dst_dev, e->logits, (size_t)rows * e->cfg.vocab_size * 2, hipMemcpyDeviceToDevice, e->stream));
+    return TL_OK;
+}
+extern "C" const int32_t *tl_engine_tokens_dev(const tl_engine *e) { return e ? e->tokens : nullptr; }
+
+extern "C" int tl_engine_get_stats(const tl_engine *e, tl_engine_stats *out) {
+    TL_REQUIRE(e && out, "engine_get_stats: null argument");
+    *out = e->stats;
+    out->pages_free = (int)e->free_pages.size();
+    return TL_OK;
+}
+
+extern "C" size_t tl_engine_step_bytes(const tl_engine *e, int batch) {
+    if (!e) return 0;
+    const tl_engine_config &c = e->cfg;
+    auto w4_bytes = [](const tl_w4 &w) { return (size_t)w.rows * w.cols / 2 + (size_t)w.rows * (w.cols / 128) * 4; };
+    size_t total = 0;
+    for (const auto &l : e->layers) total += w4_bytes(l.wqkv) + w4_bytes(l.wo) + w4_bytes(l.wgu) + w4_bytes(l.wdown);
+    total += w4_bytes(e->head());
+    const size_t kv_per_token = (size_t)2 * c.num_layers * c.num_kv_heads * c.head_dim * 2;
+    for (int b = 0; b < batch && b < c.max_batch; ++b)
+        if (e->slot_live[b]) total += kv_per_token * (size_t)e->slot_ctx[b];
+    return total;
+}

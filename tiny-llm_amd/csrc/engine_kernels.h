@@ -1,0 +1,515 @@
+// Device kernels private to the decode engine (engine.hip).  See include/tinyllm_engine.h for the step
+// structure; every kernel here keeps the reference's op boundaries as bf16 rounding points.
+#pragma once
+#include "common.h"
+
+namespace tl {
+
+constexpr float ENG_LOG2E = 1.44269504089f;
+constexpr int AD_RQ = 4;  // query heads of one GQA group handled per workgroup
+
+// ---------------------------------------------------------------------------------------------
+// Shared prologue: RMSNorm over one head row (D = 16*VD, lane t holds dims [t*VD, t*VD+VD)) rounded to bf16
+// (FastRMSNorm, week2_kernels.metal:41-47), then non-traditional RoPE at `pos` rounded to bf16
+// (FastRoPE, week2_kernels.metal:86-104; pair (d, d+D/2) lives in lane t^8).  Same expression order as
+// rms_norm_kernel / rope_kernel (pointwise.hip) so the fused and op-by-op paths agree.
+// ---------------------------------------------------------------------------------------------
+template <int VD>
+__device__ __forceinline__ void load_row(const uint16_t *src, float (&f)[VD]) {
+    uint16_t raw[VD];
+    if constexpr (VD == 8) {
+        *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(src);
+    } else if constexpr (VD == 4) {
+        *reinterpret_cast<uint2 *>(raw) = *reinterpret_cast<const uint2 *>(src);
+    } else if constexpr (VD == 2) {
+        *reinterpret_cast<uint32_t *>(raw) = *reinterpret_cast<const uint32_t *>(src);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VD; ++i) raw[i] = src[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VD; ++i) f[i] = BF16::to_float(raw[i]);
+}
+
+template <int VD>
+__device__ __forceinline__ void store_row(uint16_t *dst, const float (&f)[VD]) {
+    uint16_t raw[VD];
+#pragma unroll
+    for (int i = 0; i < VD; ++i) raw[i] = BF16::from_float(f[i]);
+    if constexpr (VD == 8) {
+        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(raw);
+    } else if constexpr (VD == 4) {
+        *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(raw);
+    } else if constexpr (VD == 2) {
+        *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(raw);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VD; ++i) dst[i] = raw[i];
+    }
+}
+
+template <int VD>
+__device__ __forceinline__ void rope_factors(int t, int pos, float base, float (&cs)[VD], float (&sn)[VD]) {
+    constexpr int half = 8 * VD;
+    const float lb = log2f(base);
+#pragma unroll
+    for (int i = 0; i < VD; ++i) {
+        const int item = (t & 7) * VD + i;
+        const float fp = -(float)item / (float)half;
+        const float angle = (float)pos * exp2f(fp * lb);
+        sincosf(angle, &sn[i], &cs[i]);
+    }
+}
+
+template <int VD>
+__device__ __forceinline__ void head_norm_rope(const uint16_t *src, const uint16_t *w, int t, float eps,
+                                               const float (&cs)[VD], const float (&sn)[VD], float (&out)[VD]) {
+    constexpr int D = 16 * VD;
+    float f[VD], g[VD];
+    load_row<VD>(src + t * VD, f);
+    load_row<VD>(w + t * VD, g);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VD; ++i) ss += f[i] * f[i];
+    ss = group16_sum(ss);
+    const float inv = rsqrtf(ss / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < VD; ++i) {
+        const float n = bf16_round(f[i] * inv * g[i]);
+        const float partner = __shfl_xor(n, 8, 64);
+        const float r = (t < 8) ? (n * cs[i] - partner * sn[i]) : (n * cs[i] + partner * sn[i]);
+        out[i] = bf16_round(r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decode attention with fused q/k-norm + RoPE + paged KV append (L = 1).
+//   grid = (n_splits * n_row_chunks, Hkv, batch); workgroup = 16 groups x 16 lanes.
+//   A workgroup owns one KV head, up to AD_RQ query heads of its GQA group and one slice of the cached
+//   context; a 16-lane group reads one token's K row and V row as 16 x 16 B (coalesced 256 B), U tokens in
+//   flight per group.  The token being decoded never round-trips through HBM: its K/V come from registers
+//   (split 0) and are written to the page by one group.  n_splits == 1 writes the output row, otherwise
+//   (m, l, acc) partials for attn_merge_kernel.
+//   reference semantics: paged_attention.metal:108-248 (decode), paged_cache_update :82-106,
+//   qwen3_week3.py:63-86 for the op order.
+// ---------------------------------------------------------------------------------------------
+struct AttnDecodeArgs {
+    const uint16_t *qkv;  // [batch, (Hq + 2 Hkv) * D]
+    const uint16_t *q_norm_w, *k_norm_w;
+    uint16_t *key_pages, *value_pages;  // this layer's pools [P, Hkv, page, D]
+    const int32_t *block_table;         // [max_batch, max_pages]
+    const int32_t *context_lens;        // [max_batch] tokens already cached (= position of the new token)
+    uint16_t *out;                      // [batch, Hq * D]
+    float *ws;                          // [batch * Hq, n_splits, D + 2]
+    int page_size, max_pages, num_heads, num_kv_heads;
+    float scale, eps, rope_base;
+    int n_splits, n_row_chunks;
+};
+
+template <int VD, int U>
+__global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecodeArgs p) {
+    constexpr int D = 16 * VD;
+    constexpr int STRIDE = D + 2;
+    extern __shared__ __attribute__((aligned(16))) float psm[];  // [16][AD_RQ][STRIDE]
+    const int split = blockIdx.x % p.n_splits;
+    const int chunk = blockIdx.x / p.n_splits;
+    const int kvh = blockIdx.y;
+    const int b = blockIdx.z;
+    const int Hq = p.num_heads, Hkv = p.num_kv_heads;
+    const int rep = Hq / Hkv;
+    const int g = threadIdx.x >> 4;
+    const int t = threadIdx.x & 15;
+    const int ctx = p.context_lens[b];
+    const int wp = ctx / p.page_size;
+    const int wslot = ctx - wp * p.page_size;
+    const int wpage = wp < p.max_pages ? p.block_table[(long)b * p.max_pages + wp] : -1;
+    const bool live = wpage >= 0;  // idle slots have an all -1 row: they produce zeros
+    const uint16_t *row = p.qkv + (long)b * (Hq + 2 * Hkv) * D;
+    const float scale_log2 = p.scale * ENG_LOG2E;
+
+    float cs[VD], sn[VD];
+    rope_factors<VD>(t, ctx, p.rope_base, cs, sn);
+
+    float k_new[VD], v_new[VD];
+    head_norm_rope<VD>(row + (long)(Hq + kvh) * D, p.k_norm_w, t, p.eps, cs, sn, k_new);
+    load_row<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, v_new);
+    if (live && split == 0 && chunk == 0 && g == 0) {
+        const long off = (((long)wpage * Hkv + kvh) * p.page_size + wslot) * D + t * VD;
+        store_row<VD>(p.key_pages + off, k_new);
+        store_row<VD>(p.value_pages + off, v_new);
+    }
+
+    float qv[AD_RQ][VD], acc[AD_RQ][VD], m[AD_RQ], l[AD_RQ];
+    bool rq_ok[AD_RQ];
+#pragma unroll
+    for (int r = 0; r < AD_RQ; ++r) {
+        const int hq = chunk * AD_RQ + r;
+        rq_ok[r] = hq < rep;
+        float qn[VD];
+        head_norm_rope<VD>(row + (long)(kvh * rep + (rq_ok[r] ? hq : 0)) * D, p.q_norm_w, t, p.eps, cs, sn, qn);
+#pragma unroll
+        for (int i = 0; i < VD; ++i) {
+            qv[r][i] = qn[i] * scale_log2;
+            acc[r][i] = 0.f;
+        }
+        m[r] = -1e30f;
+        l[r] = 0.f;
+    }
+
+    const int per = ((ctx + p.n_splits - 1) / p.n_splits + 15) & ~15;
+    const int t_begin = split * per;
+    const int t_end = live ? min(t_begin + per, ctx) : 0;
+
+    for (int base = t_begin; base < t_end; base += 16 * U) {
+        float kf[U][VD], vf[U][VD];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tok = base + u * 16 + g;
+            ok[u] = tok < t_end;
+            const int lp = tok / p.page_size;
+            const int slot = tok - lp * p.page_size;
+            int page_id = -1;
+            if (ok[u] && lp < p.max_pages) page_id = p.block_table[(long)b * p.max_pages + lp];
+            ok[u] = page_id >= 0;
+            if (ok[u]) {
+                const long off = (((long)page_id * Hkv + kvh) * p.page_size + slot) * D + t * VD;
+                load_row<VD>(p.key_pages + off, kf[u]);
+                load_row<VD>(p.value_pages + off, vf[u]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VD; ++i) {
+                    kf[u][i] = 0.f;
+                    vf[u][i] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < AD_RQ; ++r) {
+                float part = 0.f;
+#pragma unroll
+                for (int i = 0; i < VD; ++i) part += qv[r][i] * kf[u][i];
+                const float score = group16_sum(part);
+                if (ok[u]) {
+                    const float nm = fmaxf(m[r], score);
+                    const float of = exp2f(m[r] - nm);
+                    const float sf = exp2f(score - nm);
+                    l[r] = l[r] * of + sf;
+#pragma unroll
+                    for (int i = 0; i < VD; ++i) acc[r][i] = acc[r][i] * of + sf * vf[u][i];
+                    m[r] = nm;
+                }
+            }
+        }
+    }
+    // the token being decoded (position ctx), straight from registers
+    if (split == 0) {
+#pragma unroll
+        for (int r = 0; r < AD_RQ; ++r) {
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < VD; ++i) part += qv[r][i] * k_new[i];
+            const float score = group16_sum(part);
+            if (live && g == 0) {
+                const float nm = fmaxf(m[r], score);
+                const float of = exp2f(m[r] - nm);
+                const float sf = exp2f(score - nm);
+                l[r] = l[r] * of + sf;
+#pragma unroll
+                for (int i = 0; i < VD; ++i) acc[r][i] = acc[r][i] * of + sf * v_new[i];
+                m[r] = nm;
+            }
+        }
+    }
+
+    // merge the 16 groups through LDS
+#pragma unroll
+    for (int r = 0; r < AD_RQ; ++r) {
+        float *dst = psm + ((long)g * AD_RQ + r) * STRIDE;
+#pragma unroll
+        for (int i = 0; i < VD; ++i) dst[t * VD + i] = acc[r][i];
+        if (t == 0) {
+            dst[D] = m[r];
+            dst[D + 1] = l[r];
+        }
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < AD_RQ * D; item += 256) {
+        const int r = item / D;
+        const int d = item - r * D;
+        const int hq = chunk * AD_RQ + r;
+        if (hq >= rep) continue;
+        float gm = -1e30f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gm = fmaxf(gm, psm[((long)j * AD_RQ + r) * STRIDE + D]);
+        float gl = 0.f, vs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float *src = psm + ((long)j * AD_RQ + r) * STRIDE;
+            const float f = exp2f(src[D] - gm);
+            gl += src[D + 1] * f;
+            vs += src[d] * f;
+        }
+        const long orow = (long)b * Hq + kvh * rep + hq;
+        if (p.n_splits == 1) {
+            p.out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : vs / gl);
+        } else {
+            float *w = p.ws + (orow * p.n_splits + split) * STRIDE;
+            w[d] = vs;
+            if (d == 0) {
+                w[D] = gm;
+                w[D + 1] = gl;
+            }
+        }
+    }
+}
+
+// partials [rows, n_splits, D+2] -> out [rows, D]
+__global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out,
+                                                         int D, int n_splits) {
+    const long orow = blockIdx.x;
+    const int stride = D + 2;
+    const float *base = ws + orow * n_splits * stride;
+    float gm = -1e30f;
+    for (int s = 0; s < n_splits; ++s) gm = fmaxf(gm, base[s * stride + D]);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float gl = 0.f, vs = 0.f;
+        for (int s = 0; s < n_splits; ++s) {
+            const float f = exp2f(base[s * stride + D] - gm);
+            gl += base[s * stride + D + 1] * f;
+            vs += base[s * stride + d] * f;
+        }
+        out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : vs / gl);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// End of step: greedy argmax over bf16 logits (first maximum wins, like argmax), record the id, advance
+// the slot, and dequantize the id's embedding row into the next step's input activation.
+//   grid = rows; block = 1024.  Block i reads logits row i and serves slot slot0 + i.
+//   reference: mx.argmax(logits[:, -1]) (benches/bench.py:234-243) + QuantizedEmbedding (embedding.py:38-54).
+// ---------------------------------------------------------------------------------------------
+struct StepEndArgs {
+    const uint16_t *logits;  // [rows, vocab]
+    int vocab;
+    int slot0;
+    int32_t *tokens;        // [max_batch] pending input token per slot
+    int32_t *context_lens;  // [max_batch]
+    const int32_t *live;    // [max_batch] 1 = slot holds a sequence
+    int32_t *produced;      // [max_batch] number of ids recorded so far
+    int32_t *ring;          // [max_batch, ring_cap]
+    int ring_cap;
+    int advance;  // 1: context_lens[slot] += 1 (decode); 0: prefill sets it on the host side
+    // next-step embedding
+    const uint32_t *emb_w;
+    const uint16_t *emb_s, *emb_b;
+    uint16_t *x;  // [max_batch, hidden], row = slot
+    int hidden;
+};
+
+__global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
+    __shared__ float s_val[16];
+    __shared__ int s_idx[16];
+    __shared__ int s_token;
+    const int i = blockIdx.x;
+    const int slot = p.slot0 + i;
+    const uint16_t *lg = p.logits + (long)i * p.vocab;
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    const int vec_end = ((uintptr_t)lg % 16 == 0) ? (p.vocab & ~7) : 0;
+    for (int c = threadIdx.x * 8; c < vec_end; c += 1024 * 8) {
+        uint16_t raw[8];
+        *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(lg + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = BF16::to_float(raw[e]);
+            if (v > best) {  // strictly greater: the earliest index of a tie stays
+                best = v;
+                best_i = c + e;
+            }
+        }
+    }
+    for (int c = vec_end + threadIdx.x; c < p.vocab; c += 1024) {
+        const float v = BF16::to_float(lg[c]);
+        if (v > best || (v == best && c < best_i)) {
+            best = v;
+            best_i = c;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_i, o, 64);
+        if (ov > best || (ov == best && oi < best_i)) {
+            best = ov;
+            best_i = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_val[threadIdx.x >> 6] = best;
+        s_idx[threadIdx.x >> 6] = best_i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bv = s_val[0];
+        int bi = s_idx[0];
+        for (int w = 1; w < 16; ++w) {
+            if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) {
+                bv = s_val[w];
+                bi = s_idx[w];
+            }
+        }
+        if (bi < 0 || bi >= p.vocab) bi = 0;  // all-NaN / -inf row
+        s_token = bi;
+        if (p.live[slot]) {
+            p.tokens[slot] = bi;
+            const int n = p.produced[slot];
+            p.ring[(long)slot * p.ring_cap + (n % p.ring_cap)] = bi;
+            p.produced[slot] = n + 1;
+            if (p.advance) p.context_lens[slot] += 1;
+        }
+    }
+    __syncthreads();
+    const int token = s_token;
+    const int words = p.hidden / 8;
+    const int groups = p.hidden / 128;
+    for (int w = threadIdx.x; w < words; w += 1024) {
+        const uint32_t packed = p.emb_w[(long)token * words + w];
+        const float scale = BF16::to_float(p.emb_s[(long)token * groups + w / 16]);
+        const float bias = BF16::to_float(p.emb_b[(long)token * groups + w / 16]);
+        uint16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = BF16::from_float((float)((packed >> (4 * e)) & 0xfu) * scale + bias);
+        *reinterpret_cast<uint4 *>(p.x + (long)slot * p.hidden + w * 8) = *reinterpret_cast<const uint4 *>(o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-token (prefill) glue kernels
+// ---------------------------------------------------------------------------------------------
+// qkv [T, (Hq+2Hkv)*D] -> q_t [Hq, T, D] (normed + roped) and K/V appended to the slot's pages at
+// positions start + r.  grid = T; block = 256 (16 groups of 16 lanes; a group owns one head at a time).
+struct QkvPostArgs {
+    const uint16_t *qkv;
+    const uint16_t *q_norm_w, *k_norm_w;
+    uint16_t *q_t;
+    uint16_t *key_pages, *value_pages;
+    const int32_t *block_row;  // this slot's block-table row [max_pages]
+    int T, start, page_size, max_pages, num_heads, num_kv_heads;
+    float eps, rope_base;
+};
+
+template <int VD>
+__global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs p) {
+    constexpr int D = 16 * VD;
+    const int r = blockIdx.x;
+    const int g = threadIdx.x >> 4;
+    const int t = threadIdx.x & 15;
+    const int Hq = p.num_heads, Hkv = p.num_kv_heads;
+    const int pos = p.start + r;
+    const uint16_t *row = p.qkv + (long)r * (Hq + 2 * Hkv) * D;
+    float cs[VD], sn[VD];
+    rope_factors<VD>(t, pos, p.rope_base, cs, sn);
+    const int lp = pos / p.page_size;
+    const int slot = pos - lp * p.page_size;
+    const int page_id = lp < p.max_pages ? p.block_row[lp] : -1;
+    for (int h = g; h < Hq + 2 * Hkv; h += 16) {
+        float v[VD];
+        if (h < Hq) {
+            head_norm_rope<VD>(row + (long)h * D, p.q_norm_w, t, p.eps, cs, sn, v);
+            store_row<VD>(p.q_t + ((long)h * p.T + r) * D + t * VD, v);
+        } else if (h < Hq + Hkv) {
+            head_norm_rope<VD>(row + (long)h * D, p.k_norm_w, t, p.eps, cs, sn, v);
+            if (page_id >= 0)
+                store_row<VD>(p.key_pages + (((long)page_id * Hkv + (h - Hq)) * p.page_size + slot) * D + t * VD, v);
+        } else {
+            load_row<VD>(row + (long)h * D + t * VD, v);
+            if (page_id >= 0)
+                store_row<VD>(p.value_pages + (((long)page_id * Hkv + (h - Hq - Hkv)) * p.page_size + slot) * D + t * VD,
+                              v);
+        }
+    }
+}
+
+// [H, T, D] -> [T, H*D], 16 B per thread (D % 8 == 0)
+__global__ __launch_bounds__(256) void heads_to_rows_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out,
+                                                            int H, int T, int D) {
+    const int vpr = D / 8;
+    const long total = (long)H * T * vpr;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int v = (int)(idx % vpr);
+    const int h = (int)((idx / vpr) % H);
+    const int t = (int)(idx / ((long)vpr * H));
+    *reinterpret_cast<uint4 *>(out + ((long)t * H + h) * D + v * 8) =
+        *reinterpret_cast<const uint4 *>(in + ((long)h * T + t) * D + v * 8);
+}
+
+// out = bf16(a + b), n % 8 == 0
+__global__ __launch_bounds__(256) void residual_add_kernel(const uint16_t *__restrict__ a, const uint16_t *__restrict__ b,
+                                                           uint16_t *__restrict__ out, long n8) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n8) return;
+    uint16_t x[8], y[8], o[8];
+    *reinterpret_cast<uint4 *>(x) = reinterpret_cast<const uint4 *>(a)[idx];
+    *reinterpret_cast<uint4 *>(y) = reinterpret_cast<const uint4 *>(b)[idx];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = BF16::from_float(BF16::to_float(x[e]) + BF16::to_float(y[e]));
+    reinterpret_cast<uint4 *>(out)[idx] = *reinterpret_cast<const uint4 *>(o);
+}
+
+// gu [T, 2I] with (gate_i, up_i) interleaved -> act [T, I] = bf16(silu(gate) * up)   (I % 4 == 0)
+__global__ __launch_bounds__(256) void swiglu_interleaved_kernel(const uint16_t *__restrict__ gu,
+                                                                 uint16_t *__restrict__ act, long n4) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    uint16_t x[8], o[4];
+    *reinterpret_cast<uint4 *>(x) = reinterpret_cast<const uint4 *>(gu)[idx];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float gt = BF16::to_float(x[2 * e]);
+        const float up = BF16::to_float(x[2 * e + 1]);
+        o[e] = BF16::from_float((gt / (1.0f + expf(-gt))) * up);
+    }
+    reinterpret_cast<uint2 *>(act)[idx] = *reinterpret_cast<const uint2 *>(o);
+}
+
+// tokens[max_batch] -> x[slot, hidden] for slots [0, batch): one block per slot
+__global__ __launch_bounds__(256) void embed_slots_kernel(const int32_t *__restrict__ tokens,
+                                                          const uint32_t *__restrict__ emb_w,
+                                                          const uint16_t *__restrict__ emb_s,
+                                                          const uint16_t *__restrict__ emb_b, uint16_t *__restrict__ x,
+                                                          int hidden, int vocab) {
+    const int slot = blockIdx.x;
+    int token = tokens[slot];
+    token = token < 0 ? 0 : (token >= vocab ? vocab - 1 : token);
+    const int words = hidden / 8;
+    const int groups = hidden / 128;
+    for (int w = threadIdx.x; w < words; w += 256) {
+        const uint32_t packed = emb_w[(long)token * words + w];
+        const float scale = BF16::to_float(emb_s[(long)token * groups + w / 16]);
+        const float bias = BF16::to_float(emb_b[(long)token * groups + w / 16]);
+        uint16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = BF16::from_float((float)((packed >> (4 * e)) & 0xfu) * scale + bias);
+        *reinterpret_cast<uint4 *>(x + (long)slot * hidden + w * 8) = *reinterpret_cast<const uint4 *>(o);
+    }
+}
+
+// host-by-value writes of a few int32 words (block-table entries, context lengths, tokens) in stream order
+struct PokeArgs {
+    int32_t *addr[8];
+    int32_t value[8];
+    int n;
+};
+__global__ void poke_kernel(const PokeArgs p) {
+    if ((int)threadIdx.x < p.n) *p.addr[threadIdx.x] = p.value[threadIdx.x];
+}
+__global__ void fill_i32_kernel(int32_t *dst, int32_t value, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+
+}  // namespace tl

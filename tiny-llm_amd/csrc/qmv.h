@@ -373,4 +373,8 @@ inline QmvPlan qmv_plan(int M, int N, int K) {
     return pl;
 }
 
+// Fused-variant launcher (bf16 only), defined in qmv_fused.hip.  pro/epi are PRO_* / EPI_*.
+// Returns 0, or -1 when the activation tile does not fit in LDS, -2 for an unknown plan.
+int launch_qmv_fused_bf16(const QmvArgs &args, int pro, int epi, hipStream_t st);
+
 }  // namespace tl

@@ -63,6 +63,57 @@ _SIGNATURES = {
     "tl_paged_attention_workspace_bytes": (_c_size_t, [_c_int] * 8),
 }
 
+
+
+# ---- decode engine ABI (include/tinyllm_engine.h) ------------------------------------------------
+class TlW4(ctypes.Structure):
+    _fields_ = [("weight_dev", _c_void_p), ("scales_dev", _c_void_p), ("biases_dev", _c_void_p),
+                ("rows", _c_int), ("cols", _c_int)]
+
+
+class TlLayerWeights(ctypes.Structure):
+    _fields_ = [("wqkv", TlW4), ("wo", TlW4), ("wgu", TlW4), ("wdown", TlW4),
+                ("input_norm_dev", _c_void_p), ("post_norm_dev", _c_void_p),
+                ("q_norm_dev", _c_void_p), ("k_norm_dev", _c_void_p)]
+
+
+class TlEngineConfig(ctypes.Structure):
+    _fields_ = [("hidden_size", _c_int), ("num_layers", _c_int), ("num_heads", _c_int), ("num_kv_heads", _c_int),
+                ("head_dim", _c_int), ("intermediate_size", _c_int), ("vocab_size", _c_int),
+                ("rope_theta", _c_float), ("rms_norm_eps", _c_float),
+                ("page_size", _c_int), ("num_pages", _c_int), ("max_batch", _c_int), ("max_pages_per_seq", _c_int),
+                ("max_prefill_rows", _c_int)]
+
+
+class TlEngineStats(ctypes.Structure):
+    _fields_ = [("pages_in_use", _c_int), ("pages_free", _c_int), ("peak_pages_in_use", _c_int),
+                ("page_allocations", ctypes.c_long), ("reused_page_allocations", ctypes.c_long),
+                ("decode_steps", ctypes.c_long), ("graph_captures", ctypes.c_long), ("graph_replays", ctypes.c_long),
+                ("prefill_tokens", ctypes.c_long), ("kv_bytes", _c_size_t), ("workspace_bytes", _c_size_t)]
+
+
+_P = ctypes.POINTER
+_SIGNATURES.update({
+    "tl_engine_create": (_c_int, [_P(TlEngineConfig), _P(TlLayerWeights), _P(TlW4), _c_void_p, _P(TlW4), _c_void_p,
+                                  _P(_c_void_p)]),
+    "tl_engine_destroy": (None, [_c_void_p]),
+    "tl_engine_synchronize": (_c_int, [_c_void_p]),
+    "tl_engine_begin": (_c_int, [_c_void_p, _c_int]),
+    "tl_engine_reserve": (_c_int, [_c_void_p, _c_int, _c_int]),
+    "tl_engine_release": (_c_int, [_c_void_p, _c_int]),
+    "tl_engine_rewind": (_c_int, [_c_void_p, _c_int, _c_int]),
+    "tl_engine_context_len": (_c_int, [_c_void_p, _c_int]),
+    "tl_engine_prefill": (_c_int, [_c_void_p, _c_int, _P(ctypes.c_int32), _c_int, _c_int]),
+    "tl_engine_set_token": (_c_int, [_c_void_p, _c_int, ctypes.c_int32]),
+    "tl_engine_decode": (_c_int, [_c_void_p, _c_int, _c_int, _c_int]),
+    "tl_engine_read_tokens": (_c_int, [_c_void_p, _c_int, _c_int, _P(ctypes.c_int32)]),
+    "tl_engine_logits_dev": (_c_void_p, [_c_void_p]),
+    "tl_engine_copy_logits": (_c_int, [_c_void_p, _c_void_p, _c_int]),
+    "tl_engine_tokens_dev": (_c_void_p, [_c_void_p]),
+    "tl_engine_get_stats": (_c_int, [_c_void_p, _P(TlEngineStats)]),
+    "tl_engine_step_bytes": (_c_size_t, [_c_void_p, _c_int]),
+})
+
 for _name, (_res, _args) in _SIGNATURES.items():
     _fn = getattr(_lib, _name)
     _fn.restype = _res
@@ -81,6 +132,11 @@ def _bind_optional(name: str, restype, argtypes) -> bool:
 def lib() -> ctypes.CDLL:
     """The loaded shared library (used by the decode engine binding)."""
     return _lib
+
+
+def check(status: int) -> None:
+    """Raise RuntimeError(tl_last_error()) for a non-zero tl_status."""
+    _check(status)
 
 
 def library_path() -> str:

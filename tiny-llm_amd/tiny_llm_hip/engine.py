@@ -1,0 +1,190 @@
+"""Fused decode engine: host mirror of include/tinyllm_engine.h.
+
+The reference decodes by calling its operators one by one from Python (``Qwen3ModelWeek3.__call__``,
+src/tiny_llm_ref/qwen3_week3.py:320-338, driven by benches/bench.py:run_one_request_week2 277-312).  That
+loop is kept (``Qwen3ModelWeek2/3`` in this package run it op by op on the HIP operators); this module is
+the production path behind it: the same arithmetic issued as 5 fused kernels per layer inside one replayed
+hipGraph, with tokens / context lengths / block tables resident on the device.
+
+``DecodeEngine.from_model(mlx_shaped_model)`` re-packs the checkpoint once (QKV rows concatenated, gate/up
+rows interleaved) and then exposes a request-level API: ``begin`` / ``prefill`` / ``decode`` / ``release``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Any, Sequence
+
+import torch
+
+from ._ext import tiny_llm_ext_hip as _ext
+
+_lib = _ext.lib()
+
+
+def _w4(weight: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor) -> "_ext.TlW4":
+    rows, words = weight.shape
+    return _ext.TlW4(weight.data_ptr(), scales.data_ptr(), biases.data_ptr(), rows, words * 8)
+
+
+def _bits(t: torch.Tensor) -> torch.Tensor:
+    return t.view(torch.int32) if t.dtype != torch.int32 else t
+
+
+class _Fused:
+    """Keeps the re-packed tensors alive for the lifetime of the engine."""
+
+    def __init__(self, weight, scales, biases):
+        self.weight = _bits(weight).contiguous()
+        self.scales = scales.to(torch.bfloat16).contiguous()
+        self.biases = biases.to(torch.bfloat16).contiguous()
+
+    @staticmethod
+    def concat(layers: Sequence[Any]) -> "_Fused":
+        return _Fused(torch.cat([_bits(l.weight) for l in layers], 0), torch.cat([l.scales for l in layers], 0),
+                      torch.cat([l.biases for l in layers], 0))
+
+    @staticmethod
+    def interleave(a: Any, b: Any) -> "_Fused":
+        def il(x, y):
+            return torch.stack([x, y], dim=1).reshape(x.shape[0] * 2, *x.shape[1:])
+
+        return _Fused(il(_bits(a.weight), _bits(b.weight)), il(a.scales, b.scales), il(a.biases, b.biases))
+
+    def c(self) -> "_ext.TlW4":
+        return _w4(self.weight, self.scales, self.biases)
+
+
+class DecodeEngine:
+    """Owns the fused weights, the paged KV pools and the captured decode graphs for one model on one GPU."""
+
+    def __init__(self, mlx_model: Any, *, page_size: int = 128, num_pages: int = 512, max_batch: int = 1,
+                 max_pages_per_seq: int | None = None, max_prefill_rows: int = 2048):
+        args = mlx_model.args
+        if not torch.cuda.is_available():
+            raise RuntimeError("DecodeEngine: the course extension is GPU-only")
+        self.args = args
+        self._keep: list[Any] = []
+        layers = (_ext.TlLayerWeights * args.num_hidden_layers)()
+        for i, layer in enumerate(mlx_model.model.layers):
+            attn, mlp = layer.self_attn, layer.mlp
+            qkv = _Fused.concat([attn.q_proj, attn.k_proj, attn.v_proj])
+            wo = _Fused(attn.o_proj.weight, attn.o_proj.scales, attn.o_proj.biases)
+            gu = _Fused.interleave(mlp.gate_proj, mlp.up_proj)
+            down = _Fused(mlp.down_proj.weight, mlp.down_proj.scales, mlp.down_proj.biases)
+            norms = [layer.input_layernorm.weight, layer.post_attention_layernorm.weight, attn.q_norm.weight,
+                     attn.k_norm.weight]
+            norms = [n.to(torch.bfloat16).contiguous() for n in norms]
+            self._keep += [qkv, wo, gu, down, norms]
+            layers[i] = _ext.TlLayerWeights(qkv.c(), wo.c(), gu.c(), down.c(), norms[0].data_ptr(),
+                                            norms[1].data_ptr(), norms[2].data_ptr(), norms[3].data_ptr())
+        emb = mlx_model.model.embed_tokens
+        embed = _Fused(emb.weight, emb.scales, emb.biases)
+        final_norm = mlx_model.model.norm.weight.to(torch.bfloat16).contiguous()
+        self._keep += [embed, final_norm]
+        head = None
+        if not getattr(args, "tie_word_embeddings", True):
+            hl = mlx_model.lm_head
+            head = _Fused(hl.weight, hl.scales, hl.biases)
+            self._keep.append(head)
+        if max_pages_per_seq is None:
+            max_pages_per_seq = num_pages
+        cfg = _ext.TlEngineConfig(
+            args.hidden_size, args.num_hidden_layers, args.num_attention_heads, args.num_key_value_heads,
+            args.head_dim, args.intermediate_size, args.vocab_size, float(args.rope_theta), float(args.rms_norm_eps),
+            page_size, num_pages, max_batch, max_pages_per_seq, max_prefill_rows)
+        self.page_size, self.max_batch, self.vocab_size = page_size, max_batch, args.vocab_size
+        self.device = emb.weight.device
+        handle = ctypes.c_void_p()
+        embed_c = embed.c()
+        head_c = head.c() if head is not None else None
+        _ext.check(_lib.tl_engine_create(
+            ctypes.byref(cfg), layers, ctypes.byref(embed_c), final_norm.data_ptr(),
+            ctypes.byref(head_c) if head_c is not None else None, None, ctypes.byref(handle)))
+        self._h = handle
+
+    @classmethod
+    def from_model(cls, mlx_model: Any, **kwargs) -> "DecodeEngine":
+        return cls(mlx_model, **kwargs)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _lib.tl_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- slots -------------------------------------------------------------------------------------
+    def begin(self, slot: int = 0) -> None:
+        _ext.check(_lib.tl_engine_begin(self._h, slot))
+
+    def reserve(self, slot: int, total_tokens: int) -> None:
+        _ext.check(_lib.tl_engine_reserve(self._h, slot, total_tokens))
+
+    def release(self, slot: int = 0) -> None:
+        _ext.check(_lib.tl_engine_release(self._h, slot))
+
+    def rewind(self, slot: int, n: int) -> None:
+        _ext.check(_lib.tl_engine_rewind(self._h, slot, n))
+
+    def context_len(self, slot: int = 0) -> int:
+        return _lib.tl_engine_context_len(self._h, slot)
+
+    def set_token(self, slot: int, token: int) -> None:
+        _ext.check(_lib.tl_engine_set_token(self._h, slot, int(token)))
+
+    # -- compute -----------------------------------------------------------------------------------
+    def prefill(self, slot: int, tokens: Sequence[int], *, chunk: int = 2048, want_logits: bool = True) -> None:
+        """Chunked prefill (reference Request.try_prefill, batch.py:48-76): all chunks append K/V, the last one
+        also produces the first generated token."""
+        tokens = [int(t) for t in tokens]
+        if not tokens:
+            raise ValueError("prefill needs at least one token")
+        for start in range(0, len(tokens), chunk):
+            part = tokens[start:start + chunk]
+            arr = (ctypes.c_int32 * len(part))(*part)
+            last = start + chunk >= len(tokens)
+            _ext.check(_lib.tl_engine_prefill(self._h, slot, arr, len(part), int(last and want_logits)))
+
+    def decode(self, steps: int, batch: int | None = None, use_graph: bool = True) -> None:
+        """Enqueue ``steps`` greedy decode steps over slots [0, batch); does not synchronise."""
+        _ext.check(_lib.tl_engine_decode(self._h, batch or self.max_batch, int(steps), int(use_graph)))
+
+    def read_tokens(self, slot: int, count: int) -> list[int]:
+        out = (ctypes.c_int32 * count)()
+        _ext.check(_lib.tl_engine_read_tokens(self._h, slot, count, out))
+        return list(out)
+
+    def logits(self, rows: int = 1) -> torch.Tensor:
+        """A copy of the most recent logits [rows, vocab] (bf16)."""
+        out = torch.empty((rows, self.vocab_size), dtype=torch.bfloat16, device=self.device)
+        torch.cuda.current_stream().synchronize()  # `out` is allocated on torch's stream
+        _ext.check(_lib.tl_engine_copy_logits(self._h, out.data_ptr(), rows))
+        self.synchronize()
+        return out
+
+    def synchronize(self) -> None:
+        _ext.check(_lib.tl_engine_synchronize(self._h))
+
+    def step_bytes(self, batch: int | None = None) -> int:
+        return int(_lib.tl_engine_step_bytes(self._h, batch or self.max_batch))
+
+    def stats(self) -> dict:
+        s = _ext.TlEngineStats()
+        _ext.check(_lib.tl_engine_get_stats(self._h, ctypes.byref(s)))
+        return {name: getattr(s, name) for name, _ in s._fields_}
+
+    # -- convenience: one request, like benches/bench.py:run_one_request_week2 --------------------------
+    def generate(self, prompt: Sequence[int], max_new_tokens: int, *, slot: int = 0, chunk: int = 2048) -> list[int]:
+        self.begin(slot)
+        try:
+            self.prefill(slot, prompt, chunk=chunk)
+            if max_new_tokens > 1:
+                self.decode(max_new_tokens - 1, batch=slot + 1)
+            return self.read_tokens(slot, max_new_tokens)
+        finally:
+            self.release(slot)
