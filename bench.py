@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Qwen3-4B int4 (W4A16, group 128) single-stream KV-cache decode on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): one request per GPU, a
+128-token synthetic prompt (token ids drawn like the reference's build_requests, benches/bench.py:201-225),
+chunked prefill, then greedy decode.  A "step" is one decode step = one generated token per GPU.  Weights are
+random-init Qwen3-4B-shaped W4 tensors (N(0, 0.02) bf16 -> affine group-128 quantizer); no checkpoint can be
+downloaded here.  N > 1: one process per GPU (torch.distributed.run), every rank decodes its own request —
+request-level data parallelism with NO collective on the data path; RCCL is used only for the
+barrier and the max-over-ranks of the elapsed time.
+
+One JSON line on stdout (rank 0).  Extra objects:
+  roofline     — the dominant kernel (tl::qmv_kernel, the W4A16 decode GEMV: 145 launches per step streaming
+                 all 2.137 GB of weights).  `achieved` = algorithmic bytes of those launches / the sum of their
+                 device-clock durations, measured live right after the timed region by tl_engine_profile_step
+                 (every kernel stamps the device wall clock at its first workgroup's start and last wave's end —
+                 hipEvents cannot bracket kernels inside a replayed graph, and around 2-10 us kernels their own
+                 overhead is of the order of the thing measured).  `step_*` keys give the same ratio for the
+                 whole production step (graph replay, launch gaps included) — that is the number `value` follows.
+  cpu_baseline — oracle/qwen3_decode.c (plain-C OpenMP port of the same decode step) on the host cores, on a
+                 bounded sample; also used as a checker: the GPU engine must reproduce its greedy tokens.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "tiny-llm_amd", ROOT / "tiny-llm_amd" / "extensions_hip"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); measured copy ceiling 6290
+HBM_COPY_GBPS = 6290.0
+
+
+def build_prompt(rng: random.Random, length: int, vocab: int) -> list[int]:
+    """Synthetic prompt ids in [256, vocab) like the reference harness (benches/bench.py:201-225)."""
+    return [rng.randrange(256, vocab) for _ in range(length)]
+
+
+def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_steps: int) -> dict:
+    """Time the plain-C port (oracle/) on the host cores on a bounded sample and use it as a checker."""
+    import numpy as np
+    import torch
+
+    from oracle import c_oracle
+
+    if not c_oracle.available():
+        return {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
+                "sample": "oracle/libqwen3_oracle.so missing (run __graft_entry__.build())"}
+
+    def host_w4(layer):
+        return (layer.weight.cpu().numpy().view(np.uint32), layer.scales.view(torch.int16).cpu().numpy().view(np.uint16),
+                layer.biases.view(torch.int16).cpu().numpy().view(np.uint16))
+
+    def host_norm(t):
+        return t.to(torch.bfloat16).view(torch.int16).cpu().numpy().view(np.uint16)
+
+    layers = []
+    for layer in mlx_model.model.layers:
+        a, m = layer.self_attn, layer.mlp
+        layers.append(dict(q=host_w4(a.q_proj), k=host_w4(a.k_proj), v=host_w4(a.v_proj), o=host_w4(a.o_proj),
+                           gate=host_w4(m.gate_proj), up=host_w4(m.up_proj), down=host_w4(m.down_proj),
+                           q_norm=host_norm(a.q_norm.weight), k_norm=host_norm(a.k_norm.weight),
+                           input_norm=host_norm(layer.input_layernorm.weight),
+                           post_norm=host_norm(layer.post_attention_layernorm.weight)))
+    weights = dict(embed=host_w4(mlx_model.model.embed_tokens), layers=layers, norm=host_norm(mlx_model.model.norm.weight))
+    cores = os.cpu_count() or 1
+    model = c_oracle.COracleQwen3(cfg, weights, max_ctx=sample_prompt + sample_steps + 1)
+    prompt = build_prompt(random.Random(1234), sample_prompt, cfg["vocab_size"])
+    tid = 0
+    for t in prompt:  # token-by-token prefill: untimed warm-up of the CPU path
+        tid, _ = model.step(t)
+    cpu_ids = [tid]
+    t0 = time.perf_counter()
+    for _ in range(sample_steps):
+        tid, _ = model.step(cpu_ids[-1])
+        cpu_ids.append(tid)
+    dt = time.perf_counter() - t0
+    model.close()
+    # checker: the engine on the same prompt must produce the same greedy ids (teacher-forced on the CPU ids)
+    engine.begin(0)
+    engine.prefill(0, prompt, chunk=8)
+    gpu_ids = engine.read_tokens(0, 1)
+    for s in range(sample_steps):
+        engine.set_token(0, cpu_ids[s])
+        engine.decode(1, batch=1)
+        gpu_ids.append(engine.read_tokens(0, 1)[0])
+    engine.release(0)
+    match = sum(int(a == b) for a, b in zip(cpu_ids, gpu_ids))
+    return {"value": round(sample_steps / dt, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_steps} decode steps after a {sample_prompt}-token prompt, same Qwen3-4B W4 checkpoint, "
+                      f"oracle/qwen3_decode.c with OpenMP on {cores} threads",
+            "greedy_ids_matching_gpu": f"{match}/{len(cpu_ids)}"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--model", default="qwen3-4b")
+    ap.add_argument("--prompt-len", type=int, default=128)
+    ap.add_argument("--prefill-step", type=int, default=128)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--profile-steps", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (for rocprofv3 kernel traces)")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from tiny_llm_hip.engine import DecodeEngine
+    from tiny_llm_hip.synthetic import QWEN3_CONFIGS, synthetic_qwen3
+
+    cfg = dict(QWEN3_CONFIGS[args.model])
+    device = f"cuda:{local_rank}"
+    mlx_model = synthetic_qwen3(cfg, seed=args.seed, sigma=0.02, device=device)
+    total_ctx = args.prompt_len + args.warmup + args.steps + args.profile_steps + 64
+    page = 128
+    engine = DecodeEngine(mlx_model, page_size=page, num_pages=(total_ctx + page - 1) // page + 2, max_batch=1,
+                          max_prefill_rows=max(args.prefill_step, 8))
+    prompt = build_prompt(random.Random(args.seed * 1000 + rank), args.prompt_len, cfg["vocab_size"])
+    use_graph = not args.no_graph
+
+    def barrier():
+        engine.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    engine.begin(0)
+    t_p0 = time.perf_counter()
+    engine.prefill(0, prompt, chunk=args.prefill_step)
+    engine.synchronize()
+    prefill_s = time.perf_counter() - t_p0
+    engine.decode(max(args.warmup, 2), batch=1, use_graph=use_graph)  # >= 2: eager warm step + graph capture
+    barrier()
+    bytes_first = engine.step_bytes(1)
+    t0 = time.perf_counter()
+    engine.decode(args.steps, batch=1, use_graph=use_graph)
+    engine.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    bytes_last = engine.step_bytes(1)
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ids = engine.read_tokens(0, 8)
+
+    # ---- roofline leg: per-kernel device-clock durations of real decode steps (not part of the timed region)
+    prof = None
+    for _ in range(max(args.profile_steps, 0)):
+        p = engine.profile_step(1)
+        if prof is None:
+            prof = p
+        else:
+            for k, v in p["kinds"].items():
+                prof["kinds"][k]["us"] += v["us"]
+            prof["span_us"] += p["span_us"]
+    stats = engine.stats()
+    engine.release(0)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    step_bytes = 0.5 * (bytes_first + bytes_last)
+    step_gbps = step_bytes / (elapsed / args.steps) / 1e9
+    roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
+    if prof:
+        n = max(args.profile_steps, 1)
+        kinds = prof["kinds"]
+        gemv = [k for k in kinds if k.startswith("gemv_")]
+        g_us = sum(kinds[k]["us"] for k in gemv) / n
+        g_bytes = sum(kinds[k]["bytes"] for k in gemv)
+        g_launch = sum(kinds[k]["launches"] for k in gemv)
+        ach = g_bytes / g_us / 1e3
+        roofline.update({
+            "kernel": "tl::qmv_kernel<BF16,...> (W4A16 decode GEMV, fused RMSNorm / residual / SwiGLU variants)",
+            "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4),
+            "frac_of_measured_copy_peak": round(ach / HBM_COPY_GBPS, 4),
+            "launches_per_step": g_launch, "bytes_per_launch_avg": round(g_bytes / g_launch),
+            "avg_launch_us": round(g_us / g_launch, 3),
+            "timing": "in-kernel device wall clock, tl_engine_profile_step, mean of %d steps" % n,
+            "per_kind": {k: {"us_per_step": round(v["us"] / n, 2), "launches": v["launches"],
+                             "GBps": round(v["bytes"] / (v["us"] / n) / 1e3, 1) if v["bytes"] and v["us"] else None}
+                         for k, v in kinds.items()},
+            "kernel_time_us_per_step": round(sum(v["us"] for v in kinds.values()) / n, 1),
+        })
+        traffic_file = ROOT / "profiles" / "traffic.json"
+        if traffic_file.exists():
+            try:
+                roofline["traffic"] = json.loads(traffic_file.read_text()).get("qmv_hbm_bytes_per_launch")
+            except Exception:
+                roofline["traffic"] = None
+    roofline["step_achieved"] = round(step_gbps, 1)
+    roofline["step_frac"] = round(step_gbps / HBM_PEAK_GBPS, 4)
+    roofline["step_bytes"] = int(step_bytes)
+
+    cpu = None
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg(mlx_model, cfg, engine, sample_prompt=8, sample_steps=16)
+
+    out = {
+        "metric": "Qwen3-4B int4 decode tokens/sec/GPU; achieved HBM GB/s vs roofline",
+        "value": round(args.gpus * args.steps / elapsed, 2),
+        "unit": "tokens/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16 activations x int4 (W4A16 g128) weights, fp32 accumulate",
+        "data": "synthetic (random-init Qwen3-4B-shaped W4 weights, synthetic token ids)",
+        "config": {"workload": "Qwen3-4B int4 single-prompt KV-cache decode (BASELINE.json configs[1])",
+                   "prompt_tokens": args.prompt_len, "decode_steps": args.steps, "batch_per_gpu": 1,
+                   "parallelism": f"request-parallel x{args.gpus} (no collective on the data path)",
+                   "page_size": page, "graph_replay": use_graph, "prefill_step": args.prefill_step},
+        "tokens_per_s_per_gpu": round(args.steps / elapsed, 2),
+        "prefill_tokens_per_s": round(args.prompt_len / prefill_s, 1),
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "engine": {k: stats[k] for k in ("graph_captures", "graph_replays", "decode_steps", "kv_bytes")},
+        "first_ids": ids,
+    }
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

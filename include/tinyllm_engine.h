@@ -153,6 +153,24 @@ int tl_engine_get_stats(const tl_engine *e, tl_engine_stats *out);
  * streamed once + K/V of every live context. */
 size_t tl_engine_step_bytes(const tl_engine *e, int batch);
 
+/* Measurement aid: runs ONE real decode step eagerly (same kernels, same state update as
+ * tl_engine_decode(e, batch, 1, 0)) with every kernel stamping the device wall clock at its first
+ * workgroup's start and its last wave's end.  kernel_us[k] / launches[k] are summed per kind:
+ *   0 qkv GEMV, 1 wo GEMV, 2 gate|up GEMV, 3 w_down GEMV, 4 lm_head GEMV, 5 attention, 6 attention merge,
+ *   7 step end (argmax + embed).
+ * gemv_bytes[k] = algorithmic W4 bytes those launches stream (packed nibbles + bf16 scales and biases).
+ * span_us = first start to last end of the step (includes the small reduce kernels this mode inserts
+ * between launches, so it is NOT the production step time).  Synchronises the stream. */
+typedef struct tl_step_profile {
+    double kernel_us[8];
+    int launches[8];
+    double gemv_bytes[5];
+    double span_us;
+    int clock_khz;
+    int n_splits;
+} tl_step_profile;
+int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,20 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
+// ---- optional in-kernel timing (engine profile step) ---------------------------------------------
+// buf = nullptr in normal operation.  Otherwise buf[2*wg] receives the workgroup's first timestamp and
+// buf[2*wg+1] the maximum end timestamp over its waves (constant-rate wall clock, hipDeviceAttributeWallClockRate).
+typedef unsigned long long prof_t;
+__device__ __forceinline__ unsigned prof_wg() {
+    return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+}
+__device__ __forceinline__ void prof_begin(prof_t *buf) {
+    if (buf && threadIdx.x == 0) buf[2 * (size_t)prof_wg()] = wall_clock64();
+}
+__device__ __forceinline__ void prof_end(prof_t *buf) {
+    if (buf && (threadIdx.x & 63) == 0) atomicMax(&buf[2 * (size_t)prof_wg() + 1], (prof_t)wall_clock64());
+}
+
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace tl

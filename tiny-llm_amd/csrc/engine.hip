@@ -13,6 +13,7 @@
 #include "common.h"
 #include "engine_kernels.h"
 #include "qmv.h"
+#include "qmv3.h"
 
 namespace tl {
 
@@ -49,6 +50,12 @@ struct tl_engine {
     size_t layer_pool_elems = 0, kv_bytes = 0;
     void *splitk_ws = nullptr;
     size_t splitk_ws_bytes = 0;
+    // decode-path copy of every W4 matrix in the tiled MFMA layout (qmv3.h); keyed by the checkpoint pointer
+    struct Tiled {
+        uint32_t *wt = nullptr, *sbt = nullptr;
+    };
+    std::map<const uint32_t *, Tiled> tiled;
+    size_t tiled_bytes = 0;
 
     int32_t *block_table = nullptr, *context_lens = nullptr, *tokens = nullptr, *live = nullptr, *produced = nullptr,
             *ring = nullptr, *scratch_ctx = nullptr, *prefill_tokens = nullptr;
@@ -81,6 +88,17 @@ struct tl_engine {
 
 namespace tl {
 
+// ---- profile step bookkeeping -------------------------------------------------------------------------
+// kinds: 0..4 GEMV (qkv, o, gate_up, down, lm_head), 5 attention, 6 merge, 7 step end
+struct ProfCtx {
+    prof_t *buf = nullptr;    // per-workgroup (start, end) pairs of the launch in flight
+    prof_t *pairs = nullptr;  // [n][2] reduced (start, end) per launch
+    std::vector<int> kinds;
+    int cap = 0;
+};
+
+static void prof_after(tl_engine *e, ProfCtx *pc, int kind, int n_wg);
+
 // ---- small launch helpers ----------------------------------------------------------------------
 static int poke(tl_engine *e, std::vector<std::pair<int32_t *, int32_t>> &items) {
     for (size_t i = 0; i < items.size(); i += 8) {
@@ -111,9 +129,13 @@ static int check_w4(const tl_w4 &w, int rows, int cols, const char *name) {
 
 // GEMV with fused prologue/epilogue over M <= 8 rows; splits the rows when the activation tile exceeds LDS.
 static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
-                      const void *norm_w, const uint16_t *residual) {
+                      const void *norm_w, const uint16_t *residual, ProfCtx *pc = nullptr, int kind = 0) {
     int step = M;
-    while (qmv_plan(step, w.cols, w.rows).lds > 150 * 1024 && step > 1) step = (step + 1) / 2;
+    const bool has_tiled = e->tiled.count(w.weight_dev) != 0;
+    auto fits = [&](int rows) {
+        return (has_tiled && qmv3_plan(rows, w.cols, w.rows).ok) || qmv_plan(rows, w.cols, w.rows).lds <= 150 * 1024;
+    };
+    while (!fits(step) && step > 1) step = (step + 1) / 2;
     const int out_cols = epi == EPI_SWIGLU ? w.rows / 2 : w.rows;
     for (int m0 = 0; m0 < M; m0 += step) {
         QmvArgs args{};
@@ -128,8 +150,30 @@ static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
         args.M = std::min(step, M - m0);
         args.N = w.cols;
         args.K = w.rows;
+        args.prof = pc ? pc->buf : nullptr;
+        const auto tiled = e->tiled.find(w.weight_dev);
+        const Qmv3Plan p3 = qmv3_plan(args.M, args.N, args.K);
+        if (tiled != e->tiled.end() && p3.ok) {
+            Qmv3Args a3{};
+            a3.wt = tiled->second.wt;
+            a3.sbt = tiled->second.sbt;
+            a3.a = args.a;
+            a3.out = args.out;
+            a3.norm_w = args.norm_w;
+            a3.residual = args.residual;
+            a3.eps = args.eps;
+            a3.M = args.M;
+            a3.N = args.N;
+            a3.K = args.K;
+            a3.prof = args.prof;
+            if (launch_qmv3_bf16(a3, pro, epi, e->stream) != 0)
+                return fail(TL_ERR_UNSUPPORTED, "engine: MFMA GEMV launch failed");
+            if (pc) prof_after(e, pc, kind, p3.blocks);
+            continue;
+        }
         if (launch_qmv_fused_bf16(args, pro, epi, e->stream) != 0)
             return fail(TL_ERR_UNSUPPORTED, "engine: no GEMV configuration for this shape");
+        if (pc) prof_after(e, pc, kind, qmv_plan(args.M, args.N, args.K).blocks);
     }
     TL_CHECK_LAUNCH("engine gemv");
     return TL_OK;
@@ -154,14 +198,14 @@ static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t s
 }
 
 // One fused decode step over slots [0, batch).
-static int enqueue_step(tl_engine *e, int batch, int n_splits) {
+static int enqueue_step(tl_engine *e, int batch, int n_splits, ProfCtx *pc = nullptr) {
     const tl_engine_config &c = e->cfg;
     const int D = c.head_dim;
     const int rep = c.num_heads / c.num_kv_heads;
     const int chunks = (rep + AD_RQ - 1) / AD_RQ;
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
-        TL_TRY(engine_qmv(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr));
+        TL_TRY(engine_qmv(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0));
         AttnDecodeArgs a{};
         a.qkv = e->qkv;
         a.q_norm_w = (const uint16_t *)w.q_norm_dev;
@@ -181,6 +225,7 @@ static int enqueue_step(tl_engine *e, int batch, int n_splits) {
         a.rope_base = c.rope_theta;
         a.n_splits = n_splits;
         a.n_row_chunks = chunks;
+        a.prof = pc ? pc->buf : nullptr;
         const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
         switch (D) {
             case 128: launch_attn_decode<8>(a, grid, e->stream); break;
@@ -188,15 +233,18 @@ static int enqueue_step(tl_engine *e, int batch, int n_splits) {
             case 32: launch_attn_decode<2>(a, grid, e->stream); break;
             default: return fail(TL_ERR_UNSUPPORTED, "engine: head_dim must be 32, 64 or 128");
         }
-        if (n_splits > 1)
+        if (pc) prof_after(e, pc, 5, (int)(grid.x * grid.y * grid.z));
+        if (n_splits > 1) {
             hipLaunchKernelGGL(attn_merge_kernel, dim3(batch * c.num_heads), dim3(128), 0, e->stream, e->attn_ws,
-                               e->attn, D, n_splits);
+                               e->attn, D, n_splits, pc ? pc->buf : nullptr);
+            if (pc) prof_after(e, pc, 6, batch * c.num_heads);
+        }
         TL_CHECK_LAUNCH("engine attention");
-        TL_TRY(engine_qmv(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x));
-        TL_TRY(engine_qmv(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr));
-        TL_TRY(engine_qmv(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h));
+        TL_TRY(engine_qmv(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1));
+        TL_TRY(engine_qmv(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2));
+        TL_TRY(engine_qmv(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3));
     }
-    TL_TRY(engine_qmv(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr));
+    TL_TRY(engine_qmv(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4));
     StepEndArgs s{};
     s.logits = e->logits;
     s.vocab = c.vocab_size;
@@ -213,9 +261,18 @@ static int enqueue_step(tl_engine *e, int batch, int n_splits) {
     s.emb_b = (const uint16_t *)e->embed.biases_dev;
     s.x = e->x;
     s.hidden = c.hidden_size;
+    s.prof = pc ? pc->buf : nullptr;
     hipLaunchKernelGGL(step_end_kernel, dim3(batch), dim3(1024), 0, e->stream, s);
+    if (pc) prof_after(e, pc, 7, batch);
     TL_CHECK_LAUNCH("engine step end");
     return TL_OK;
+}
+
+static void prof_after(tl_engine *e, ProfCtx *pc, int kind, int n_wg) {
+    const int idx = (int)pc->kinds.size();
+    if (idx >= pc->cap) return;
+    hipLaunchKernelGGL(prof_reduce_kernel, dim3(1), dim3(1024), 0, e->stream, pc->buf, n_wg, pc->pairs + 2 * (size_t)idx);
+    pc->kinds.push_back(kind);
 }
 
 static int reserve_locked(tl_engine *e, int slot, int total_tokens,
@@ -374,6 +431,39 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     hipLaunchKernelGGL(fill_i32_kernel, dim3(ceil_div(bt_n, 256)), dim3(256), 0, e->stream, e->block_table, -1, bt_n);
     if (hipGetLastError() != hipSuccess) return cleanup_fail("engine_create: block-table init failed");
 
+    // decode-path weight copies in the tiled MFMA layout
+    {
+        auto add_tiled = [&](const tl_w4 &w) -> bool {
+            if (w.rows % 16 != 0 || w.cols % 128 != 0 || e->tiled.count(w.weight_dev)) return true;
+            tl_engine::Tiled t;
+            const size_t wbytes = (size_t)w.rows * w.cols / 2, sbytes = (size_t)w.rows * (w.cols / 128) * 4;
+            if (hipMalloc((void **)&t.wt, wbytes + 16384) != hipSuccess) return false;  // + slack: fixed-length wave slices
+            if (hipMalloc((void **)&t.sbt, sbytes + 1024) != hipSuccess) {
+                (void)hipFree(t.wt);
+                return false;
+            }
+            if (repack_w4_tiled(w.weight_dev, (const uint16_t *)w.scales_dev, (const uint16_t *)w.biases_dev, t.wt, t.sbt, w.rows,
+                                w.cols, e->stream) != 0) {
+                (void)hipFree(t.wt);
+                (void)hipFree(t.sbt);
+                return false;
+            }
+            e->tiled[w.weight_dev] = t;
+            e->tiled_bytes += wbytes + sbytes;
+            return true;
+        };
+        bool ok = true;
+        for (const auto &l : e->layers) ok = ok && add_tiled(l.wqkv) && add_tiled(l.wo) && add_tiled(l.wgu) && add_tiled(l.wdown);
+        ok = ok && add_tiled(e->head());
+        if (!ok) {
+            for (auto &kv : e->tiled) {
+                (void)hipFree(kv.second.wt);
+                (void)hipFree(kv.second.sbt);
+            }
+            return cleanup_fail("engine_create: hipMalloc(tiled weights) failed");
+        }
+    }
+
     e->slot_pages.assign(c.max_batch, {});
     e->slot_ctx.assign(c.max_batch, 0);
     e->slot_live.assign(c.max_batch, 0);
@@ -383,7 +473,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->page_was_used.assign(c.num_pages, 0);
     e->stats.pages_free = c.num_pages;
     e->stats.kv_bytes = e->kv_bytes;
-    e->stats.workspace_bytes = e->arena_bytes;
+    e->stats.workspace_bytes = e->arena_bytes + e->tiled_bytes;
     *out = e;
     return TL_OK;
 }
@@ -396,6 +486,10 @@ extern "C" void tl_engine_destroy(tl_engine *e) {
     if (e->kpool) (void)hipFree(e->kpool);
     if (e->vpool) (void)hipFree(e->vpool);
     if (e->splitk_ws) (void)hipFree(e->splitk_ws);
+    for (auto &kv : e->tiled) {
+        (void)hipFree(kv.second.wt);
+        (void)hipFree(kv.second.sbt);
+    }
     if (e->owns_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -703,4 +797,91 @@ extern "C" size_t tl_engine_step_bytes(const tl_engine *e, int batch) {
     for (int b = 0; b < batch && b < c.max_batch; ++b)
         if (e->slot_live[b]) total += kv_per_token * (size_t)e->slot_ctx[b];
     return total;
+}
+
+// One REAL decode step (state advances exactly like tl_engine_decode(e, batch, 1, 0)) launched eagerly with
+// in-kernel wall-clock stamps; see tl_step_profile in the header.
+extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *out) {
+    TL_REQUIRE(e && out, "engine_profile_step: null argument");
+    TL_REQUIRE(batch > 0 && batch <= e->cfg.max_batch, "engine_profile_step: batch out of range");
+    const tl_engine_config &c = e->cfg;
+    int rate_khz = 0;
+    int dev = 0;
+    TL_HIP(hipGetDevice(&dev));
+    TL_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev));
+    TL_REQUIRE(rate_khz > 0, "engine_profile_step: device reports no wall clock rate");
+    // largest grid of the step: the lm_head GEMV (4 rows per workgroup at worst) or the attention grid
+    const int max_wg = std::max(c.vocab_size / 4 + 64, 64 * 4 * c.num_kv_heads * batch) + 1024;
+    ProfCtx pc;
+    pc.cap = c.num_layers * 8 + 8;
+    TL_HIP(hipStreamSynchronize(e->stream));
+    TL_HIP(hipMalloc((void **)&pc.buf, (size_t)max_wg * 2 * sizeof(prof_t)));
+    TL_HIP(hipMalloc((void **)&pc.pairs, (size_t)pc.cap * 2 * sizeof(prof_t)));
+    auto cleanup = [&]() {
+        (void)hipFree(pc.buf);
+        (void)hipFree(pc.pairs);
+    };
+    if (hipMemsetAsync(pc.buf, 0, (size_t)max_wg * 2 * sizeof(prof_t), e->stream) != hipSuccess) {
+        cleanup();
+        return fail(TL_ERR_HIP, "engine_profile_step: memset failed");
+    }
+    hipLaunchKernelGGL(embed_slots_kernel, dim3(batch), dim3(256), 0, e->stream, e->tokens, e->embed.weight_dev,
+                       (const uint16_t *)e->embed.scales_dev, (const uint16_t *)e->embed.biases_dev, e->x, c.hidden_size,
+                       c.vocab_size);
+    std::vector<std::pair<int32_t *, int32_t>> pk;
+    int max_ctx = 1;
+    for (int b = 0; b < batch; ++b) {
+        if (!e->slot_live[b]) continue;
+        const int rc = reserve_locked(e, b, e->slot_ctx[b] + 1, pk);
+        if (rc != TL_OK) {
+            cleanup();
+            return rc;
+        }
+        max_ctx = std::max(max_ctx, e->slot_ctx[b] + 1);
+    }
+    int rc = pk.empty() ? TL_OK : poke(e, pk);
+    const int n_splits = pick_decode_splits(e, batch, max_ctx);
+    if (rc == TL_OK) rc = enqueue_step(e, batch, n_splits, &pc);
+    if (rc != TL_OK) {
+        (void)hipStreamSynchronize(e->stream);
+        cleanup();
+        return rc;
+    }
+    e->warmed = true;
+    for (int b = 0; b < batch; ++b) {
+        if (!e->slot_live[b]) continue;
+        e->slot_ctx[b] += 1;
+        e->slot_produced[b] += 1;
+    }
+    e->stats.decode_steps++;
+    e->logits_rows = batch;
+    std::vector<prof_t> pairs(pc.kinds.size() * 2);
+    hipError_t he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = hipMemcpy(pairs.data(), pc.pairs, pairs.size() * sizeof(prof_t), hipMemcpyDeviceToHost);
+    cleanup();
+    if (he != hipSuccess) return fail(TL_ERR_HIP, std::string("engine_profile_step: ") + hipGetErrorString(he));
+
+    *out = tl_step_profile{};
+    out->clock_khz = rate_khz;
+    out->n_splits = n_splits;
+    const double us_per_tick = 1e3 / (double)rate_khz;
+    prof_t first = ~0ull, last = 0;
+    for (size_t i = 0; i < pc.kinds.size(); ++i) {
+        const prof_t t0 = pairs[2 * i], t1 = pairs[2 * i + 1];
+        const double us = (t1 > t0 ? (double)(t1 - t0) : 0.0) * us_per_tick;
+        first = std::min(first, t0);
+        last = std::max(last, t1);
+        out->kernel_us[pc.kinds[i]] += us;
+        out->launches[pc.kinds[i]] += 1;
+    }
+    out->span_us = (last > first ? (double)(last - first) : 0.0) * us_per_tick;
+    auto w4_bytes = [](const tl_w4 &w) { return (double)w.rows * w.cols / 2 + (double)w.rows * (w.cols / 128) * 4; };
+    for (const auto &l : e->layers) {
+        out->gemv_bytes[0] += w4_bytes(l.wqkv);
+        out->gemv_bytes[1] += w4_bytes(l.wo);
+        out->gemv_bytes[2] += w4_bytes(l.wgu);
+        out->gemv_bytes[3] += w4_bytes(l.wdown);
+    }
+    out->gemv_bytes[4] = w4_bytes(e->head());
+    return TL_OK;
 }

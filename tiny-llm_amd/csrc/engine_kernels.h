@@ -104,6 +104,7 @@ struct AttnDecodeArgs {
     int page_size, max_pages, num_heads, num_kv_heads;
     float scale, eps, rope_base;
     int n_splits, n_row_chunks;
+    prof_t *prof;
 };
 
 template <int VD, int U>
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     constexpr int D = 16 * VD;
     constexpr int STRIDE = D + 2;
     extern __shared__ __attribute__((aligned(16))) float psm[];  // [16][AD_RQ][STRIDE]
+    prof_begin(p.prof);
     const int split = blockIdx.x % p.n_splits;
     const int chunk = blockIdx.x / p.n_splits;
     const int kvh = blockIdx.y;
@@ -264,11 +266,13 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             }
         }
     }
+    prof_end(p.prof);
 }
 
 // partials [rows, n_splits, D+2] -> out [rows, D]
 __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out,
-                                                         int D, int n_splits) {
+                                                         int D, int n_splits, prof_t *prof) {
+    prof_begin(prof);
     const long orow = blockIdx.x;
     const int stride = D + 2;
     const float *base = ws + orow * n_splits * stride;
@@ -283,6 +287,7 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict
         }
         out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : vs / gl);
     }
+    prof_end(prof);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -307,12 +312,14 @@ struct StepEndArgs {
     const uint16_t *emb_s, *emb_b;
     uint16_t *x;  // [max_batch, hidden], row = slot
     int hidden;
+    prof_t *prof;
 };
 
 __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
     __shared__ float s_val[16];
     __shared__ int s_idx[16];
     __shared__ int s_token;
+    prof_begin(p.prof);
     const int i = blockIdx.x;
     const int slot = p.slot0 + i;
     const uint16_t *lg = p.logits + (long)i * p.vocab;
@@ -383,6 +390,37 @@ __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = BF16::from_float((float)((packed >> (4 * e)) & 0xfu) * scale + bias);
         *reinterpret_cast<uint4 *>(p.x + (long)slot * p.hidden + w * 8) = *reinterpret_cast<const uint4 *>(o);
+    }
+    prof_end(p.prof);
+}
+
+// (start, end) of one instrumented launch: min over workgroup starts, max over ends; clears the buffer.
+__global__ __launch_bounds__(1024) void prof_reduce_kernel(prof_t *buf, int n_wg, prof_t *out_pair) {
+    __shared__ prof_t s_min[16], s_max[16];
+    prof_t lo = ~0ull, hi = 0ull;
+    for (int i = threadIdx.x; i < n_wg; i += 1024) {
+        lo = min(lo, buf[2 * i]);
+        hi = max(hi, buf[2 * i + 1]);
+        buf[2 * i] = 0;
+        buf[2 * i + 1] = 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (prof_t)__shfl_xor((unsigned long long)lo, o, 64));
+        hi = max(hi, (prof_t)__shfl_xor((unsigned long long)hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_min[threadIdx.x >> 6] = lo;
+        s_max[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) {
+            lo = min(lo, s_min[w]);
+            hi = max(hi, s_max[w]);
+        }
+        out_pair[0] = lo;
+        out_pair[1] = hi;
     }
 }
 

@@ -45,6 +45,8 @@ struct QmvArgs {
     const uint16_t *residual;  // [M, K]   EPI_RESIDUAL
     float eps;
     int M, N, K;
+    prof_t *prof;   // nullptr except during an engine profile step
+    prof_t *trace;  // lab-only phase stamps (QMV2_TRACE builds)
 };
 
 template <typename TT>
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void qmv_kernel(const QmvArgs p) {
     constexpr int RB = 4 * WR * RPL;
     using D2 = Dot2<TT>;
 
+    prof_begin(p.prof);
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
@@ -296,7 +299,10 @@ __global__ __launch_bounds__(256) void qmv_kernel(const QmvArgs p) {
                 for (int m = 0; m < MR; ++m) red[((wave * RPL + rp) * 4 + rg) * MR + m] = acc[rp][m];
         }
         __syncthreads();
-        if (wn != 0) return;
+        if (wn != 0) {
+            prof_end(p.prof);
+            return;
+        }
 #pragma unroll
         for (int rp = 0; rp < RPL; ++rp)
 #pragma unroll
@@ -333,6 +339,7 @@ __global__ __launch_bounds__(256) void qmv_kernel(const QmvArgs p) {
             }
         }
     }
+    prof_end(p.prof);
 }
 
 // Host-side launch heuristic shared by the operator and the decode fast path.

@@ -1,0 +1,385 @@
+// W4A16 (group 128) decode GEMV on the matrix cores, over the engine's TILED weight layout (gfx950).
+//
+//   out[m,k] = sum_n a[m,n] * (q[k,n]*s[k,g] + beta[k,g])          (reference: quantized_matvec_x4_fast,
+//   quantized_matmul.metal:441-538; algebraic form sum_g (s_g sum a q + beta_g sum a), :510-521)
+//
+// What the measurements said (tools/lab, profiles/): the packed-dot GEMV (qmv.h) is VALU-bound at ~3.3 TB/s because
+// int4 carries 4x the multiply-adds per byte of bf16; a first MFMA version over the checkpoint layout spent its time
+// ISSUING loads (a lane-load of "16 rows x 64 B" touches 16 half-used cache lines, ~1.2 us to issue 10 of them) and
+// in a per-workgroup activation-staging prologue that sat in the same in-order vmcnt queue as the weight stream.
+// This kernel removes all three:
+//
+//  * TILED WEIGHTS (tl_repack_w4_tiled, done once when the engine adopts a checkpoint): for every 16-row tile and
+//    quantisation group the 16 x 64 B of packed nibbles are stored as one contiguous 1 KiB block in MFMA B-operand
+//    lane order, [tile][g][lane = r + 16 c][4 words]; a wave-load is one fully coalesced 1 KiB burst.  Inside a
+//    word the nibbles are reordered (n_i = q_2i, n_{i+4} = q_{2i+1}) so that (w >> 4i) & 0x000f000f | 0x43004300
+//    yields the bf16 pair (128+q_2i, 128+q_2i+1): weights unpack straight into natural k order and the activations
+//    need no permutation.  Scales and biases ride along as one dword (s | beta << 16) per (tile, g, row).
+//  * MATRIX CORES: D[act row][weight row] += A[act rows x 32 k] * B[32 k x 16 weight rows] with
+//    v_mfma_f32_16x16x32_bf16; a second MFMA against an all-ones B yields sum_k a for the bias term, so the VALU
+//    only unpacks nibbles (7 ops per 8 weights).  The 16 A rows are the decode batch (M <= 8; rows >= M repeat).
+//  * WAVE SPECIALISATION: the CW compute waves do nothing but put their whole weight slice in flight and wait at
+//    a barrier; one extra STAGER wave loads the activation rows (its own vmcnt queue), applies the fused RMSNorm,
+//    and writes bf16 rows to LDS.  Activation latency hides under the weight stream.
+//  * every load is unconditional from a clamped address (a divergent branch around a load makes hipcc wait for it
+//    at the join), and every compute wave runs a fixed Q3_LMAX-group body (surplus groups carry a zero scale).
+#pragma once
+#include "common.h"
+#include "qmv.h"
+
+namespace tl {
+
+constexpr int Q3_LMAX = 10;  // groups (1 KiB wave-loads) per compute wave
+constexpr int Q3_PAD = 8;    // bf16 elements of padding per activation row in LDS
+
+struct Qmv3Args {
+    const uint32_t *wt;   // tiled packed weights [K/16][G][64][4]
+    const uint32_t *sbt;  // tiled scale|bias<<16 (bf16 pair) [K/16][G][16]
+    const uint16_t *a;    // [M, N]
+    uint16_t *out;        // [M, K]  (EPI_SWIGLU: [M, K/2])
+    const uint16_t *norm_w;
+    const uint16_t *residual;
+    float eps;
+    int M, N, K;
+    prof_t *prof;
+#ifdef QMV3_LAB
+    int ablate;  // lab only: 1 = skip MFMA math, 2 = skip the activation barrier wait, 4 = stager does nothing
+#endif
+};
+
+#ifdef QMV3_LAB
+#define Q3_ABL(bit) (p.ablate & (bit))
+#else
+#define Q3_ABL(bit) 0
+#endif
+
+// LDS: activation rows [MR][N + Q3_PAD] bf16, then Q3_LMAX zero groups (a wave's fixed-length body may run past the
+// end of the row: it then reads finite data it multiplies by a zero scale); per-group sums [G + Q3_LMAX][16] fp32;
+// split-K partials.
+__host__ __device__ inline size_t qmv3_lds_xsum_off(int MR, int N) {
+    return (((size_t)MR * (N + Q3_PAD) + (size_t)Q3_LMAX * 128) * 2 + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t qmv3_lds_red_off(int MR, int N) {
+    return qmv3_lds_xsum_off(MR, N) + (size_t)(N / 128 + Q3_LMAX) * 16 * 4;
+}
+__host__ __device__ inline size_t qmv3_lds_bytes(int MR, int N, int KS, int CW) {
+    size_t red = KS > 1 ? (size_t)CW * MR * 16 * 4 : 0;
+    return qmv3_lds_red_off(MR, N) + red + (size_t)MR * CW * 4 + 64;  // + RMSNorm partial sums of squares
+}
+
+// 8 packed nibbles (n_i = q_2i, n_{i+4} = q_{2i+1}) -> four bf16 pairs (128+q_2i, 128+q_2i+1): 3 shifts + 4 v_bfi_b32
+// ((w & mask) | (magic & ~mask)).  hipcc emits v_and + v_or (11 ops) for the C expression because VOP3 on gfx9
+// cannot take two literals; here the mask sits in an SGPR and the magic in a VGPR.  The trailing s_nop covers the
+// VALU-write -> MFMA-read hazard that the compiler cannot see through an asm statement.
+__device__ __forceinline__ u32x4 unpack_w4_bf16(uint32_t w, uint32_t mask_s, uint32_t magic_v) {
+    uint32_t o0, o1, o2, o3;
+    asm("v_bfi_b32 %0, %5, %4, %6\n\t"
+        "v_lshrrev_b32 %1, 4, %4\n\t"
+        "v_lshrrev_b32 %2, 8, %4\n\t"
+        "v_lshrrev_b32 %3, 12, %4\n\t"
+        "v_bfi_b32 %1, %5, %1, %6\n\t"
+        "v_bfi_b32 %2, %5, %2, %6\n\t"
+        "v_bfi_b32 %3, %5, %3, %6\n\t"
+        "s_nop 1"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+        : "v"(w), "s"(mask_s), "v"(magic_v));
+    return u32x4{o0, o1, o2, o3};
+}
+
+template <int MR, int KS, int CW, int PRO, int EPI>
+__global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = CW * 64;
+    constexpr int WR = CW / KS;
+    constexpr int ROWS = MR < 4 ? MR : 4;  // accumulator rows a lane actually needs (lanes c > 0 only when MR > 4)
+    constexpr int XU = 4;                  // activation chunks a thread keeps in registers
+    prof_begin(p.prof);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the slice arithmetic on the SALU
+    const int lane = tid & 63;
+    const int N = p.N, K = p.K, G = N >> 7;
+    const int xstride = N + Q3_PAD;
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);
+    float *xsum = reinterpret_cast<float *>(smem + qmv3_lds_xsum_off(MR, N));  // [G + Q3_LMAX][16 activation rows]
+    float *red = reinterpret_cast<float *>(smem + qmv3_lds_red_off(MR, N));
+
+    const int r = lane & 15;  // B: weight row in tile | A: activation row | D: weight row (column)
+    const int c = lane >> 4;  // A, B: k-block         | D: activation rows 4c .. 4c+3
+    const int wt = wave / KS;
+    const int ks = wave - wt * KS;
+    const int tiles = K >> 4;
+    const int tile = blockIdx.x * WR + wt;
+    const bool tile_ok = tile < tiles;
+    const int tile_c = tile_ok ? tile : 0;
+    const int Lper = (G + KS - 1) / KS;
+    const int g0 = ks * Lper;
+    const int g1 = min(g0 + Lper, G);
+
+    // ---- 1. every load of the workgroup goes out first, smallest (and first needed) first: vmcnt retires in order ----
+    const int cpr = N >> 3;  // 16-byte chunks per activation row (a multiple of 16: one group = 16 chunks)
+    const int total = MR * cpr;
+    const bool reg_path = total <= XU * T;  // all activation chunks fit in registers: one global round trip
+    u32x4 xv[XU], nwv[XU];
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+        const int i = tid + u * T;
+        int m = 0, cc = i;
+        if constexpr (MR > 1) {
+            m = i / cpr;
+            cc = i - m * cpr;
+        }
+        const bool ok = reg_path && i < total && m < p.M;
+        xv[u] = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0));
+        if (!ok) xv[u] = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (PRO == PRO_RMSNORM)
+            nwv[u] = *reinterpret_cast<const u32x4 *>(p.norm_w + (size_t)((reg_path && i < total) ? cc : 0) * 8);
+        else
+            nwv[u] = u32x4{0u, 0u, 0u, 0u};
+    }
+    u32x4 wq[Q3_LMAX];
+    uint32_t sq[Q3_LMAX];
+    {
+        const uint32_t *sp = p.sbt + (size_t)tile_c * G * 16 + r;
+#pragma unroll
+        for (int i = 0; i < Q3_LMAX; ++i) sq[i] = sp[(size_t)min(g0 + i, G - 1) * 16];
+        const u32x4 *wp = reinterpret_cast<const u32x4 *>(p.wt) + (size_t)tile_c * G * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < Q3_LMAX; ++i) wq[i] = __builtin_nontemporal_load(wp + (size_t)min(g0 + i, G - 1) * 64);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 2. activation rows -> LDS (bf16, natural order) + per-group sums; fused RMSNorm ----------------------------
+    {
+        // zero tails (read by the fixed-length compute body, multiplied by a zero scale)
+        u32x4 *zx = reinterpret_cast<u32x4 *>(xs + (size_t)MR * xstride);
+        for (int i = tid; i < Q3_LMAX * 16; i += T) zx[i] = u32x4{0u, 0u, 0u, 0u};
+        if (tid < MR) *reinterpret_cast<u32x4 *>(xs + (size_t)tid * xstride + N) = u32x4{0u, 0u, 0u, 0u};  // row padding (Q3_PAD = 8)
+        f32x4 *zs = reinterpret_cast<f32x4 *>(xsum + (size_t)G * 16);
+        for (int i = tid; i < Q3_LMAX * 4; i += T) zs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto chunk_sumsq = [](const u32x4 &v) {
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = BF16::to_float((uint16_t)(v[e] & 0xffffu));
+            const float hi = BF16::to_float((uint16_t)(v[e] >> 16));
+            part += lo * lo + hi * hi;
+        }
+        return part;
+    };
+    // normalise (optional), store chunk (m, cc), and contribute to its group's sum (16 consecutive lanes = one group)
+    auto finish_chunk = [&](int m, int cc, u32x4 v, const u32x4 &g, float iv) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[2 * e] = BF16::to_float((uint16_t)(v[e] & 0xffffu));
+            f[2 * e + 1] = BF16::to_float((uint16_t)(v[e] >> 16));
+        }
+        if constexpr (PRO == PRO_RMSNORM) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = bf16_round(f[2 * e] * iv * BF16::to_float((uint16_t)(g[e] & 0xffffu)));
+                f[2 * e + 1] = bf16_round(f[2 * e + 1] * iv * BF16::to_float((uint16_t)(g[e] >> 16)));
+                v[e] = BF16::pack2(f[2 * e], f[2 * e + 1]);
+            }
+        }
+        *reinterpret_cast<u32x4 *>(xs + (size_t)m * xstride + (size_t)cc * 8) = v;
+        float sum = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+        sum = group16_sum(sum);
+        if ((cc & 15) == 0) xsum[(cc >> 4) * 16 + m] = sum;
+    };
+    float inv[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) inv[m] = 1.0f;
+    if constexpr (PRO == PRO_RMSNORM) {
+        float ss[MR];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) ss[m] = 0.f;
+        if (reg_path) {
+#pragma unroll
+            for (int u = 0; u < XU; ++u) {
+                const float part = chunk_sumsq(xv[u]);
+                if constexpr (MR == 1) {
+                    ss[0] += part;
+                } else {
+                    const int m = (tid + u * T) / cpr;
+#pragma unroll
+                    for (int mm = 0; mm < MR; ++mm) ss[mm] += (mm == m) ? part : 0.f;
+                }
+            }
+        } else {
+            // many / long rows: pass 1 parks the raw rows in LDS and accumulates the sums of squares
+            for (int i = tid; i < total; i += T) {
+                const int m = i / cpr;
+                const int cc = i - m * cpr;
+                const bool ok = m < p.M;
+                u32x4 v = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0));
+                if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4 *>(xs + (size_t)m * xstride + (size_t)cc * 8) = v;
+                const float part = chunk_sumsq(v);
+#pragma unroll
+                for (int mm = 0; mm < MR; ++mm) ss[mm] += (mm == m) ? part : 0.f;
+            }
+        }
+        float *scratch = red + (KS > 1 ? (size_t)CW * MR * 16 : 0);  // sized in qmv3_lds_bytes
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const float v = wave_sum(ss[m]);
+            if (lane == 0) scratch[m * CW + wave] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < CW; ++w) tot += scratch[m * CW + w];
+            inv[m] = rsqrtf(tot / (float)N + p.eps);
+        }
+    }
+    if (reg_path) {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = tid + u * T;
+            if (i < total) {  // uniform per 16 lanes (total % 16 == 0)
+                int m = 0, cc = i;
+                float iv = inv[0];
+                if constexpr (MR > 1) {
+                    m = i / cpr;
+                    cc = i - m * cpr;
+#pragma unroll
+                    for (int mm = 0; mm < MR; ++mm) iv = (mm == m) ? inv[mm] : iv;
+                }
+                finish_chunk(m, cc, xv[u], nwv[u], iv);
+            }
+        }
+    } else {
+        for (int i = tid; i < total; i += T) {  // each thread revisits exactly the chunks it parked
+            const int m = i / cpr;
+            const int cc = i - m * cpr;
+            u32x4 v, g = u32x4{0u, 0u, 0u, 0u};
+            if constexpr (PRO == PRO_RMSNORM) {
+                v = *reinterpret_cast<const u32x4 *>(xs + (size_t)m * xstride + (size_t)cc * 8);
+                g = *reinterpret_cast<const u32x4 *>(p.norm_w + (size_t)cc * 8);
+            } else {
+                const bool ok = m < p.M;
+                v = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0));
+                if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+            }
+            float iv = 1.0f;
+#pragma unroll
+            for (int mm = 0; mm < MR; ++mm) iv = (mm == m) ? inv[mm] : iv;
+            finish_chunk(m, cc, v, g, iv);
+        }
+    }
+    __syncthreads();  // activations are staged
+
+    float acc[ROWS];
+#pragma unroll
+    for (int i2 = 0; i2 < ROWS; ++i2) acc[i2] = 0.f;
+    // LDS addresses: one VGPR base + compile-time offsets (rows >= MR of the A operand repeat row r % MR; never stored)
+    const uint16_t *xbase = xs + (size_t)(r % MR) * xstride + 32 * c + (size_t)g0 * 128;
+    const float *sbase = xsum + (size_t)g0 * 16 + 4 * c;
+    const uint32_t nib_mask = 0x000f000fu;
+    uint32_t magic = 0x43004300u;
+    asm volatile("" : "+v"(magic));  // keep the constant in a VGPR (VOP3 takes one scalar operand)
+#pragma unroll
+    for (int i = 0; i < Q3_LMAX; ++i) {
+        if (Q3_ABL(1)) {
+            acc[0] += __uint_as_float((wq[i][0] ^ wq[i][1] ^ wq[i][2] ^ wq[i][3]) & 0x3fffffffu) + __uint_as_float(sq[i] & 0x3fffffffu);
+            continue;
+        }
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u32x4 bq = unpack_w4_bf16(wq[i][t], nib_mask, magic);
+            const u32x4 ax = *reinterpret_cast<const u32x4 *>(xbase + i * 128 + 8 * t);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax), __builtin_bit_cast(bf16x8_t, bq), d,
+                                                        0, 0, 0);
+        }
+        const uint32_t sw = (g0 + i) < g1 ? sq[i] : 0u;  // surplus groups of the fixed-length body contribute nothing
+        const float sc = __uint_as_float(sw << 16);
+        const float be = __uint_as_float(sw & 0xffff0000u) - 128.0f * sc;
+        if constexpr (ROWS == 4) {
+            const f32x4 xg = *reinterpret_cast<const f32x4 *>(sbase + i * 16);
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) acc[i2] += sc * d[i2] + be * xg[i2];
+        } else {
+#pragma unroll
+            for (int i2 = 0; i2 < ROWS; ++i2) acc[i2] += sc * d[i2] + be * sbase[i * 16 + i2];
+        }
+    }
+
+    if constexpr (KS > 1) {
+#pragma unroll
+        for (int i2 = 0; i2 < ROWS; ++i2) {
+            const int arow = 4 * c + i2;
+            if (arow < MR) red[((size_t)wave * MR + arow) * 16 + r] = acc[i2];
+        }
+        __syncthreads();
+        if (ks != 0) {
+            prof_end(p.prof);
+            return;
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < ROWS; ++i2) {
+            const int arow = 4 * c + i2;
+            if (arow < MR) {
+#pragma unroll
+                for (int k2 = 1; k2 < KS; ++k2) acc[i2] += red[((size_t)(wave + k2) * MR + arow) * 16 + r];
+            }
+        }
+    }
+
+    // epilogue: lane (weight row r, c) holds activation rows 4c .. 4c + ROWS - 1
+    const int orow = (tile_c << 4) + r;
+#pragma unroll
+    for (int i2 = 0; i2 < ROWS; ++i2) {
+        const int arow = 4 * c + i2;
+        const bool live = tile_ok && arow < MR && arow < p.M;
+        if constexpr (EPI == EPI_SWIGLU) {
+            const float gv = bf16_round(acc[i2]);  // rows interleaved: even = gate_i, odd = up_i
+            const float uv = __shfl_down(gv, 1, 64);
+            if (live && (r & 1) == 0)
+                p.out[(size_t)arow * (K >> 1) + (orow >> 1)] = BF16::from_float((gv / (1.0f + expf(-gv))) * uv);
+        } else if constexpr (EPI == EPI_RESIDUAL) {
+            if (live) {
+                const size_t o = (size_t)arow * K + orow;
+                p.out[o] = BF16::from_float(BF16::to_float(p.residual[o]) + bf16_round(acc[i2]));
+            }
+        } else {
+            if (live) p.out[(size_t)arow * K + orow] = BF16::from_float(acc[i2]);
+        }
+    }
+    prof_end(p.prof);
+}
+
+struct Qmv3Plan {
+    int MR, KS, CW, blocks;
+    size_t lds;
+    bool ok;
+};
+inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0) {
+    Qmv3Plan pl{};
+    pl.MR = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
+    const int G = N / 128;
+    const int tiles = K / 16;
+    int ks = 1;
+    while (ks < 8 && (G + ks - 1) / ks > Q3_LMAX) ks *= 2;
+    if (force_ks > 0) ks = force_ks;
+    pl.KS = ks;
+    pl.CW = ks == 8 ? 8 : 4;
+    const int wr = pl.CW / pl.KS;
+    pl.blocks = (tiles + wr - 1) / wr;
+    pl.lds = qmv3_lds_bytes(pl.MR, N, pl.KS, pl.CW);
+    pl.ok = K > 0 && K % 16 == 0 && N % 128 == 0 && M >= 1 && M <= 8 && (G + ks - 1) / ks <= Q3_LMAX &&
+            pl.lds <= 150 * 1024;
+    return pl;
+}
+
+// qmv3.hip
+int launch_qmv3_bf16(const Qmv3Args &args, int pro, int epi, hipStream_t st, int force_ks = 0);  // -1: not applicable
+// standard checkpoint layout -> tiled layout (device to device, stream ordered)
+int repack_w4_tiled(const uint32_t *w, const uint16_t *scales, const uint16_t *biases, uint32_t *wt, uint32_t *sbt, int K,
+                    int N, hipStream_t st);
+
+}  // namespace tl

@@ -1,0 +1,81 @@
+// Launcher of the tiled-layout MFMA decode GEMV (qmv3.h) + the one-time checkpoint repack.
+#include "qmv3.h"
+
+namespace tl {
+
+// standard [K][N/8] words (nibble i of word j = element 8j+i, reference quantize.py:113-115) + [K][G] bf16 scales/biases
+//   -> wt  [K/16][G][64 lanes][4 words]  lane = r + 16c, word t = original word g*16 + 4c + t of row 16*tile + r,
+//          nibbles reordered to (q0,q2,q4,q6,q1,q3,q5,q7)
+//   -> sbt [K/16][G][16]  scale | bias << 16
+__global__ __launch_bounds__(256) void repack_w4_tiled_kernel(const uint32_t *__restrict__ w,
+                                                              const uint16_t *__restrict__ scales,
+                                                              const uint16_t *__restrict__ biases,
+                                                              uint32_t *__restrict__ wt, uint32_t *__restrict__ sbt, int K,
+                                                              int N) {
+    const int G = N >> 7, words = N >> 3;
+    const size_t total = (size_t)K * words;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // output word index
+    if (idx < total) {
+        const int t = (int)(idx & 3);
+        const int lane = (int)((idx >> 2) & 63);
+        const size_t tg = idx >> 8;  // tile * G + g
+        const int g = (int)(tg % G);
+        const size_t tile = tg / G;
+        const int r = lane & 15, c = lane >> 4;
+        const uint32_t v = w[(tile * 16 + r) * words + g * 16 + 4 * c + t];
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o |= ((v >> (8 * i)) & 0xfu) << (4 * i);            // q_2i   -> nibble i
+            o |= ((v >> (8 * i + 4)) & 0xfu) << (4 * i + 16);   // q_2i+1 -> nibble i + 4
+        }
+        wt[idx] = o;
+    }
+    const size_t stotal = (size_t)K * G;
+    if (idx < stotal) {
+        const int r = (int)(idx & 15);
+        const size_t tg = idx >> 4;
+        const int g = (int)(tg % G);
+        const size_t tile = tg / G;
+        const size_t src = (tile * 16 + r) * G + g;
+        sbt[idx] = (uint32_t)scales[src] | ((uint32_t)biases[src] << 16);
+    }
+}
+
+int repack_w4_tiled(const uint32_t *w, const uint16_t *scales, const uint16_t *biases, uint32_t *wt, uint32_t *sbt, int K,
+                    int N, hipStream_t st) {
+    const size_t total = (size_t)K * (N / 8);
+    hipLaunchKernelGGL(repack_w4_tiled_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, scales, biases, wt,
+                       sbt, K, N);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int PRO, int EPI>
+static int launch_variant3(const Qmv3Args &args, hipStream_t st, int force_ks) {
+    const Qmv3Plan pl = qmv3_plan(args.M, args.N, args.K, force_ks);
+    if (!pl.ok) return -1;
+    const dim3 grid(pl.blocks), block(pl.CW * 64);
+#define Q3_CASE(MRv, KSv, CWv)                                                                                      \
+    if (pl.MR == MRv && pl.KS == KSv && pl.CW == CWv) {                                                             \
+        auto kern = qmv3_kernel<MRv, KSv, CWv, PRO, EPI>;                                                           \
+        if (pl.lds > 64 * 1024)                                                                                     \
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
+        hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                                    \
+        return 0;                                                                                                   \
+    }
+#define Q3_MR(MRv) Q3_CASE(MRv, 1, 4) Q3_CASE(MRv, 2, 4) Q3_CASE(MRv, 4, 4) Q3_CASE(MRv, 8, 8)
+    Q3_MR(1) Q3_MR(2) Q3_MR(4) Q3_MR(8)
+#undef Q3_MR
+#undef Q3_CASE
+    return -2;
+}
+
+int launch_qmv3_bf16(const Qmv3Args &args, int pro, int epi, hipStream_t st, int force_ks) {
+    if (pro == PRO_NONE && epi == EPI_STORE) return launch_variant3<PRO_NONE, EPI_STORE>(args, st, force_ks);
+    if (pro == PRO_RMSNORM && epi == EPI_STORE) return launch_variant3<PRO_RMSNORM, EPI_STORE>(args, st, force_ks);
+    if (pro == PRO_NONE && epi == EPI_RESIDUAL) return launch_variant3<PRO_NONE, EPI_RESIDUAL>(args, st, force_ks);
+    if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) return launch_variant3<PRO_RMSNORM, EPI_SWIGLU>(args, st, force_ks);
+    return -2;
+}
+
+}  // namespace tl

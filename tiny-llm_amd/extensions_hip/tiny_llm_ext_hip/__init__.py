@@ -92,8 +92,14 @@ class TlEngineStats(ctypes.Structure):
                 ("prefill_tokens", ctypes.c_long), ("kv_bytes", _c_size_t), ("workspace_bytes", _c_size_t)]
 
 
+class TlStepProfile(ctypes.Structure):
+    _fields_ = [("kernel_us", ctypes.c_double * 8), ("launches", _c_int * 8), ("gemv_bytes", ctypes.c_double * 5),
+                ("span_us", ctypes.c_double), ("clock_khz", _c_int), ("n_splits", _c_int)]
+
+
 _P = ctypes.POINTER
 _SIGNATURES.update({
+    "tl_engine_profile_step": (_c_int, [_c_void_p, _c_int, _P(TlStepProfile)]),
     "tl_engine_create": (_c_int, [_P(TlEngineConfig), _P(TlLayerWeights), _P(TlW4), _c_void_p, _P(TlW4), _c_void_p,
                                   _P(_c_void_p)]),
     "tl_engine_destroy": (None, [_c_void_p]),

@@ -173,6 +173,19 @@ class DecodeEngine:
     def step_bytes(self, batch: int | None = None) -> int:
         return int(_lib.tl_engine_step_bytes(self._h, batch or self.max_batch))
 
+    PROFILE_KINDS = ("gemv_qkv", "gemv_o", "gemv_gate_up", "gemv_down", "gemv_lm_head", "attention",
+                     "attention_merge", "step_end")
+
+    def profile_step(self, batch: int | None = None) -> dict:
+        """One real decode step with in-kernel clock stamps (tl_engine_profile_step): per-kind kernel time."""
+        p = _ext.TlStepProfile()
+        _ext.check(_lib.tl_engine_profile_step(self._h, batch or self.max_batch, ctypes.byref(p)))
+        out = {"span_us": p.span_us, "clock_khz": p.clock_khz, "n_splits": p.n_splits, "kinds": {}}
+        for i, name in enumerate(self.PROFILE_KINDS):
+            out["kinds"][name] = {"us": p.kernel_us[i], "launches": p.launches[i],
+                                  "bytes": p.gemv_bytes[i] if i < 5 else 0.0}
+        return out
+
     def stats(self) -> dict:
         s = _ext.TlEngineStats()
         _ext.check(_lib.tl_engine_get_stats(self._h, ctypes.byref(s)))
