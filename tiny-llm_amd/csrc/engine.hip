@@ -76,7 +76,9 @@ struct tl_engine {
     tl_engine_stats stats{};
 
     bool warmed = false;
-    std::map<std::pair<int, int>, hipGraphExec_t> graphs;
+    std::map<std::pair<int, long>, hipGraphExec_t> graphs;  // (batch, n_splits << 32 | tokens_per_split)
+    float2 *rope_table = nullptr;
+    int rope_positions = 0;
     int logits_rows = 0;
 
     int qkv_dim() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
@@ -179,16 +181,19 @@ static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
     return TL_OK;
 }
 
-static int pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
+// Context split of the decode attention: power-of-two bucket >= context, fixed windows of C tokens per workgroup.
+struct SplitPlan {
+    int n_splits, tokens_per_split;
+};
+static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
     const int rep = e->cfg.num_heads / e->cfg.num_kv_heads;
     const int chunks = (rep + AD_RQ - 1) / AD_RQ;
     const int base = std::max(1, batch * e->cfg.num_kv_heads * chunks);
     int bucket = 64;
     while (bucket < max_ctx) bucket *= 2;
-    int s = bucket / 64;                        // >= 64 cached tokens per workgroup
-    s = std::min(s, std::max(1, 1024 / base));  // ~4 workgroups per CU is plenty
-    s = std::min(s, 64);
-    return std::max(s, 1);
+    int s = 1;
+    while (s * 2 <= bucket / 64 && s * 2 * base <= 1024 && s * 2 <= 64) s *= 2;  // >= 64 tokens per workgroup
+    return SplitPlan{s, bucket / s};
 }
 
 template <int VD>
@@ -198,7 +203,8 @@ static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t s
 }
 
 // One fused decode step over slots [0, batch).
-static int enqueue_step(tl_engine *e, int batch, int n_splits, ProfCtx *pc = nullptr) {
+static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nullptr) {
+    const int n_splits = sp.n_splits;
     const tl_engine_config &c = e->cfg;
     const int D = c.head_dim;
     const int rep = c.num_heads / c.num_kv_heads;
@@ -225,6 +231,9 @@ static int enqueue_step(tl_engine *e, int batch, int n_splits, ProfCtx *pc = nul
         a.rope_base = c.rope_theta;
         a.n_splits = n_splits;
         a.n_row_chunks = chunks;
+        a.tokens_per_split = sp.tokens_per_split;
+        a.rope_table = e->rope_table;
+        a.rope_positions = e->rope_positions;
         a.prof = pc ? pc->buf : nullptr;
         const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
         switch (D) {
@@ -235,8 +244,16 @@ static int enqueue_step(tl_engine *e, int batch, int n_splits, ProfCtx *pc = nul
         }
         if (pc) prof_after(e, pc, 5, (int)(grid.x * grid.y * grid.z));
         if (n_splits > 1) {
-            hipLaunchKernelGGL(attn_merge_kernel, dim3(batch * c.num_heads), dim3(128), 0, e->stream, e->attn_ws,
-                               e->attn, D, n_splits, pc ? pc->buf : nullptr);
+            const dim3 mg(batch * c.num_heads), mb(128);
+            prof_t *pb = pc ? pc->buf : nullptr;
+            switch (n_splits) {
+                case 2: hipLaunchKernelGGL(attn_merge_kernel<2>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
+                case 4: hipLaunchKernelGGL(attn_merge_kernel<4>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
+                case 8: hipLaunchKernelGGL(attn_merge_kernel<8>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
+                case 16: hipLaunchKernelGGL(attn_merge_kernel<16>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
+                case 32: hipLaunchKernelGGL(attn_merge_kernel<32>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
+                default: hipLaunchKernelGGL(attn_merge_kernel<64>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
+            }
             if (pc) prof_after(e, pc, 6, batch * c.num_heads);
         }
         TL_CHECK_LAUNCH("engine attention");
@@ -392,6 +409,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
         if (e->arena) (void)hipFree(e->arena);
         if (e->kpool) (void)hipFree(e->kpool);
         if (e->vpool) (void)hipFree(e->vpool);
+        if (e->rope_table) (void)hipFree(e->rope_table);
         if (e->owns_stream) (void)hipStreamDestroy(e->stream);
         delete e;
         return fail(TL_ERR_HIP, msg);
@@ -402,6 +420,11 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (hipMalloc((void **)&e->kpool, pool_bytes) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(key pages) failed");
     if (hipMalloc((void **)&e->vpool, pool_bytes) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(value pages) failed");
     e->kv_bytes = 2 * pool_bytes;
+    // Masked (out-of-context) token slots are still loaded and multiplied by a zero weight in the decode kernel,
+    // so the pools must never hold NaN/Inf bit patterns: start from zeros (kernels only ever write finite values).
+    if (hipMemsetAsync(e->kpool, 0, pool_bytes, e->stream) != hipSuccess ||
+        hipMemsetAsync(e->vpool, 0, pool_bytes, e->stream) != hipSuccess)
+        return cleanup_fail("engine_create: memset(KV pools) failed");
 
     char *A = e->arena;
     e->block_table = (int32_t *)(A + o_bt);
@@ -430,6 +453,18 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const int bt_n = c.max_batch * c.max_pages_per_seq;
     hipLaunchKernelGGL(fill_i32_kernel, dim3(ceil_div(bt_n, 256)), dim3(256), 0, e->stream, e->block_table, -1, bt_n);
     if (hipGetLastError() != hipSuccess) return cleanup_fail("engine_create: block-table init failed");
+
+    // RoPE table for every position a sequence can reach
+    {
+        const long max_pos = std::min<long>((long)c.max_pages_per_seq * c.page_size + 1, 1 << 20);
+        e->rope_positions = (int)max_pos;
+        const int half = c.head_dim / 2;
+        if (hipMalloc((void **)&e->rope_table, (size_t)max_pos * half * sizeof(float2)) != hipSuccess)
+            return cleanup_fail("engine_create: hipMalloc(rope table) failed");
+        hipLaunchKernelGGL(rope_table_kernel, dim3(ceil_div(max_pos * half, 256)), dim3(256), 0, e->stream, e->rope_table,
+                           (int)max_pos, half, c.rope_theta);
+        if (hipGetLastError() != hipSuccess) return cleanup_fail("engine_create: rope table kernel failed");
+    }
 
     // decode-path weight copies in the tiled MFMA layout
     {
@@ -486,6 +521,7 @@ extern "C" void tl_engine_destroy(tl_engine *e) {
     if (e->kpool) (void)hipFree(e->kpool);
     if (e->vpool) (void)hipFree(e->vpool);
     if (e->splitk_ws) (void)hipFree(e->splitk_ws);
+    if (e->rope_table) (void)hipFree(e->rope_table);
     for (auto &kv : e->tiled) {
         (void)hipFree(kv.second.wt);
         (void)hipFree(kv.second.sbt);
@@ -720,14 +756,14 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
             e->stats.pages_free = (int)e->free_pages.size();
             TL_TRY(poke(e, pk));
         }
-        const int n_splits = pick_decode_splits(e, batch, max_ctx);
+        const SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
         if (use_graph && e->warmed) {
-            const auto key = std::make_pair(batch, n_splits);
+            const auto key = std::make_pair(batch, ((long)sp.n_splits << 32) | (long)sp.tokens_per_split);
             auto it = e->graphs.find(key);
             if (it == e->graphs.end()) {
                 hipGraph_t graph = nullptr;
                 TL_HIP(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-                const int rc = enqueue_step(e, batch, n_splits);
+                const int rc = enqueue_step(e, batch, sp);
                 const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
                 if (rc != TL_OK) {
                     if (graph) (void)hipGraphDestroy(graph);
@@ -744,7 +780,7 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
             TL_HIP(hipGraphLaunch(it->second, e->stream));
             e->stats.graph_replays++;
         } else {
-            TL_TRY(enqueue_step(e, batch, n_splits));
+            TL_TRY(enqueue_step(e, batch, sp));
             e->warmed = true;
         }
         for (int b = 0; b < batch; ++b) {
@@ -840,8 +876,9 @@ extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *
         max_ctx = std::max(max_ctx, e->slot_ctx[b] + 1);
     }
     int rc = pk.empty() ? TL_OK : poke(e, pk);
-    const int n_splits = pick_decode_splits(e, batch, max_ctx);
-    if (rc == TL_OK) rc = enqueue_step(e, batch, n_splits, &pc);
+    const SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
+    const int n_splits = sp.n_splits;
+    if (rc == TL_OK) rc = enqueue_step(e, batch, sp, &pc);
     if (rc != TL_OK) {
         (void)hipStreamSynchronize(e->stream);
         cleanup();

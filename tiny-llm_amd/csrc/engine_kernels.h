@@ -83,13 +83,60 @@ __device__ __forceinline__ void head_norm_rope(const uint16_t *src, const uint16
 }
 
 // ---------------------------------------------------------------------------------------------
+// RoPE table: (cos, sin) of position * base^(-item / half) for every position the engine can hold, computed on the
+// device with the SAME expression as rope_kernel (pointwise.hip) / the reference fast kernel
+// (week2_kernels.metal:86-104), so table and on-the-fly values are bit-identical.  Decode then does no trig at all.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_table_kernel(float2 *__restrict__ table, int max_pos, int half, float base) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)max_pos * half) return;
+    const int pos = (int)(idx / half);
+    const int item = (int)(idx - (long)pos * half);
+    const float fp = -(float)item / (float)half;
+    const float angle = (float)pos * exp2f(fp * log2f(base));
+    float s, c;
+    sincosf(angle, &s, &c);
+    table[idx] = make_float2(c, s);
+}
+
+template <int VD>
+__device__ __forceinline__ void rope_from_table(const float2 *__restrict__ row, int t, float (&cs)[VD], float (&sn)[VD]) {
+    const float2 *p = row + (t & 7) * VD;
+#pragma unroll
+    for (int i = 0; i < VD; ++i) {
+        const float2 v = p[i];
+        cs[i] = v.x;
+        sn[i] = v.y;
+    }
+}
+
+// all-reduce over an aligned group of 16 lanes with DPP row rotations (4 VALU ops, no LDS crossbar traffic)
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float group16_allsum(float v) {
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Decode attention with fused q/k-norm + RoPE + paged KV append (L = 1).
 //   grid = (n_splits * n_row_chunks, Hkv, batch); workgroup = 16 groups x 16 lanes.
-//   A workgroup owns one KV head, up to AD_RQ query heads of its GQA group and one slice of the cached
-//   context; a 16-lane group reads one token's K row and V row as 16 x 16 B (coalesced 256 B), U tokens in
-//   flight per group.  The token being decoded never round-trips through HBM: its K/V come from registers
-//   (split 0) and are written to the page by one group.  n_splits == 1 writes the output row, otherwise
-//   (m, l, acc) partials for attn_merge_kernel.
+//   A workgroup owns one KV head, up to AD_RQ query heads of its GQA group and the FIXED token window
+//   [split * C, split * C + C) of the context (C = tokens_per_split, chosen by the host from a power-of-two bucket,
+//   so no address depends on the device-side context length — only the masks do).  A 16-lane group reads one
+//   token's K row and V row as 16 x 16 B (coalesced 256 B); U tokens per group are in flight, and the next
+//   window's page ids and K/V are requested before the current one is reduced.
+//   Latency structure (decode attention at short context is pure latency): one round trip for
+//   {context length, page ids, the q/k/v row, norm weights}, one dependent round trip for {K/V rows, RoPE table row,
+//   the append slot}; every load is unconditional from a clamped address (hipcc waits at the join of any divergent
+//   branch that contains a load).
+//   The token being decoded never round-trips through HBM: its K/V come from registers (split 0) and are written to
+//   the page by one group.  n_splits == 1 writes the output row, otherwise (m, l, acc) partials for the merge kernel.
 //   reference semantics: paged_attention.metal:108-248 (decode), paged_cache_update :82-106,
 //   qwen3_week3.py:63-86 for the op order.
 // ---------------------------------------------------------------------------------------------
@@ -101,11 +148,39 @@ struct AttnDecodeArgs {
     const int32_t *context_lens;        // [max_batch] tokens already cached (= position of the new token)
     uint16_t *out;                      // [batch, Hq * D]
     float *ws;                          // [batch * Hq, n_splits, D + 2]
+    const float2 *rope_table;           // [rope_positions, D / 2] (cos, sin)
+    int rope_positions;
     int page_size, max_pages, num_heads, num_kv_heads;
     float scale, eps, rope_base;
-    int n_splits, n_row_chunks;
+    int n_splits, n_row_chunks, tokens_per_split;
     prof_t *prof;
 };
+
+template <int VD>
+struct alignas(2 * VD) RawRow {
+    uint16_t v[VD];
+};
+template <int VD>
+__device__ __forceinline__ void load_raw(const uint16_t *src, RawRow<VD> &r) {
+    if constexpr (VD == 8) {
+        *reinterpret_cast<uint4 *>(r.v) = *reinterpret_cast<const uint4 *>(src);
+    } else if constexpr (VD == 4) {
+        *reinterpret_cast<uint2 *>(r.v) = *reinterpret_cast<const uint2 *>(src);
+    } else {
+        *reinterpret_cast<uint32_t *>(r.v) = *reinterpret_cast<const uint32_t *>(src);
+    }
+}
+
+template <int VD>
+__device__ __forceinline__ void store_raw(uint16_t *dst, const RawRow<VD> &r) {
+    if constexpr (VD == 8) {
+        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(r.v);
+    } else if constexpr (VD == 4) {
+        *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(r.v);
+    } else {
+        *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(r.v);
+    }
+}
 
 template <int VD, int U>
 __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecodeArgs p) {
@@ -121,34 +196,89 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     const int rep = Hq / Hkv;
     const int g = threadIdx.x >> 4;
     const int t = threadIdx.x & 15;
-    const int ctx = p.context_lens[b];
-    const int wp = ctx / p.page_size;
-    const int wslot = ctx - wp * p.page_size;
-    const int wpage = wp < p.max_pages ? p.block_table[(long)b * p.max_pages + wp] : -1;
-    const bool live = wpage >= 0;  // idle slots have an all -1 row: they produce zeros
+    const int32_t *brow = p.block_table + (long)b * p.max_pages;
     const uint16_t *row = p.qkv + (long)b * (Hq + 2 * Hkv) * D;
     const float scale_log2 = p.scale * ENG_LOG2E;
+    const int C = p.tokens_per_split;
+    const int t_begin = split * C;
+    const int n_it = (C + 16 * U - 1) / (16 * U);
 
+    // ---- round trip 1: everything whose address is known at launch ---------------------------------------------
+    const int ctx = p.context_lens[b];
+    int pid[U], pid_next[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int tok = t_begin + u * 16 + g;
+        pid[u] = brow[min(tok / p.page_size, p.max_pages - 1)];
+        pid_next[u] = brow[min((tok + 16 * U) / p.page_size, p.max_pages - 1)];
+    }
+    RawRow<VD> kraw_new, vraw_new, qraw[AD_RQ], qw, kw;
+    load_raw<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
+    load_raw<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
+    load_raw<VD>(p.q_norm_w + t * VD, qw);
+    load_raw<VD>(p.k_norm_w + t * VD, kw);
+#pragma unroll
+    for (int r = 0; r < AD_RQ; ++r) {
+        const int hq = min(chunk * AD_RQ + r, rep - 1);
+        load_raw<VD>(row + (long)(kvh * rep + hq) * D + t * VD, qraw[r]);
+    }
+
+    // ---- round trip 2: addresses that depend on the context length / page ids -----------------------------------
+    const int wp = ctx / p.page_size;
+    const int wslot = ctx - wp * p.page_size;
+    const int wpage = brow[min(wp, p.max_pages - 1)];
+    const bool live = wp < p.max_pages && wpage >= 0;  // idle slots have an all -1 row: they produce zeros
     float cs[VD], sn[VD];
-    rope_factors<VD>(t, ctx, p.rope_base, cs, sn);
+    rope_from_table<VD>(p.rope_table + (long)min(ctx, p.rope_positions - 1) * (D / 2), t, cs, sn);
+    RawRow<VD> kr[U], vr[U], kr_next[U], vr_next[U];
+    bool ok[U];
+    auto issue_kv = [&](int base, const int (&ids)[U], RawRow<VD> (&kk)[U], RawRow<VD> (&vv)[U], bool (&valid)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tok = base + u * 16 + g;
+            const int lp = tok / p.page_size;
+            const int slot = tok - lp * p.page_size;
+            valid[u] = tok < ctx && tok < t_begin + C && lp < p.max_pages && ids[u] >= 0;
+            const long off = (((long)max(ids[u], 0) * Hkv + kvh) * p.page_size + slot) * D + t * VD;
+            load_raw<VD>(p.key_pages + off, kk[u]);
+            load_raw<VD>(p.value_pages + off, vv[u]);
+        }
+    };
+    issue_kv(t_begin, pid, kr, vr, ok);
 
+    // ---- prologue math while the K/V rows are in flight ---------------------------------------------------------------
+    auto norm_rope = [&](const RawRow<VD> &x, const RawRow<VD> &w, float (&out)[VD]) {
+        float f[VD];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < VD; ++i) {
+            f[i] = BF16::to_float(x.v[i]);
+            ss += f[i] * f[i];
+        }
+        ss = group16_allsum(ss);
+        const float inv = rsqrtf(ss / (float)D + p.eps);
+#pragma unroll
+        for (int i = 0; i < VD; ++i) {
+            const float n = bf16_round(f[i] * inv * BF16::to_float(w.v[i]));
+            const float partner = row_ror<8>(n);  // lane t ^ 8 of the same 16-lane group
+            const float r2 = (t < 8) ? (n * cs[i] - partner * sn[i]) : (n * cs[i] + partner * sn[i]);
+            out[i] = bf16_round(r2);
+        }
+    };
     float k_new[VD], v_new[VD];
-    head_norm_rope<VD>(row + (long)(Hq + kvh) * D, p.k_norm_w, t, p.eps, cs, sn, k_new);
-    load_row<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, v_new);
+    norm_rope(kraw_new, kw, k_new);
+#pragma unroll
+    for (int i = 0; i < VD; ++i) v_new[i] = BF16::to_float(vraw_new.v[i]);
     if (live && split == 0 && chunk == 0 && g == 0) {
         const long off = (((long)wpage * Hkv + kvh) * p.page_size + wslot) * D + t * VD;
         store_row<VD>(p.key_pages + off, k_new);
-        store_row<VD>(p.value_pages + off, v_new);
+        store_raw<VD>(p.value_pages + off, vraw_new);
     }
-
     float qv[AD_RQ][VD], acc[AD_RQ][VD], m[AD_RQ], l[AD_RQ];
-    bool rq_ok[AD_RQ];
 #pragma unroll
     for (int r = 0; r < AD_RQ; ++r) {
-        const int hq = chunk * AD_RQ + r;
-        rq_ok[r] = hq < rep;
         float qn[VD];
-        head_norm_rope<VD>(row + (long)(kvh * rep + (rq_ok[r] ? hq : 0)) * D, p.q_norm_w, t, p.eps, cs, sn, qn);
+        norm_rope(qraw[r], qw, qn);
 #pragma unroll
         for (int i = 0; i < VD; ++i) {
             qv[r][i] = qn[i] * scale_log2;
@@ -158,51 +288,54 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         l[r] = 0.f;
     }
 
-    const int per = ((ctx + p.n_splits - 1) / p.n_splits + 15) & ~15;
-    const int t_begin = split * per;
-    const int t_end = live ? min(t_begin + per, ctx) : 0;
-
-    for (int base = t_begin; base < t_end; base += 16 * U) {
-        float kf[U][VD], vf[U][VD];
-        bool ok[U];
+    // ---- walk the window: request the next batch, then reduce the current one ------------------------------------------
+    for (int it = 0; it < n_it; ++it) {
+        bool ok_next[U];
+        const bool more = it + 1 < n_it;
+        if (more) {  // uniform
+            issue_kv(t_begin + (it + 1) * 16 * U, pid_next, kr_next, vr_next, ok_next);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int tok = base + u * 16 + g;
-            ok[u] = tok < t_end;
-            const int lp = tok / p.page_size;
-            const int slot = tok - lp * p.page_size;
-            int page_id = -1;
-            if (ok[u] && lp < p.max_pages) page_id = p.block_table[(long)b * p.max_pages + lp];
-            ok[u] = page_id >= 0;
-            if (ok[u]) {
-                const long off = (((long)page_id * Hkv + kvh) * p.page_size + slot) * D + t * VD;
-                load_row<VD>(p.key_pages + off, kf[u]);
-                load_row<VD>(p.value_pages + off, vf[u]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < VD; ++i) {
-                    kf[u][i] = 0.f;
-                    vf[u][i] = 0.f;
-                }
-            }
+            for (int u = 0; u < U; ++u)
+                pid_next[u] = brow[min((t_begin + (it + 2) * 16 * U + u * 16 + g) / p.page_size, p.max_pages - 1)];
         }
+        float sc[AD_RQ][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            float kf[VD];
+#pragma unroll
+            for (int i = 0; i < VD; ++i) kf[i] = BF16::to_float(kr[u].v[i]);
 #pragma unroll
             for (int r = 0; r < AD_RQ; ++r) {
                 float part = 0.f;
 #pragma unroll
-                for (int i = 0; i < VD; ++i) part += qv[r][i] * kf[u][i];
-                const float score = group16_sum(part);
-                if (ok[u]) {
-                    const float nm = fmaxf(m[r], score);
-                    const float of = exp2f(m[r] - nm);
-                    const float sf = exp2f(score - nm);
-                    l[r] = l[r] * of + sf;
+                for (int i = 0; i < VD; ++i) part += qv[r][i] * kf[i];
+                sc[r][u] = (ok[u] && live) ? group16_allsum(part) : -1e30f;
+            }
+        }
 #pragma unroll
-                    for (int i = 0; i < VD; ++i) acc[r][i] = acc[r][i] * of + sf * vf[u][i];
-                    m[r] = nm;
-                }
+        for (int r = 0; r < AD_RQ; ++r) {
+            float nm = m[r];
+#pragma unroll
+            for (int u = 0; u < U; ++u) nm = fmaxf(nm, sc[r][u]);
+            const float of = exp2f(m[r] - nm);
+            m[r] = nm;
+            l[r] *= of;
+#pragma unroll
+            for (int i = 0; i < VD; ++i) acc[r][i] *= of;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float pw = (ok[u] && live) ? exp2f(sc[r][u] - nm) : 0.f;
+                l[r] += pw;
+#pragma unroll
+                for (int i = 0; i < VD; ++i) acc[r][i] += pw * BF16::to_float(vr[u].v[i]);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                kr[u] = kr_next[u];
+                vr[u] = vr_next[u];
+                ok[u] = ok_next[u];
             }
         }
     }
@@ -213,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             float part = 0.f;
 #pragma unroll
             for (int i = 0; i < VD; ++i) part += qv[r][i] * k_new[i];
-            const float score = group16_sum(part);
+            const float score = group16_allsum(part);
             if (live && g == 0) {
                 const float nm = fmaxf(m[r], score);
                 const float of = exp2f(m[r] - nm);
@@ -269,24 +402,33 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     prof_end(p.prof);
 }
 
-// partials [rows, n_splits, D+2] -> out [rows, D]
+// partials [rows, NS, D+2] -> out [rows, D]; all loads of a thread are independent and issued together
+template <int NS>
 __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out,
-                                                         int D, int n_splits, prof_t *prof) {
+                                                         int D, prof_t *prof) {
     prof_begin(prof);
     const long orow = blockIdx.x;
     const int stride = D + 2;
-    const float *base = ws + orow * n_splits * stride;
-    float gm = -1e30f;
-    for (int s = 0; s < n_splits; ++s) gm = fmaxf(gm, base[s * stride + D]);
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float gl = 0.f, vs = 0.f;
-        for (int s = 0; s < n_splits; ++s) {
-            const float f = exp2f(base[s * stride + D] - gm);
-            gl += base[s * stride + D + 1] * f;
-            vs += base[s * stride + d] * f;
-        }
-        out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : vs / gl);
+    const float *base = ws + orow * NS * stride;
+    const int d = threadIdx.x < D ? threadIdx.x : 0;
+    float ms[NS], ls[NS], vs[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+        ms[s2] = base[s2 * stride + D];
+        ls[s2] = base[s2 * stride + D + 1];
+        vs[s2] = base[s2 * stride + d];
     }
+    float gm = -1e30f;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) gm = fmaxf(gm, ms[s2]);
+    float gl = 0.f, acc = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+        const float f = exp2f(ms[s2] - gm);
+        gl += ls[s2] * f;
+        acc += vs[s2] * f;
+    }
+    if ((int)threadIdx.x < D) out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : acc / gl);
     prof_end(prof);
 }
 
