@@ -47,6 +47,31 @@ def build_prompt(rng: random.Random, length: int, vocab: int) -> list[int]:
     return [rng.randrange(256, vocab) for _ in range(length)]
 
 
+def timed_steps(run, sync, steps: int, dist=None, device=None):
+    """The driver's timing contract: barrier + device sync on both sides of EXACTLY `steps` steps, MAX over ranks.
+    `run(steps)` enqueues the work, `sync()` blocks until the device is idle.  Returns (elapsed_max_s, elapsed_local_s)."""
+    import torch
+
+    sync()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run(steps)
+    sync()
+    local = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([local], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), local
+    return local, local
+
+
+def aggregate_value(n_gpus: int, steps: int, elapsed_max_s: float) -> float:
+    """Whole-job tokens/s: every rank decodes its own request (weak scaling), the job takes as long as its slowest rank."""
+    return n_gpus * steps / elapsed_max_s
+
+
 def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_steps: int) -> dict:
     """Time the plain-C port (oracle/) on the host cores on a bounded sample and use it as a checker."""
     import numpy as np
@@ -74,33 +99,49 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
                            input_norm=host_norm(layer.input_layernorm.weight),
                            post_norm=host_norm(layer.post_attention_layernorm.weight)))
     weights = dict(embed=host_w4(mlx_model.model.embed_tokens), layers=layers, norm=host_norm(mlx_model.model.norm.weight))
-    cores = os.cpu_count() or 1
-    model = c_oracle.COracleQwen3(cfg, weights, max_ctx=sample_prompt + sample_steps + 1)
+    # OpenMP fork/join per matvec (7 x 36 per token) stops scaling long before a 2-socket host runs out of cores
+    cores = min(os.cpu_count() or 1, 32)
+    model = c_oracle.COracleQwen3(cfg, weights, max_ctx=sample_prompt + sample_steps + 1, threads=cores)
     prompt = build_prompt(random.Random(1234), sample_prompt, cfg["vocab_size"])
-    tid = 0
+    tid, logits = 0, None
     for t in prompt:  # token-by-token prefill: untimed warm-up of the CPU path
-        tid, _ = model.step(t)
-    cpu_ids = [tid]
+        tid, logits = model.step(t)
+    cpu_ids, cpu_logits = [tid], [logits]
     t0 = time.perf_counter()
     for _ in range(sample_steps):
-        tid, _ = model.step(cpu_ids[-1])
+        tid, logits = model.step(cpu_ids[-1])
         cpu_ids.append(tid)
+        cpu_logits.append(logits)
     dt = time.perf_counter() - t0
     model.close()
-    # checker: the engine on the same prompt must produce the same greedy ids (teacher-forced on the CPU ids)
+
+    # checker: the engine on the same prompt, teacher-forced on the CPU ids, must give the same logits (log-softmax
+    # within the band one bf16 ulp of a logit can move it) and the same greedy id wherever the top-2 margin is clear
+    def logsm(x):
+        x = np.asarray(x, dtype=np.float64)
+        return x - x.max() - np.log(np.exp(x - x.max()).sum())
+
     engine.begin(0)
     engine.prefill(0, prompt, chunk=8)
-    gpu_ids = engine.read_tokens(0, 1)
+    gpu_ids, gpu_logits = engine.read_tokens(0, 1), [engine.logits(1)[0].float().cpu().numpy()]
     for s in range(sample_steps):
         engine.set_token(0, cpu_ids[s])
         engine.decode(1, batch=1)
         gpu_ids.append(engine.read_tokens(0, 1)[0])
+        gpu_logits.append(engine.logits(1)[0].float().cpu().numpy())
     engine.release(0)
-    match = sum(int(a == b) for a, b in zip(cpu_ids, gpu_ids))
+    worst, clear, agree = 0.0, 0, 0
+    for cl, gl, ci, gi in zip(cpu_logits, gpu_logits, cpu_ids, gpu_ids):
+        worst = max(worst, float(np.abs(logsm(cl) - logsm(gl)).max()))
+        top2 = np.sort(cl)[-2:]
+        if top2[1] - top2[0] > 0.125:
+            clear += 1
+            agree += int(ci == gi)
     return {"value": round(sample_steps / dt, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"{sample_steps} decode steps after a {sample_prompt}-token prompt, same Qwen3-4B W4 checkpoint, "
                       f"oracle/qwen3_decode.c with OpenMP on {cores} threads",
-            "greedy_ids_matching_gpu": f"{match}/{len(cpu_ids)}"}
+            "gpu_vs_cpu_max_logprob_diff": round(worst, 4),
+            "gpu_vs_cpu_greedy_ids": f"{agree}/{clear} equal where the CPU top-2 logit margin > 0.125 ({len(cpu_ids)} steps)"}
 
 
 def main() -> None:
@@ -149,11 +190,9 @@ def main() -> None:
     prompt = build_prompt(random.Random(args.seed * 1000 + rank), args.prompt_len, cfg["vocab_size"])
     use_graph = not args.no_graph
 
-    def barrier():
+    def sync():
         engine.synchronize()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
 
     engine.begin(0)
     t_p0 = time.perf_counter()
@@ -161,19 +200,10 @@ def main() -> None:
     engine.synchronize()
     prefill_s = time.perf_counter() - t_p0
     engine.decode(max(args.warmup, 2), batch=1, use_graph=use_graph)  # >= 2: eager warm step + graph capture
-    barrier()
+    sync()
     bytes_first = engine.step_bytes(1)
-    t0 = time.perf_counter()
-    engine.decode(args.steps, batch=1, use_graph=use_graph)
-    engine.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, _ = timed_steps(lambda k: engine.decode(k, batch=1, use_graph=use_graph), sync, args.steps, dist, device)
     bytes_last = engine.step_bytes(1)
-    if dist is not None:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     ids = engine.read_tokens(0, 8)
 
     # ---- roofline leg: per-kernel device-clock durations of real decode steps (not part of the timed region)
@@ -234,7 +264,7 @@ def main() -> None:
 
     out = {
         "metric": "Qwen3-4B int4 decode tokens/sec/GPU; achieved HBM GB/s vs roofline",
-        "value": round(args.gpus * args.steps / elapsed, 2),
+        "value": round(aggregate_value(args.gpus, args.steps, elapsed), 2),
         "unit": "tokens/s",
         "n_gpus": args.gpus,
         "steps": args.steps,

@@ -12,7 +12,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
-for extra in (ROOT, ROOT / "tiny-llm_amd", ROOT / "tiny-llm_amd" / "extensions_hip"):
+for extra in (ROOT, ROOT / "tests", ROOT / "tiny-llm_amd", ROOT / "tiny-llm_amd" / "extensions_hip"):
     if str(extra) not in sys.path:
         sys.path.insert(0, str(extra))
 
@@ -30,3 +30,29 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def built_libs():
+    """libtinyllm_hip.so (hipcc cross-compiles without a GPU) and the C oracle; built on demand."""
+    lib = ROOT / "tiny-llm_amd" / "extensions_hip" / "tiny_llm_ext_hip" / "libtinyllm_hip.so"
+    ora = ROOT / "oracle" / "libqwen3_oracle.so"
+    if not lib.exists() or not ora.exists():
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return lib, ora
+
+
+@pytest.fixture()
+def cpu_ext(built_libs, monkeypatch):
+    """Route the host-logic modules' extension calls to the oracle-backed fake (tests/fake_ext.py)."""
+    from fake_ext import FakeExt
+
+    import tiny_llm_hip.attention
+    import tiny_llm_hip.paged_kv_cache
+
+    fake = FakeExt()
+    for module in (tiny_llm_hip.attention, tiny_llm_hip.paged_kv_cache):
+        monkeypatch.setattr(module, "tiny_llm_ext_hip", fake)
+    return fake

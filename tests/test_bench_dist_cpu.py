@@ -1,0 +1,69 @@
+"""CPU tier, world_size 2 over gloo: the request-parallel launch path of bench.py — per-rank request shards with no
+data-path collective, barrier-bracketed timing, MAX over ranks, whole-job aggregate (driver contract)."""
+
+import os
+import random
+import socket
+import sys
+import time
+from pathlib import Path
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, steps, queue):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import bench
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prompt = bench.build_prompt(random.Random(0 * 1000 + rank), 16, 1000)  # same derivation as bench.main
+    step_time = 0.002 * (rank + 1)  # rank 1 is the slow rank
+
+    def run(k):
+        time.sleep(step_time * k)
+
+    elapsed_max, local = bench.timed_steps(run, lambda: None, steps, dist, torch.device("cpu"))
+    queue.put((rank, prompt, elapsed_max, local, bench.aggregate_value(world, steps, elapsed_max)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_request_parallel_timing():
+    world, steps = 2, 25
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(queue.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, prompt0, max0, local0, value0), (r1, prompt1, max1, local1, value1) = got
+    assert prompt0 != prompt1, "every rank must decode its own request"
+    assert max0 == pytest.approx(max1, rel=1e-9), "all ranks agree on the MAX-reduced elapsed time"
+    assert max0 >= local1 * 0.999 and local1 > local0, "the job takes as long as its slowest rank"
+    assert value0 == pytest.approx(world * steps / max0)
+    assert value0 < world * steps / local0, "aggregate must not be extrapolated from the fast rank"
+
+
+def test_single_rank_needs_no_process_group():
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    elapsed, local = bench.timed_steps(lambda k: time.sleep(0.001 * k), lambda: None, 10)
+    assert elapsed == local and elapsed >= 0.01
+    assert bench.aggregate_value(1, 10, elapsed) == pytest.approx(10 / elapsed)

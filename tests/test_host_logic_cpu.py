@@ -1,0 +1,379 @@
+"""CPU tier: host-side logic above the extension — page pool, request caches, batching metadata, the paged_attention
+wrapper's validation, chunked prefill and the continuous-batching scheduler with fault injection.
+
+The extension itself is GPU-only; these tests route the two ops this logic touches through tests/fake_ext.py (oracle
+backed, test-only).  Expected values are the reference's own known-answer literals
+(tests/golden/reference_literals.json) and behaviours from tests_refsol/test_week_3_day_{1,2,3,4}.py.
+"""
+
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+LIT = json.loads((Path(__file__).resolve().parent / "golden" / "reference_literals.json").read_text())
+NEG = float("-inf")
+
+
+def T(a, dtype=torch.float32):
+    def conv(x):
+        return [conv(v) for v in x] if isinstance(x, list) else (NEG if x == "-inf" else float(x))
+
+    return torch.tensor(conv(a), dtype=dtype)
+
+
+def chunk(n, heads=2, dim=4, seed=None):
+    g = torch.Generator().manual_seed(n if seed is None else seed)
+    return torch.randn((1, heads, n, dim), generator=g), torch.randn((1, heads, n, dim), generator=g)
+
+
+# ------------------------------------------------------------------------------------------------ dense batching
+def test_batching_kv_cache_dense_literals():
+    from tiny_llm_hip import BatchingKvCache, TinyKvFullCache
+
+    lit = LIT["batching_kv_cache"]
+    cache = BatchingKvCache(max_active_requests=3)
+    assert cache.max_seq_len is None
+    slot0, slot2 = TinyKvFullCache(), TinyKvFullCache()
+    slot0.update_and_fetch(T(lit["slot0"]["key"]), T(lit["slot0"]["value"]))
+    slot2.update_and_fetch(T(lit["slot2"]["key"]), T(lit["slot2"]["value"]))
+    cache.add_request(slot0, 0)
+    cache.add_request(slot2, 2)
+    keys, values, seq_len, mask = cache.update_and_fetch(T(lit["keys"]), T(lit["values"]), mask_length=2)
+    assert seq_len is None
+    assert torch.equal(keys, T(lit["expected_keys"]))
+    assert torch.equal(values, T(lit["expected_values"]))
+    assert torch.equal(mask, T(lit["expected_mask"]).reshape(3, 1, 2, 4))
+    assert cache.last_batch_bytes == lit["last_batch_bytes"]
+    assert cache.staging_copy_bytes == lit["staging_copy_bytes"]
+
+
+# ------------------------------------------------------------------------------------------------ page pool
+def test_paged_pool_growth_reset_and_reuse(cpu_ext):
+    from tiny_llm_hip import TinyKvPagedCache, TinyKvPagedPool
+
+    lit = LIT["paged_pool_growth"]
+    pool = TinyKvPagedPool(page_size=lit["page_size"])
+    cache = TinyKvPagedCache(pool=pool)
+    cache.update_and_fetch_paged(*chunk(lit["tokens"]))
+    assert pool.num_pages == lit["num_pages"] and pool.capacity == lit["capacity"]
+    assert pool.key_pages.shape[0] == pool.num_pages == pool.value_pages.shape[0]
+    assert pool.storage_growths == lit["storage_growths"]
+    assert pool.copied_pages_on_growth == lit["copied_pages_on_growth"]
+    assert pool.copied_bytes_on_growth == lit["copied_bytes_on_growth"]
+    with pytest.raises(ValueError):
+        pool.reset()  # a live request still owns pages (reference paged_kv_cache.py:184-186)
+    cache.release()
+    assert pool.capacity == 8 and pool.num_free_pages == 5 and pool.used_page_ids == set()
+    # released pages are handed out again before the pool grows
+    again = TinyKvPagedCache(pool=pool)
+    again.update_and_fetch_paged(*chunk(6))
+    assert pool.reused_page_allocations == 2 and pool.num_pages == 5
+    again.release()
+    pool.reset()
+    assert (pool.capacity, pool.num_pages, pool.num_free_pages, pool.storage_nbytes) == (0, 0, 0, 0)
+    assert (pool.storage_growths, pool.copied_pages_on_growth, pool.copied_bytes_on_growth) == (0, 0, 0)
+
+
+def test_paged_cache_contents_block_table_identity_and_rewind(cpu_ext):
+    from tiny_llm_hip import TinyKvPagedCache, TinyKvPagedPool
+
+    pool = TinyKvPagedPool(page_size=4)
+    blocker, cache = TinyKvPagedCache(pool=pool), TinyKvPagedCache(pool=pool)
+    k1, v1 = chunk(3, seed=1)
+    cache.update_and_fetch_paged(k1, v1)
+    first = cache.block_table()
+    assert cache.block_table() is first  # cached until the page ids change (reference paged_kv_cache.py:364-377)
+    blocker.update_and_fetch_paged(*chunk(2, seed=2))  # takes physical page 1
+    k2, v2 = chunk(1, seed=3)
+    cache.update_and_fetch_paged(k2, v2)               # fills the tail of page 0
+    assert cache.block_table() is first
+    k3, v3 = chunk(6, seed=4)
+    meta = cache.update_and_fetch_paged(k3, v3, mask="causal")  # needs two more pages -> ids [0, 2, 3]
+    assert cache.block_table() is not first
+    assert meta.block_table.tolist() == [[0, 2, 3]] and meta.context_lens.tolist() == [10]
+    assert meta.block_table.dtype == torch.int32 and meta.context_lens.dtype == torch.int32
+    dense_k, dense_v = cache.gather_dense()
+    assert torch.equal(dense_k, torch.cat([k1, k2, k3], dim=2)) and torch.equal(dense_v, torch.cat([v1, v2, v3], dim=2))
+    cache.rewind(5)  # drops page 3 and half of page 2 (reference paged_kv_cache.py:414-434)
+    assert cache.offset == 5 and cache.block_table().tolist() == [[0, 2]]
+    assert torch.equal(cache.gather_dense()[0], torch.cat([k1, k2, k3], dim=2)[:, :, :5])
+    with pytest.raises(AssertionError):  # the reference asserts 0 <= n <= offset (paged_kv_cache.py:414-416)
+        cache.rewind(6)
+    cache.release()
+    blocker.release()
+    assert pool.used_page_ids == set()
+
+
+def test_paged_append_is_transactional(cpu_ext, monkeypatch):
+    """An injected write failure must leave pool and cache exactly as before (test_week_3_day_3.py:199-219)."""
+    from tiny_llm_hip import TinyKvPagedCache, TinyKvPagedPool
+
+    pool = TinyKvPagedPool(page_size=4)
+    cache = TinyKvPagedCache(pool=pool)
+    cache.update_and_fetch_paged(*chunk(3))
+    before = (list(cache.page_ids), cache.offset, pool.num_pages, sorted(pool.used_page_ids), list(pool.free_page_ids))
+    calls = {"n": 0}
+    real = pool.write_page_slice
+
+    def flaky(*args, **kwargs):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise RuntimeError("injected write failure")
+        return real(*args, **kwargs)
+
+    monkeypatch.setattr(pool, "write_page_slice", flaky)
+    with pytest.raises(RuntimeError, match="injected"):
+        cache.update_and_fetch_paged(*chunk(7))
+    after = (list(cache.page_ids), cache.offset, pool.num_pages, sorted(pool.used_page_ids), list(pool.free_page_ids))
+    assert after == before
+
+
+# ------------------------------------------------------------------------------------------------ paged metadata
+def test_paged_metadata_literals_and_attention_matches_dense(cpu_ext):
+    from tiny_llm_hip import (BatchingKvCache, TinyKvPagedCache, TinyKvPagedPool, paged_attention,
+                              scaled_dot_product_attention_grouped)
+
+    single = LIT["paged_metadata_single"]
+    pool = TinyKvPagedPool(page_size=single["page_size"])
+    cache = TinyKvPagedCache(pool=pool)
+    cache.update_and_fetch(*chunk(single["appends"][0], seed=1))
+    key2, value2 = chunk(single["appends"][1], seed=2)
+    meta = cache.update_and_fetch_paged(key2, value2, mask="causal")
+    assert meta.block_table.tolist() == single["block_table"] and meta.context_lens.tolist() == single["context_lens"]
+    assert tuple(meta.key_pages.shape) == (2, 2, 4, 4)
+    q = torch.randn((1, 4, 3, 4), generator=torch.Generator().manual_seed(9))
+    dense_k, dense_v = cache.gather_dense()
+    want = scaled_dot_product_attention_grouped(q, dense_k, dense_v, mask="causal")
+    got = paged_attention(q, meta.key_pages, meta.value_pages, meta.block_table, meta.context_lens, meta.page_size,
+                          mask=meta.mask)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+
+    batch_lit = LIT["paged_metadata_batch"]
+    pool = TinyKvPagedPool(page_size=4)
+    first, second = TinyKvPagedCache(pool=pool), TinyKvPagedCache(pool=pool)
+    first.update_and_fetch(*chunk(batch_lit["prefilled"]["0"], seed=3))
+    second.update_and_fetch(*chunk(batch_lit["prefilled"]["2"], seed=4))
+    batch = BatchingKvCache(max_active_requests=3, max_seq_len=16)
+    batch.add_request(first, 0)
+    batch.add_request(second, 2)
+    keys = torch.zeros((3, 2, 1, 4))
+    values = torch.zeros((3, 2, 1, 4))
+    keys[0:1], values[0:1] = chunk(1, seed=5)
+    keys[2:3], values[2:3] = chunk(1, seed=6)
+    meta = batch.update_and_fetch_paged(keys, values, mask_length=1, mask="causal")
+    assert meta.context_lens.tolist() == batch_lit["context_lens"]
+    assert tuple(meta.block_table.shape) == (3, 2) and meta.block_table.tolist()[1] == batch_lit["idle_row"]
+    assert tuple(meta.key_pages.shape) == (3, 2, 4, 4)
+    q = torch.randn((3, 4, 1, 4), generator=torch.Generator().manual_seed(10))
+    out = paged_attention(q, meta.key_pages, meta.value_pages, meta.block_table, meta.context_lens, meta.page_size,
+                          mask=meta.mask)
+    for row, req in ((0, first), (2, second)):
+        k, v = req.gather_dense()
+        want = scaled_dot_product_attention_grouped(q[row:row + 1], k, v, mask="causal")
+        torch.testing.assert_close(out[row:row + 1], want, rtol=1e-5, atol=1e-6)
+    assert not out[1].any()  # idle slot
+
+
+def test_batching_paged_update_rejects_mixed_pools_without_side_effects(cpu_ext):
+    from tiny_llm_hip import BatchingKvCache, TinyKvPagedCache, TinyKvPagedPool
+
+    first = TinyKvPagedCache(pool=TinyKvPagedPool(page_size=4))
+    second = TinyKvPagedCache(pool=TinyKvPagedPool(page_size=4))
+    first.update_and_fetch(*chunk(2, seed=1))
+    second.update_and_fetch(*chunk(2, seed=2))
+    batch = BatchingKvCache(max_active_requests=2, max_seq_len=8)
+    batch.add_request(first, 0)
+    batch.add_request(second, 1)
+    state = lambda c: (list(c.page_ids), c.offset, sorted(c.pool.used_page_ids))  # noqa: E731
+    before = (state(first), state(second))
+    keys = torch.zeros((2, 2, 1, 4))
+    with pytest.raises(ValueError, match="share one page pool"):
+        batch.update_and_fetch_paged(keys, keys, mask_length=1)
+    assert (state(first), state(second)) == before
+
+
+@pytest.mark.parametrize("mutate,message", [
+    (lambda m: m["ctx"].__setitem__(0, -1), "nonnegative"),
+    (lambda m: m["ctx"].__setitem__(0, 9), "not covered"),
+    (lambda m: m["table"].__setitem__((0, 1), 7), "outside physical page storage"),
+    (lambda m: m["table"].__setitem__((0, 1), 0), "aliased"),
+    (lambda m: (m["ctx"].__setitem__(0, 3), m["table"].__setitem__((0, 1), 1)), "must use the -1 sentinel"),
+    (lambda m: m.__setitem__("page_size", 0), "positive integer"),
+    (lambda m: (m["ctx"].__setitem__(0, 1), m["table"].__setitem__((0, 1), -1)), "must be zero or at least query length"),
+])
+def test_paged_attention_validation_messages(cpu_ext, mutate, message):
+    """The wrapper's host-side checks and their message substrings (tests_refsol/test_week_3_day_4.py:248-322)."""
+    from tiny_llm_hip import paged_attention
+
+    m = {"ctx": torch.tensor([6], dtype=torch.int32), "table": torch.tensor([[0, 1]], dtype=torch.int32), "page_size": 4}
+    mutate(m)
+    q = torch.zeros((1, 2, 2, 4))
+    pages = torch.zeros((2, 2, 4, 4))
+    with pytest.raises(ValueError, match=message):
+        paged_attention(q, pages, pages, m["table"], m["ctx"], m["page_size"], mask="causal")
+
+
+def test_paged_attention_rejects_array_masks(cpu_ext):
+    from tiny_llm_hip import paged_attention
+
+    pages = torch.zeros((1, 1, 4, 4))
+    with pytest.raises(NotImplementedError):
+        paged_attention(torch.zeros((1, 1, 1, 4)), pages, pages, torch.zeros((1, 1), dtype=torch.int32),
+                        torch.ones(1, dtype=torch.int32), 4, mask=torch.zeros((1, 1)))
+
+
+# ------------------------------------------------------------------------------------------------ scheduler
+class FakeDetokenizer:
+    def __init__(self, _):
+        self.text = ""
+
+    def add_token(self, token):
+        self.text += str(token)
+
+
+class FakeTokenizer:
+    eos_token_id = 99
+    _tokenizer = object()
+    detokenizer = FakeDetokenizer(_tokenizer)
+
+    def encode(self, prompt, add_special_tokens=False):
+        assert not add_special_tokens
+        return list(range(1, len(prompt) + 1))
+
+
+class FailingTextDetokenizer(FakeDetokenizer):
+    def __init__(self, _):
+        self._text = ""
+
+    def add_token(self, token):
+        self._text += str(token)
+
+    @property
+    def text(self):
+        raise RuntimeError("injected detokenization failure")
+
+
+class FailingTextTokenizer(FakeTokenizer):
+    detokenizer = FailingTextDetokenizer(FakeTokenizer._tokenizer)
+
+
+def make_paged_fake_model(output_token=1, fail_at=None):
+    from tiny_llm_hip import BatchingKvCache, TinyKvPagedCache, TinyKvPagedPool
+
+    class FailingMaterialize(TinyKvPagedCache):
+        def materialize(self):
+            super().materialize()
+            raise RuntimeError("injected materialization failure")
+
+    class Model:
+        num_hidden_layers = 1
+
+        def __init__(self):
+            self.pool = TinyKvPagedPool(page_size=4)
+            self.calls, self.cache_creations = [], 0
+
+        def create_kv_cache(self):
+            self.cache_creations += 1
+            return [(FailingMaterialize if fail_at == "materialize" else TinyKvPagedCache)(self.pool)]
+
+        def __call__(self, inputs, offsets, cache, logits_to_keep=1):
+            offset = offsets[0] if isinstance(offsets, list) else int(offsets)
+            n = len(self.calls) + 1
+            self.calls.append((offset, inputs.shape[1]))
+            key = torch.zeros((inputs.shape[0], 1, inputs.shape[1], 1))
+            if isinstance(cache[0], BatchingKvCache):
+                cache[0].update_and_fetch_paged(key, key, mask_length=inputs.shape[1])
+            else:
+                cache[0].update_and_fetch_paged(key, key)
+            if fail_at == "prefill" and n == 1:
+                raise RuntimeError("injected prefill failure")
+            if fail_at == "decode" and n == 2:
+                raise RuntimeError("injected decode failure")
+            logits = torch.zeros((inputs.shape[0], 1, 128))
+            logits[..., output_token] += 1
+            return logits
+
+    return Model()
+
+
+def test_chunked_prefill_advances_in_bounded_steps(cpu_ext):
+    from tiny_llm_hip import Request, TinyKvFullCache
+
+    class Model:
+        num_hidden_layers = 1
+        calls = []
+
+        def create_kv_cache(self):
+            return [TinyKvFullCache()]
+
+        def __call__(self, inputs, offsets, cache, logits_to_keep=1):
+            self.calls.append((offsets[0], inputs.shape[1]))
+            key = torch.zeros((1, 1, inputs.shape[1], 1))
+            cache[0].update_and_fetch(key, key)
+            logits = torch.zeros((1, 1, 4))
+            logits[..., 1] += 1
+            return logits
+
+    model = Model()
+    request = Request(model, FakeTokenizer(), "1234567", prefill_max_step=3, device="cpu")
+    for want in (3, 6):
+        request.try_prefill()
+        assert request.offset == want == request.kv_cache[0].offset and not request.is_prefill_done
+    request.try_prefill()
+    assert request.offset == 7 and request.is_prefill_done and request.next_token == 1
+    assert model.calls == [(0, 3), (3, 3), (6, 1)]
+    with pytest.raises(ValueError, match="after done"):
+        request.try_prefill()
+
+
+def test_batch_generate_schedules_and_returns_every_page(cpu_ext):
+    from tiny_llm_hip import batch_generate
+
+    model = make_paged_fake_model()
+    result = batch_generate(model, FakeTokenizer(), ["1234567"], max_seq_len=9, batch_size=1, prefill_step=3)
+    assert result == [(0, "11")]
+    assert model.calls == [(0, 3), (3, 3), (6, 1), (7, 1)]
+    assert model.pool.used_page_ids == set() and model.pool.num_free_pages == model.pool.num_pages
+
+    model = make_paged_fake_model(output_token=FakeTokenizer.eos_token_id)
+    assert batch_generate(model, FakeTokenizer(), ["12345"], max_seq_len=10, batch_size=1, prefill_step=10) == [(0, "")]
+    assert model.calls == [(0, 5)] and model.pool.used_page_ids == set()
+
+
+@pytest.mark.parametrize("prompt,result,calls,creations", [("12", [(0, "1")], [(0, 2)], 1), ("123", [(0, "")], [(0, 3)], 1),
+                                                            ("1234", None, [], 0)])
+def test_batch_generate_enforces_max_seq_len(cpu_ext, prompt, result, calls, creations):
+    from tiny_llm_hip import batch_generate
+
+    model = make_paged_fake_model()
+    if result is None:
+        with pytest.raises(ValueError, match="exceeds max_seq_len"):
+            batch_generate(model, FakeTokenizer(), [prompt], max_seq_len=3)
+    else:
+        assert batch_generate(model, FakeTokenizer(), [prompt], max_seq_len=3, batch_size=1) == result
+    assert model.calls == calls and model.cache_creations == creations and model.pool.used_page_ids == set()
+
+
+@pytest.mark.parametrize("failure_point", ["prefill", "materialize", "decode", "detokenize"])
+def test_batch_generate_releases_pages_on_injected_failures(cpu_ext, failure_point):
+    """Every live cache is released in the scheduler's finally block (reference batch.py:271-284)."""
+    from tiny_llm_hip import batch_generate
+
+    tokenizer = FailingTextTokenizer() if failure_point == "detokenize" else FakeTokenizer()
+    model = make_paged_fake_model(fail_at=failure_point)
+    with pytest.raises(RuntimeError, match="injected"):
+        batch_generate(model, tokenizer, ["1"], max_seq_len=4, batch_size=1, prefill_step=4)
+    assert model.pool.used_page_ids == set() and model.pool.num_free_pages == model.pool.num_pages
+
+
+def test_batch_generate_interleaves_requests_across_slots(cpu_ext):
+    from tiny_llm_hip import batch_generate
+
+    model = make_paged_fake_model()
+    result = batch_generate(model, FakeTokenizer(), ["12", "1234", "1"], max_seq_len=6, batch_size=2, prefill_step=2)
+    assert sorted(idx for idx, _ in result) == [0, 1, 2]
+    assert all(set(text) <= {"1"} and text for _, text in result)
+    assert model.pool.used_page_ids == set() and model.pool.num_free_pages == model.pool.num_pages

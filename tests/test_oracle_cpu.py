@@ -1,0 +1,139 @@
+"""CPU tier: pins the oracle (oracle/tiny_oracle.py, oracle/qwen3_decode.c) before anything trusts it.
+
+  * known-answer literals the reference's own tests hold for this path (tests/golden/reference_literals.json,
+    each entry cites the reference file:line),
+  * independent PyTorch-CPU vectors for the floating-point operators (tests/golden/torch_vectors.npz),
+  * internal consistency that the reference's test ladder relies on (paged == dense over scattered pages,
+    decode kernel semantics == grouped attention, split-K == unsplit up to the extra rounding, C port == numpy).
+Mirrors tests_refsol/test_week_1_day_{1,2,3,4}.py, test_week_2_day_{3,5,7}.py, test_week_3_day_{4,5}.py.
+"""
+
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import tiny_oracle as O
+
+GOLD = Path(__file__).resolve().parent / "golden"
+LIT = json.loads((GOLD / "reference_literals.json").read_text())
+VEC = np.load(GOLD / "torch_vectors.npz")
+
+
+def lit(a):
+    return np.array([[float(v) if v != "-inf" else -np.inf for v in row] for row in a], dtype=np.float32)
+
+
+def sin_fixture(shape, phase):
+    n = int(np.prod(shape))
+    return np.sin(np.arange(n, dtype=np.float32) * 0.017 + phase).reshape(shape)
+
+
+def test_causal_mask_literals():
+    np.testing.assert_array_equal(O.causal_mask(3, 3), lit(LIT["causal_mask_3x3"]["value"]))
+    np.testing.assert_array_equal(O.causal_mask(3, 5), lit(LIT["causal_mask_3x5"]["value"]))
+
+
+def test_packing_order_literal():
+    word = np.array([[LIT["packing_order"]["word"]]], dtype=np.uint32)
+    assert O.unpack_codes(word).tolist() == [LIT["packing_order"]["elements"]]
+
+
+@pytest.mark.parametrize("name", ["attn_gqa4_causal", "attn_gqa1_plain", "attn_decode_causal"])
+def test_grouped_attention_vs_torch(name):
+    B, Hq, Hkv, L, S, D, causal = VEC[name + "_shape"]
+    q, k, v = sin_fixture((B, Hq, L, D), 0.1), sin_fixture((B, Hkv, S, D), 0.7), sin_fixture((B, Hkv, S, D), 1.3)
+    got = O.scaled_dot_product_attention_grouped(q, k, v, scale=D ** -0.5, mask="causal" if causal else None, dtype="f32")
+    np.testing.assert_allclose(got, VEC[name + "_out"], rtol=1e-5, atol=1e-6)  # reference f32 tolerance (utils.py:72-107)
+    # the decode-kernel restatement must agree with the grouped form on the same inputs (test_week_2_day_5.py:119-163)
+    dec = O.decode_attention(q.reshape(B * Hq, L, D), k.reshape(B * Hkv, S, D), v.reshape(B * Hkv, S, D), D ** -0.5,
+                             int(Hq), int(Hkv), is_causal=bool(causal), dtype="f32")
+    np.testing.assert_allclose(dec.reshape(B, Hq, L, D), VEC[name + "_out"], rtol=1e-5, atol=1e-6)
+
+
+def test_rms_norm_rope_swiglu_vs_torch():
+    np.testing.assert_allclose(O.rms_norm_fast(VEC["rms_x"], VEC["rms_w"], 1e-6, "f32"), VEC["rms_out"], rtol=1e-5, atol=1e-6)
+    # the readable order (cast, then multiply) differs only by the extra rounding, invisible in f32
+    np.testing.assert_allclose(O.rms_norm_readable(VEC["rms_x"], VEC["rms_w"], 1e-6, "f32"), VEC["rms_out"], rtol=1e-5, atol=1e-6)
+    for trad, key in ((False, "rope_out_default"), (True, "rope_out_traditional")):
+        got = O.rope(VEC["rope_x"], VEC["rope_offsets"], 64, 1000000.0, trad, "f32")
+        np.testing.assert_allclose(got, VEC[key], rtol=1e-4, atol=2e-4)  # fp32 angle at position ~1e3
+    np.testing.assert_allclose(O.swiglu(VEC["swiglu_gate"], VEC["swiglu_up"], "f32"), VEC["swiglu_out"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_quantize_roundtrip_and_matmul_definition(dtype):
+    """Any valid affine quantiser exercises the path (the reference never pins mx.quantize bit-exactly): codes are
+    4-bit, the reconstruction error is bounded by half a step, and the matmul equals x @ dequant(w).T."""
+    rng = np.random.default_rng(0)
+    w = O.cast(rng.standard_normal((24, 256), dtype=np.float32) * 0.05, dtype)
+    packed, s, b = O.quantize_affine(w, dtype=dtype)
+    assert packed.dtype == np.uint32 and packed.shape == (24, 32) and s.shape == (24, 2)
+    deq = O.dequantize_weights(packed, s, b, dtype="f32")
+    step = np.repeat(np.abs(s), 128, axis=1)
+    ulp = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -11  # scale and bias are themselves rounded to `dtype`
+    # (the far end of a group can clip by up to one step after the scale is snapped to edge/q0)
+    bound = 1.0 * step + 15 * step * ulp + np.repeat(np.abs(b), 128, axis=1) * ulp + 1e-6
+    assert np.all(np.abs(deq - w) <= bound)
+    x = O.cast(rng.standard_normal((3, 256), dtype=np.float32), dtype)
+    want = O.cast(x.astype(np.float64) @ deq.astype(np.float64).T, dtype)
+    got = O.quantized_matmul(s, b, x, packed, dtype)
+    np.testing.assert_allclose(got, want, rtol=2 ** -7 if dtype == "bf16" else 2 ** -10, atol=1e-3)
+    emb = O.quantized_embedding(np.array([[3, 0]]), s, b, packed, dtype)
+    np.testing.assert_array_equal(emb[0, 0], O.cast(deq[3], dtype))
+
+
+def test_split_k_semantics():
+    """split_k == 1 is bit-identical to the unsplit tile kernel (test_week_2_day_7.py:80-109); split_k > 1 differs
+    only by the partials' rounding to T (book week2-07, one extra rounding)."""
+    rng = np.random.default_rng(1)
+    packed, s, b = O.quantize_affine(O.bf16(rng.standard_normal((16, 1024), dtype=np.float32) * 0.05))
+    x = O.bf16(rng.standard_normal((20, 1024), dtype=np.float32))
+    base = O.quantized_matmul_tile(s, b, x, packed, "bf16")
+    np.testing.assert_array_equal(O.quantized_matmul_tile(s, b, x, packed, "bf16", split_k=1), base)
+    split = O.quantized_matmul_tile(s, b, x, packed, "bf16", split_k=4)
+    np.testing.assert_allclose(split, base, rtol=2 ** -6, atol=2 ** -6 * np.abs(base).max())
+
+
+@pytest.mark.parametrize("L", [1, 9, 65])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_paged_equals_dense_over_scattered_pages(L, dtype):
+    """Non-contiguous pages [0, 1, 3] (a blocker owns page 2) exactly like tests_refsol/test_week_3_day_5.py:23-61."""
+    rng = np.random.default_rng(L)
+    page, Hkv, Hq, D = 32, 2, 4, 32
+    S = L + 3 if L > 1 else 70
+    pages = [0, 1, 3][: (S + page - 1) // page]
+    kp = O.cast(rng.standard_normal((5, Hkv, page, D), dtype=np.float32), dtype)
+    vp = O.cast(rng.standard_normal((5, Hkv, page, D), dtype=np.float32), dtype)
+    table = np.array([pages + [-1] * (4 - len(pages))], dtype=np.int32)
+    ctx = np.array([S], dtype=np.int32)
+    q = O.cast(rng.standard_normal((Hq, L, D), dtype=np.float32), dtype)
+    got = O.paged_attention(q, kp, vp, table, ctx, D ** -0.5, True, Hkv, Hq, dtype)
+    k = O.gather_pages(kp, table[0], S)[0][None]
+    v = O.gather_pages(vp, table[0], S)[0][None]
+    want = O.scaled_dot_product_attention_grouped(q[None], k, v, scale=D ** -0.5, mask="causal", dtype=dtype)[0]
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(got, want, **tol)
+    # idle row: context 0 and an all -1 table row give zeros (paged_attention.metal:238-240)
+    z = O.paged_attention(q, kp, vp, -np.ones((1, 4), np.int32), np.zeros(1, np.int32), 1.0, True, Hkv, Hq, dtype)
+    assert not z.any()
+
+
+def test_c_port_matches_numpy_oracle(built_libs):
+    """oracle/qwen3_decode.c vs OracleQwen3 on a seeded 2-layer model: same greedy ids, log-probs within the band
+    one bf16 ulp of a logit can move them (different fp32 summation order)."""
+    from helpers import TINY_CFG, log_softmax
+    from oracle import c_oracle
+
+    w = O.make_qwen3_weights(TINY_CFG, seed=3, sigma=0.05)
+    ref = O.OracleQwen3(TINY_CFG, w)
+    port = c_oracle.COracleQwen3(TINY_CFG, w, max_ctx=32, threads=2)
+    for t in [5, 17, 900, 33, 2, 640]:
+        want = ref.forward([t])[0, -1]
+        tid, got = port.step(t)
+        np.testing.assert_allclose(log_softmax(got), log_softmax(want), atol=4e-2, rtol=0)
+        top2 = np.sort(want)[-2:]
+        if top2[1] - top2[0] > 0.1:
+            assert tid == int(np.argmax(want))
+    port.close()

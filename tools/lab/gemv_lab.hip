@@ -6,6 +6,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <string>
 #include <algorithm>
 #include "../../tiny-llm_amd/csrc/qmv.h"
 #include "../../tiny-llm_amd/csrc/qmv2.h"
@@ -60,6 +61,7 @@ struct Timer {
 };
 
 int main(int argc, char **argv) {
+    const bool pmc_mode = argc > 1 && std::string(argv[1]) == "pmc";
     const int COPIES = 40;
     struct Shape { const char *name; int K, N; } shapes[] = {
         {"qkv", 6144, 2560}, {"o", 2560, 4096}, {"gate_up", 19456, 2560}, {"down", 2560, 9728}, {"lm_head", 151936, 2560}};
@@ -84,6 +86,7 @@ int main(int argc, char **argv) {
         printf("== %s K=%d N=%d  %.2f MB  copies=%d\n", sh.name, K, N, wbytes / 1e6, copies);
         // floor
         for (int variant = 0; variant < 4; ++variant) {
+            if (pmc_mode && variant != 2) continue;
             const int grids[2] = {512, 2048};
             for (int gi = 0; gi < 2; ++gi) {
                 const int grid = grids[gi];
@@ -103,6 +106,7 @@ int main(int argc, char **argv) {
         }
         // current GEMV variants
         for (int M : {1, 4}) {
+            if (pmc_mode) break;
             struct V { const char *n; int pro, epi; } vs[] = {{"plain", PRO_NONE, EPI_STORE}, {"rms", PRO_RMSNORM, EPI_STORE}, {"resid", PRO_NONE, EPI_RESIDUAL}, {"rms+swiglu", PRO_RMSNORM, EPI_SWIGLU}};
             for (auto &v : vs) {
                 const QmvPlan pl = qmv_plan(M, N, K);
@@ -119,6 +123,7 @@ int main(int argc, char **argv) {
         }
         // qmv2 (MFMA) variants + correctness vs qmv
         for (int M : {1, 4}) {
+            if (pmc_mode) break;
             struct V { const char *n; int pro, epi; } vs[] = {{"plain", PRO_NONE, EPI_STORE}, {"rms", PRO_RMSNORM, EPI_STORE}, {"resid", PRO_NONE, EPI_RESIDUAL}, {"rms+swiglu", PRO_RMSNORM, EPI_SWIGLU}};
             for (auto &v : vs) {
                 for (int fks : {0, 1, 2, 4, 8}) {
@@ -158,6 +163,7 @@ int main(int argc, char **argv) {
                 struct V { const char *n; int pro, epi; } vs[] = {{"plain", PRO_NONE, EPI_STORE}, {"rms", PRO_RMSNORM, EPI_STORE}, {"resid", PRO_NONE, EPI_RESIDUAL}, {"rms+swiglu", PRO_RMSNORM, EPI_SWIGLU}};
                 for (auto &v : vs) {
                     for (int fks : {0, 1, 2, 4, 8}) {
+                        if (pmc_mode && (fks != 0 || M != 1)) continue;
                         const Qmv3Plan pl = qmv3_plan(M, N, K, fks);
                         if (!pl.ok) continue;
                         if (fks && M > 1) continue;
