@@ -115,6 +115,9 @@ int tl_engine_reserve(tl_engine *e, int slot, int total_tokens);
 int tl_engine_release(tl_engine *e, int slot);
 int tl_engine_rewind(tl_engine *e, int slot, int n);
 int tl_engine_context_len(const tl_engine *e, int slot);  /* host mirror, <0 if slot free */
+/* Adopt the sequence of slot `src` into the free slot `dst` (reference BatchingKvCache.add_request,
+ * kv_cache.py:226-238): block-table row, context length and pending token change hands, no K/V bytes move. */
+int tl_engine_move(tl_engine *e, int src, int dst);
 
 /* Chunked prefill of ONE slot: runs `n` tokens (host int32 ids) at positions
  * [context, context+n) through the multi-token path, appends their K/V, and, when
@@ -138,6 +141,9 @@ int tl_engine_decode(tl_engine *e, int batch, int steps, int use_graph);
 /* Copy the ids produced by the last `count` decode steps for `slot` to host
  * (synchronises the stream). */
 int tl_engine_read_tokens(tl_engine *e, int slot, int count, int32_t *out);
+
+/* Pending token ids of slots [0, count) to host memory, after synchronising the stream. */
+int tl_engine_read_pending(tl_engine *e, int count, int32_t *out);
 
 /* Device pointer to the most recent logits, [rows, vocab] bf16 (decode: rows =
  * batch of the last step; prefill with want_logits: 1 row). */

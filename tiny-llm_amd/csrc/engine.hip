@@ -5,6 +5,7 @@
 //     captured into a hipGraph per (batch, n_splits) and replayed
 //   * multi-token prefill on the MFMA W4 GEMM + paged FlashAttention operators of tinyllm_hip.h
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -181,6 +182,50 @@ static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
     return TL_OK;
 }
 
+static int ensure_splitk(tl_engine *e, size_t bytes) {
+    if (bytes <= e->splitk_ws_bytes) return TL_OK;
+    TL_HIP(hipStreamSynchronize(e->stream));
+    if (e->splitk_ws) (void)hipFree(e->splitk_ws);
+    e->splitk_ws = nullptr;
+    e->splitk_ws_bytes = 0;
+    const size_t want = std::max(bytes, (size_t)64 << 20);
+    TL_HIP(hipMalloc(&e->splitk_ws, want));
+    e->splitk_ws_bytes = want;
+    return TL_OK;
+}
+
+static int engine_qmm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M) {
+    const size_t need = tl_quantized_matmul_workspace_bytes(M, w.cols, w.rows, TL_BF16, 1, 1);
+    TL_TRY(ensure_splitk(e, need));
+    return tl_quantized_matmul(w.scales_dev, w.biases_dev, a, w.weight_dev, out, M, w.cols, w.rows, 128, 4, TL_BF16, 1, 1,
+                               e->splitk_ws, e->splitk_ws_bytes, e->stream);
+}
+
+// One projection of the decode step over `M` activation rows.  M <= 8: the fused MFMA GEMV (weights streamed once,
+// RMSNorm / residual / SwiGLU inside).  M > 8 (large decode batches): the reference's own op sequence — RMSNorm kernel,
+// W4 MFMA GEMM (quantize.py:54-65 routes rows > 8 to the matmul path), then SwiGLU / residual kernels.
+static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
+                         const void *norm_w, const uint16_t *residual, ProfCtx *pc, int kind) {
+    if (M <= 8) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
+    const tl_engine_config &c = e->cfg;
+    const uint16_t *in = a;
+    if (pro == PRO_RMSNORM) {
+        TL_TRY(tl_rms_norm(a, norm_w, e->xn, M, w.cols, c.rms_norm_eps, TL_BF16, e->stream));
+        in = e->xn;
+    }
+    uint16_t *gemm_out = epi == EPI_STORE ? out : (epi == EPI_SWIGLU ? e->gu : e->tmp);
+    TL_TRY(engine_qmm(e, w, in, gemm_out, M));
+    if (epi == EPI_SWIGLU) {
+        const long n4 = (long)M * (w.rows / 2) / 4;
+        hipLaunchKernelGGL(swiglu_interleaved_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, e->stream, e->gu, out, n4);
+    } else if (epi == EPI_RESIDUAL) {
+        const long n8 = (long)M * w.rows / 8;
+        hipLaunchKernelGGL(residual_add_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, residual, e->tmp, out, n8);
+    }
+    TL_CHECK_LAUNCH("engine batched projection");
+    return TL_OK;
+}
+
 // Context split of the decode attention: power-of-two bucket >= context, fixed windows of C tokens per workgroup.
 struct SplitPlan {
     int n_splits, tokens_per_split;
@@ -192,7 +237,8 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     int bucket = 64;
     while (bucket < max_ctx) bucket *= 2;
     int s = 1;
-    while (s * 2 <= bucket / 64 && s * 2 * base <= 1024 && s * 2 <= 64) s *= 2;  // >= 64 tokens per workgroup
+    const int min_tokens = getenv("TL_ATTN_MIN_TOKENS") ? atoi(getenv("TL_ATTN_MIN_TOKENS")) : 64;
+    while (s * 2 <= bucket / min_tokens && s * 2 * base <= 1024 && s * 2 <= 64) s *= 2;  // >= min_tokens per workgroup
     return SplitPlan{s, bucket / s};
 }
 
@@ -211,7 +257,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     const int chunks = (rep + AD_RQ - 1) / AD_RQ;
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
-        TL_TRY(engine_qmv(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0));
+        TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0));
         AttnDecodeArgs a{};
         a.qkv = e->qkv;
         a.q_norm_w = (const uint16_t *)w.q_norm_dev;
@@ -257,11 +303,11 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             if (pc) prof_after(e, pc, 6, batch * c.num_heads);
         }
         TL_CHECK_LAUNCH("engine attention");
-        TL_TRY(engine_qmv(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1));
-        TL_TRY(engine_qmv(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2));
-        TL_TRY(engine_qmv(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3));
+        TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1));
+        TL_TRY(engine_linear(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2));
+        TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3));
     }
-    TL_TRY(engine_qmv(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4));
+    TL_TRY(engine_linear(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4));
     StepEndArgs s{};
     s.logits = e->logits;
     s.vocab = c.vocab_size;
@@ -337,8 +383,8 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     TL_REQUIRE(c.head_dim == 32 || c.head_dim == 64 || c.head_dim == 128, "engine_create: head_dim must be 32, 64 or 128");
     TL_REQUIRE((c.num_heads * c.head_dim) % 128 == 0 && c.intermediate_size % 128 == 0,
                "engine_create: projection widths must be multiples of the quantization group (128)");
-    TL_REQUIRE(c.page_size > 0 && c.num_pages > 0 && c.max_batch > 0 && c.max_batch <= 8 && c.max_pages_per_seq > 0,
-               "engine_create: need page_size, num_pages, max_pages_per_seq > 0 and 1 <= max_batch <= 8");
+    TL_REQUIRE(c.page_size > 0 && c.num_pages > 0 && c.max_batch > 0 && c.max_batch <= 256 && c.max_pages_per_seq > 0,
+               "engine_create: need page_size, num_pages, max_pages_per_seq > 0 and 1 <= max_batch <= 256");
     TL_REQUIRE(c.max_prefill_rows > 0, "engine_create: max_prefill_rows must be positive");
     const int qkv_dim = (c.num_heads + 2 * c.num_kv_heads) * c.head_dim;
     const int q_dim = c.num_heads * c.head_dim;
@@ -499,6 +545,20 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
         }
     }
 
+    if (c.max_batch > 8) {
+        // batched decode goes through the W4 GEMM inside a captured graph: its split-K workspace must exist up front
+        size_t need = 0;
+        for (int M = 9; M <= c.max_batch; ++M) {
+            const tl_w4 *mats[5] = {&e->layers[0].wqkv, &e->layers[0].wo, &e->layers[0].wgu, &e->layers[0].wdown, &e->head()};
+            for (const tl_w4 *w : mats)
+                need = std::max(need, tl_quantized_matmul_workspace_bytes(M, w->cols, w->rows, TL_BF16, 1, 1));
+        }
+        if (need > 0) {
+            if (hipMalloc(&e->splitk_ws, need) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(split-K workspace) failed");
+            e->splitk_ws_bytes = need;
+        }
+    }
+
     e->slot_pages.assign(c.max_batch, {});
     e->slot_ctx.assign(c.max_batch, 0);
     e->slot_live.assign(c.max_batch, 0);
@@ -597,6 +657,49 @@ extern "C" int tl_engine_rewind(tl_engine *e, int slot, int n) {
     return poke(e, pk);
 }
 
+// Move a (prefilled) sequence from slot `src` to the free slot `dst`: the reference prefills a request in its own
+// cache and then adopts it into a batch slot (BatchingKvCache.add_request, kv_cache.py:226-238); here only the
+// block-table row, context length and pending token change hands — no K/V byte moves.
+extern "C" int tl_engine_move(tl_engine *e, int src, int dst) {
+    TL_TRY(slot_check(e, src, true));
+    TL_TRY(slot_check(e, dst, false));
+    TL_REQUIRE(src != dst, "engine_move: source and destination are the same slot");
+    TL_REQUIRE(!e->slot_live[dst], "engine_move: destination slot already holds a sequence");
+    const int W = e->cfg.max_pages_per_seq;
+    std::vector<std::pair<int32_t *, int32_t>> pk;
+    auto &pages = e->slot_pages[src];
+    for (size_t j = 0; j < pages.size(); ++j) {
+        pk.emplace_back(e->block_table + (size_t)dst * W + j, pages[j]);
+        pk.emplace_back(e->block_table + (size_t)src * W + j, -1);
+    }
+    pk.emplace_back(e->context_lens + dst, e->slot_ctx[src]);
+    pk.emplace_back(e->context_lens + src, 0);
+    pk.emplace_back(e->live + dst, 1);
+    pk.emplace_back(e->live + src, 0);
+    pk.emplace_back(e->produced + dst, 0);
+    TL_TRY(poke(e, pk));
+    TL_HIP(hipMemcpyAsync(e->tokens + dst, e->tokens + src, 4, hipMemcpyDeviceToDevice, e->stream));
+    e->slot_pages[dst] = std::move(e->slot_pages[src]);
+    e->slot_pages[src].clear();
+    e->slot_ctx[dst] = e->slot_ctx[src];
+    e->slot_ctx[src] = 0;
+    e->slot_live[dst] = 1;
+    e->slot_live[src] = 0;
+    e->slot_produced[dst] = 0;
+    e->slot_produced[src] = 0;
+    return TL_OK;
+}
+
+// Pending token ids of slots [0, count) after synchronising the stream (one copy per decode step instead of one
+// ring read per slot).
+extern "C" int tl_engine_read_pending(tl_engine *e, int count, int32_t *out) {
+    TL_REQUIRE(e && out, "engine_read_pending: null argument");
+    TL_REQUIRE(count > 0 && count <= e->cfg.max_batch, "engine_read_pending: count out of range");
+    TL_HIP(hipStreamSynchronize(e->stream));
+    TL_HIP(hipMemcpy(out, e->tokens, (size_t)count * 4, hipMemcpyDeviceToHost));
+    return TL_OK;
+}
+
 extern "C" int tl_engine_context_len(const tl_engine *e, int slot) {
     if (!e || slot < 0 || slot >= e->cfg.max_batch || !e->slot_live[slot]) return -1;
     return e->slot_ctx[slot];
@@ -608,25 +711,6 @@ extern "C" int tl_engine_set_token(tl_engine *e, int slot, int32_t token) {
     std::vector<std::pair<int32_t *, int32_t>> pk;
     pk.emplace_back(e->tokens + slot, token);
     return poke(e, pk);
-}
-
-static int ensure_splitk(tl_engine *e, size_t bytes) {
-    if (bytes <= e->splitk_ws_bytes) return TL_OK;
-    TL_HIP(hipStreamSynchronize(e->stream));
-    if (e->splitk_ws) (void)hipFree(e->splitk_ws);
-    e->splitk_ws = nullptr;
-    e->splitk_ws_bytes = 0;
-    const size_t want = std::max(bytes, (size_t)64 << 20);
-    TL_HIP(hipMalloc(&e->splitk_ws, want));
-    e->splitk_ws_bytes = want;
-    return TL_OK;
-}
-
-static int engine_qmm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M) {
-    const size_t need = tl_quantized_matmul_workspace_bytes(M, w.cols, w.rows, TL_BF16, 1, 1);
-    TL_TRY(ensure_splitk(e, need));
-    return tl_quantized_matmul(w.scales_dev, w.biases_dev, a, w.weight_dev, out, M, w.cols, w.rows, 128, 4, TL_BF16, 1, 1,
-                               e->splitk_ws, e->splitk_ws_bytes, e->stream);
 }
 
 extern "C" int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, int n, int want_logits) {

@@ -131,6 +131,16 @@ class DecodeEngine:
     def rewind(self, slot: int, n: int) -> None:
         _ext.check(_lib.tl_engine_rewind(self._h, slot, n))
 
+    def move(self, src: int, dst: int) -> None:
+        _ext.check(_lib.tl_engine_move(self._h, src, dst))
+
+    def read_pending(self, count: int | None = None) -> list[int]:
+        """Pending (= most recently generated) token id of slots [0, count); synchronises."""
+        count = count or self.max_batch
+        out = (ctypes.c_int32 * count)()
+        _ext.check(_lib.tl_engine_read_pending(self._h, count, out))
+        return list(out)
+
     def context_len(self, slot: int = 0) -> int:
         return _lib.tl_engine_context_len(self._h, slot)
 
@@ -201,3 +211,78 @@ class DecodeEngine:
             return self.read_tokens(slot, max_new_tokens)
         finally:
             self.release(slot)
+
+
+def batch_generate_ids(engine: DecodeEngine, prompts: Sequence[Sequence[int]], max_new_tokens: int | Sequence[int],
+                       batch_size: int, prefill_step: int = 128, eos_token_id: int | None = None,
+                       on_step=None) -> list[tuple[int, list[int]]]:
+    """Continuous batching over engine slots with the reference scheduler's shape (batch_generate,
+    src/tiny_llm_ref/batch.py:136-285; benches/bench.py:run_batch_requests_serving 351-572): every loop turn
+    (a) admits one pending request and prefills ONE chunk of at most ``prefill_step`` tokens in the staging slot,
+    (b) adopts it into a free decode slot once its prefill is complete, (c) runs one batched decode step over all
+    ``batch_size`` slots (idle slots carry context 0), (d) retires finished requests and returns their pages.
+    Token-id in, token-id out (no tokenizer can be downloaded here).  Needs ``engine.max_batch >= batch_size + 1``:
+    the last slot is the prefill staging slot.  Returns [(prompt_idx, generated ids)] in completion order."""
+    if batch_size <= 0 or prefill_step <= 0:
+        raise ValueError("batch_size and prefill_step must be positive")
+    if engine.max_batch < batch_size + 1:
+        raise ValueError("engine needs batch_size + 1 slots (one prefill staging slot)")
+    limits = [max_new_tokens] * len(prompts) if isinstance(max_new_tokens, int) else list(max_new_tokens)
+    staging = batch_size
+    queue = list(range(len(prompts)))
+    slots: list[dict | None] = [None] * batch_size
+    pending: dict | None = None
+    finished: list[tuple[int, list[int]]] = []
+    live_slots: set[int] = set()
+    try:
+        while queue or pending is not None or any(s is not None for s in slots):
+            if queue and pending is None:
+                idx = queue.pop(0)
+                engine.begin(staging)
+                live_slots.add(staging)
+                pending = {"idx": idx, "tokens": [int(t) for t in prompts[idx]], "offset": 0, "out": [], "limit": limits[idx]}
+            if pending is not None:
+                total = len(pending["tokens"])
+                if pending["offset"] < total:
+                    chunk = pending["tokens"][pending["offset"]:pending["offset"] + prefill_step]
+                    last = pending["offset"] + len(chunk) >= total
+                    engine.prefill(staging, chunk, chunk=len(chunk), want_logits=last)
+                    pending["offset"] += len(chunk)
+                    if last:
+                        pending["out"].append(engine.read_tokens(staging, 1)[0])
+                if pending["offset"] >= total:
+                    done = len(pending["out"]) >= pending["limit"] or pending["out"][-1] == eos_token_id
+                    if done:
+                        engine.release(staging)
+                        live_slots.discard(staging)
+                        finished.append((pending["idx"], pending["out"]))
+                        pending = None
+                    else:
+                        free = next((i for i, s in enumerate(slots) if s is None), None)
+                        if free is not None:
+                            engine.move(staging, free)
+                            live_slots.discard(staging)
+                            live_slots.add(free)
+                            slots[free] = pending
+                            pending = None
+            if any(s is not None for s in slots):
+                engine.decode(1, batch=batch_size)
+                tokens = engine.read_pending(batch_size)
+                if on_step is not None:
+                    on_step(sum(s is not None for s in slots))
+                for i, req in enumerate(slots):
+                    if req is None:
+                        continue
+                    req["out"].append(tokens[i])
+                    if len(req["out"]) >= req["limit"] or tokens[i] == eos_token_id:
+                        engine.release(i)
+                        live_slots.discard(i)
+                        finished.append((req["idx"], req["out"]))
+                        slots[i] = None
+    finally:
+        for slot in list(live_slots):
+            try:
+                engine.release(slot)
+            except RuntimeError:
+                pass
+    return finished

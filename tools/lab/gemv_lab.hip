@@ -62,7 +62,7 @@ struct Timer {
 
 int main(int argc, char **argv) {
     const bool pmc_mode = argc > 1 && std::string(argv[1]) == "pmc";
-    const int COPIES = 40;
+    const int COPIES = getenv("LAB_COPIES") ? atoi(getenv("LAB_COPIES")) : 40;
     struct Shape { const char *name; int K, N; } shapes[] = {
         {"qkv", 6144, 2560}, {"o", 2560, 4096}, {"gate_up", 19456, 2560}, {"down", 2560, 9728}, {"lm_head", 151936, 2560}};
     Timer T(200000, 4096);
@@ -71,7 +71,7 @@ int main(int argc, char **argv) {
         const int K = sh.K, N = sh.N, G = N / 128;
         const size_t wwords = (size_t)K * N / 8;
         const size_t wbytes = wwords * 4 + (size_t)K * G * 4;
-        const int copies = (int)std::max<size_t>(2, std::min<size_t>(COPIES, ((size_t)700 << 20) / wbytes + 1));
+        const int copies = (int)std::max<size_t>(1, std::min<size_t>(COPIES, ((size_t)700 << 20) / wbytes + 1));
         uint32_t *w; uint16_t *s, *b, *x, *out, *nw, *res;
         CK(hipMalloc(&w, wwords * 4 * copies)); CK(hipMalloc(&s, (size_t)K * G * 2 * copies)); CK(hipMalloc(&b, (size_t)K * G * 2 * copies));
         CK(hipMalloc(&x, N * 2 * 8)); CK(hipMalloc(&out, (size_t)K * 2 * 8)); CK(hipMalloc(&nw, N * 2)); CK(hipMalloc(&res, (size_t)K * 2 * 8));
