@@ -92,7 +92,6 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
     constexpr int T = CW * 64;
     constexpr int WR = CW / KS;
     constexpr int ROWS = MR < 4 ? MR : 4;  // accumulator rows a lane actually needs (lanes c > 0 only when MR > 4)
-    constexpr int XU = 4;                  // activation chunks a thread keeps in registers
     prof_begin(p.prof);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the slice arithmetic on the SALU
@@ -117,25 +116,28 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
 
     // ---- 1. every load of the workgroup goes out first, smallest (and first needed) first: vmcnt retires in order ----
     const int cpr = N >> 3;  // 16-byte chunks per activation row (a multiple of 16: one group = 16 chunks)
-    const int total = MR * cpr;
-    const bool reg_path = total <= XU * T;  // all activation chunks fit in registers: one global round trip
-    u32x4 xv[XU], nwv[XU];
+    // Thread t owns column chunks cc = t + k*T (k < CCU) of EVERY activation row: the norm weights are fetched once per
+    // column, the per-row sums of squares need no row selects, and a 16-lane group still covers one quantisation group.
+    constexpr int CCU = MR <= 2 ? 3 : 2;
+    const bool reg_path = cpr <= CCU * T;  // all activation chunks fit in registers: one global round trip
+    u32x4 xv[CCU][MR], nwv[CCU];
 #pragma unroll
-    for (int u = 0; u < XU; ++u) {
-        const int i = tid + u * T;
-        int m = 0, cc = i;
-        if constexpr (MR > 1) {
-            m = i / cpr;
-            cc = i - m * cpr;
+    for (int k = 0; k < CCU; ++k) {
+        const int cc = tid + k * T;
+        const bool okc = reg_path && cc < cpr;
+        const size_t coff = (size_t)(okc ? cc : 0) * 8;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const bool ok = okc && m < p.M;
+            xv[k][m] = *reinterpret_cast<const u32x4 *>(p.a + (ok ? (size_t)m * N + coff : 0));
+            if (!ok) xv[k][m] = u32x4{0u, 0u, 0u, 0u};
         }
-        const bool ok = reg_path && i < total && m < p.M;
-        xv[u] = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0));
-        if (!ok) xv[u] = u32x4{0u, 0u, 0u, 0u};
         if constexpr (PRO == PRO_RMSNORM)
-            nwv[u] = *reinterpret_cast<const u32x4 *>(p.norm_w + (size_t)((reg_path && i < total) ? cc : 0) * 8);
+            nwv[k] = *reinterpret_cast<const u32x4 *>(p.norm_w + coff);
         else
-            nwv[u] = u32x4{0u, 0u, 0u, 0u};
+            nwv[k] = u32x4{0u, 0u, 0u, 0u};
     }
+    __builtin_amdgcn_sched_barrier(0);  // activations first: vmcnt retires in issue order, and they are needed first
     u32x4 wq[Q3_LMAX];
     uint32_t sq[Q3_LMAX];
     {
@@ -197,28 +199,20 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
         for (int m = 0; m < MR; ++m) ss[m] = 0.f;
         if (reg_path) {
 #pragma unroll
-            for (int u = 0; u < XU; ++u) {
-                const float part = chunk_sumsq(xv[u]);
-                if constexpr (MR == 1) {
-                    ss[0] += part;
-                } else {
-                    const int m = (tid + u * T) / cpr;
+            for (int k = 0; k < CCU; ++k)
 #pragma unroll
-                    for (int mm = 0; mm < MR; ++mm) ss[mm] += (mm == m) ? part : 0.f;
-                }
-            }
+                for (int m = 0; m < MR; ++m) ss[m] += chunk_sumsq(xv[k][m]);
         } else {
-            // many / long rows: pass 1 parks the raw rows in LDS and accumulates the sums of squares
-            for (int i = tid; i < total; i += T) {
-                const int m = i / cpr;
-                const int cc = i - m * cpr;
-                const bool ok = m < p.M;
-                u32x4 v = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0));
-                if (!ok) v = u32x4{0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x4 *>(xs + (size_t)m * xstride + (size_t)cc * 8) = v;
-                const float part = chunk_sumsq(v);
+            // long rows: pass 1 parks the raw rows in LDS and accumulates the sums of squares
+            for (int cc = tid; cc < cpr; cc += T) {
 #pragma unroll
-                for (int mm = 0; mm < MR; ++mm) ss[mm] += (mm == m) ? part : 0.f;
+                for (int m = 0; m < MR; ++m) {
+                    const bool ok = m < p.M;
+                    u32x4 v = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0));
+                    if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4 *>(xs + (size_t)m * xstride + (size_t)cc * 8) = v;
+                    ss[m] += chunk_sumsq(v);
+                }
             }
         }
         float *scratch = red + (KS > 1 ? (size_t)CW * MR * 16 : 0);  // sized in qmv3_lds_bytes
@@ -238,37 +232,29 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
     }
     if (reg_path) {
 #pragma unroll
-        for (int u = 0; u < XU; ++u) {
-            const int i = tid + u * T;
-            if (i < total) {  // uniform per 16 lanes (total % 16 == 0)
-                int m = 0, cc = i;
-                float iv = inv[0];
-                if constexpr (MR > 1) {
-                    m = i / cpr;
-                    cc = i - m * cpr;
+        for (int k = 0; k < CCU; ++k) {
+            const int cc = tid + k * T;
+            if (cc < cpr) {  // uniform per 16 lanes (cpr % 16 == 0)
 #pragma unroll
-                    for (int mm = 0; mm < MR; ++mm) iv = (mm == m) ? inv[mm] : iv;
-                }
-                finish_chunk(m, cc, xv[u], nwv[u], iv);
+                for (int m = 0; m < MR; ++m) finish_chunk(m, cc, xv[k][m], nwv[k], inv[m]);
             }
         }
     } else {
-        for (int i = tid; i < total; i += T) {  // each thread revisits exactly the chunks it parked
-            const int m = i / cpr;
-            const int cc = i - m * cpr;
-            u32x4 v, g = u32x4{0u, 0u, 0u, 0u};
-            if constexpr (PRO == PRO_RMSNORM) {
-                v = *reinterpret_cast<const u32x4 *>(xs + (size_t)m * xstride + (size_t)cc * 8);
-                g = *reinterpret_cast<const u32x4 *>(p.norm_w + (size_t)cc * 8);
-            } else {
-                const bool ok = m < p.M;
-                v = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0));
-                if (!ok) v = u32x4{0u, 0u, 0u, 0u};
-            }
-            float iv = 1.0f;
+        for (int cc = tid; cc < cpr; cc += T) {  // each thread revisits exactly the chunks it parked
+            u32x4 g = u32x4{0u, 0u, 0u, 0u};
+            if constexpr (PRO == PRO_RMSNORM) g = *reinterpret_cast<const u32x4 *>(p.norm_w + (size_t)cc * 8);
 #pragma unroll
-            for (int mm = 0; mm < MR; ++mm) iv = (mm == m) ? inv[mm] : iv;
-            finish_chunk(m, cc, v, g, iv);
+            for (int m = 0; m < MR; ++m) {
+                u32x4 v;
+                if constexpr (PRO == PRO_RMSNORM) {
+                    v = *reinterpret_cast<const u32x4 *>(xs + (size_t)m * xstride + (size_t)cc * 8);
+                } else {
+                    const bool ok = m < p.M;
+                    v = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0));
+                    if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+                }
+                finish_chunk(m, cc, v, g, inv[m]);
+            }
         }
     }
     __syncthreads();  // activations are staged
@@ -358,7 +344,7 @@ struct Qmv3Plan {
     size_t lds;
     bool ok;
 };
-inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0) {
+inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0, int force_cw = 0) {
     Qmv3Plan pl{};
     pl.MR = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
     const int G = N / 128;
@@ -368,6 +354,7 @@ inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0) {
     if (force_ks > 0) ks = force_ks;
     pl.KS = ks;
     pl.CW = ks == 8 ? 8 : 4;
+    if (force_cw > 0 && force_cw >= ks) pl.CW = force_cw;
     const int wr = pl.CW / pl.KS;
     pl.blocks = (tiles + wr - 1) / wr;
     pl.lds = qmv3_lds_bytes(pl.MR, N, pl.KS, pl.CW);
@@ -377,7 +364,7 @@ inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0) {
 }
 
 // qmv3.hip
-int launch_qmv3_bf16(const Qmv3Args &args, int pro, int epi, hipStream_t st, int force_ks = 0);  // -1: not applicable
+int launch_qmv3_bf16(const Qmv3Args &args, int pro, int epi, hipStream_t st, int force_ks = 0, int force_cw = 0);  // -1: not applicable
 // standard checkpoint layout -> tiled layout (device to device, stream ordered)
 int repack_w4_tiled(const uint32_t *w, const uint16_t *scales, const uint16_t *biases, uint32_t *wt, uint32_t *sbt, int K,
                     int N, hipStream_t st);

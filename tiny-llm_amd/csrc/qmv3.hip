@@ -51,8 +51,8 @@ int repack_w4_tiled(const uint32_t *w, const uint16_t *scales, const uint16_t *b
 }
 
 template <int PRO, int EPI>
-static int launch_variant3(const Qmv3Args &args, hipStream_t st, int force_ks) {
-    const Qmv3Plan pl = qmv3_plan(args.M, args.N, args.K, force_ks);
+static int launch_variant3(const Qmv3Args &args, hipStream_t st, int force_ks, int force_cw) {
+    const Qmv3Plan pl = qmv3_plan(args.M, args.N, args.K, force_ks, force_cw);
     if (!pl.ok) return -1;
     const dim3 grid(pl.blocks), block(pl.CW * 64);
 #define Q3_CASE(MRv, KSv, CWv)                                                                                      \
@@ -63,18 +63,18 @@ static int launch_variant3(const Qmv3Args &args, hipStream_t st, int force_ks) {
         hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                                    \
         return 0;                                                                                                   \
     }
-#define Q3_MR(MRv) Q3_CASE(MRv, 1, 4) Q3_CASE(MRv, 2, 4) Q3_CASE(MRv, 4, 4) Q3_CASE(MRv, 8, 8)
+#define Q3_MR(MRv) Q3_CASE(MRv, 1, 4) Q3_CASE(MRv, 2, 4) Q3_CASE(MRv, 4, 4) Q3_CASE(MRv, 8, 8) Q3_CASE(MRv, 2, 8) Q3_CASE(MRv, 4, 8)
     Q3_MR(1) Q3_MR(2) Q3_MR(4) Q3_MR(8)
 #undef Q3_MR
 #undef Q3_CASE
     return -2;
 }
 
-int launch_qmv3_bf16(const Qmv3Args &args, int pro, int epi, hipStream_t st, int force_ks) {
-    if (pro == PRO_NONE && epi == EPI_STORE) return launch_variant3<PRO_NONE, EPI_STORE>(args, st, force_ks);
-    if (pro == PRO_RMSNORM && epi == EPI_STORE) return launch_variant3<PRO_RMSNORM, EPI_STORE>(args, st, force_ks);
-    if (pro == PRO_NONE && epi == EPI_RESIDUAL) return launch_variant3<PRO_NONE, EPI_RESIDUAL>(args, st, force_ks);
-    if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) return launch_variant3<PRO_RMSNORM, EPI_SWIGLU>(args, st, force_ks);
+int launch_qmv3_bf16(const Qmv3Args &args, int pro, int epi, hipStream_t st, int force_ks, int force_cw) {
+    if (pro == PRO_NONE && epi == EPI_STORE) return launch_variant3<PRO_NONE, EPI_STORE>(args, st, force_ks, force_cw);
+    if (pro == PRO_RMSNORM && epi == EPI_STORE) return launch_variant3<PRO_RMSNORM, EPI_STORE>(args, st, force_ks, force_cw);
+    if (pro == PRO_NONE && epi == EPI_RESIDUAL) return launch_variant3<PRO_NONE, EPI_RESIDUAL>(args, st, force_ks, force_cw);
+    if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) return launch_variant3<PRO_RMSNORM, EPI_SWIGLU>(args, st, force_ks, force_cw);
     return -2;
 }
 

@@ -162,16 +162,19 @@ int main(int argc, char **argv) {
             for (int M : {1, 4, 8}) {
                 struct V { const char *n; int pro, epi; } vs[] = {{"plain", PRO_NONE, EPI_STORE}, {"rms", PRO_RMSNORM, EPI_STORE}, {"resid", PRO_NONE, EPI_RESIDUAL}, {"rms+swiglu", PRO_RMSNORM, EPI_SWIGLU}};
                 for (auto &v : vs) {
+                    for (int fcw : {0, 8})
                     for (int fks : {0, 1, 2, 4, 8}) {
                         if (pmc_mode && (fks != 0 || M != 1)) continue;
-                        const Qmv3Plan pl = qmv3_plan(M, N, K, fks);
+                        if (fcw && (fks != 0 || M != 1)) continue;
+                        const Qmv3Plan pl = qmv3_plan(M, N, K, fks, fcw);
+                        if (fcw && pl.CW != fcw) continue;
                         if (!pl.ok) continue;
                         if (fks && M > 1) continue;
                         uint16_t *out2; CK(hipMalloc(&out2, (size_t)K * 2 * 8));
                         QmvArgs a{}; a.scales = s; a.biases = b; a.b = w; a.a = x; a.norm_w = nw; a.residual = res; a.eps = 1e-6f; a.M = M; a.N = N; a.K = K;
                         a.out = out; launch_qmv_fused_bf16(a, v.pro, v.epi, 0);
                         Qmv3Args a3{}; a3.wt = wt3; a3.sbt = sb3; a3.a = x; a3.out = out2; a3.norm_w = nw; a3.residual = res; a3.eps = 1e-6f; a3.M = M; a3.N = N; a3.K = K;
-                        if (launch_qmv3_bf16(a3, v.pro, v.epi, 0, fks) != 0) { printf("qmv3 launch failed\n"); continue; }
+                        if (launch_qmv3_bf16(a3, v.pro, v.epi, 0, fks, fcw) != 0) { printf("qmv3 launch failed\n"); continue; }
                         const size_t ncmp = (size_t)M * (v.epi == EPI_SWIGLU ? K / 2 : K);
                         std::vector<uint16_t> h1(ncmp), h2(ncmp);
                         CK(hipDeviceSynchronize());
@@ -182,7 +185,7 @@ int main(int argc, char **argv) {
                         for (int i = 0; i < iters; ++i) {
                             const int cidx = i % copies;
                             a3.wt = wt3 + (size_t)cidx * wwords; a3.sbt = sb3 + (size_t)cidx * K * G; a3.prof = T.buf;
-                            launch_qmv3_bf16(a3, v.pro, v.epi, 0, fks);
+                            launch_qmv3_bf16(a3, v.pro, v.epi, 0, fks, fcw);
                             T.after(pl.blocks);
                         }
                         double mn; double med = T.finish(&mn);
