@@ -12,7 +12,7 @@ request-level data parallelism with NO collective on the data path (SURVEY.md §
 barrier and the max-over-ranks of the elapsed time.
 
 One JSON line on stdout (rank 0).  Extra objects:
-  roofline     — the dominant kernel (tl::qmv_kernel, the W4A16 decode GEMV: 145 launches per step streaming
+  roofline     — the dominant kernel (tl::qmv3_kernel, the W4A16 decode GEMV: 145 launches per step streaming
                  all 2.137 GB of weights).  `achieved` = algorithmic bytes of those launches / the sum of their
                  device-clock durations, measured live right after the timed region by tl_engine_profile_step
                  (every kernel stamps the device wall clock at its first workgroup's start and last wave's end —
@@ -237,7 +237,7 @@ def main() -> None:
         g_launch = sum(kinds[k]["launches"] for k in gemv)
         ach = g_bytes / g_us / 1e3
         roofline.update({
-            "kernel": "tl::qmv_kernel<BF16,...> (W4A16 decode GEMV, fused RMSNorm / residual / SwiGLU variants)",
+            "kernel": "tl::qmv3_kernel<...> (W4A16 decode GEMV on MFMA over the tiled weight layout; fused RMSNorm / residual / SwiGLU variants)",
             "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4),
             "frac_of_measured_copy_peak": round(ach / HBM_COPY_GBPS, 4),
             "launches_per_step": g_launch, "bytes_per_launch_avg": round(g_bytes / g_launch),
@@ -273,7 +273,8 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16 activations x int4 (W4A16 g128) weights, fp32 accumulate",
+        "dtype": "bf16",
+        "dtype_note": "int4 (W4A16, group 128) weights x bf16 activations on bf16 MFMA, fp32 accumulate",
         "data": "synthetic (random-init Qwen3-4B-shaped W4 weights, synthetic token ids)",
         "config": {"workload": "Qwen3-4B int4 single-prompt KV-cache decode (BASELINE.json configs[1])",
                    "prompt_tokens": args.prompt_len, "decode_steps": args.steps, "batch_per_gpu": 1,

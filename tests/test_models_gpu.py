@@ -1,0 +1,133 @@
+"""GPU tier: the host mirror of the reference models on the HIP operators — the reference's model-level ladder
+(tests_refsol/test_week_2_day_1.py, test_week_2_day_6.py:92-153, test_week_3_day_3.py:386-402,
+test_week_3_day_4.py:325-345): every Week-2 checkpoint of the kernel ladder, the Week-3 paged model and the Week-1
+dense model must agree on log-probs for the same seeded W4 checkpoint, and all of them with the numpy oracle.
+
+Tolerance: log-softmax within 8e-2 absolute (reference: rtol 0.1 / atol 2.0 on full models, 1e-3 between two paths
+that share every kernel).  Paths here differ in kernel family and rounding points (e.g. the readable RMSNorm rounds
+twice, Week-1 uses dense bf16 weights), so single-ulp bf16 flips propagate through the two layers.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tiny_oracle as O
+from helpers import TINY_CFG, log_softmax, to_mlx_shaped
+
+pytestmark = pytest.mark.gpu
+ATOL = 8e-2
+
+
+@pytest.fixture(scope="module")
+def ckpt():
+    w = O.make_qwen3_weights(TINY_CFG, seed=11, sigma=0.05)
+    return w, to_mlx_shaped(TINY_CFG, w)
+
+
+def run_cached(model, prompt, steps):
+    """prefill + greedy decode through a KV-cached model; returns per-step last-row logits."""
+    cache = model.create_kv_cache()
+    try:
+        toks = torch.tensor([prompt], dtype=torch.int32, device="cuda")
+        out = [model(toks, 0, cache, logits_to_keep=1)[0, -1].float().cpu().numpy()]
+        offset = len(prompt)
+        for _ in range(steps):
+            t = torch.tensor([[int(np.argmax(out[-1]))]], dtype=torch.int32, device="cuda")
+            out.append(model(t, offset, cache, logits_to_keep=1)[0, -1].float().cpu().numpy())
+            offset += 1
+        return np.stack(out)
+    finally:
+        for c in cache:
+            c.release()
+
+
+def test_week2_ladder_week3_and_oracle_agree(ckpt):
+    from tiny_llm_hip import Qwen3ModelWeek2, Qwen3ModelWeek3
+    from tiny_llm_hip.qwen3_week2 import WEEK2_CHECKPOINTS
+
+    w, mlx_model = ckpt
+    prompt = [7, 300, 12, 901, 44, 5, 610, 73, 250, 18, 999]  # 11 tokens: the prefill takes the GEMM path
+    ref = O.OracleQwen3(TINY_CFG, w)
+    want = [ref.forward(prompt)[0, -1]]
+    for _ in range(4):
+        want.append(ref.forward([int(np.argmax(want[-1]))])[0, -1])
+    want = log_softmax(np.stack(want))
+    week3 = log_softmax(run_cached(Qwen3ModelWeek3(mlx_model, page_size=4), prompt, 4))
+    np.testing.assert_allclose(week3, want, atol=ATOL, rtol=0)
+    for name in WEEK2_CHECKPOINTS:
+        got = log_softmax(run_cached(Qwen3ModelWeek2(mlx_model, checkpoint=name), prompt, 4))
+        np.testing.assert_allclose(got, want, atol=ATOL, rtol=0, err_msg=f"Week-2 checkpoint {name}")
+
+
+def test_week1_dense_model_matches_cached_models(ckpt):
+    """Week 1 re-runs the whole context without a cache, on dequantised bf16 weights (qwen3_week1.py:206-217)."""
+    from tiny_llm_hip import Qwen3ModelWeek1, Qwen3ModelWeek3
+
+    _, mlx_model = ckpt
+    prompt = [9, 8, 700, 6, 55, 4]
+    toks = torch.tensor([prompt], dtype=torch.int32, device="cuda")
+    dense = Qwen3ModelWeek1(mlx_model)(toks)[0, -1].float().cpu().numpy()
+    paged = run_cached(Qwen3ModelWeek3(mlx_model, page_size=4), prompt, 0)[0]
+    np.testing.assert_allclose(log_softmax(dense), log_softmax(paged), atol=ATOL, rtol=0)
+
+
+def test_week2_offset_mismatch_is_rejected(ckpt):
+    from tiny_llm_hip import Qwen3ModelWeek2
+
+    model = Qwen3ModelWeek2(ckpt[1])
+    cache = model.create_kv_cache()
+    toks = torch.tensor([[1, 2, 3]], dtype=torch.int32, device="cuda")
+    model(toks, 0, cache, logits_to_keep=1)
+    with pytest.raises(ValueError, match="does not match model offset"):
+        model(toks[:, :1], 7, cache, logits_to_keep=1)
+    for c in cache:
+        c.release()
+
+
+def test_paged_pool_counters_on_device():
+    """The reference's pool literals with the real extension op (tests_refsol/test_week_3_day_3.py:238-270)."""
+    from tiny_llm_hip import TinyKvPagedCache, TinyKvPagedPool
+
+    pool = TinyKvPagedPool(page_size=4)
+    cache = TinyKvPagedCache(pool=pool)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    k = torch.randn((1, 2, 17, 4), device="cuda", generator=g)
+    v = torch.randn((1, 2, 17, 4), device="cuda", generator=g)
+    cache.update_and_fetch_paged(k, v)
+    assert (pool.num_pages, pool.capacity, pool.storage_growths, pool.copied_pages_on_growth, pool.copied_bytes_on_growth) \
+        == (5, 8, 2, 4, 1024)
+    dk, dv = cache.gather_dense()
+    assert torch.equal(dk, k) and torch.equal(dv, v)
+    cache.release()
+    assert pool.used_page_ids == set() and pool.num_free_pages == 5
+
+
+def test_batch_generate_with_real_model(ckpt):
+    """Continuous batching of the op-by-op Week-3 model (reference batch.py:136-285) over real kernels: every request
+    finishes, pages come back, and a request served alone produces the same text."""
+    from tiny_llm_hip import Qwen3ModelWeek3, batch_generate
+
+    class Detok:
+        def __init__(self, _):
+            self.text = ""
+
+        def add_token(self, token):
+            self.text += f"{token},"
+
+    class Tok:
+        eos_token_id = -1
+        _tokenizer = object()
+        detokenizer = Detok(_tokenizer)
+
+        def encode(self, prompt, add_special_tokens=False):
+            return [int(t) for t in prompt.split()]
+
+    model = Qwen3ModelWeek3(ckpt[1], page_size=4)
+    prompts = ["5 6 7 8 9 10 11", "100 200 300", "42 43 44 45 46 47 48 49 50 51 52 53", "9"]
+    batched = dict(batch_generate(model, Tok(), prompts, max_seq_len=20, batch_size=2, prefill_step=4))
+    assert sorted(batched) == [0, 1, 2, 3] and all(batched.values())
+    solo = dict(batch_generate(model, Tok(), [prompts[1]], max_seq_len=20, batch_size=1, prefill_step=4))
+    assert solo[0].split(",")[0] == batched[1].split(",")[0]
+    for pool in model.page_pools:
+        assert pool.used_page_ids == set()
