@@ -9,7 +9,6 @@
 #include <string>
 #include <algorithm>
 #include "../../tiny-llm_amd/csrc/qmv.h"
-#include "../../tiny-llm_amd/csrc/qmv2.h"
 #include "../../tiny-llm_amd/csrc/qmv3.h"
 #include "../../tiny-llm_amd/csrc/engine_kernels.h"
 
@@ -121,40 +120,7 @@ int main(int argc, char **argv) {
                 printf("   qmv M=%d %-10s (MR%d WN%d RPL%d blocks %5d): med %7.2f us  min %7.2f -> %7.1f GB/s\n", M, v.n, pl.MR, pl.WN, pl.RPL, pl.blocks, med, mn, wbytes / med / 1e3);
             }
         }
-        // qmv2 (MFMA) variants + correctness vs qmv
-        for (int M : {1, 4}) {
-            if (pmc_mode) break;
-            struct V { const char *n; int pro, epi; } vs[] = {{"plain", PRO_NONE, EPI_STORE}, {"rms", PRO_RMSNORM, EPI_STORE}, {"resid", PRO_NONE, EPI_RESIDUAL}, {"rms+swiglu", PRO_RMSNORM, EPI_SWIGLU}};
-            for (auto &v : vs) {
-                for (int fks : {0, 1, 2, 4, 8}) {
-                    const Qmv2Plan pl = qmv2_plan(M, N, K, v.pro == PRO_RMSNORM, fks);
-                    if (!pl.ok || (fks && (G + fks - 1) / fks > 2 * Q2_LMAX)) continue;
-                    if (fks && M > 1) continue;
-                    // correctness on copy 0
-                    uint16_t *out2; CK(hipMalloc(&out2, (size_t)K * 2 * 8));
-                    QmvArgs a{}; a.scales = s; a.biases = b; a.b = w; a.a = x; a.norm_w = nw; a.residual = res; a.eps = 1e-6f; a.M = M; a.N = N; a.K = K; a.prof = nullptr;
-                    a.out = out; launch_qmv_fused_bf16(a, v.pro, v.epi, 0);
-                    a.out = out2; if (launch_qmv2_bf16(a, v.pro, v.epi, 0, fks) != 0) { printf("qmv2 launch failed\n"); continue; }
-                    const size_t ncmp = (size_t)M * (v.epi == EPI_SWIGLU ? K / 2 : K);
-                    std::vector<uint16_t> h1(ncmp), h2(ncmp);
-                    CK(hipDeviceSynchronize());
-                    CK(hipMemcpy(h1.data(), out, ncmp * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), out2, ncmp * 2, hipMemcpyDeviceToHost));
-                    double maxd = 0, maxv = 0; size_t bad = 0;
-                    for (size_t i = 0; i < ncmp; ++i) { uint32_t u1 = (uint32_t)h1[i] << 16, u2 = (uint32_t)h2[i] << 16; float f1, f2; memcpy(&f1, &u1, 4); memcpy(&f2, &u2, 4);
-                        double d = fabs((double)f1 - f2); if (!(d <= 0.02 * fabs(f1) + 1e-2)) ++bad; maxd = std::max(maxd, d); maxv = std::max(maxv, (double)fabs(f1)); }
-                    for (int i = 0; i < iters; ++i) {
-                        const int cidx = i % copies;
-                        a.scales = s + (size_t)cidx * K * G; a.biases = b + (size_t)cidx * K * G; a.b = w + (size_t)cidx * wwords; a.prof = T.buf;
-                        launch_qmv2_bf16(a, v.pro, v.epi, 0, fks);
-                        T.after(pl.blocks);
-                    }
-                    double mn; double med = T.finish(&mn);
-                    printf("   qmv2 M=%d %-10s (MR%d KS%d W%d blocks %5d lds %6zu): med %7.2f us  min %7.2f -> %7.1f GB/s | maxdiff %.4f (max|v| %.2f) bad %zu\n", M, v.n, pl.MR, pl.KS, pl.WAVES, pl.blocks, pl.lds, med, mn, wbytes / med / 1e3, maxd, maxv, bad);
-                    CK(hipFree(out2));
-                }
-            }
-        }
-        // qmv3 (tiled layout, MFMA, stager wave)
+        // qmv3 (tiled layout, MFMA)
         {
             uint32_t *wt3, *sb3; CK(hipMalloc(&wt3, wwords * 4 * copies)); CK(hipMalloc(&sb3, (size_t)K * G * 4 * copies));
             for (int c2 = 0; c2 < copies; ++c2) repack_w4_tiled(w + (size_t)c2 * wwords, s + (size_t)c2 * K * G, b + (size_t)c2 * K * G, wt3 + (size_t)c2 * wwords, sb3 + (size_t)c2 * K * G, K, N, 0);
