@@ -78,7 +78,7 @@ struct tl_engine {
 
     bool warmed = false;
     std::map<std::pair<int, long>, hipGraphExec_t> graphs;  // (batch, n_splits << 32 | tokens_per_split)
-    float2 *rope_table = nullptr;
+    float2 *rope_table = nullptr, *rope_cur = nullptr;
     int rope_positions = 0;
     int logits_rows = 0;
 
@@ -278,8 +278,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
         a.n_splits = n_splits;
         a.n_row_chunks = chunks;
         a.tokens_per_split = sp.tokens_per_split;
-        a.rope_table = e->rope_table;
-        a.rope_positions = e->rope_positions;
+        a.rope_cur = e->rope_cur;
         a.prof = pc ? pc->buf : nullptr;
         const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
         switch (D) {
@@ -324,6 +323,10 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     s.emb_b = (const uint16_t *)e->embed.biases_dev;
     s.x = e->x;
     s.hidden = c.hidden_size;
+    s.rope_table = e->rope_table;
+    s.rope_cur = e->rope_cur;
+    s.rope_positions = e->rope_positions;
+    s.rope_half = c.head_dim / 2;
     s.prof = pc ? pc->buf : nullptr;
     hipLaunchKernelGGL(step_end_kernel, dim3(batch), dim3(1024), 0, e->stream, s);
     if (pc) prof_after(e, pc, 7, batch);
@@ -456,6 +459,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
         if (e->kpool) (void)hipFree(e->kpool);
         if (e->vpool) (void)hipFree(e->vpool);
         if (e->rope_table) (void)hipFree(e->rope_table);
+        if (e->rope_cur) (void)hipFree(e->rope_cur);
         if (e->owns_stream) (void)hipStreamDestroy(e->stream);
         delete e;
         return fail(TL_ERR_HIP, msg);
@@ -510,6 +514,9 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
         hipLaunchKernelGGL(rope_table_kernel, dim3(ceil_div(max_pos * half, 256)), dim3(256), 0, e->stream, e->rope_table,
                            (int)max_pos, half, c.rope_theta);
         if (hipGetLastError() != hipSuccess) return cleanup_fail("engine_create: rope table kernel failed");
+        if (hipMalloc((void **)&e->rope_cur, (size_t)c.max_batch * half * sizeof(float2)) != hipSuccess ||
+            hipMemsetAsync(e->rope_cur, 0, (size_t)c.max_batch * half * sizeof(float2), e->stream) != hipSuccess)
+            return cleanup_fail("engine_create: hipMalloc(rope state) failed");
     }
 
     // decode-path weight copies in the tiled MFMA layout
@@ -582,6 +589,7 @@ extern "C" void tl_engine_destroy(tl_engine *e) {
     if (e->vpool) (void)hipFree(e->vpool);
     if (e->splitk_ws) (void)hipFree(e->splitk_ws);
     if (e->rope_table) (void)hipFree(e->rope_table);
+    if (e->rope_cur) (void)hipFree(e->rope_cur);
     for (auto &kv : e->tiled) {
         (void)hipFree(kv.second.wt);
         (void)hipFree(kv.second.sbt);
@@ -810,6 +818,10 @@ extern "C" int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, 
         s.emb_b = (const uint16_t *)e->embed.biases_dev;
         s.x = e->h;  // scratch: the prefill activations in x[0..n) must stay intact; decode re-embeds from tokens
         s.hidden = c.hidden_size;
+        s.rope_table = e->rope_table;
+        s.rope_cur = e->rope_cur;
+        s.rope_positions = e->rope_positions;
+        s.rope_half = c.head_dim / 2;
         hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(1024), 0, e->stream, s);
         TL_CHECK_LAUNCH("engine prefill argmax");
         e->slot_produced[slot] += 1;
@@ -826,7 +838,7 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
     // input activations of the first step come from the pending token ids
     hipLaunchKernelGGL(embed_slots_kernel, dim3(batch), dim3(256), 0, e->stream, e->tokens, e->embed.weight_dev,
                        (const uint16_t *)e->embed.scales_dev, (const uint16_t *)e->embed.biases_dev, e->x, c.hidden_size,
-                       c.vocab_size);
+                       c.vocab_size, e->context_lens, e->rope_table, e->rope_cur, e->rope_positions, c.head_dim / 2);
     TL_CHECK_LAUNCH("engine embed");
     std::vector<std::pair<int32_t *, int32_t>> pk;
     for (int s = 0; s < steps; ++s) {
@@ -947,7 +959,7 @@ extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *
     }
     hipLaunchKernelGGL(embed_slots_kernel, dim3(batch), dim3(256), 0, e->stream, e->tokens, e->embed.weight_dev,
                        (const uint16_t *)e->embed.scales_dev, (const uint16_t *)e->embed.biases_dev, e->x, c.hidden_size,
-                       c.vocab_size);
+                       c.vocab_size, e->context_lens, e->rope_table, e->rope_cur, e->rope_positions, c.head_dim / 2);
     std::vector<std::pair<int32_t *, int32_t>> pk;
     int max_ctx = 1;
     for (int b = 0; b < batch; ++b) {

@@ -148,8 +148,7 @@ struct AttnDecodeArgs {
     const int32_t *context_lens;        // [max_batch] tokens already cached (= position of the new token)
     uint16_t *out;                      // [batch, Hq * D]
     float *ws;                          // [batch * Hq, n_splits, D + 2]
-    const float2 *rope_table;           // [rope_positions, D / 2] (cos, sin)
-    int rope_positions;
+    const float2 *rope_cur;             // [max_batch, D / 2] (cos, sin) of each slot's NEXT position, kept by step_end
     int page_size, max_pages, num_heads, num_kv_heads;
     float scale, eps, rope_base;
     int n_splits, n_row_chunks, tokens_per_split;
@@ -223,13 +222,14 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         load_raw<VD>(row + (long)(kvh * rep + hq) * D + t * VD, qraw[r]);
     }
 
-    // ---- round trip 2: addresses that depend on the context length / page ids -----------------------------------
+    const bool live = brow[0] >= 0;  // a sequence always owns its first page; idle slots have an all -1 row and produce zeros
+    float cs[VD], sn[VD];
+    rope_from_table<VD>(p.rope_cur + (long)b * (D / 2), t, cs, sn);
+
+    // ---- round trip 2: addresses that depend on the page ids (K/V rows) or on the context length (append slot) ------
     const int wp = ctx / p.page_size;
     const int wslot = ctx - wp * p.page_size;
-    const int wpage = brow[min(wp, p.max_pages - 1)];
-    const bool live = wp < p.max_pages && wpage >= 0;  // idle slots have an all -1 row: they produce zeros
-    float cs[VD], sn[VD];
-    rope_from_table<VD>(p.rope_table + (long)min(ctx, p.rope_positions - 1) * (D / 2), t, cs, sn);
+    const int wpage = brow[min(wp, p.max_pages - 1)];  // consumed at the very end of the kernel
     RawRow<VD> kr[U], vr[U], kr_next[U], vr_next[U];
     bool ok[U];
     auto issue_kv = [&](int base, const int (&ids)[U], RawRow<VD> (&kk)[U], RawRow<VD> (&vv)[U], bool (&valid)[U]) {
@@ -269,11 +269,6 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     norm_rope(kraw_new, kw, k_new);
 #pragma unroll
     for (int i = 0; i < VD; ++i) v_new[i] = BF16::to_float(vraw_new.v[i]);
-    if (live && split == 0 && chunk == 0 && g == 0) {
-        const long off = (((long)wpage * Hkv + kvh) * p.page_size + wslot) * D + t * VD;
-        store_row<VD>(p.key_pages + off, k_new);
-        store_raw<VD>(p.value_pages + off, vraw_new);
-    }
     float qv[AD_RQ][VD], acc[AD_RQ][VD], m[AD_RQ], l[AD_RQ];
 #pragma unroll
     for (int r = 0; r < AD_RQ; ++r) {
@@ -399,6 +394,13 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             }
         }
     }
+    // append the new token's K (normed + roped) and V to the slot's page: last, so the page-id lookup that depends on
+    // the context length never sits on the critical path
+    if (live && wp < p.max_pages && wpage >= 0 && split == 0 && chunk == 0 && g == 0) {
+        const long off = (((long)wpage * Hkv + kvh) * p.page_size + wslot) * D + t * VD;
+        store_row<VD>(p.key_pages + off, k_new);
+        store_raw<VD>(p.value_pages + off, vraw_new);
+    }
     prof_end(p.prof);
 }
 
@@ -454,13 +456,17 @@ struct StepEndArgs {
     const uint16_t *emb_s, *emb_b;
     uint16_t *x;  // [max_batch, hidden], row = slot
     int hidden;
+    // RoPE factors of the slot's next position (read by the next step's attention kernels)
+    const float2 *rope_table;
+    float2 *rope_cur;
+    int rope_positions, rope_half;
     prof_t *prof;
 };
 
 __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
     __shared__ float s_val[16];
     __shared__ int s_idx[16];
-    __shared__ int s_token;
+    __shared__ int s_token, s_ctx;
     prof_begin(p.prof);
     const int i = blockIdx.x;
     const int slot = p.slot0 + i;
@@ -512,15 +518,21 @@ __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
         }
         if (bi < 0 || bi >= p.vocab) bi = 0;  // all-NaN / -inf row
         s_token = bi;
+        int ctx_now = p.context_lens[slot];
         if (p.live[slot]) {
             p.tokens[slot] = bi;
             const int n = p.produced[slot];
             p.ring[(long)slot * p.ring_cap + (n % p.ring_cap)] = bi;
             p.produced[slot] = n + 1;
-            if (p.advance) p.context_lens[slot] += 1;
+            if (p.advance) p.context_lens[slot] = ++ctx_now;
         }
+        s_ctx = ctx_now;
     }
     __syncthreads();
+    if ((int)threadIdx.x < p.rope_half) {
+        const int pos = min(s_ctx, p.rope_positions - 1);  // the slot's NEXT position
+        p.rope_cur[(long)slot * p.rope_half + threadIdx.x] = p.rope_table[(long)pos * p.rope_half + threadIdx.x];
+    }
     const int token = s_token;
     const int words = p.hidden / 8;
     const int groups = p.hidden / 128;
@@ -661,7 +673,10 @@ __global__ __launch_bounds__(256) void embed_slots_kernel(const int32_t *__restr
                                                           const uint32_t *__restrict__ emb_w,
                                                           const uint16_t *__restrict__ emb_s,
                                                           const uint16_t *__restrict__ emb_b, uint16_t *__restrict__ x,
-                                                          int hidden, int vocab) {
+                                                          int hidden, int vocab, const int32_t *__restrict__ context_lens,
+                                                          const float2 *__restrict__ rope_table,
+                                                          float2 *__restrict__ rope_cur, int rope_positions,
+                                                          int rope_half) {
     const int slot = blockIdx.x;
     int token = tokens[slot];
     token = token < 0 ? 0 : (token >= vocab ? vocab - 1 : token);
@@ -675,6 +690,11 @@ __global__ __launch_bounds__(256) void embed_slots_kernel(const int32_t *__restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = BF16::from_float((float)((packed >> (4 * e)) & 0xfu) * scale + bias);
         *reinterpret_cast<uint4 *>(x + (long)slot * hidden + w * 8) = *reinterpret_cast<const uint4 *>(o);
+    }
+    // whatever changed the slot's context on the host side (prefill, rewind, move), the step starts from fresh factors
+    if ((int)threadIdx.x < rope_half) {
+        const int pos = min(context_lens[slot], rope_positions - 1);
+        rope_cur[(long)slot * rope_half + threadIdx.x] = rope_table[(long)pos * rope_half + threadIdx.x];
     }
 }
 
