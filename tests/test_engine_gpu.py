@@ -58,16 +58,17 @@ def margin_ok(logits_row, band=LOGPROB_ATOL * 2):
     return (top2[1] - top2[0]) > band
 
 
-@pytest.mark.parametrize("n_prompt", [1, 5, 20, 37])
+@pytest.mark.parametrize("n_prompt", [1, 5, 20, 37, 90, 150, 300])
 def test_engine_matches_oracle(ckpt, engine, n_prompt):
     """prefill (GEMV path for <=8 rows, MFMA GEMM + paged FlashAttention above) then 12 fused decode steps,
-    crossing page boundaries (page_size 16)."""
+    crossing page boundaries (page_size 16).  Contexts above 64 tokens split the decode attention over 2/4/8
+    workgroups per head, merged by a second launch."""
     w, _ = ckpt
     prompt = prompt_ids(n_prompt, seed=n_prompt)
     steps = 12
     want_logits, want_ids = oracle_run(w, prompt, steps)
     engine.begin(0)
-    engine.prefill(0, prompt)
+    engine.prefill(0, prompt, chunk=64)
     got = [engine.logits(1)[0].float().cpu().numpy()]
     ids = engine.read_tokens(0, 1)
     for s in range(steps):
@@ -124,7 +125,7 @@ def test_engine_matches_op_by_op_model(ckpt, engine):
         for c in cache:
             c.release()
     engine.begin(0)
-    engine.prefill(0, prompt)
+    engine.prefill(0, prompt, chunk=64)
     got = [engine.logits(1)[0].float().cpu().numpy()]
     for s in range(8):
         engine.set_token(0, ids[s])

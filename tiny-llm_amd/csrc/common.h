@@ -96,15 +96,19 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 // ---- optional in-kernel timing (engine profile step) ---------------------------------------------
 // buf = nullptr in normal operation.  Otherwise buf[2*wg] receives the workgroup's first timestamp and
 // buf[2*wg+1] the maximum end timestamp over its waves (constant-rate wall clock, hipDeviceAttributeWallClockRate).
+// prof_begin only READS the clock: a store at the top of a kernel makes hipcc treat every later load as possibly
+// clobbered, which turns the wave-uniform loads of the prologue (context length, page id) from s_load into vector
+// loads.  Both stamps are written by prof_end.
 typedef unsigned long long prof_t;
 __device__ __forceinline__ unsigned prof_wg() {
     return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
 }
-__device__ __forceinline__ void prof_begin(prof_t *buf) {
-    if (buf && threadIdx.x == 0) buf[2 * (size_t)prof_wg()] = wall_clock64();
-}
-__device__ __forceinline__ void prof_end(prof_t *buf) {
-    if (buf && (threadIdx.x & 63) == 0) atomicMax(&buf[2 * (size_t)prof_wg() + 1], (prof_t)wall_clock64());
+__device__ __forceinline__ prof_t prof_begin(const prof_t *buf) { return buf ? (prof_t)wall_clock64() : (prof_t)0; }
+__device__ __forceinline__ void prof_end(prof_t *buf, prof_t t0) {
+    if (buf) {
+        if (threadIdx.x == 0) buf[2 * (size_t)prof_wg()] = t0;
+        if ((threadIdx.x & 63) == 0) atomicMax(&buf[2 * (size_t)prof_wg() + 1], (prof_t)wall_clock64());
+    }
 }
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

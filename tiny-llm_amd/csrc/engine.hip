@@ -63,6 +63,9 @@ struct tl_engine {
     uint16_t *x = nullptr, *h = nullptr, *xn = nullptr, *qkv = nullptr, *q_t = nullptr, *attn_t = nullptr,
              *attn = nullptr, *gu = nullptr, *act = nullptr, *tmp = nullptr, *logits = nullptr;
     float *attn_ws = nullptr;
+    int attn_rq = 0;             // query heads per decode-attention workgroup; 0 = by context (TL_ATTN_RQ at create: 1 or 4)
+    int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup (TL_ATTN_RQ1_CTX)
+    int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
     size_t attn_ws_bytes = 0;
     int rows_cap = 0;
     int ring_cap = 4096;
@@ -229,23 +232,37 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
 // Context split of the decode attention: power-of-two bucket >= context, fixed windows of C tokens per workgroup.
 struct SplitPlan {
     int n_splits, tokens_per_split;
+    int rq;  // query heads per workgroup
 };
+// Measured on MI355X (profiles/README.md): a decode-attention workgroup is bound by its dependent VALU chain, not by
+// bytes, so short contexts want the LEAST work per workgroup: one query head (rq = 1) and a window of attn_min_tokens
+// tokens.  Long contexts go back to one workgroup per GQA group so that the K/V window is read from HBM once.
 static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
     const int rep = e->cfg.num_heads / e->cfg.num_kv_heads;
-    const int chunks = (rep + AD_RQ - 1) / AD_RQ;
+    int rq = e->attn_rq;
+    if (rq <= 0) rq = max_ctx <= e->attn_rq1_ctx ? 1 : AD_RQ;
+    if (rq != 1) rq = AD_RQ;
+    const int chunks = (rep + rq - 1) / rq;
     const int base = std::max(1, batch * e->cfg.num_kv_heads * chunks);
     int bucket = 64;
     while (bucket < max_ctx) bucket *= 2;
     int s = 1;
-    const int min_tokens = getenv("TL_ATTN_MIN_TOKENS") ? atoi(getenv("TL_ATTN_MIN_TOKENS")) : 64;
-    while (s * 2 <= bucket / min_tokens && s * 2 * base <= 1024 && s * 2 <= 64) s *= 2;  // >= min_tokens per workgroup
-    return SplitPlan{s, bucket / s};
+    const int min_tokens = e->attn_min_tokens;
+    while (s * 2 <= bucket / min_tokens && s * 2 * base <= 2048 && s * 2 <= 64) s *= 2;  // >= min_tokens per workgroup
+    return SplitPlan{s, bucket / s, rq};
 }
 
+template <int VD, bool SP>
+static void launch_attn_decode_sp(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq) {
+    const size_t lds = (size_t)16 * rq * (16 * VD + 2) * sizeof(float);
+    if (rq == 1) hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, 1, SP>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP>), grid, dim3(256), lds, st, a);
+}
 template <int VD>
-static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t st) {
-    const size_t lds = (size_t)16 * AD_RQ * (16 * VD + 2) * sizeof(float);
-    hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4>), grid, dim3(256), lds, st, a);
+static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq) {
+    const bool single_page = a.tokens_per_split <= a.page_size && a.page_size % a.tokens_per_split == 0;
+    if (single_page) launch_attn_decode_sp<VD, true>(a, grid, st, rq);
+    else launch_attn_decode_sp<VD, false>(a, grid, st, rq);
 }
 
 // One fused decode step over slots [0, batch).
@@ -254,7 +271,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     const tl_engine_config &c = e->cfg;
     const int D = c.head_dim;
     const int rep = c.num_heads / c.num_kv_heads;
-    const int chunks = (rep + AD_RQ - 1) / AD_RQ;
+    const int chunks = (rep + sp.rq - 1) / sp.rq;
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
         TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0));
@@ -278,13 +295,19 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
         a.n_splits = n_splits;
         a.n_row_chunks = chunks;
         a.tokens_per_split = sp.tokens_per_split;
+        a.split_shift = 0;
+        while ((1 << a.split_shift) < n_splits) ++a.split_shift;
+        a.rep = rep;
+        a.page_shift = -1;
+        for (int sh = 0; sh < 30; ++sh)
+            if ((1 << sh) == c.page_size) a.page_shift = sh;
         a.rope_cur = e->rope_cur;
         a.prof = pc ? pc->buf : nullptr;
         const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
         switch (D) {
-            case 128: launch_attn_decode<8>(a, grid, e->stream); break;
-            case 64: launch_attn_decode<4>(a, grid, e->stream); break;
-            case 32: launch_attn_decode<2>(a, grid, e->stream); break;
+            case 128: launch_attn_decode<8>(a, grid, e->stream, sp.rq); break;
+            case 64: launch_attn_decode<4>(a, grid, e->stream, sp.rq); break;
+            case 32: launch_attn_decode<2>(a, grid, e->stream, sp.rq); break;
             default: return fail(TL_ERR_UNSUPPORTED, "engine: head_dim must be 32, 64 or 128");
         }
         if (pc) prof_after(e, pc, 5, (int)(grid.x * grid.y * grid.z));
@@ -497,6 +520,9 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->act = (uint16_t *)(A + o_act);
     e->logits = (uint16_t *)(A + o_log);
     e->attn_ws = (float *)(A + o_ws);
+    if (const char *q = getenv("TL_ATTN_RQ")) e->attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
+    if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e->attn_rq1_ctx = atoi(q);
+    if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q));
 
     // state words: zero everything up to the activations, then the block table to -1
     if (hipMemsetAsync(e->arena, 0, o_x, e->stream) != hipSuccess) return cleanup_fail("engine_create: memset failed");
@@ -854,7 +880,7 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
         }
         const SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
         if (use_graph && e->warmed) {
-            const auto key = std::make_pair(batch, ((long)sp.n_splits << 32) | (long)sp.tokens_per_split);
+            const auto key = std::make_pair(batch, ((long)sp.rq << 48) | ((long)sp.n_splits << 32) | (long)sp.tokens_per_split);
             auto it = e->graphs.find(key);
             if (it == e->graphs.end()) {
                 hipGraph_t graph = nullptr;

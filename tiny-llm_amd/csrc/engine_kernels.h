@@ -6,7 +6,7 @@
 namespace tl {
 
 constexpr float ENG_LOG2E = 1.44269504089f;
-constexpr int AD_RQ = 4;  // query heads of one GQA group handled per workgroup
+constexpr int AD_RQ = 4;  // most query heads of one GQA group handled per workgroup
 
 // ---------------------------------------------------------------------------------------------
 // Shared prologue: RMSNorm over one head row (D = 16*VD, lane t holds dims [t*VD, t*VD+VD)) rounded to bf16
@@ -152,8 +152,21 @@ struct AttnDecodeArgs {
     int page_size, max_pages, num_heads, num_kv_heads;
     float scale, eps, rope_base;
     int n_splits, n_row_chunks, tokens_per_split;
+    int split_shift;  // log2(n_splits): the split count is a power of two
+    int rep;          // query heads per KV head
+    int page_shift;   // log2(page_size), or -1 when the page size is not a power of two (then: integer division)
     prof_t *prof;
 };
+
+// Scalar (wave-uniform) 32-bit load through the scalar cache, and the wait that makes its result usable.  The address must
+// be wave-uniform.  Words read this way were written by EARLIER launches (scalar caches are invalidated at kernel start).
+__device__ __forceinline__ void sload_i32(const int32_t *ptr, int &dst) {
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(dst) : "s"(ptr));
+}
+__device__ __forceinline__ void sload_wait(int &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
+__device__ __forceinline__ void sload_wait(int &a, int &b2, int &c2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b2), "+s"(c2));
+}
 
 template <int VD>
 struct alignas(2 * VD) RawRow {
@@ -181,18 +194,26 @@ __device__ __forceinline__ void store_raw(uint16_t *dst, const RawRow<VD> &r) {
     }
 }
 
-template <int VD, int U>
+// RQ = query heads of the GQA group handled per workgroup (1, 2 or 4): fewer heads per workgroup shorten the dependent
+// VALU chain of a step at the price of re-reading the K/V window from L2 once per extra workgroup
+// SP = the workgroup's token window lies inside ONE page (tokens_per_split divides page_size): the page id is then a
+// scalar load that returns long before the vector round trip, and the K/V rows no longer wait for it
+template <int VD, int U, int RQ, bool SP>
 __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecodeArgs p) {
     constexpr int D = 16 * VD;
     constexpr int STRIDE = D + 2;
-    extern __shared__ __attribute__((aligned(16))) float psm[];  // [16][AD_RQ][STRIDE]
-    prof_begin(p.prof);
-    const int split = blockIdx.x % p.n_splits;
-    const int chunk = blockIdx.x / p.n_splits;
-    const int kvh = blockIdx.y;
-    const int b = blockIdx.z;
+    extern __shared__ __attribute__((aligned(16))) float psm[];  // [16][RQ][STRIDE]
+    const prof_t prof_t0 = prof_begin(p.prof);
+    // wave-uniform indices stay on the scalar unit (readfirstlane: hipcc otherwise parks blockIdx in VGPRs after the
+    // profiling branch and emulates every division below on the VALU, in front of the first load)
+    const int bx = __builtin_amdgcn_readfirstlane(blockIdx.x);
+    const int split = bx & (p.n_splits - 1);
+    const int chunk = bx >> p.split_shift;
+    const int kvh = __builtin_amdgcn_readfirstlane(blockIdx.y);
+    const int b = __builtin_amdgcn_readfirstlane(blockIdx.z);
     const int Hq = p.num_heads, Hkv = p.num_kv_heads;
-    const int rep = Hq / Hkv;
+    const int rep = p.rep;
+    auto page_of = [&](int tok) { return p.page_shift >= 0 ? (tok >> p.page_shift) : tok / p.page_size; };
     const int g = threadIdx.x >> 4;
     const int t = threadIdx.x & 15;
     const int32_t *brow = p.block_table + (long)b * p.max_pages;
@@ -203,40 +224,55 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     const int n_it = (C + 16 * U - 1) / (16 * U);
 
     // ---- round trip 1: everything whose address is known at launch ---------------------------------------------
-    const int ctx = p.context_lens[b];
+    // Wave-uniform words (context length, first page id, and with SP the window's page id) come through the scalar cache:
+    // explicit s_load, because hipcc turns such loads into "vector load + wait + readfirstlane" at the top of the kernel.
+    // They are waited for (lgkmcnt) only after the vector loads of this round trip have been issued.
+    int ctx, first_page, pid_s = 0;
+    sload_i32(p.context_lens + b, ctx);
+    sload_i32(brow, first_page);
+    if constexpr (SP) sload_i32(brow + min(page_of(t_begin), p.max_pages - 1), pid_s);
     int pid[U], pid_next[U];
+    if constexpr (!SP) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int tok = t_begin + u * 16 + g;
-        pid[u] = brow[min(tok / p.page_size, p.max_pages - 1)];
-        pid_next[u] = brow[min((tok + 16 * U) / p.page_size, p.max_pages - 1)];
+        for (int u = 0; u < U; ++u) {
+            const int tok = t_begin + u * 16 + g;
+            pid[u] = brow[min(page_of(tok), p.max_pages - 1)];
+            pid_next[u] = brow[min(page_of(tok + 16 * U), p.max_pages - 1)];
+        }
     }
-    RawRow<VD> kraw_new, vraw_new, qraw[AD_RQ], qw, kw;
+    RawRow<VD> kraw_new, vraw_new, qraw[RQ], qw, kw;
     load_raw<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
     load_raw<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
     load_raw<VD>(p.q_norm_w + t * VD, qw);
     load_raw<VD>(p.k_norm_w + t * VD, kw);
 #pragma unroll
-    for (int r = 0; r < AD_RQ; ++r) {
-        const int hq = min(chunk * AD_RQ + r, rep - 1);
+    for (int r = 0; r < RQ; ++r) {
+        const int hq = min(chunk * RQ + r, rep - 1);
         load_raw<VD>(row + (long)(kvh * rep + hq) * D + t * VD, qraw[r]);
     }
 
-    const bool live = brow[0] >= 0;  // a sequence always owns its first page; idle slots have an all -1 row and produce zeros
     float cs[VD], sn[VD];
     rope_from_table<VD>(p.rope_cur + (long)b * (D / 2), t, cs, sn);
+    __builtin_amdgcn_sched_barrier(0);
+    sload_wait(ctx, first_page, pid_s);
+    const bool live = first_page >= 0;  // a sequence always owns its first page; idle slots have an all -1 row and produce zeros
+    if constexpr (SP) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) pid[u] = pid_next[u] = pid_s;
+    }
 
     // ---- round trip 2: addresses that depend on the page ids (K/V rows) or on the context length (append slot) ------
-    const int wp = ctx / p.page_size;
+    const int wp = page_of(ctx);
     const int wslot = ctx - wp * p.page_size;
-    const int wpage = brow[min(wp, p.max_pages - 1)];  // consumed at the very end of the kernel
+    int wpage;
+    sload_i32(brow + min(wp, p.max_pages - 1), wpage);  // waited for at the very end of the kernel
     RawRow<VD> kr[U], vr[U], kr_next[U], vr_next[U];
     bool ok[U];
     auto issue_kv = [&](int base, const int (&ids)[U], RawRow<VD> (&kk)[U], RawRow<VD> (&vv)[U], bool (&valid)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int tok = base + u * 16 + g;
-            const int lp = tok / p.page_size;
+            const int lp = page_of(tok);
             const int slot = tok - lp * p.page_size;
             valid[u] = tok < ctx && tok < t_begin + C && lp < p.max_pages && ids[u] >= 0;
             const long off = (((long)max(ids[u], 0) * Hkv + kvh) * p.page_size + slot) * D + t * VD;
@@ -269,9 +305,9 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     norm_rope(kraw_new, kw, k_new);
 #pragma unroll
     for (int i = 0; i < VD; ++i) v_new[i] = BF16::to_float(vraw_new.v[i]);
-    float qv[AD_RQ][VD], acc[AD_RQ][VD], m[AD_RQ], l[AD_RQ];
+    float qv[RQ][VD], acc[RQ][VD], m[RQ], l[RQ];
 #pragma unroll
-    for (int r = 0; r < AD_RQ; ++r) {
+    for (int r = 0; r < RQ; ++r) {
         float qn[VD];
         norm_rope(qraw[r], qw, qn);
 #pragma unroll
@@ -289,18 +325,20 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         const bool more = it + 1 < n_it;
         if (more) {  // uniform
             issue_kv(t_begin + (it + 1) * 16 * U, pid_next, kr_next, vr_next, ok_next);
+            if constexpr (!SP) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                pid_next[u] = brow[min((t_begin + (it + 2) * 16 * U + u * 16 + g) / p.page_size, p.max_pages - 1)];
+                for (int u = 0; u < U; ++u)
+                    pid_next[u] = brow[min(page_of(t_begin + (it + 2) * 16 * U + u * 16 + g), p.max_pages - 1)];
+            }
         }
-        float sc[AD_RQ][U];
+        float sc[RQ][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float kf[VD];
 #pragma unroll
             for (int i = 0; i < VD; ++i) kf[i] = BF16::to_float(kr[u].v[i]);
 #pragma unroll
-            for (int r = 0; r < AD_RQ; ++r) {
+            for (int r = 0; r < RQ; ++r) {
                 float part = 0.f;
 #pragma unroll
                 for (int i = 0; i < VD; ++i) part += qv[r][i] * kf[i];
@@ -308,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             }
         }
 #pragma unroll
-        for (int r = 0; r < AD_RQ; ++r) {
+        for (int r = 0; r < RQ; ++r) {
             float nm = m[r];
 #pragma unroll
             for (int u = 0; u < U; ++u) nm = fmaxf(nm, sc[r][u]);
@@ -337,7 +375,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     // the token being decoded (position ctx), straight from registers
     if (split == 0) {
 #pragma unroll
-        for (int r = 0; r < AD_RQ; ++r) {
+        for (int r = 0; r < RQ; ++r) {
             float part = 0.f;
 #pragma unroll
             for (int i = 0; i < VD; ++i) part += qv[r][i] * k_new[i];
@@ -356,8 +394,8 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
 
     // merge the 16 groups through LDS
 #pragma unroll
-    for (int r = 0; r < AD_RQ; ++r) {
-        float *dst = psm + ((long)g * AD_RQ + r) * STRIDE;
+    for (int r = 0; r < RQ; ++r) {
+        float *dst = psm + ((long)g * RQ + r) * STRIDE;
 #pragma unroll
         for (int i = 0; i < VD; ++i) dst[t * VD + i] = acc[r][i];
         if (t == 0) {
@@ -366,18 +404,18 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         }
     }
     __syncthreads();
-    for (int item = threadIdx.x; item < AD_RQ * D; item += 256) {
+    for (int item = threadIdx.x; item < RQ * D; item += 256) {
         const int r = item / D;
         const int d = item - r * D;
-        const int hq = chunk * AD_RQ + r;
+        const int hq = chunk * RQ + r;
         if (hq >= rep) continue;
         float gm = -1e30f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) gm = fmaxf(gm, psm[((long)j * AD_RQ + r) * STRIDE + D]);
+        for (int j = 0; j < 16; ++j) gm = fmaxf(gm, psm[((long)j * RQ + r) * STRIDE + D]);
         float gl = 0.f, vs = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const float *src = psm + ((long)j * AD_RQ + r) * STRIDE;
+            const float *src = psm + ((long)j * RQ + r) * STRIDE;
             const float f = exp2f(src[D] - gm);
             gl += src[D + 1] * f;
             vs += src[d] * f;
@@ -396,19 +434,20 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     }
     // append the new token's K (normed + roped) and V to the slot's page: last, so the page-id lookup that depends on
     // the context length never sits on the critical path
+    sload_wait(wpage);
     if (live && wp < p.max_pages && wpage >= 0 && split == 0 && chunk == 0 && g == 0) {
         const long off = (((long)wpage * Hkv + kvh) * p.page_size + wslot) * D + t * VD;
         store_row<VD>(p.key_pages + off, k_new);
         store_raw<VD>(p.value_pages + off, vraw_new);
     }
-    prof_end(p.prof);
+    prof_end(p.prof, prof_t0);
 }
 
 // partials [rows, NS, D+2] -> out [rows, D]; all loads of a thread are independent and issued together
 template <int NS>
 __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out,
                                                          int D, prof_t *prof) {
-    prof_begin(prof);
+    const prof_t prof_t0 = prof_begin(prof);
     const long orow = blockIdx.x;
     const int stride = D + 2;
     const float *base = ws + orow * NS * stride;
@@ -431,7 +470,7 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict
         acc += vs[s2] * f;
     }
     if ((int)threadIdx.x < D) out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : acc / gl);
-    prof_end(prof);
+    prof_end(prof, prof_t0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,7 +506,7 @@ __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
     __shared__ float s_val[16];
     __shared__ int s_idx[16];
     __shared__ int s_token, s_ctx;
-    prof_begin(p.prof);
+    const prof_t prof_t0 = prof_begin(p.prof);
     const int i = blockIdx.x;
     const int slot = p.slot0 + i;
     const uint16_t *lg = p.logits + (long)i * p.vocab;
@@ -545,7 +584,7 @@ __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
         for (int e = 0; e < 8; ++e) o[e] = BF16::from_float((float)((packed >> (4 * e)) & 0xfu) * scale + bias);
         *reinterpret_cast<uint4 *>(p.x + (long)slot * p.hidden + w * 8) = *reinterpret_cast<const uint4 *>(o);
     }
-    prof_end(p.prof);
+    prof_end(p.prof, prof_t0);
 }
 
 // (start, end) of one instrumented launch: min over workgroup starts, max over ends; clears the buffer.

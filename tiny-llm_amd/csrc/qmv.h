@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void qmv_kernel(const QmvArgs p) {
     constexpr int RB = 4 * WR * RPL;
     using D2 = Dot2<TT>;
 
-    prof_begin(p.prof);
+    const prof_t prof_t0 = prof_begin(p.prof);
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void qmv_kernel(const QmvArgs p) {
         }
         __syncthreads();
         if (wn != 0) {
-            prof_end(p.prof);
+            prof_end(p.prof, prof_t0);
             return;
         }
 #pragma unroll
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void qmv_kernel(const QmvArgs p) {
             }
         }
     }
-    prof_end(p.prof);
+    prof_end(p.prof, prof_t0);
 }
 
 // Host-side launch heuristic shared by the operator and the decode fast path.

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
     constexpr int T = CW * 64;
     constexpr int WR = CW / KS;
     constexpr int ROWS = MR < 4 ? MR : 4;  // accumulator rows a lane actually needs (lanes c > 0 only when MR > 4)
-    prof_begin(p.prof);
+    const prof_t prof_t0 = prof_begin(p.prof);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the slice arithmetic on the SALU
     const int lane = tid & 63;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
         }
         __syncthreads();
         if (ks != 0) {
-            prof_end(p.prof);
+            prof_end(p.prof, prof_t0);
             return;
         }
 #pragma unroll
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
             if (live) p.out[(size_t)arow * K + orow] = BF16::from_float(acc[i2]);
         }
     }
-    prof_end(p.prof);
+    prof_end(p.prof, prof_t0);
 }
 
 struct Qmv3Plan {

@@ -18,7 +18,7 @@ using namespace tl;
 // ---- H3: pure streaming floor: every lane reads 16 B chunks, xor-reduces, one store per WG ---------
 template <int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void stream_kernel(const u32x4 *__restrict__ src, size_t n16, uint32_t *out, prof_t *prof) {
-    prof_begin(prof);
+    const prof_t prof_t0 = prof_begin(prof);
     const size_t per_wg = (n16 + gridDim.x - 1) / gridDim.x;
     const size_t begin = blockIdx.x * per_wg;
     const size_t end = min(begin + per_wg, n16);
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void stream_kernel(const u32x4 *__restrict__ s
     }
     uint32_t r = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
     if (r == 0x12345678u) out[blockIdx.x] = r;  // practically never
-    prof_end(prof);
+    prof_end(prof, prof_t0);
 }
 
 struct Timer {
