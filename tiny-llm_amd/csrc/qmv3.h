@@ -29,7 +29,7 @@
 
 namespace tl {
 
-constexpr int Q3_LMAX = 10;  // groups (1 KiB wave-loads) per compute wave
+constexpr int Q3_LMAX = 10;  // most groups (1 KiB wave-loads) per compute wave; kernels are specialised on LM <= Q3_LMAX
 constexpr int Q3_PAD = 8;    // bf16 elements of padding per activation row in LDS
 
 struct Qmv3Args {
@@ -86,7 +86,9 @@ __device__ __forceinline__ u32x4 unpack_w4_bf16(uint32_t w, uint32_t mask_s, uin
     return u32x4{o0, o1, o2, o3};
 }
 
-template <int MR, int KS, int CW, int PRO, int EPI>
+// LM = groups per compute wave (the fixed-length body): the per-wave dependent chain (unpack + MFMA per group) is what
+// bounds the small projections, so LM is the smallest listed value that covers ceil(G / KS)
+template <int MR, int KS, int CW, int PRO, int EPI, int LM>
 __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = CW * 64;
@@ -138,15 +140,15 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
             nwv[k] = u32x4{0u, 0u, 0u, 0u};
     }
     __builtin_amdgcn_sched_barrier(0);  // activations first: vmcnt retires in issue order, and they are needed first
-    u32x4 wq[Q3_LMAX];
-    uint32_t sq[Q3_LMAX];
+    u32x4 wq[LM];
+    uint32_t sq[LM];
     {
         const uint32_t *sp = p.sbt + (size_t)tile_c * G * 16 + r;
 #pragma unroll
-        for (int i = 0; i < Q3_LMAX; ++i) sq[i] = sp[(size_t)min(g0 + i, G - 1) * 16];
+        for (int i = 0; i < LM; ++i) sq[i] = sp[(size_t)min(g0 + i, G - 1) * 16];
         const u32x4 *wp = reinterpret_cast<const u32x4 *>(p.wt) + (size_t)tile_c * G * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < Q3_LMAX; ++i) wq[i] = __builtin_nontemporal_load(wp + (size_t)min(g0 + i, G - 1) * 64);
+        for (int i = 0; i < LM; ++i) wq[i] = __builtin_nontemporal_load(wp + (size_t)min(g0 + i, G - 1) * 64);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
     uint32_t magic = 0x43004300u;
     asm volatile("" : "+v"(magic));  // keep the constant in a VGPR (VOP3 takes one scalar operand)
 #pragma unroll
-    for (int i = 0; i < Q3_LMAX; ++i) {
+    for (int i = 0; i < LM; ++i) {
         if (Q3_ABL(1)) {
             acc[0] += __uint_as_float((wq[i][0] ^ wq[i][1] ^ wq[i][2] ^ wq[i][3]) & 0x3fffffffu) + __uint_as_float(sq[i] & 0x3fffffffu);
             continue;
@@ -340,10 +342,11 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
 }
 
 struct Qmv3Plan {
-    int MR, KS, CW, blocks;
+    int MR, KS, CW, LM, blocks;
     size_t lds;
     bool ok;
 };
+inline int qmv3_round_lm(int lper) { return lper <= 4 ? 4 : (lper <= 5 ? 5 : (lper <= 8 ? 8 : Q3_LMAX)); }
 inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0, int force_cw = 0) {
     Qmv3Plan pl{};
     pl.MR = M <= 1 ? 1 : (M <= 2 ? 2 : (M <= 4 ? 4 : 8));
@@ -353,8 +356,9 @@ inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0, int force_cw = 
     while (ks < 8 && (G + ks - 1) / ks > Q3_LMAX) ks *= 2;
     if (force_ks > 0) ks = force_ks;
     pl.KS = ks;
-    pl.CW = ks == 8 ? 8 : 4;
+    pl.CW = ks >= 8 ? ks : 4;
     if (force_cw > 0 && force_cw >= ks) pl.CW = force_cw;
+    pl.LM = qmv3_round_lm((G + ks - 1) / ks);
     const int wr = pl.CW / pl.KS;
     pl.blocks = (tiles + wr - 1) / wr;
     pl.lds = qmv3_lds_bytes(pl.MR, N, pl.KS, pl.CW);

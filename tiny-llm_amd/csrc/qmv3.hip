@@ -55,16 +55,19 @@ static int launch_variant3(const Qmv3Args &args, hipStream_t st, int force_ks, i
     const Qmv3Plan pl = qmv3_plan(args.M, args.N, args.K, force_ks, force_cw);
     if (!pl.ok) return -1;
     const dim3 grid(pl.blocks), block(pl.CW * 64);
-#define Q3_CASE(MRv, KSv, CWv)                                                                                      \
-    if (pl.MR == MRv && pl.KS == KSv && pl.CW == CWv) {                                                             \
-        auto kern = qmv3_kernel<MRv, KSv, CWv, PRO, EPI>;                                                           \
+#define Q3_CASE(MRv, KSv, CWv, LMv)                                                                                 \
+    if (pl.MR == MRv && pl.KS == KSv && pl.CW == CWv && pl.LM == LMv) {                                             \
+        auto kern = qmv3_kernel<MRv, KSv, CWv, PRO, EPI, LMv>;                                                      \
         if (pl.lds > 64 * 1024)                                                                                     \
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
         hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                                    \
         return 0;                                                                                                   \
     }
-#define Q3_MR(MRv) Q3_CASE(MRv, 1, 4) Q3_CASE(MRv, 2, 4) Q3_CASE(MRv, 4, 4) Q3_CASE(MRv, 8, 8) Q3_CASE(MRv, 2, 8) Q3_CASE(MRv, 4, 8)
+#define Q3_LM(MRv, KSv, CWv) Q3_CASE(MRv, KSv, CWv, 4) Q3_CASE(MRv, KSv, CWv, 5) Q3_CASE(MRv, KSv, CWv, 8) Q3_CASE(MRv, KSv, CWv, 10)
+#define Q3_MR(MRv) Q3_LM(MRv, 1, 4) Q3_LM(MRv, 2, 4) Q3_LM(MRv, 4, 4) Q3_LM(MRv, 8, 8) Q3_LM(MRv, 2, 8) Q3_LM(MRv, 4, 8)
     Q3_MR(1) Q3_MR(2) Q3_MR(4) Q3_MR(8)
+    if (pl.MR == 1) { Q3_LM(1, 16, 16) }
+#undef Q3_LM
 #undef Q3_MR
 #undef Q3_CASE
     return -2;

@@ -128,14 +128,14 @@ int main(int argc, char **argv) {
             for (int M : {1, 4, 8}) {
                 struct V { const char *n; int pro, epi; } vs[] = {{"plain", PRO_NONE, EPI_STORE}, {"rms", PRO_RMSNORM, EPI_STORE}, {"resid", PRO_NONE, EPI_RESIDUAL}, {"rms+swiglu", PRO_RMSNORM, EPI_SWIGLU}};
                 for (auto &v : vs) {
-                    for (int fcw : {0, 8})
-                    for (int fks : {0, 1, 2, 4, 8}) {
+                    const int combos[][2] = {{0, 0}, {1, 4}, {2, 4}, {4, 4}, {2, 8}, {4, 8}, {8, 8}, {16, 16}};
+                    for (auto &cb : combos) {
+                        const int fks = cb[0], fcw = cb[1];
                         if (pmc_mode && (fks != 0 || M != 1)) continue;
-                        if (fcw && (fks != 0 || M != 1)) continue;
+                        if (fks && M != 1) continue;
                         const Qmv3Plan pl = qmv3_plan(M, N, K, fks, fcw);
                         if (fcw && pl.CW != fcw) continue;
                         if (!pl.ok) continue;
-                        if (fks && M > 1) continue;
                         uint16_t *out2; CK(hipMalloc(&out2, (size_t)K * 2 * 8));
                         QmvArgs a{}; a.scales = s; a.biases = b; a.b = w; a.a = x; a.norm_w = nw; a.residual = res; a.eps = 1e-6f; a.M = M; a.N = N; a.K = K;
                         a.out = out; launch_qmv_fused_bf16(a, v.pro, v.epi, 0);
@@ -155,7 +155,7 @@ int main(int argc, char **argv) {
                             T.after(pl.blocks);
                         }
                         double mn; double med = T.finish(&mn);
-                        printf("   qmv3 M=%d %-10s (MR%d KS%d CW%d blocks %5d lds %6zu): med %7.2f us  min %7.2f -> %7.1f GB/s | maxdiff %.4f (max|v| %.2f) bad %zu\n", M, v.n, pl.MR, pl.KS, pl.CW, pl.blocks, pl.lds, med, mn, wbytes / med / 1e3, maxd, maxv, bad);
+                        printf("   qmv3 M=%d %-10s (MR%d KS%d CW%d LM%2d blocks %5d lds %6zu): med %7.2f us  min %7.2f -> %7.1f GB/s | maxdiff %.4f (max|v| %.2f) bad %zu\n", M, v.n, pl.MR, pl.KS, pl.CW, pl.LM, pl.blocks, pl.lds, med, mn, wbytes / med / 1e3, maxd, maxv, bad);
                         CK(hipFree(out2));
                     }
                 }
