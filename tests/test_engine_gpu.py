@@ -237,31 +237,74 @@ def test_continuous_batching_matches_solo_generation(ckpt):
         eng.close()
 
 
-def test_large_batch_decode_uses_gemm_path(ckpt):
-    """More than 8 decode rows go through RMSNorm + W4 MFMA GEMM + SwiGLU/residual kernels (reference quantize.py:54-65
-    sends rows > 8 to the matmul path, whose weights are rounded to bf16 first): same tokens as solo decoding wherever
-    the oracle-free margin is clear, log-probs within the model-level band."""
+def _solo_vs_batch(model, n_seq, steps=3, page_size=16, env_pages=None):
+    """Logits of every sequence decoded alone (slot 0, fused GEMV) and decoded together (one batch of n_seq rows)."""
     from tiny_llm_hip.engine import DecodeEngine
 
-    eng = DecodeEngine(ckpt[1], page_size=16, num_pages=128, max_batch=12, max_prefill_rows=64)
+    vocab = model.args.vocab_size if hasattr(model, "args") else TINY_CFG["vocab_size"]
+    eng = DecodeEngine(model, page_size=page_size, num_pages=env_pages or (8 * n_seq + 8), max_batch=n_seq,
+                       max_prefill_rows=64)
     try:
-        prompts = [prompt_ids(4 + 3 * i, seed=200 + i) for i in range(12)]
-        eng1 = eng
-        solo_logits = []
+        rng = np.random.default_rng(77)
+        prompts = [[int(t) for t in rng.integers(1, vocab, size=4 + (3 * i) % 23)] for i in range(n_seq)]
+        solo = []
         for p in prompts:
-            eng1.begin(0)
-            eng1.prefill(0, p)
-            eng1.decode(3, batch=1)
-            solo_logits.append(eng1.logits(1)[0].float().cpu().numpy())
-            eng1.release(0)
+            eng.begin(0)
+            eng.prefill(0, p)
+            eng.decode(steps, batch=1)
+            solo.append(eng.logits(1)[0].float().cpu().numpy())
+            eng.release(0)
         for i, p in enumerate(prompts):
             eng.begin(i)
             eng.prefill(i, p)
-        eng.decode(3, batch=12)
-        got = eng.logits(12).float().cpu().numpy()
-        for i in range(12):
+        eng.decode(steps, batch=n_seq)
+        got = eng.logits(n_seq).float().cpu().numpy()
+        for i in range(n_seq):
             eng.release(i)
-        np.testing.assert_allclose(log_softmax(got), log_softmax(np.stack(solo_logits)), atol=0.15, rtol=0)
         assert eng.stats()["pages_in_use"] == 0
+        return got, np.stack(solo)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("n_seq", [9, 12, 24, 40, 64])
+def test_batched_decode_skinny_matmul_matches_solo(ckpt, monkeypatch, n_seq):
+    """9..64 decode rows run the K-sliced skinny MFMA matmul (csrc/qmm3.h): the GEMV's algebraic form (reference
+    quantized_matmul.metal:510-521) with the slices summed in fp32, so a sequence must decode to (nearly) the same
+    logits alone and in a batch -- same band as the oracle comparison."""
+    monkeypatch.delenv("TL_NO_QMM3", raising=False)
+    got, solo = _solo_vs_batch(ckpt[1], n_seq)
+    np.testing.assert_allclose(log_softmax(got), log_softmax(solo), atol=LOGPROB_ATOL, rtol=0)
+
+
+def test_batched_decode_reference_gemm_path(ckpt, monkeypatch):
+    """TL_NO_QMM3=1: more than 8 decode rows go through RMSNorm + W4 MFMA GEMM + SwiGLU/residual kernels (reference
+    quantize.py:54-65 sends rows > 8 to the matmul path, whose weights are rounded to bf16 first): log-probs within
+    the model-level band of solo decoding."""
+    monkeypatch.setenv("TL_NO_QMM3", "1")
+    got, solo = _solo_vs_batch(ckpt[1], 12)
+    np.testing.assert_allclose(log_softmax(got), log_softmax(solo), atol=0.15, rtol=0)
+
+
+WIDE_CFG = dict(hidden_size=1280, num_hidden_layers=1, num_attention_heads=10, num_key_value_heads=2, head_dim=128,
+                intermediate_size=2560, vocab_size=4096, rope_theta=1000000, rms_norm_eps=1e-6,
+                max_position_embeddings=4096, tie_word_embeddings=True)
+
+
+@pytest.mark.parametrize("n_seq", [16, 32, 64])
+def test_skinny_matmul_wide_shapes(n_seq):
+    """Reduction dims of 10 / 20 quantisation groups (hidden 1280, intermediate 2560) reach the 10-, 8- and 5-group slice
+    variants and several slices per row; batch rows vs the same rows decoded alone, and one row against the oracle."""
+    w = O.make_qwen3_weights(WIDE_CFG, seed=5, sigma=0.03)
+    model = to_mlx_shaped(WIDE_CFG, w)
+    got, solo = _solo_vs_batch(model, n_seq, steps=2, page_size=16)
+    np.testing.assert_allclose(log_softmax(got), log_softmax(solo), atol=LOGPROB_ATOL, rtol=0)
+    # row 0 against the oracle: prompt of 4 tokens, 2 greedy steps
+    rng = np.random.default_rng(77)
+    prompt = [int(t) for t in rng.integers(1, WIDE_CFG["vocab_size"], size=4)]
+    orc = O.OracleQwen3(WIDE_CFG, w)
+    logits = orc.forward(prompt)[0, -1]
+    for _ in range(2):
+        logits = orc.forward([int(np.argmax(logits))])[0, -1]
+    if margin_ok(logits):
+        np.testing.assert_allclose(log_softmax(got[0]), log_softmax(logits), atol=LOGPROB_ATOL, rtol=0)

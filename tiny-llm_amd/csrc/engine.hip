@@ -15,6 +15,7 @@
 #include "engine_kernels.h"
 #include "qmv.h"
 #include "qmv3.h"
+#include "qmm3.h"
 
 namespace tl {
 
@@ -63,6 +64,8 @@ struct tl_engine {
     uint16_t *x = nullptr, *h = nullptr, *xn = nullptr, *qkv = nullptr, *q_t = nullptr, *attn_t = nullptr,
              *attn = nullptr, *gu = nullptr, *act = nullptr, *tmp = nullptr, *logits = nullptr;
     float *attn_ws = nullptr;
+    int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
+    bool use_qmm3 = true;   // TL_NO_QMM3=1 at create: rows > 8 go through the prefill GEMM path instead
     int attn_rq = 0;             // query heads per decode-attention workgroup; 0 = by context (TL_ATTN_RQ at create: 1 or 4)
     int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup (TL_ATTN_RQ1_CTX)
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
@@ -204,14 +207,44 @@ static int engine_qmm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
                                e->splitk_ws, e->splitk_ws_bytes, e->stream);
 }
 
-// One projection of the decode step over `M` activation rows.  M <= 8: the fused MFMA GEMV (weights streamed once,
-// RMSNorm / residual / SwiGLU inside).  M > 8 (large decode batches): the reference's own op sequence — RMSNorm kernel,
-// W4 MFMA GEMM (quantize.py:54-65 routes rows > 8 to the matmul path), then SwiGLU / residual kernels.
+// One projection of the decode step over `M` activation rows.  Few rows: the fused MFMA GEMV (weights streamed once,
+// RMSNorm / residual / SwiGLU inside).  5 .. 64 rows: the skinny matmul (qmm3.h).  More rows, or TL_NO_QMM3: the
+// reference's own op sequence -- RMSNorm kernel, W4 MFMA GEMM (quantize.py:54-65 routes rows > 8 to the matmul path),
+// then SwiGLU / residual kernels.
 static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
                          const void *norm_w, const uint16_t *residual, ProfCtx *pc, int kind) {
-    if (M <= 8) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
+    if (M < e->qmm3_min_rows || (M <= 8 && !e->use_qmm3))
+        return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
     const tl_engine_config &c = e->cfg;
     const uint16_t *in = a;
+    // qmm3_min_rows .. 64 rows (batched decode): K-sliced skinny MFMA matmul over the tiled weights, then the slice
+    // reduction with the epilogue.  RMSNorm runs as its own launch (a slice does not see the whole row).
+    const auto tiled = e->tiled.find(w.weight_dev);
+    const Qmm3Plan p3 = qmm3_plan(M, w.cols, w.rows);
+    if (e->use_qmm3 && M <= 64 && tiled != e->tiled.end() && p3.ok) {
+        if (pro == PRO_RMSNORM) {
+            TL_TRY(tl_rms_norm(a, norm_w, e->xn, M, w.cols, c.rms_norm_eps, TL_BF16, e->stream));
+            in = e->xn;
+        }
+        TL_TRY(ensure_splitk(e, p3.partial_bytes));
+        Qmm3Args q{};
+        q.wt = tiled->second.wt;
+        q.sbt = tiled->second.sbt;
+        q.a = in;
+        q.partial = (float *)e->splitk_ws;
+        q.M = M;
+        q.N = w.cols;
+        q.K = w.rows;
+        q.prof = pc ? pc->buf : nullptr;
+        if (launch_qmm3_bf16(q, e->stream) != 0) return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul launch failed");
+        if (pc) prof_after(e, pc, kind, p3.tile_groups * p3.slices);
+        if (launch_qmm3_reduce_bf16(q.partial, p3.slices, M, w.rows, epi, residual, out, q.prof, e->stream) != 0)
+            return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul reduction launch failed");
+        if (pc) prof_after(e, pc, kind, (int)(((long)M * (w.rows / (epi == EPI_SWIGLU ? 8 : 4)) + 255) / 256));
+        TL_CHECK_LAUNCH("engine skinny matmul");
+        return TL_OK;
+    }
+    if (M <= 8) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
     if (pro == PRO_RMSNORM) {
         TL_TRY(tl_rms_norm(a, norm_w, e->xn, M, w.cols, c.rms_norm_eps, TL_BF16, e->stream));
         in = e->xn;
@@ -240,7 +273,7 @@ struct SplitPlan {
 static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
     const int rep = e->cfg.num_heads / e->cfg.num_kv_heads;
     int rq = e->attn_rq;
-    if (rq <= 0) rq = max_ctx <= e->attn_rq1_ctx ? 1 : AD_RQ;
+    if (rq <= 0) rq = (max_ctx <= e->attn_rq1_ctx && batch <= 4) ? 1 : AD_RQ;
     if (rq != 1) rq = AD_RQ;
     const int chunks = (rep + rq - 1) / rq;
     const int base = std::max(1, batch * e->cfg.num_kv_heads * chunks);
@@ -248,7 +281,10 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     while (bucket < max_ctx) bucket *= 2;
     int s = 1;
     const int min_tokens = e->attn_min_tokens;
-    while (s * 2 <= bucket / min_tokens && s * 2 * base <= 2048 && s * 2 <= 64) s *= 2;  // >= min_tokens per workgroup
+    // few sequences: split for latency (up to 2048 short-lived workgroups); many sequences: the chip is already full, longer
+    // windows amortise the per-workgroup prologue and skip the merge launch (measured at 16 and 64 sequences)
+    const int wg_cap = batch <= 4 ? 2048 : 512;
+    while (s * 2 <= bucket / min_tokens && s * 2 * base <= wg_cap && s * 2 <= 64) s *= 2;  // >= min_tokens per workgroup
     return SplitPlan{s, bucket / s, rq};
 }
 
@@ -520,6 +556,8 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->act = (uint16_t *)(A + o_act);
     e->logits = (uint16_t *)(A + o_log);
     e->attn_ws = (float *)(A + o_ws);
+    e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
+    if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
     if (const char *q = getenv("TL_ATTN_RQ")) e->attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e->attn_rq1_ctx = atoi(q);
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q));

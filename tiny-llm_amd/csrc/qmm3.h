@@ -1,0 +1,203 @@
+// W4A16 (group 128) SKINNY matmul for batched decode (9 .. 64 activation rows) over the engine's tiled weight layout.
+//
+//   out[m,k] = sum_n a[m,n] * (q[k,n]*s[k,g] + beta[k,g]),  algebraic form sum_g (s_g sum a q + beta_g sum a) in fp32
+//   (reference: quantized_matvec_x4_fast, quantized_matmul.metal:441-538 / :510-521 -- the decode GEMV semantics, so a
+//   sequence decodes to the same values whether it runs alone or in a batch).
+//
+// Why a second kernel next to qmv3.h: the GEMV stages (and, fused, normalises) ALL activation rows in every workgroup.
+// With M rows that prologue costs M times more while the weight stream stays the same; at M = 8 it already takes
+// 60 % of the kernel (profiles/r01_labs).  Here the reduction dimension is SLICED ACROSS WORKGROUPS instead:
+//
+//   grid.x = groups of 8*TW weight tiles (16 rows each), grid.y = slices of LM quantisation groups (128 columns each).
+//   A workgroup (8 waves) stages only its slice of the activations, [16 MB rows][LM*128] bf16 (<= 83 KiB of LDS), once;
+//   each wave owns TW tiles, holds their LM 1-KiB weight blocks in registers (issued before the staging, as in qmv3),
+//   and runs v_mfma_f32_16x16x32_bf16 against every 16-row block of the slice: the nibble unpack (7 VALU per 8 weights)
+//   is amortised over MB row blocks, and with TW = 2 each LDS fragment feeds two MFMAs.
+//   Partial sums go to an fp32 workspace [slices][M][K]; qmm3_reduce_kernel adds the slices in a fixed order and applies
+//   the epilogue (store / residual add / SwiGLU over interleaved gate-up rows), so results do not depend on timing.
+//
+// RMSNorm is NOT fused here (a slice cannot see the whole row): the engine runs rms_norm once per projection (M rows).
+#pragma once
+#include "common.h"
+#include "qmv.h"
+#include "qmv3.h"
+
+namespace tl {
+
+constexpr int QM3_WAVES = 8;
+constexpr int QM3_PAD = 8;  // bf16 elements of padding per staged activation row
+
+struct Qmm3Args {
+    const uint32_t *wt;   // tiled packed weights [K/16][G][64][4]
+    const uint32_t *sbt;  // tiled scale|bias<<16 [K/16][G][16]
+    const uint16_t *a;    // [M, N] bf16 (already normalised where the projection has a norm)
+    float *partial;       // [slices][M][K] fp32
+    int M, N, K;
+    prof_t *prof;
+};
+
+__host__ __device__ inline size_t qmm3_lds_bytes(int MB, int LM) {
+    return (size_t)MB * 16 * (LM * 128 + QM3_PAD) * 2 + (size_t)LM * MB * 16 * 4;
+}
+
+template <int MB, int TW, int LM>
+__global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = QM3_WAVES * 64;
+    constexpr int ROWS = MB * 16;
+    constexpr int XS = LM * 128 + QM3_PAD;  // staged row stride (elements)
+    const prof_t prof_t0 = prof_begin(p.prof);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int r = lane & 15, c = lane >> 4;
+    const int N = p.N, K = p.K, G = N >> 7;
+    const int tiles = K >> 4;
+    const int slice = blockIdx.y;
+    const int g0 = slice * LM;
+    const int gn = min(LM, G - g0);  // groups this slice really has (the last slice may be short)
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);
+    float *xsum = reinterpret_cast<float *>(smem + (size_t)ROWS * XS * 2);  // [LM][ROWS]
+
+    // ---- 1. weights of this wave's tiles: everything in flight before the staging ----------------------------------
+    u32x4 wq[TW][LM];
+    uint32_t sq[TW][LM];
+    int tile[TW];
+#pragma unroll
+    for (int tw = 0; tw < TW; ++tw) {
+        tile[tw] = (blockIdx.x * QM3_WAVES + wave) * TW + tw;
+        const int tc = min(tile[tw], tiles - 1);
+        const uint32_t *sp = p.sbt + (size_t)tc * G * 16 + r;
+        const u32x4 *wp = reinterpret_cast<const u32x4 *>(p.wt) + (size_t)tc * G * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < LM; ++i) sq[tw][i] = sp[(size_t)min(g0 + i, G - 1) * 16];
+#pragma unroll
+        for (int i = 0; i < LM; ++i) wq[tw][i] = __builtin_nontemporal_load(wp + (size_t)min(g0 + i, G - 1) * 64);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 2. activation slice -> LDS, per-(group,row) sums ------------------------------------------------------------
+    // chunk = 8 consecutive elements; a row of the slice has LM*16 chunks; 16 consecutive lanes cover one group of one row
+    {
+        constexpr int CPR = LM * 16;
+        constexpr int CHUNKS = ROWS * CPR;
+        constexpr int ITER = (CHUNKS + T - 1) / T;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {  // CHUNKS is a multiple of 64: whole waves drop out, a 16-lane group stays in one row/group
+            const int ch = tid + it * T;
+            if (ch >= CHUNKS) break;
+            const int row = ch / CPR;
+            const int cc = ch - row * CPR;
+            const int g = cc >> 4;
+            const bool ok = row < p.M && g < gn;
+            u32x4 v = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)row * N + (size_t)g0 * 128 + (size_t)cc * 8) : 0));
+            if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4 *>(xs + (size_t)row * XS + (size_t)cc * 8) = v;
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = BF16::to_float((uint16_t)(v[e] & 0xffffu));
+                f[2 * e + 1] = BF16::to_float((uint16_t)(v[e] >> 16));
+            }
+            float sum = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+            sum = group16_sum(sum);
+            if ((cc & 15) == 0) xsum[g * ROWS + row] = sum;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. MFMA over the slice --------------------------------------------------------------------------------------
+    f32x4 acc[TW][MB];
+#pragma unroll
+    for (int tw = 0; tw < TW; ++tw)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[tw][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint16_t *xbase = xs + (size_t)r * XS + 32 * c;  // A operand: lane (row r of the block, k-block c)
+    const uint32_t nib_mask = 0x000f000fu;
+    uint32_t magic = 0x43004300u;
+    asm volatile("" : "+v"(magic));
+#pragma unroll
+    for (int i = 0; i < LM; ++i) {
+        f32x4 d[TW][MB];
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) d[tw][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            u32x4 bq[TW];
+#pragma unroll
+            for (int tw = 0; tw < TW; ++tw) bq[tw] = unpack_w4_bf16(wq[tw][i][t], nib_mask, magic);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const u32x4 ax = *reinterpret_cast<const u32x4 *>(xbase + (size_t)mb * 16 * XS + i * 128 + 8 * t);
+#pragma unroll
+                for (int tw = 0; tw < TW; ++tw)
+                    d[tw][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax),
+                                                                        __builtin_bit_cast(bf16x8_t, bq[tw]), d[tw][mb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) {
+            const uint32_t sw = i < gn ? sq[tw][i] : 0u;  // groups past the end of the row contribute nothing
+            const float sc = __uint_as_float(sw << 16);
+            const float be = __uint_as_float(sw & 0xffff0000u) - 128.0f * sc;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const f32x4 xg = *reinterpret_cast<const f32x4 *>(xsum + i * ROWS + mb * 16 + 4 * c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[tw][mb][j] += sc * d[tw][mb][j] + be * xg[j];
+            }
+        }
+    }
+
+    // ---- 4. partial sums: lane (weight row r, c) holds activation rows 16 mb + 4c + j --------------------------------
+#pragma unroll
+    for (int tw = 0; tw < TW; ++tw) {
+        if (tile[tw] >= tiles) continue;
+        const int ocol = (tile[tw] << 4) + r;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = mb * 16 + 4 * c + j;
+                if (row < p.M) p.partial[((size_t)slice * p.M + row) * K + ocol] = acc[tw][mb][j];
+            }
+    }
+    prof_end(p.prof, prof_t0);
+}
+
+struct Qmm3Plan {
+    int MB, TW, LM, slices, tile_groups;
+    size_t lds, partial_bytes;
+    bool ok;
+};
+// LM is the largest of {10, 8, 5, 4} whose slice fits the LDS and that still yields about one workgroup per CU.
+inline Qmm3Plan qmm3_plan(int M, int N, int K) {
+    Qmm3Plan pl{};
+    pl.ok = M >= 1 && M <= 64 && N > 0 && N % 128 == 0 && K > 0 && K % 16 == 0;
+    if (!pl.ok) return pl;
+    pl.MB = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    const int G = N / 128, tiles = K / 16;
+    pl.TW = (pl.MB == 4 && tiles >= 2048) ? 2 : 1;
+    pl.tile_groups = (tiles + QM3_WAVES * pl.TW - 1) / (QM3_WAVES * pl.TW);
+    const int cand[4] = {10, 8, 5, 4};
+    pl.LM = 4;
+    for (int lm : cand) {
+        if (qmm3_lds_bytes(pl.MB, lm) > 100 * 1024) continue;
+        const int slices = (G + lm - 1) / lm;
+        pl.LM = lm;
+        if ((long)slices * pl.tile_groups >= 192 || lm == 4) break;
+    }
+    pl.slices = (G + pl.LM - 1) / pl.LM;
+    pl.lds = qmm3_lds_bytes(pl.MB, pl.LM);
+    pl.partial_bytes = (size_t)pl.slices * M * K * 4;
+    return pl;
+}
+
+// qmm3.hip
+int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st);
+// out = epilogue(sum over slices); epi = EPI_STORE / EPI_RESIDUAL (residual [M,K]) / EPI_SWIGLU (out [M,K/2])
+int launch_qmm3_reduce_bf16(const float *partial, int slices, int M, int K, int epi, const uint16_t *residual, uint16_t *out,
+                            prof_t *prof, hipStream_t st);
+}  // namespace tl
