@@ -110,7 +110,8 @@ int tl_paged_cache_update(void *pages, const void *values, int num_pages, int he
  * q,out [N=B*Hq, L, D]; key_pages,value_pages [P,Hkv,page_size,D];
  * block_table [B,max_pages] int32 (-1 = unused), context_lens [B] int32.
  * L<=8 -> split-context decode kernel (+ merge); L>8 bf16 D==128 -> MFMA
- * FlashAttention; L>8 f32 -> scalar tile kernel.
+ * FlashAttention (the context is also split, + merge, when few query rows
+ * meet a long context); L>8 f32 -> scalar tile kernel.
  * max_context_hint: upper bound of context_lens known to the host (<=0: use
  * max_pages*page_size); it only sizes the context split, never correctness.
  * workspace: tl_paged_attention_workspace_bytes(...) bytes, may be NULL if 0. */

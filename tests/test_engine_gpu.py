@@ -308,3 +308,34 @@ def test_skinny_matmul_wide_shapes(n_seq):
         logits = orc.forward([int(np.argmax(logits))])[0, -1]
     if margin_ok(logits):
         np.testing.assert_allclose(log_softmax(got[0]), log_softmax(logits), atol=LOGPROB_ATOL, rtol=0)
+
+
+def _prefill_logits(model, prompt, rows):
+    from tiny_llm_hip.engine import DecodeEngine
+
+    eng = DecodeEngine(model, page_size=16, num_pages=64, max_batch=1, max_prefill_rows=rows)
+    try:
+        eng.begin(0)
+        eng.prefill(0, prompt, chunk=rows)
+        out = eng.logits(1)[0].float().cpu().numpy()
+        eng.release(0)
+        return out
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("n_prompt,rows", [(100, 128), (200, 256), (300, 128), (77, 80)])
+def test_prefill_long_chunks(ckpt, wide, n_prompt, rows):
+    """Chunks of 80 .. 256 rows: W4 MFMA GEMM (row tiles of 32 / 64 / 128, split-K where the tiles alone cannot fill the
+    chip), paged FlashAttention with ragged last query blocks and -- for the later chunks of the 300-token prompt -- a
+    non-empty cached context.  Checked against the oracle forward in the same band as the decode tests."""
+    if wide:
+        cfg, w = WIDE_CFG, O.make_qwen3_weights(WIDE_CFG, seed=5, sigma=0.03)
+        model = to_mlx_shaped(WIDE_CFG, w)
+    else:
+        cfg, (w, model) = TINY_CFG, ckpt
+    prompt = [int(t) for t in np.random.default_rng(n_prompt).integers(1, cfg["vocab_size"], size=n_prompt)]
+    got = _prefill_logits(model, prompt, rows)
+    want = O.OracleQwen3(cfg, w).forward(prompt)[0, -1]
+    np.testing.assert_allclose(log_softmax(got), log_softmax(want), atol=LOGPROB_ATOL, rtol=0)

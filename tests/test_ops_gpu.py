@@ -331,6 +331,25 @@ def test_paged_attention_prefill_mfma(ext, L, ctxs, rep, page):
         close(host(got), want, "bf16")
 
 
+@pytest.mark.parametrize("L,ctxs", [(64, [2048]), (40, [1500, 700]), (128, [4096])])
+def test_paged_attention_prefill_context_splits(ext, L, ctxs):
+    """A late chunk of a chunked prefill: few query rows against a long cached context.  The MFMA kernel then cuts the
+    context into several workgroups per (head, query block) and paged_merge_kernel combines the partials
+    (attention.hip: pick_fa_splits); causal and non-causal, two sequences of different length."""
+    rng = np.random.default_rng(L + ctxs[0])
+    Hkv, rep, D, page = 2, 4, 128, 128
+    Hq = Hkv * rep
+    B = len(ctxs)
+    kp, vp, table, ctx = scattered_pages(rng, B, Hkv, page, D, ctxs, "bf16")
+    q = O.bf16(rng.standard_normal((B * Hq, L, D), dtype=np.float32))
+    for causal in (True, False):
+        want = O.paged_attention(q, kp, vp, table, ctx, D ** -0.5, causal, Hkv, Hq, "bf16", round_p=True)
+        got = ext.paged_attention(dev(q, "bf16"), dev(kp, "bf16"), dev(vp, "bf16"), torch.from_numpy(table).to(DEV),
+                                  torch.from_numpy(ctx).to(DEV), D ** -0.5, causal, num_kv_heads=Hkv, num_heads=Hq,
+                                  max_context_hint=max(ctxs))
+        close(host(got), want, "bf16")
+
+
 def test_paged_attention_prefill_f32_fallback(ext):
     rng = np.random.default_rng(8)
     kp, vp, table, ctx = scattered_pages(rng, 1, 2, 8, 64, [30], "f32")

@@ -331,7 +331,8 @@ constexpr int FA_LDV = 36;
 __global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ key_pages, const uint16_t *__restrict__ value_pages,
     const int32_t *__restrict__ block_table, const int32_t *__restrict__ context_lens, uint16_t *__restrict__ out,
-    int L, int page_size, int max_pages, int num_heads, int num_kv_heads, float scale, int is_causal) {
+    float *__restrict__ ws, int n_splits, int L, int page_size, int max_pages, int num_heads, int num_kv_heads, float scale,
+    int is_causal) {
     constexpr int D = 128;
     __shared__ __attribute__((aligned(16))) uint16_t ks[32 * D];        // [token][dim] swizzled
     __shared__ __attribute__((aligned(16))) uint16_t vt[D * FA_LDV];     // [dim][token]
@@ -347,7 +348,11 @@ __global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
     const int rep = num_heads / num_kv_heads;
     const int QB = (L + 31) / 32;
     const int items = rep * QB;
-    const int item = blockIdx.x * 4 + wave;
+    // blockIdx.x = item block * n_splits + context split: with few query rows (chunked prefill of a long prompt) the KV
+    // range is cut into n_splits pieces, one workgroup each, merged by paged_merge_kernel (flash-decoding style)
+    const int split = blockIdx.x % n_splits;
+    const int item_block = blockIdx.x / n_splits;
+    const int item = item_block * 4 + wave;
     const bool wave_live = item < items;
     const int hq = wave_live ? item % rep : 0;
     const int qb = wave_live ? item / rep : 0;
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
     int blk_tiles;
     {
         // items of a block differ at most in q-block; the last wave_live item has the largest limit
-        const int last_item = min(blockIdx.x * 4 + 3, items - 1);
+        const int last_item = min(item_block * 4 + 3, items - 1);
         const int last_qb = last_item / rep;
         if (is_causal) {
             const int lq = min((last_qb + 1) * 32, L) - 1;
@@ -438,12 +443,15 @@ __global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
         }
     };
 
-    for (int tile = 0; tile < blk_tiles; ++tile) {
-        if (tile == 0) stage_load(0);
+    const int tiles_per_split = (total_tiles + n_splits - 1) / n_splits;
+    const int tile_begin = split * tiles_per_split;
+    const int tile_end = min(tile_begin + tiles_per_split, blk_tiles);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        if (tile == tile_begin) stage_load(tile);
         __syncthreads();  // previous tile's LDS reads are complete
         stage_store();
         __syncthreads();
-        if (tile + 1 < blk_tiles) stage_load(tile + 1);
+        if (tile + 1 < tile_end) stage_load(tile + 1);
         if (tile >= my_tiles) continue;  // wave-uniform: this wave's rows see nothing here (still hits barriers)
 
         // S^T = K Q^T
@@ -509,6 +517,21 @@ __global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
     }
 
     if (!q_valid) return;
+    if (n_splits > 1) {
+        // un-normalised partial: D values, running max (log2 domain), running sum
+        float *w = ws + (((long)n * L + qrow) * n_splits + split) * (D + 2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[db * 32 + 8 * rg + 4 * h + e] = o[db][4 * rg + e];
+        if (h == 0) {
+            w[D] = run_max == -INFINITY ? -1e30f : run_max;
+            w[D + 1] = run_sum;
+        }
+        return;
+    }
     uint16_t *orow = out + ((long)n * L + qrow) * D;
     const float inv = run_sum == 0.f ? 0.f : 1.0f / run_sum;
 #pragma unroll
@@ -522,6 +545,16 @@ __global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
             *reinterpret_cast<u32x2 *>(orow + db * 32 + 8 * rg + 4 * h) = pk;
         }
     }
+}
+
+// context splits of the MFMA prefill kernel: only when the (head, query block) items alone leave most CUs idle, and never
+// below 256 tokens per split
+static int pick_fa_splits(int B, int Hkv, int item_blocks, int max_ctx) {
+    const int base = std::max(1, B * Hkv * item_blocks);
+    int s = 512 / base;
+    s = std::min(s, std::max(1, max_ctx / 256));
+    s = std::min(s, 32);
+    return std::max(s, 1);
 }
 
 static int pick_splits(int B, int Hkv, int row_chunks, int max_ctx) {
@@ -605,7 +638,9 @@ extern "C" size_t tl_paged_attention_workspace_bytes(int N, int L, int D, int pa
     const int rep = num_heads / num_kv_heads;
     const int row_chunks = (rep * L + PD_RQ - 1) / PD_RQ;
     const int max_ctx = max_context_hint > 0 ? max_context_hint : max_pages * page_size;
-    const int splits = pick_splits(B, num_kv_heads, row_chunks, max_ctx);
+    int splits = pick_splits(B, num_kv_heads, row_chunks, max_ctx);
+    if (L > 8 && D == 128)  // the bf16 prefill kernel's own split rule (an fp32 call of this shape needs no more)
+        splits = std::max(splits, pick_fa_splits(B, num_kv_heads, (rep * ((L + 31) / 32) + 3) / 4, max_ctx));
     if (splits <= 1) return 0;
     return (size_t)N * L * splits * (D + 2) * sizeof(float);
 }
@@ -632,11 +667,22 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
     if (L > 8 && dtype == TL_BF16) {
         if (D != 128) return fail(TL_ERR_UNSUPPORTED, "paged_attention: bfloat16 prefill requires head dimension 128");
         const int items = rep * ((L + 31) / 32);
-        const dim3 grid((items + 3) / 4, num_kv_heads, B);
+        const int item_blocks = (items + 3) / 4;
+        const int max_ctx_fa = max_context_hint > 0 ? max_context_hint : max_pages * page_size;
+        int fa_splits = pick_fa_splits(B, num_kv_heads, item_blocks, max_ctx_fa);
+        const size_t fa_need = fa_splits > 1 ? (size_t)N * L * fa_splits * (D + 2) * sizeof(float) : 0;
+        if (fa_need > 0 && (!workspace || workspace_bytes < fa_need)) fa_splits = 1;  // no workspace: one pass, still correct
+        const dim3 grid(item_blocks * fa_splits, num_kv_heads, B);
         hipLaunchKernelGGL(paged_fa_bf16_d128_kernel, grid, dim3(256), 0, st, (const uint16_t *)q,
                            (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,
-                           (uint16_t *)out, L, page_size, max_pages, num_heads, num_kv_heads, scale, is_causal);
+                           (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, max_pages, num_heads, num_kv_heads,
+                           scale, is_causal);
         TL_CHECK_LAUNCH("paged_attention(prefill)");
+        if (fa_splits > 1) {
+            hipLaunchKernelGGL((paged_merge_kernel<BF16>), dim3(N * L), dim3(128), 0, st, (const float *)workspace,
+                               (uint16_t *)out, D, fa_splits);
+            TL_CHECK_LAUNCH("paged_attention(prefill merge)");
+        }
         return TL_OK;
     }
 

@@ -65,6 +65,7 @@ struct tl_engine {
              *attn = nullptr, *gu = nullptr, *act = nullptr, *tmp = nullptr, *logits = nullptr;
     float *attn_ws = nullptr;
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
+    size_t qmm3_small_elems = (size_t)20 << 20;  // TL_QMM3_SMALL_ELEMS: see engine_linear
     bool use_qmm3 = true;   // TL_NO_QMM3=1 at create: rows > 8 go through the prefill GEMM path instead
     int attn_rq = 0;             // query heads per decode-attention workgroup; 0 = by context (TL_ATTN_RQ at create: 1 or 4)
     int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup (TL_ATTN_RQ1_CTX)
@@ -200,11 +201,30 @@ static int ensure_splitk(tl_engine *e, size_t bytes) {
     return TL_OK;
 }
 
+// Reference-semantics GEMM over the checkpoint layout (weights rounded to bf16 first): tl_quantized_matmul.
 static int engine_qmm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M) {
     const size_t need = tl_quantized_matmul_workspace_bytes(M, w.cols, w.rows, TL_BF16, 1, 1);
     TL_TRY(ensure_splitk(e, need));
     return tl_quantized_matmul(w.scales_dev, w.biases_dev, a, w.weight_dev, out, M, w.cols, w.rows, 128, 4, TL_BF16, 1, 1,
                                e->splitk_ws, e->splitk_ws_bytes, e->stream);
+}
+
+// out = epilogue(a @ W^T) for any number of rows (chunked prefill, batches above 64): the reference's own op sequence --
+// W4 MFMA GEMM over the checkpoint layout (quantize.py:54-65 routes rows > 8 to the matmul path, whose tile kernel rounds
+// the dequantised weights to bf16 first), then SwiGLU / residual as separate launches.
+static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int epi,
+                       const uint16_t *residual) {
+    uint16_t *plain = epi == EPI_STORE ? out : (epi == EPI_SWIGLU ? e->gu : e->tmp);
+    TL_TRY(engine_qmm(e, w, a, plain, M));
+    if (epi == EPI_SWIGLU) {
+        const long n4 = (long)M * (w.rows / 2) / 4;
+        hipLaunchKernelGGL(swiglu_interleaved_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, e->stream, plain, out, n4);
+    } else if (epi == EPI_RESIDUAL) {
+        const long n8 = (long)M * w.rows / 8;
+        hipLaunchKernelGGL(residual_add_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, residual, plain, out, n8);
+    }
+    TL_CHECK_LAUNCH("engine matmul");
+    return TL_OK;
 }
 
 // One projection of the decode step over `M` activation rows.  Few rows: the fused MFMA GEMV (weights streamed once,
@@ -214,6 +234,11 @@ static int engine_qmm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
 static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
                          const void *norm_w, const uint16_t *residual, ProfCtx *pc, int kind) {
     if (M < e->qmm3_min_rows || (M <= 8 && !e->use_qmm3))
+        return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
+    // 5 .. 8 rows: the fused GEMV still wins on the small projections (one launch instead of norm + matmul + reduction)
+    // as long as all rows fit its LDS in one pass; the big ones (down: 9728 columns, lm_head) go to the skinny matmul
+    if (M <= 8 && e->tiled.count(w.weight_dev) != 0 && qmv3_plan(M, w.cols, w.rows).ok &&
+        (size_t)w.rows * w.cols <= e->qmm3_small_elems)
         return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
     const tl_engine_config &c = e->cfg;
     const uint16_t *in = a;
@@ -249,17 +274,7 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
         TL_TRY(tl_rms_norm(a, norm_w, e->xn, M, w.cols, c.rms_norm_eps, TL_BF16, e->stream));
         in = e->xn;
     }
-    uint16_t *gemm_out = epi == EPI_STORE ? out : (epi == EPI_SWIGLU ? e->gu : e->tmp);
-    TL_TRY(engine_qmm(e, w, in, gemm_out, M));
-    if (epi == EPI_SWIGLU) {
-        const long n4 = (long)M * (w.rows / 2) / 4;
-        hipLaunchKernelGGL(swiglu_interleaved_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, e->stream, e->gu, out, n4);
-    } else if (epi == EPI_RESIDUAL) {
-        const long n8 = (long)M * w.rows / 8;
-        hipLaunchKernelGGL(residual_add_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, residual, e->tmp, out, n8);
-    }
-    TL_CHECK_LAUNCH("engine batched projection");
-    return TL_OK;
+    return engine_gemm(e, w, in, out, M, epi, residual);
 }
 
 // Context split of the decode attention: power-of-two bucket >= context, fixed windows of C tokens per workgroup.
@@ -510,6 +525,10 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     // attention partials: decode (batch*Hq rows x 64 splits) or the L<=8 operator path during short prefills
     e->attn_ws_bytes = std::max((size_t)c.max_batch * c.num_heads * 64 * (c.head_dim + 2) * 4,
                                 (size_t)c.num_heads * 8 * 64 * (c.head_dim + 2) * 4);
+    for (int L = 1; L <= c.max_prefill_rows; ++L)  // the paged attention operator may split the context for any chunk length
+        e->attn_ws_bytes = std::max(e->attn_ws_bytes, tl_paged_attention_workspace_bytes(c.num_heads, L, c.head_dim, c.page_size,
+                                                                                         c.max_pages_per_seq, c.num_heads,
+                                                                                         c.num_kv_heads, 0));
     const size_t o_ws = carve(e->attn_ws_bytes);
     e->arena_bytes = off;
 
@@ -558,6 +577,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->attn_ws = (float *)(A + o_ws);
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
+    if (const char *q = getenv("TL_QMM3_SMALL_ELEMS")) e->qmm3_small_elems = (size_t)atoll(q);
     if (const char *q = getenv("TL_ATTN_RQ")) e->attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e->attn_rq1_ctx = atoi(q);
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q));
@@ -809,7 +829,7 @@ extern "C" int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, 
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
         TL_TRY(tl_rms_norm(e->x, w.input_norm_dev, e->xn, n, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
-        TL_TRY(engine_qmm(e, w.wqkv, e->xn, e->qkv, n));
+        TL_TRY(engine_gemm(e, w.wqkv, e->xn, e->qkv, n, EPI_STORE, nullptr));
         QkvPostArgs q{};
         q.qkv = e->qkv;
         q.q_norm_w = (const uint16_t *)w.q_norm_dev;
@@ -839,22 +859,10 @@ extern "C" int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, 
             const long total = (long)Hq * n * (D / 8);
             hipLaunchKernelGGL(heads_to_rows_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, e->stream, e->attn_t, e->attn, Hq, n, D);
         }
-        TL_TRY(engine_qmm(e, w.wo, e->attn, e->tmp, n));
-        {
-            const long n8 = (long)n * c.hidden_size / 8;
-            hipLaunchKernelGGL(residual_add_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, e->x, e->tmp, e->h, n8);
-        }
+        TL_TRY(engine_gemm(e, w.wo, e->attn, e->h, n, EPI_RESIDUAL, e->x));
         TL_TRY(tl_rms_norm(e->h, w.post_norm_dev, e->xn, n, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
-        TL_TRY(engine_qmm(e, w.wgu, e->xn, e->gu, n));
-        {
-            const long n4 = (long)n * c.intermediate_size / 4;
-            hipLaunchKernelGGL(swiglu_interleaved_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, e->stream, e->gu, e->act, n4);
-        }
-        TL_TRY(engine_qmm(e, w.wdown, e->act, e->tmp, n));
-        {
-            const long n8 = (long)n * c.hidden_size / 8;
-            hipLaunchKernelGGL(residual_add_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, e->h, e->tmp, e->x, n8);
-        }
+        TL_TRY(engine_gemm(e, w.wgu, e->xn, e->act, n, EPI_SWIGLU, nullptr));
+        TL_TRY(engine_gemm(e, w.wdown, e->act, e->x, n, EPI_RESIDUAL, e->h));
         TL_CHECK_LAUNCH("engine prefill layer");
     }
     e->slot_ctx[slot] = start + n;
