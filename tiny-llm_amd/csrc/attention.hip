@@ -326,17 +326,20 @@ __global__ __launch_bounds__(128) void paged_merge_kernel(const float *__restric
 //   fp32 scores/softmax, P rounded to bf16 before PV, causal tile skipping and
 //   zero output for empty rows, as the reference.
 // ---------------------------------------------------------------------------
-constexpr int FA_LDV = 36;
+constexpr int FA_BK = 64;            // tokens staged per barrier phase (two 32-token MFMA sub-tiles)
+constexpr int FA_SUB = FA_BK / 32;
+constexpr int FA_CPT = FA_BK / 16;    // 16-byte K (and V) chunks per thread and stage
+constexpr int FA_LDV = FA_BK + 4;    // row length of the transposed V tile
 
-__global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
+__global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ key_pages, const uint16_t *__restrict__ value_pages,
     const int32_t *__restrict__ block_table, const int32_t *__restrict__ context_lens, uint16_t *__restrict__ out,
-    float *__restrict__ ws, int n_splits, int L, int page_size, int max_pages, int num_heads, int num_kv_heads, float scale,
-    int is_causal) {
+    float *__restrict__ ws, int n_splits, int L, int page_size, int page_shift, int max_pages, int num_heads, int num_kv_heads,
+    float scale, int is_causal) {
     constexpr int D = 128;
-    __shared__ __attribute__((aligned(16))) uint16_t ks[32 * D];        // [token][dim] swizzled
+    __shared__ __attribute__((aligned(16))) uint16_t ks[FA_BK * D];     // [token][dim] swizzled
     __shared__ __attribute__((aligned(16))) uint16_t vt[D * FA_LDV];     // [dim][token]
-    __shared__ int tile_page[2][32];
+    __shared__ int tile_page[2][FA_BK];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -404,55 +407,101 @@ __global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
     }
 
     // staging: thread -> (token = c/16, chunk = c%16) for c = tid, tid+256
-    u32x4 kreg[2], vreg[2];
-    auto stage_load = [&](int tile) {
+    // A STAGE is FA_BK tokens (FA_SUB sub-tiles of 32): one pair of barriers and one global round trip per stage.  With
+    // 32-token stages the MFMA work of a stage (~0.5 us) could not cover the latency of the next stage's rows.
+    u32x4 kreg[FA_CPT], vreg[FA_CPT];
+    // page ids travel one stage ahead of the K/V rows they address: a stage's loads are then ONE global round trip behind
+    // the MFMAs of the previous stage instead of two dependent ones (block table, then rows)
+    // K chunk c = tid + 256 i  ->  (token c / 16, 16-byte chunk c % 16): coalesced rows, b128 stores into the swizzled K tile.
+    // V chunk c            ->  (token c % FA_BK, chunk c / FA_BK): the 64 lanes of a wave hold 64 consecutive TOKENS of one
+    // chunk, so the 2-byte stores into the transposed tile vt[dim][token] hit consecutive addresses (the K mapping would
+    // put 16 lanes on two LDS banks).  The price is a strided global read of V (rows 256 B apart), absorbed by the L1.
+    int pid_reg[FA_CPT], pidv_reg[FA_CPT];
+    bool kv_ok[FA_CPT], v_ok[FA_CPT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < FA_CPT; ++i) kv_ok[i] = v_ok[i] = false;
+    // page_shift = log2(page_size), or -1 (integer division, ~30 VALU ops each, 16 of them per stage and thread)
+    auto logical_page = [&](int tok) { return page_shift >= 0 ? (tok >> page_shift) : tok / page_size; };
+    auto page_of_token = [&](int tok) {
+        const int lp = logical_page(tok);
+        const bool in = tok < ctx && lp < max_pages;
+        const int id = block_table[(long)b * max_pages + (in ? lp : 0)];  // unconditional load from a clamped address
+        return in ? id : -1;
+    };
+    auto load_pids = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < FA_CPT; ++i) {
+            pid_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) >> 4));
+            pidv_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) & (FA_BK - 1)));
+        }
+    };
+    auto stage_load = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < FA_CPT; ++i) {
             const int c = tid + i * 256;
             const int tok_in = c >> 4;
             const int ch = c & 15;
-            const int tok = tile * 32 + tok_in;
-            const int lp = tok / page_size;
+            const int tok = stage * FA_BK + tok_in;
+            const int lp = logical_page(tok);
             const int slot = tok - lp * page_size;
-            int page_id = -1;
-            if (tok < ctx && lp < max_pages) page_id = block_table[(long)b * max_pages + lp];
-            if (page_id >= 0) {
-                const long off = (((long)page_id * num_kv_heads + kvh) * page_size + slot) * D + ch * 8;
-                kreg[i] = *reinterpret_cast<const u32x4 *>(key_pages + off);
-                vreg[i] = *reinterpret_cast<const u32x4 *>(value_pages + off);
-            } else {
-                kreg[i] = u32x4{0u, 0u, 0u, 0u};
-                vreg[i] = u32x4{0u, 0u, 0u, 0u};
-            }
-            if (ch == 0) tile_page[tile & 1][tok_in] = page_id;  // read one iteration later, after two barriers
+            const int page_id = pid_reg[i];
+            // unconditional loads from a clamped address (a divergent branch around a load makes hipcc wait for it at the
+            // join, i.e. before the MFMAs it should overlap); rows of unused pages are zeroed when they are stored to LDS
+            const long off = (((long)max(page_id, 0) * num_kv_heads + kvh) * page_size + slot) * D + ch * 8;
+            kreg[i] = *reinterpret_cast<const u32x4 *>(key_pages + off);
+            kv_ok[i] = page_id >= 0;
+            if (ch == 0) tile_page[stage & 1][tok_in] = page_id;  // read one iteration later, after two barriers
+            const int tokv = stage * FA_BK + (c & (FA_BK - 1));
+            const int lpv = logical_page(tokv);
+            const int slotv = tokv - lpv * page_size;
+            const long offv = (((long)max(pidv_reg[i], 0) * num_kv_heads + kvh) * page_size + slotv) * D + (c / FA_BK) * 8;
+            vreg[i] = *reinterpret_cast<const u32x4 *>(value_pages + offv);
+            v_ok[i] = pidv_reg[i] >= 0;
         }
     };
 
     auto stage_store = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < FA_CPT; ++i) {
             const int c = tid + i * 256;
             const int tok_in = c >> 4;
             const int ch = c & 15;
+            if (!kv_ok[i]) kreg[i] = u32x4{0u, 0u, 0u, 0u};
+            if (!v_ok[i]) vreg[i] = u32x4{0u, 0u, 0u, 0u};
             *reinterpret_cast<u32x4 *>(&ks[tok_in * D + ((ch ^ (tok_in & 15)) * 8)]) = kreg[i];
+            const int tokv = c & (FA_BK - 1), chv = c / FA_BK;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                vt[(ch * 8 + 2 * e) * FA_LDV + tok_in] = (uint16_t)(vreg[i][e] & 0xffffu);
-                vt[(ch * 8 + 2 * e + 1) * FA_LDV + tok_in] = (uint16_t)(vreg[i][e] >> 16);
+                vt[(chv * 8 + 2 * e) * FA_LDV + tokv] = (uint16_t)(vreg[i][e] & 0xffffu);
+                vt[(chv * 8 + 2 * e + 1) * FA_LDV + tokv] = (uint16_t)(vreg[i][e] >> 16);
             }
         }
     };
 
-    const int tiles_per_split = (total_tiles + n_splits - 1) / n_splits;
-    const int tile_begin = split * tiles_per_split;
-    const int tile_end = min(tile_begin + tiles_per_split, blk_tiles);
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        if (tile == tile_begin) stage_load(tile);
-        __syncthreads();  // previous tile's LDS reads are complete
+    // splits are whole stages; tile counts (total / mine / the block's) stay in 32-token units
+    const int total_stages = (total_tiles + FA_SUB - 1) / FA_SUB;
+    const int blk_stages = (blk_tiles + FA_SUB - 1) / FA_SUB;
+    const int stages_per_split = (total_stages + n_splits - 1) / n_splits;
+    const int stage_begin = split * stages_per_split;
+    const int stage_end = min(stage_begin + stages_per_split, blk_stages);
+    if (stage_begin < stage_end) {
+        load_pids(stage_begin);
+        stage_load(stage_begin);
+        if (stage_begin + 1 < stage_end) load_pids(stage_begin + 1);
+    }
+    for (int stage = stage_begin; stage < stage_end; ++stage) {
+        __syncthreads();  // previous stage's LDS reads are complete
         stage_store();
         __syncthreads();
-        if (tile + 1 < tile_end) stage_load(tile + 1);
-        if (tile >= my_tiles) continue;  // wave-uniform: this wave's rows see nothing here (still hits barriers)
+        if (stage + 1 < stage_end) {
+            stage_load(stage + 1);
+            if (stage + 2 < stage_end) load_pids(stage + 2);
+        }
+#pragma unroll
+        for (int sub = 0; sub < FA_SUB; ++sub) {
+        const int tile = stage * FA_SUB + sub;
+        if (tile >= my_tiles) continue;  // wave-uniform: this wave's rows see nothing here
+        const int tb = sub * 32;         // token offset of the sub-tile inside the stage
 
         // S^T = K Q^T
         f32x16 sacc;
@@ -461,7 +510,7 @@ __global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int ch = (2 * s + h) ^ (l32 & 15);
-            const u32x4 kf = *reinterpret_cast<const u32x4 *>(&ks[l32 * D + ch * 8]);
+            const u32x4 kf = *reinterpret_cast<const u32x4 *>(&ks[(tb + l32) * D + ch * 8]);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
                                                            __builtin_bit_cast(bf16x8_t, qf[s]), sacc, 0, 0, 0);
         }
@@ -470,7 +519,7 @@ __global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int tok = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            bool valid = q_valid && tok < ctx && tile_page[tile & 1][(r & 3) + 8 * (r >> 2) + 4 * h] >= 0;
+            bool valid = q_valid && tok < ctx && tile_page[stage & 1][tb + (r & 3) + 8 * (r >> 2) + 4 * h] >= 0;
             if (is_causal) valid = valid && tok <= qrow + (ctx - L);
             sacc[r] = valid ? sacc[r] * scale_log2 : -INFINITY;
             tmax = fmaxf(tmax, sacc[r]);
@@ -489,10 +538,12 @@ __global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
         tsum += __shfl_xor(tsum, 32, 64);
         run_max = new_max;
         run_sum = prev_scale * run_sum + tsum;
+        if (!__all(prev_scale == 1.0f)) {  // once the running maxima have settled the rescale is the identity for the whole wave
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+            for (int db = 0; db < 4; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= prev_scale;
+                for (int r = 0; r < 16; ++r) o[db][r] *= prev_scale;
+        }
 
         // P^T fragments (B operand), step s uses regs 8s..8s+7
         u32x4 pf[2];
@@ -507,13 +558,14 @@ __global__ __launch_bounds__(256) void paged_fa_bf16_d128_kernel(
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int d = db * 32 + l32;
-                const u32x2 lo = *reinterpret_cast<const u32x2 *>(&vt[d * FA_LDV + 16 * s + 4 * h]);
-                const u32x2 hi = *reinterpret_cast<const u32x2 *>(&vt[d * FA_LDV + 16 * s + 4 * h + 8]);
+                const u32x2 lo = *reinterpret_cast<const u32x2 *>(&vt[d * FA_LDV + tb + 16 * s + 4 * h]);
+                const u32x2 hi = *reinterpret_cast<const u32x2 *>(&vt[d * FA_LDV + tb + 16 * s + 4 * h + 8]);
                 const u32x4 vf = u32x4{lo[0], lo[1], hi[0], hi[1]};
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
                                                                 __builtin_bit_cast(bf16x8_t, pf[s]), o[db], 0, 0, 0);
             }
         }
+        }  // sub-tile
     }
 
     if (!q_valid) return;
@@ -673,10 +725,13 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
         const size_t fa_need = fa_splits > 1 ? (size_t)N * L * fa_splits * (D + 2) * sizeof(float) : 0;
         if (fa_need > 0 && (!workspace || workspace_bytes < fa_need)) fa_splits = 1;  // no workspace: one pass, still correct
         const dim3 grid(item_blocks * fa_splits, num_kv_heads, B);
+        int page_shift = -1;
+        for (int sh = 0; sh < 30; ++sh)
+            if ((1 << sh) == page_size) page_shift = sh;
         hipLaunchKernelGGL(paged_fa_bf16_d128_kernel, grid, dim3(256), 0, st, (const uint16_t *)q,
                            (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,
-                           (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, max_pages, num_heads, num_kv_heads,
-                           scale, is_causal);
+                           (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, page_shift, max_pages, num_heads,
+                           num_kv_heads, scale, is_causal);
         TL_CHECK_LAUNCH("paged_attention(prefill)");
         if (fa_splits > 1) {
             hipLaunchKernelGGL((paged_merge_kernel<BF16>), dim3(N * L), dim3(128), 0, st, (const float *)workspace,
