@@ -133,7 +133,9 @@ def run_one_request_engine(engine, request: BenchRequest, prefill_step: int):
 def run_batch_requests_engine(engine, requests: list[BenchRequest], batch_size: int, prefill_step: int,
                               metrics: ServingMetrics):
     """Reference run_batch_requests_serving: per loop turn one prefill chunk of the pending request (timed), adopt it
-    into a free slot when complete, one batched decode step over all slots (timed), retire finished requests."""
+    into a free slot when complete, one batched decode step over the occupied slots (timed), retire finished requests."""
+    from tiny_llm_hip.engine import _DECODE_ROW_BUCKETS
+
     staging = batch_size
     queue = list(range(len(requests)))
     slots: list[dict | None] = [None] * batch_size
@@ -176,8 +178,9 @@ def run_batch_requests_engine(engine, requests: list[BenchRequest], batch_size: 
                             pending = None
             active = [i for i, s in enumerate(slots) if s is not None]
             if active:
+                rows = min(next((b for b in _DECODE_ROW_BUCKETS if b >= active[-1] + 1), batch_size), batch_size)
                 t0 = time.perf_counter()
-                engine.decode(1, batch=batch_size)
+                engine.decode(1, batch=rows)  # the occupied prefix of the slots (tiny_llm_hip.engine.batch_generate_ids)
                 engine.synchronize()
                 dt = time.perf_counter() - t0
                 decode_time += dt

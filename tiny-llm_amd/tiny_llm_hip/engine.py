@@ -213,14 +213,19 @@ class DecodeEngine:
             self.release(slot)
 
 
+# decode row counts used by the scheduler: exact up to 4 rows (fused GEMV), then the row-block sizes of the skinny matmul
+_DECODE_ROW_BUCKETS = (1, 2, 3, 4, 8, 16, 32, 48, 64, 96, 128, 192, 256)
+
+
 def batch_generate_ids(engine: DecodeEngine, prompts: Sequence[Sequence[int]], max_new_tokens: int | Sequence[int],
                        batch_size: int, prefill_step: int = 128, eos_token_id: int | None = None,
                        on_step=None) -> list[tuple[int, list[int]]]:
     """Continuous batching over engine slots with the reference scheduler's shape (batch_generate,
     src/tiny_llm_ref/batch.py:136-285; benches/bench.py:run_batch_requests_serving 351-572): every loop turn
     (a) admits one pending request and prefills ONE chunk of at most ``prefill_step`` tokens in the staging slot,
-    (b) adopts it into a free decode slot once its prefill is complete, (c) runs one batched decode step over all
-    ``batch_size`` slots (idle slots carry context 0), (d) retires finished requests and returns their pages.
+    (b) adopts it into the lowest free decode slot once its prefill is complete, (c) runs one batched decode step over
+    the occupied prefix of the slots (the reference steps all ``batch_size`` rows; idle rows carry context 0 and produce
+    nothing, so skipping the idle tail changes no result), (d) retires finished requests and returns their pages.
     Token-id in, token-id out (no tokenizer can be downloaded here).  Needs ``engine.max_batch >= batch_size + 1``:
     the last slot is the prefill staging slot.  Returns [(prompt_idx, generated ids)] in completion order."""
     if batch_size <= 0 or prefill_step <= 0:
@@ -266,8 +271,13 @@ def batch_generate_ids(engine: DecodeEngine, prompts: Sequence[Sequence[int]], m
                             slots[free] = pending
                             pending = None
             if any(s is not None for s in slots):
-                engine.decode(1, batch=batch_size)
-                tokens = engine.read_pending(batch_size)
+                # slots fill lowest-first, so rows above the highest occupied one are idle: decode only a bucket that
+                # covers the occupied prefix (the engine keeps one captured graph per row count; buckets bound their number)
+                top = max(i for i, s in enumerate(slots) if s is not None) + 1
+                rows = next((b for b in _DECODE_ROW_BUCKETS if b >= top), batch_size)
+                rows = min(rows, batch_size)
+                engine.decode(1, batch=rows)
+                tokens = engine.read_pending(rows)
                 if on_step is not None:
                     on_step(sum(s is not None for s in slots))
                 for i, req in enumerate(slots):
