@@ -70,6 +70,7 @@ struct tl_engine {
     int attn_rq = 0;             // query heads per decode-attention workgroup; 0 = by context (TL_ATTN_RQ at create: 1 or 4)
     int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup (TL_ATTN_RQ1_CTX)
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
+    int attn_max_splits = 64;    // most context splits per sequence (TL_ATTN_MAX_SPLITS, a power of two <= 256)
     size_t attn_ws_bytes = 0;
     int rows_cap = 0;
     int ring_cap = 4096;
@@ -299,7 +300,7 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // few sequences: split for latency (up to 2048 short-lived workgroups); many sequences: the chip is already full, longer
     // windows amortise the per-workgroup prologue and skip the merge launch (measured at 16 and 64 sequences)
     const int wg_cap = batch <= 4 ? 2048 : 512;
-    while (s * 2 <= bucket / min_tokens && s * 2 * base <= wg_cap && s * 2 <= 64) s *= 2;  // >= min_tokens per workgroup
+    while (s * 2 <= bucket / min_tokens && s * 2 * base <= wg_cap && s * 2 <= e->attn_max_splits) s *= 2;  // >= min_tokens per workgroup
     return SplitPlan{s, bucket / s, rq};
 }
 
@@ -371,7 +372,8 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
                 case 8: hipLaunchKernelGGL(attn_merge_kernel<8>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
                 case 16: hipLaunchKernelGGL(attn_merge_kernel<16>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
                 case 32: hipLaunchKernelGGL(attn_merge_kernel<32>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
-                default: hipLaunchKernelGGL(attn_merge_kernel<64>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
+                case 64: hipLaunchKernelGGL(attn_merge_kernel<64>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
+                default: hipLaunchKernelGGL(attn_merge_many_kernel, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, n_splits, pb); break;
             }
             if (pc) prof_after(e, pc, 6, batch * c.num_heads);
         }
@@ -523,7 +525,8 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const size_t o_act = carve(R * c.intermediate_size * 2);
     const size_t o_log = carve((size_t)c.max_batch * c.vocab_size * 2);
     // attention partials: decode (batch*Hq rows x 64 splits) or the L<=8 operator path during short prefills
-    e->attn_ws_bytes = std::max((size_t)c.max_batch * c.num_heads * 64 * (c.head_dim + 2) * 4,
+    // decode partials: at most 64 splits per row with many sequences, at most 256 split-rows per head with few (pick_decode_splits)
+    e->attn_ws_bytes = std::max((size_t)std::max(c.max_batch * 64, 4 * 256) * c.num_heads * (c.head_dim + 2) * 4,
                                 (size_t)c.num_heads * 8 * 64 * (c.head_dim + 2) * 4);
     for (int L = 1; L <= c.max_prefill_rows; ++L)  // the paged attention operator may split the context for any chunk length
         e->attn_ws_bytes = std::max(e->attn_ws_bytes, tl_paged_attention_workspace_bytes(c.num_heads, L, c.head_dim, c.page_size,
@@ -580,6 +583,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (const char *q = getenv("TL_QMM3_SMALL_ELEMS")) e->qmm3_small_elems = (size_t)atoll(q);
     if (const char *q = getenv("TL_ATTN_RQ")) e->attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e->attn_rq1_ctx = atoi(q);
+    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q));
 
     // state words: zero everything up to the activations, then the block table to -1

@@ -473,6 +473,43 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict
     prof_end(prof, prof_t0);
 }
 
+// the same merge for more than 64 splits (long contexts): two passes over the partials, 32 loads in flight at a time
+__global__ __launch_bounds__(128) void attn_merge_many_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out,
+                                                              int D, int n_splits, prof_t *prof) {
+    const prof_t prof_t0 = prof_begin(prof);
+    const long orow = blockIdx.x;
+    const int stride = D + 2;
+    const float *base = ws + orow * n_splits * stride;
+    const int d = threadIdx.x < D ? threadIdx.x : 0;
+    float gm = -1e30f;
+    for (int s0 = 0; s0 < n_splits; s0 += 32) {
+        float ms[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) ms[j] = base[(size_t)min(s0 + j, n_splits - 1) * stride + D];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) gm = fmaxf(gm, ms[j]);
+    }
+    float gl = 0.f, acc = 0.f;
+    for (int s0 = 0; s0 < n_splits; s0 += 32) {
+        float ms[32], ls[32], vs[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float *row = base + (size_t)min(s0 + j, n_splits - 1) * stride;
+            ms[j] = row[D];
+            ls[j] = row[D + 1];
+            vs[j] = row[d];
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float f = s0 + j < n_splits ? exp2f(ms[j] - gm) : 0.f;
+            gl += ls[j] * f;
+            acc += vs[j] * f;
+        }
+    }
+    if ((int)threadIdx.x < D) out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : acc / gl);
+    prof_end(prof, prof_t0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // End of step: greedy argmax over bf16 logits (first maximum wins, like argmax), record the id, advance
 // the slot, and dequantize the id's embedding row into the next step's input activation.
