@@ -90,6 +90,9 @@ __device__ __forceinline__ u32x4 dequant_word(uint32_t w, float s, float beta) {
     return r;
 }
 
+#ifndef QMM_ABL
+#define QMM_ABL 0  // tools/lab/gemm_lab only: 1 = no dequant arithmetic, 2 = no MFMA, 4 = no activation re-staging
+#endif
 template <typename TT, int MT>
 __global__ __launch_bounds__(256) void qmm_mfma_kernel(const uint16_t *__restrict__ scales,
                                                        const uint16_t *__restrict__ biases,
@@ -155,10 +158,10 @@ __global__ __launch_bounds__(256) void qmm_mfma_kernel(const uint16_t *__restric
     if (wok) wcur = *reinterpret_cast<const u32x4 *>(wsrc + j0 * 8 + h * 4);
     int buf = 0;
     for (int j = j0; j < j1; ++j) {
-        store_a(buf);
+        if (!(QMM_ABL & 4) || j == j0) store_a(buf);
         __syncthreads();
         if (j + 1 < j1) {
-            load_a(j + 1);
+            if (!(QMM_ABL & 4)) load_a(j + 1);
             if (wok) wnext = *reinterpret_cast<const u32x4 *>(wsrc + (j + 1) * 8 + h * 4);
         }
         if (((j & 1) == 0 || j == j0) && wok) {
@@ -167,7 +170,10 @@ __global__ __launch_bounds__(256) void qmm_mfma_kernel(const uint16_t *__restric
         }
         u32x4 bf[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bf[s] = dequant_word<TT>(wcur[s], sc, be);
+        for (int s = 0; s < 4; ++s) {
+            if constexpr (QMM_ABL & 1) bf[s] = u32x4{wcur[s], wcur[s] ^ 0x3c003c00u, wcur[s] >> 1, __float_as_uint(sc + be)};
+            else bf[s] = dequant_word<TT>(wcur[s], sc, be);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -175,7 +181,8 @@ __global__ __launch_bounds__(256) void qmm_mfma_kernel(const uint16_t *__restric
                 const int r = mt * 32 + l32;
                 const int ch = (4 * h + s) ^ ((r >> 1) & 7);
                 const u32x4 af = *reinterpret_cast<const u32x4 *>(&atile[buf][r * 64 + ch * 8]);
-                acc[mt] = Mfma<TT>::mma(af, bf[s], acc[mt]);
+                if constexpr (QMM_ABL & 2) acc[mt][s] += __uint_as_float((af[0] ^ bf[s][1]) & 0x3f800000u);
+                else acc[mt] = Mfma<TT>::mma(af, bf[s], acc[mt]);
             }
         }
         buf ^= 1;
@@ -213,9 +220,11 @@ static int mfma_mt(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
 static int split_k_policy(int M, int N, int K) {
     const int mt = mfma_mt(M);
     const int tiles = ceil_div(M, 32 * mt) * ceil_div(K, 128);
-    constexpr int target = 512;
+    // three workgroups fit a CU (136 registers per lane): split until about 768 are in flight.  320 tiles (a 2048-row chunk
+    // against the 2560-row o / down projections) measured 471 / 482 TFLOP/s unsplit against 750 for the wide projections.
+    const int target = getenv("TL_QMM_SPLIT_TARGET") ? atoi(getenv("TL_QMM_SPLIT_TARGET")) : 768;
     constexpr int max_split = 16;
-    int s = std::min(std::min(max_split, std::max(1, target / std::max(tiles, 1))), N / 128);
+    int s = std::min(std::min(max_split, std::max(1, (target + tiles / 2) / std::max(tiles, 1))), N / 128);
     while (s > 1 && N % (s * 128) != 0) --s;
     return std::max(s, 1);
 }
