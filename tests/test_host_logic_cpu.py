@@ -377,3 +377,70 @@ def test_batch_generate_interleaves_requests_across_slots(cpu_ext):
     assert sorted(idx for idx, _ in result) == [0, 1, 2]
     assert all(set(text) <= {"1"} and text for _, text in result)
     assert model.pool.used_page_ids == set() and model.pool.num_free_pages == model.pool.num_pages
+
+
+class _FakeDecodeEngine:
+    """Host-only stand-in for tiny_llm_hip.engine.DecodeEngine: every sequence emits prompt_sum + k for its k-th token, so
+    the schedule of batch_generate_ids can be checked without a GPU."""
+
+    def __init__(self, max_batch):
+        self.max_batch = max_batch
+        self.seq = {}          # slot -> {"base": int, "n": tokens produced so far}
+        self.decode_rows = []  # rows argument of every decode call
+        self.released = []
+
+    def begin(self, slot):
+        assert slot not in self.seq
+        self.seq[slot] = {"base": 0, "n": 0}
+
+    def prefill(self, slot, tokens, *, chunk, want_logits=True):
+        assert len(tokens) <= chunk
+        self.seq[slot]["base"] += sum(tokens)
+        if want_logits:
+            self.seq[slot]["n"] = 1
+
+    def read_tokens(self, slot, n):
+        s = self.seq[slot]
+        return [s["base"] + k for k in range(s["n"] - n, s["n"])]
+
+    def move(self, src, dst):
+        assert dst not in self.seq
+        self.seq[dst] = self.seq.pop(src)
+
+    def decode(self, steps, batch):
+        assert steps == 1
+        self.decode_rows.append((batch, sorted(self.seq)))
+        for slot, s in self.seq.items():
+            if slot < batch:
+                s["n"] += 1
+
+    def read_pending(self, rows):
+        return [self.seq[i]["base"] + self.seq[i]["n"] - 1 if i in self.seq else -1 for i in range(rows)]
+
+    def release(self, slot):
+        self.seq.pop(slot)
+        self.released.append(slot)
+
+
+def test_batch_generate_ids_decodes_only_the_occupied_slot_prefix():
+    """engine.batch_generate_ids: same schedule as the reference (one prefill chunk + one decode step per turn), but a
+    decode step covers a bucket over the occupied slot prefix instead of all batch_size rows."""
+    from tiny_llm_hip.engine import _DECODE_ROW_BUCKETS, batch_generate_ids
+
+    eng = _FakeDecodeEngine(max_batch=17)
+    prompts = [[i + 1] * (3 + i % 5) for i in range(12)]
+    limits = [2 + (i * 3) % 7 for i in range(12)]
+    got = batch_generate_ids(eng, prompts, limits, batch_size=16, prefill_step=4)
+    assert sorted(i for i, _ in got) == list(range(12))
+    for idx, ids in got:
+        base = sum(prompts[idx])
+        assert ids == [base + k for k in range(limits[idx])], f"request {idx}"
+    assert not eng.seq and sorted(set(eng.released)) == sorted(set(eng.released))
+    assert eng.decode_rows, "no decode step ran"
+    for rows, live in eng.decode_rows:
+        occupied = [s for s in live if s < 16]
+        assert rows in _DECODE_ROW_BUCKETS or rows == 16
+        assert rows > max(occupied), "a live sequence was left out of the step"
+        smaller = [b for b in _DECODE_ROW_BUCKETS if b < rows]
+        assert not smaller or smaller[-1] <= max(occupied), "the step covered more rows than the bucket rule allows"
+    assert min(r for r, _ in eng.decode_rows) < 16, "short batches should not step all 16 rows"
