@@ -125,6 +125,12 @@ int tl_engine_move(tl_engine *e, int src, int dst);
  * the slot's pending input token for the next decode step.  n <= max_prefill_rows. */
 int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, int n, int want_logits);
 
+/* Speculative verification (reference speculative_generate, generate.py:84-322: one target call over the pending token
+ * plus the draft's proposals, logits_to_keep = all rows).  Appends n (1..8) tokens to the slot exactly like a prefill chunk
+ * and returns in out_ids[i] the greedy token that follows tokens[0..i].  Nothing is recorded as generated; the caller
+ * rewinds the rejected suffix with tl_engine_rewind and sets the next input with tl_engine_set_token.  Synchronises. */
+int tl_engine_verify(tl_engine *e, int slot, const int32_t *tokens, int n, int32_t *out_ids);
+
 /* Set the pending input token of a slot explicitly (e.g. sampled on the host). */
 int tl_engine_set_token(tl_engine *e, int slot, int32_t token);
 

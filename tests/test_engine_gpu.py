@@ -339,3 +339,66 @@ def test_prefill_long_chunks(ckpt, wide, n_prompt, rows):
     got = _prefill_logits(model, prompt, rows)
     want = O.OracleQwen3(cfg, w).forward(prompt)[0, -1]
     np.testing.assert_allclose(log_softmax(got), log_softmax(want), atol=LOGPROB_ATOL, rtol=0)
+
+
+def test_engine_verify_matches_oracle_rows(ckpt, engine):
+    """tl_engine_verify: rows of one multi-token call (L <= 8 through the paged decode kernel) give the oracle's greedy
+    continuation at every position, and rewinding the rejected suffix restores the cache for normal decoding."""
+    w, _ = ckpt
+    prompt = prompt_ids(11, seed=5)
+    extra = prompt_ids(5, seed=6)
+    model = O.OracleQwen3(TINY_CFG, w)
+    want = model.forward(prompt + extra, logits_to_keep=None)[0]  # logits of every position
+    engine.begin(0)
+    engine.prefill(0, prompt)
+    got = engine.verify(0, extra)
+    assert engine.context_len(0) == len(prompt) + len(extra)
+    for i in range(len(extra)):
+        row = want[len(prompt) + i]
+        if margin_ok(row):
+            assert got[i] == int(np.argmax(row)), f"row {i}"
+    # drop the last 3 verified tokens again and decode on: same result as a sequence that never saw them
+    engine.rewind(0, 3)
+    engine.set_token(0, extra[2])
+    engine.decode(1, batch=1)
+    after = engine.logits(1)[0].float().cpu().numpy()
+    engine.release(0)
+    ref = O.OracleQwen3(TINY_CFG, w).forward(prompt + extra[:3])[0, -1]
+    np.testing.assert_allclose(log_softmax(after), log_softmax(ref), atol=LOGPROB_ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("same_draft", [True, False])
+def test_speculative_decoding_over_two_engines(ckpt, same_draft):
+    """speculative_generate_ids: the result is a greedy continuation of the TARGET whatever the draft proposes, checked id
+    by id against the oracle forward of the emitted sequence; an identical draft is accepted almost always, a different one
+    rarely."""
+    from tiny_llm_hip.engine import DecodeEngine, speculative_generate_ids
+
+    w, model = ckpt
+    draft_model = model if same_draft else to_mlx_shaped(TINY_CFG, O.make_qwen3_weights(TINY_CFG, seed=11, sigma=0.05))
+    target = DecodeEngine(model, page_size=16, num_pages=64, max_batch=1, max_prefill_rows=64)
+    draft = DecodeEngine(draft_model, page_size=16, num_pages=64, max_batch=1, max_prefill_rows=64)
+    try:
+        prompts = [prompt_ids(n, seed=300 + n) for n in (7, 19, 33, 12)]
+        accepted, proposed, checked = 0, 0, 0
+        for p in prompts:
+            stats = {}
+            spec = speculative_generate_ids(target, draft, p, 28, proposal_length=4, stats=stats)
+            assert len(spec) == 28 and stats["target_calls"] <= 29
+            accepted += stats["accepted"]
+            proposed += stats["proposed"]
+            # every emitted id must be the oracle's greedy choice given the ids emitted before it (positions whose top-2
+            # logit margin is inside the comparison band may legitimately go either way and are skipped)
+            rows = O.OracleQwen3(TINY_CFG, w).forward(p + spec, logits_to_keep=None)[0]
+            for j, tok in enumerate(spec):
+                row = rows[len(p) - 1 + j]
+                if margin_ok(row):
+                    assert tok == int(np.argmax(row)), f"prompt of {len(p)} tokens, generated position {j}"
+                    checked += 1
+        assert checked > 60, "too few clear-margin positions to call this a test"
+        rate = accepted / max(proposed, 1)
+        assert (rate > 0.8) if same_draft else (rate < 0.5), f"acceptance rate {rate:.2f}"
+        assert target.stats()["pages_in_use"] == 0 and draft.stats()["pages_in_use"] == 0
+    finally:
+        target.close()
+        draft.close()

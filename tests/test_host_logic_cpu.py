@@ -444,3 +444,188 @@ def test_batch_generate_ids_decodes_only_the_occupied_slot_prefix():
         smaller = [b for b in _DECODE_ROW_BUCKETS if b < rows]
         assert not smaller or smaller[-1] <= max(occupied), "the step covered more rows than the bucket rule allows"
     assert min(r for r, _ in eng.decode_rows) < 16, "short batches should not step all 16 rows"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# speculative decoding (reference scenarios: tests_refsol/test_week_3_day_7.py) with position-scripted models
+# ---------------------------------------------------------------------------------------------------------------------
+class _SpecDetok:
+    def __init__(self):
+        self.tokens, self.finalized = [], 0
+
+    def reset(self):
+        self.tokens = []
+
+    def add_token(self, t):
+        self.tokens.append(int(t))
+
+    def finalize(self):
+        self.finalized += 1
+
+    @property
+    def text(self):
+        return " ".join(str(t) for t in self.tokens)
+
+
+class _SpecTokenizer:
+    def __init__(self, eos=0, vocab=50, shift=0, with_vocab=True):
+        self.eos_token_id = eos
+        self._vocab = {str(i): i + shift for i in range(vocab)}
+        self._detok = _SpecDetok()
+        if not with_vocab:
+            self.get_vocab = None
+
+    def encode(self, prompt, add_special_tokens=False):
+        return [int(x) for x in prompt.split()]
+
+    def get_vocab(self):
+        return dict(self._vocab)
+
+    @property
+    def detokenizer(self):
+        return self._detok
+
+
+class _SpecCache:
+    def __init__(self):
+        self.offset, self.released, self.rewinds = 0, 0, []
+
+    def rewind(self, n):
+        assert 0 < n <= self.offset
+        self.offset -= n
+        self.rewinds.append(n)
+
+    def release(self):
+        self.released += 1
+
+
+class _ScriptedModel:
+    """Predicts script[p + 1] at absolute position p, whatever it is fed (a wrong input only matters for rows the algorithm
+    must discard).  Checks the cache offset on every call and logs (rows, logits_to_keep, dtype)."""
+
+    def __init__(self, script, vocab=50, layers=2):
+        self.script, self.vocab, self.layers = list(script), vocab, layers
+        self.calls, self.caches = [], []
+
+    def create_kv_cache(self):
+        cache = [_SpecCache() for _ in range(self.layers)]
+        self.caches.append(cache)
+        return cache
+
+    def __call__(self, tokens, offset, kv_cache, logits_to_keep=1):
+        assert tokens.dtype == torch.int32 and tokens.dim() == 2 and tokens.shape[0] == 1
+        rows = tokens.shape[1]
+        for layer in kv_cache:
+            assert layer.offset == offset, "model offset does not match the cache"
+            layer.offset += rows
+        self.calls.append((rows, logits_to_keep, offset))
+        logits = torch.full((1, rows, self.vocab), -10.0)
+        for i in range(rows):
+            logits[0, i, self.script[offset + i + 1]] = 10.0
+        return logits[:, -logits_to_keep:, :]
+
+
+def _target_only_text(script, n_prompt, eos=0):
+    out = []
+    for t in script[n_prompt:]:
+        if t == eos:
+            break
+        out.append(t)
+    return " ".join(str(t) for t in out)
+
+
+def _spec_run(target_script, draft_script, prompt="5 6 7", k=4):
+    from tiny_llm_hip import speculative_generate
+
+    target, draft = _ScriptedModel(target_script), _ScriptedModel(draft_script)
+    tok, dtok = _SpecTokenizer(), _SpecTokenizer()
+    text = speculative_generate(draft, target, dtok, tok, prompt, proposal_length=k, device="cpu")
+    for m in (target, draft):
+        for cache in m.caches:
+            assert all(layer.released == 1 for layer in cache), "a KV cache was not released exactly once"
+    return text, target, draft, tok
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("k", [1, 2, 4, 7])
+def test_speculative_output_equals_target_only_decoding(seed, k):
+    """Losslessness over random agreement patterns: whatever the draft proposes, the text is the target's own greedy text;
+    every verification call feeds at most k + 1 rows and asks for all of their logits."""
+    rng = np.random.default_rng(seed)
+    n = 3
+    length = int(rng.integers(4, 40))
+    target = [5, 6, 7] + [int(t) for t in rng.integers(1, 50, size=length)] + [0] + [9] * 20
+    draft = list(target)
+    for p in range(n, len(draft)):
+        if rng.random() < 0.35:
+            draft[p] = int(rng.integers(0, 50))  # may also be an early EOS from the draft
+    text, tm, dm, tok = _spec_run(target, draft, k=k)
+    assert text == _target_only_text(target, n)
+    assert tok.detokenizer.finalized == 1
+    assert all(rows <= k + 1 and keep == rows for rows, keep, _ in tm.calls[1:])
+    assert all(rows == 1 for rows, _, _ in dm.calls[1:])
+
+
+def test_speculative_full_agreement_needs_few_target_calls():
+    target = [5, 6, 7] + list(range(10, 34)) + [0] + [9] * 10
+    text, tm, dm, _ = _spec_run(target, target, k=4)
+    assert text == _target_only_text(target, 3)
+    # 24 tokens + EOS with 5 rows per verification: prefill + ceil(25 / 5) calls, no rewinds on the target
+    assert len(tm.calls) == 1 + 5
+    assert all(not layer.rewinds for layer in tm.caches[0][:1]) or sum(tm.caches[0][0].rewinds) <= 5
+
+
+def test_speculative_mismatch_rewinds_both_caches_to_the_accepted_prefix():
+    target = [5, 6, 7, 11, 12, 13, 14, 15, 0] + [9] * 10
+    draft = [5, 6, 7, 11, 12, 40, 41, 42, 43] + [9] * 10   # agrees on positions 3, 4 and diverges at 5
+    text, tm, dm, _ = _spec_run(target, draft, k=4)
+    assert text == "11 12 13 14 15"
+    # first verification fed [11, 12, 40, 41, 42]: rows 0..1 accepted, row 2 is the first disagreement
+    assert tm.calls[1] == (5, 5, 3)
+    assert tm.caches[0][0].rewinds[0] == 3 and dm.caches[0][0].rewinds[0] == 2
+    assert tm.calls[2][2] == 5  # the target resumes at absolute position 5 with its own token
+
+
+def test_speculative_zero_proposals_never_builds_a_draft_cache_and_eos_first_stops_at_once():
+    target = [5, 6, 7, 21, 22, 0] + [9] * 5
+    text, tm, dm, _ = _spec_run(target, target, k=0)
+    assert text == "21 22" and not dm.calls and not dm.caches
+    assert all(rows == 1 for rows, _, _ in tm.calls[1:])
+    text, tm, dm, _ = _spec_run([5, 6, 7, 0] + [9] * 5, [5, 6, 7, 30] + [9] * 5, k=3)
+    assert text == "" and len(tm.calls) == 1 and not dm.calls
+
+
+def test_speculative_draft_eos_at_prefill_falls_back_to_target_only():
+    target = [5, 6, 7, 21, 22, 23, 0] + [9] * 5
+    draft = [5, 6, 7, 0] + [9] * 8
+    text, tm, dm, _ = _spec_run(target, draft, k=3)
+    assert text == "21 22 23" and len(dm.calls) == 1
+    assert all(rows == 1 for rows, _, _ in tm.calls[1:])
+
+
+@pytest.mark.parametrize("case,message", [
+    ("encode", "encode the prompt differently"), ("eos", "different EOS token ids"),
+    ("novocab", "comparable vocabularies"), ("vocab", "different token ids"), ("empty", "at least one token"),
+    ("k", "non-negative integer"), ("kbool", "non-negative integer")])
+def test_speculative_validation_runs_before_any_model_call(case, message):
+    from tiny_llm_hip import speculative_generate
+
+    target, draft = _ScriptedModel([1] * 20), _ScriptedModel([1] * 20)
+    tok, dtok, prompt, k = _SpecTokenizer(), _SpecTokenizer(), "5 6 7", 2
+    if case == "encode":
+        dtok.encode = lambda p, add_special_tokens=False: [5, 6]
+    elif case == "eos":
+        dtok.eos_token_id = 3
+    elif case == "novocab":
+        dtok = _SpecTokenizer(with_vocab=False)
+    elif case == "vocab":
+        dtok = _SpecTokenizer(shift=1)
+    elif case == "empty":
+        prompt = ""
+    elif case == "k":
+        k = -1
+    elif case == "kbool":
+        k = True
+    with pytest.raises(ValueError, match=message):
+        speculative_generate(draft, target, dtok, tok, prompt, proposal_length=k, device="cpu")
+    assert not target.calls and not draft.calls and not target.caches

@@ -64,6 +64,7 @@ struct tl_engine {
     uint16_t *x = nullptr, *h = nullptr, *xn = nullptr, *qkv = nullptr, *q_t = nullptr, *attn_t = nullptr,
              *attn = nullptr, *gu = nullptr, *act = nullptr, *tmp = nullptr, *logits = nullptr;
     float *attn_ws = nullptr;
+    int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
     size_t qmm3_small_elems = (size_t)20 << 20;  // TL_QMM3_SMALL_ELEMS: see engine_linear
     bool use_qmm3 = true;   // TL_NO_QMM3=1 at create: rows > 8 go through the prefill GEMM path instead
@@ -523,7 +524,8 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const size_t o_attn = carve(R * q_dim * 2);
     const size_t o_gu = carve(R * 2 * c.intermediate_size * 2);
     const size_t o_act = carve(R * c.intermediate_size * 2);
-    const size_t o_log = carve((size_t)c.max_batch * c.vocab_size * 2);
+    const size_t o_log = carve((size_t)std::max(c.max_batch, 8) * c.vocab_size * 2);  // decode rows, or 8 verification rows
+    const size_t o_vid = carve(8 * 4);
     // attention partials: decode (batch*Hq rows x 64 splits) or the L<=8 operator path during short prefills
     // decode partials: at most 64 splits per row with many sequences, at most 256 split-rows per head with few (pick_decode_splits)
     e->attn_ws_bytes = std::max((size_t)std::max(c.max_batch * 64, 4 * 256) * c.num_heads * (c.head_dim + 2) * 4,
@@ -578,6 +580,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->act = (uint16_t *)(A + o_act);
     e->logits = (uint16_t *)(A + o_log);
     e->attn_ws = (float *)(A + o_ws);
+    e->verify_ids = (int32_t *)(A + o_vid);
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
     if (const char *q = getenv("TL_QMM3_SMALL_ELEMS")) e->qmm3_small_elems = (size_t)atoll(q);
@@ -809,7 +812,10 @@ extern "C" int tl_engine_set_token(tl_engine *e, int slot, int32_t token) {
     return poke(e, pk);
 }
 
-extern "C" int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, int n, int want_logits) {
+// logits_mode: 0 = none, 1 = last row (greedy id recorded as the slot's pending token), 2 = every row (n <= 8: greedy ids
+// land in e->verify_ids, nothing is recorded; speculative verification)
+static int prefill_impl(tl_engine *e, int slot, const int32_t *tokens, int n, int logits_mode) {
+    const int want_logits = logits_mode == 1;
     TL_TRY(slot_check(e, slot, true));
     TL_REQUIRE(tokens && n > 0, "engine_prefill: need at least one token");
     TL_REQUIRE(n <= e->cfg.max_prefill_rows, "engine_prefill: chunk exceeds max_prefill_rows");
@@ -873,6 +879,12 @@ extern "C" int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, 
     pk.emplace_back(e->context_lens + slot, start + n);
     TL_TRY(poke(e, pk));
     e->stats.prefill_tokens += n;
+    if (logits_mode == 2) {
+        TL_TRY(engine_qmv(e, e->head(), e->x, e->logits, n, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr));
+        e->logits_rows = n;
+        hipLaunchKernelGGL(argmax_rows_kernel, dim3(n), dim3(1024), 0, e->stream, e->logits, c.vocab_size, e->verify_ids);
+        TL_CHECK_LAUNCH("engine verify argmax");
+    }
     if (want_logits) {
         // logits_to_keep = 1 (reference qwen3_week3.py:331-336): last row only
         const uint16_t *last = e->x + (size_t)(n - 1) * c.hidden_size;
@@ -902,6 +914,19 @@ extern "C" int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, 
         TL_CHECK_LAUNCH("engine prefill argmax");
         e->slot_produced[slot] += 1;
     }
+    return TL_OK;
+}
+
+extern "C" int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, int n, int want_logits) {
+    return prefill_impl(e, slot, tokens, n, want_logits ? 1 : 0);
+}
+
+extern "C" int tl_engine_verify(tl_engine *e, int slot, const int32_t *tokens, int n, int32_t *out_ids) {
+    TL_REQUIRE(e && out_ids, "engine_verify: null argument");
+    TL_REQUIRE(n >= 1 && n <= 8, "engine_verify: between 1 and 8 tokens per call (the paged decode kernel's query rows)");
+    TL_TRY(prefill_impl(e, slot, tokens, n, 2));
+    TL_HIP(hipMemcpyAsync(out_ids, e->verify_ids, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    TL_HIP(hipStreamSynchronize(e->stream));
     return TL_OK;
 }
 

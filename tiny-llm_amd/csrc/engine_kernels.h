@@ -624,6 +624,49 @@ __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
     prof_end(p.prof, prof_t0);
 }
 
+// Greedy id of every logits row (speculative verification): same tie rule as step_end_kernel (first maximum wins).
+//   grid = rows, block = 1024
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const uint16_t *__restrict__ logits, int vocab,
+                                                           int32_t *__restrict__ ids) {
+    __shared__ float s_val[16];
+    __shared__ int s_idx[16];
+    const uint16_t *lg = logits + (long)blockIdx.x * vocab;
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    for (int c = threadIdx.x; c < vocab; c += 1024) {  // ascending per thread: the earliest index of a tie stays
+        const float v = BF16::to_float(lg[c]);
+        if (v > best) {
+            best = v;
+            best_i = c;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_i, o, 64);
+        if (ov > best || (ov == best && oi < best_i)) {
+            best = ov;
+            best_i = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_val[threadIdx.x >> 6] = best;
+        s_idx[threadIdx.x >> 6] = best_i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bv = s_val[0];
+        int bi = s_idx[0];
+        for (int w = 1; w < 16; ++w) {
+            if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) {
+                bv = s_val[w];
+                bi = s_idx[w];
+            }
+        }
+        ids[blockIdx.x] = (bi < 0 || bi >= vocab) ? 0 : bi;
+    }
+}
+
 // (start, end) of one instrumented launch: min over workgroup starts, max over ends; clears the buffer.
 __global__ __launch_bounds__(1024) void prof_reduce_kernel(prof_t *buf, int n_wg, prof_t *out_pair) {
     __shared__ prof_t s_min[16], s_max[16];

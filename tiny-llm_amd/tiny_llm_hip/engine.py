@@ -160,6 +160,17 @@ class DecodeEngine:
             last = start + chunk >= len(tokens)
             _ext.check(_lib.tl_engine_prefill(self._h, slot, arr, len(part), int(last and want_logits)))
 
+    def verify(self, slot: int, tokens: Sequence[int]) -> list[int]:
+        """Speculative verification: append 1..8 tokens to the slot and return, for each of them, the greedy token that
+        follows it (reference speculative_generate's target call with logits_to_keep = all rows).  Synchronises."""
+        tokens = [int(t) for t in tokens]
+        if not 1 <= len(tokens) <= 8:
+            raise ValueError("verify takes between 1 and 8 tokens")
+        arr = (ctypes.c_int32 * len(tokens))(*tokens)
+        out = (ctypes.c_int32 * len(tokens))()
+        _ext.check(_lib.tl_engine_verify(self._h, slot, arr, len(tokens), out))
+        return list(out)
+
     def decode(self, steps: int, batch: int | None = None, use_graph: bool = True) -> None:
         """Enqueue ``steps`` greedy decode steps over slots [0, batch); does not synchronise."""
         _ext.check(_lib.tl_engine_decode(self._h, batch or self.max_batch, int(steps), int(use_graph)))
@@ -296,3 +307,73 @@ def batch_generate_ids(engine: DecodeEngine, prompts: Sequence[Sequence[int]], m
             except RuntimeError:
                 pass
     return finished
+
+
+def speculative_generate_ids(target: DecodeEngine, draft: DecodeEngine, prompt: Sequence[int], max_new_tokens: int,
+                             proposal_length: int = 4, eos_token_id: int | None = None, *, slot: int = 0,
+                             chunk: int = 2048, stats: dict | None = None) -> list[int]:
+    """Greedy speculative decoding over two engines (reference speculative_generate, src/tiny_llm_ref/generate.py:84-322;
+    token ids in, token ids out).  The draft engine free-runs ``proposal_length`` fused decode steps on the device; the
+    target scores the pending token plus the proposals in one ``verify`` call (at most 8 rows through the paged decode
+    kernel) and both KV caches are rewound to the accepted prefix.  Returns exactly the target's greedy continuation
+    (up to ``max_new_tokens`` ids, stopping before ``eos_token_id``); ``stats`` receives call and acceptance counts."""
+    if not isinstance(proposal_length, int) or isinstance(proposal_length, bool) or proposal_length < 0:
+        raise ValueError("proposal_length must be a non-negative integer")
+    if proposal_length > 7:
+        raise ValueError("proposal_length must be at most 7 (8 verification rows)")
+    prompt = [int(t) for t in prompt]
+    if not prompt:
+        raise ValueError("prompt must hold at least one token")
+    counts = {"target_calls": 0, "draft_steps": 0, "proposed": 0, "accepted": 0}
+    out: list[int] = []
+    target.begin(slot)
+    draft_live = False
+    try:
+        target.prefill(slot, prompt, chunk=chunk)
+        token = target.read_tokens(slot, 1)[0]
+        counts["target_calls"] += 1
+        if proposal_length > 0:
+            draft.begin(slot)
+            draft_live = True
+            draft.prefill(slot, prompt, chunk=chunk, want_logits=False)
+        while len(out) < max_new_tokens and token != eos_token_id:
+            room = max_new_tokens - len(out) - 1          # proposals that could still be emitted after `token`
+            k = min(proposal_length, room)
+            proposals: list[int] = []
+            if k > 0:
+                draft.set_token(slot, token)
+                draft.decode(k, batch=slot + 1)
+                proposals = draft.read_tokens(slot, k)
+                counts["draft_steps"] += k
+                if eos_token_id in proposals:              # the draft stops proposing after its own EOS
+                    keep = proposals.index(eos_token_id) + 1
+                    draft.rewind(slot, k - keep)
+                    proposals = proposals[:keep]
+            fed = [token] + proposals
+            predicted = target.verify(slot, fed)
+            counts["target_calls"] += 1
+            counts["proposed"] += len(proposals)
+            own = [token] + predicted[:-1]                 # what the target alone would have fed at each row
+            cut = next((i for i, (mine, given) in enumerate(zip(own, fed))
+                        if mine != given or mine == eos_token_id), None)
+            if cut is None:                                # everything accepted: the last prediction is a bonus token
+                out.extend(own)
+                counts["accepted"] += len(proposals)
+                if proposals:                              # the draft has not consumed its last proposal yet
+                    draft.decode(1, batch=slot + 1)
+                    counts["draft_steps"] += 1
+                token = predicted[-1]
+                continue
+            out.extend(own[:cut])
+            counts["accepted"] += cut - 1
+            target.rewind(slot, len(fed) - cut)
+            if proposals:
+                draft.rewind(slot, len(proposals) - cut)
+            token = own[cut]
+        if stats is not None:
+            stats.update(counts)
+        return out[:max_new_tokens]
+    finally:
+        target.release(slot)
+        if draft_live:
+            draft.release(slot)
