@@ -402,3 +402,27 @@ def test_speculative_decoding_over_two_engines(ckpt, same_draft):
     finally:
         target.close()
         draft.close()
+
+
+def test_engine_from_a_loaded_checkpoint_directory(ckpt, tmp_path):
+    """tiny_llm_hip.load (the mlx_lm.load replacement) -> DecodeEngine: an MLX-format 4-bit checkpoint written to disk decodes
+    bit-identically to the same weights handed over in memory, and the loaded tokenizer drives the id-level loop."""
+    from checkpoint_fixture import write_checkpoint
+    from tiny_llm_hip import load
+    from tiny_llm_hip.engine import DecodeEngine
+
+    w, in_memory = ckpt
+    words = [f"w{i}" for i in range(TINY_CFG["vocab_size"] - 2)]
+    model, tok = load(str(write_checkpoint(tmp_path / "ckpt", TINY_CFG, w, shards=2, vocab_words=words)))
+    prompt = tok.encode("w5 w17 w400 w3 w99", add_special_tokens=False)
+    assert prompt == [7, 19, 402, 5, 101]
+    outs = []
+    for m in (model, in_memory):
+        eng = DecodeEngine(m, page_size=16, num_pages=16, max_batch=1, max_prefill_rows=64)
+        try:
+            ids = eng.generate(prompt, 12)
+            outs.append((ids, eng.logits(1).clone()))
+        finally:
+            eng.close()
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    assert isinstance(tok.decode(outs[0][0]), str)

@@ -1,0 +1,97 @@
+"""Checkpoint loader (tiny_llm_hip/loader.py, the mlx_lm.load replacement of SURVEY.md §8f row 1) on CPU tensors."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tiny_oracle as O
+from helpers import TINY_CFG
+from checkpoint_fixture import write_checkpoint
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return O.make_qwen3_weights(TINY_CFG, seed=3, sigma=0.05)
+
+
+def _loader():
+    import importlib.util, pathlib, sys
+
+    path = pathlib.Path(__file__).resolve().parents[1] / "tiny-llm_amd" / "tiny_llm_hip" / "loader.py"
+    spec = importlib.util.spec_from_file_location("tl_loader_under_test", path)  # no GPU extension import on the way
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_load_reproduces_every_tensor(tmp_path, weights, shards):
+    loader = _loader()
+    ckpt = write_checkpoint(tmp_path / "ckpt", TINY_CFG, weights, shards=shards)
+    model, tok = loader.load(str(ckpt), device="cpu")
+    a = model.args
+    assert (a.hidden_size, a.num_hidden_layers, a.head_dim, a.vocab_size) == (256, 2, 128, 1024) and a.tie_word_embeddings
+    assert not hasattr(model, "lm_head") and len(model.model.layers) == 2
+
+    def same(layer, triple):
+        packed, scales, biases = triple
+        assert layer.weight.dtype == torch.int32 and layer.scales.dtype == torch.bfloat16
+        assert layer.group_size == 128 and layer.bits == 4
+        np.testing.assert_array_equal(layer.weight.numpy().view(np.uint32), np.asarray(packed, dtype=np.uint32))
+        np.testing.assert_array_equal(layer.scales.float().numpy(), np.asarray(scales, dtype=np.float32))
+        np.testing.assert_array_equal(layer.biases.float().numpy(), np.asarray(biases, dtype=np.float32))
+
+    same(model.model.embed_tokens, weights["embed"])
+    for layer, lw in zip(model.model.layers, weights["layers"]):
+        for attr, key in (("q_proj", "q"), ("k_proj", "k"), ("v_proj", "v"), ("o_proj", "o")):
+            same(getattr(layer.self_attn, attr), lw[key])
+        for attr, key in (("gate_proj", "gate"), ("up_proj", "up"), ("down_proj", "down")):
+            same(getattr(layer.mlp, attr), lw[key])
+        np.testing.assert_array_equal(layer.self_attn.q_norm.weight.float().numpy(), np.asarray(lw["q_norm"], np.float32))
+        np.testing.assert_array_equal(layer.input_layernorm.weight.float().numpy(), np.asarray(lw["input_norm"], np.float32))
+    np.testing.assert_array_equal(model.model.norm.weight.float().numpy(), np.asarray(weights["norm"], np.float32))
+
+    # tokenizer wrapper: the surface the generation loops use
+    ids = tok.encode("hello tiny llm", add_special_tokens=False)
+    assert ids == [2, 4, 5] and tok.eos_token_id == 0 and tok.eos_token_ids == {0}
+    assert tok.get_vocab()["world"] == 3
+    detok = tok.detokenizer
+    detok.reset()
+    pieces = []
+    for t in ids:
+        detok.add_token(t)
+        pieces.append(detok.last_segment)
+    assert "".join(pieces) == detok.text == tok.decode(ids)
+    prompt = tok.apply_chat_template([{"role": "user", "content": "hello"}], tokenize=False, add_generation_prompt=True)
+    assert prompt.startswith("user hello") and prompt.endswith("assistant")
+
+
+@pytest.mark.parametrize("mutate,message", [
+    (lambda cfg, path: cfg["quantization"].update(group_size=64), "group_size=64"),
+    (lambda cfg, path: cfg["quantization"].update(bits=8), "bits=8"),
+    (lambda cfg, path: cfg.pop("quantization"), "not quantized"),
+    (lambda cfg, path: cfg.update(num_hidden_layers=3), "model.layers.2"),
+    (lambda cfg, path: cfg.update(intermediate_size=1024), "do not describe"),
+    (lambda cfg, path: cfg.pop("rms_norm_eps"), "lacks"),
+])
+def test_load_rejects_what_the_hot_path_cannot_run(tmp_path, weights, mutate, message):
+    loader = _loader()
+    ckpt = write_checkpoint(tmp_path / "ckpt", TINY_CFG, weights)
+    cfg = json.loads((ckpt / "config.json").read_text())
+    mutate(cfg, ckpt)
+    (ckpt / "config.json").write_text(json.dumps(cfg))
+    with pytest.raises((ValueError, KeyError), match=message):
+        loader.load_weights(ckpt, device="cpu")
+
+
+def test_untied_head_and_missing_directory(tmp_path):
+    loader = _loader()
+    cfg = dict(TINY_CFG, tie_word_embeddings=False)
+    w = O.make_qwen3_weights(cfg, seed=9, sigma=0.05)
+    assert "lm_head" in w
+    model = loader.load_weights(write_checkpoint(tmp_path / "untied", cfg, w), device="cpu")
+    np.testing.assert_array_equal(model.lm_head.weight.numpy().view(np.uint32), np.asarray(w["lm_head"][0], np.uint32))
+    with pytest.raises(FileNotFoundError, match="neither a checkpoint directory"):
+        loader.resolve_model_dir(str(tmp_path / "nope"))
