@@ -426,3 +426,31 @@ def test_engine_from_a_loaded_checkpoint_directory(ckpt, tmp_path):
             eng.close()
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
     assert isinstance(tok.decode(outs[0][0]), str)
+
+
+def test_cli_entry_points_on_a_written_checkpoint(ckpt, tmp_path, capsys):
+    """main.py (greedy, sampled, speculative; engine and op-by-op solutions) and batch_main.py on a checkpoint directory."""
+    from checkpoint_fixture import write_checkpoint
+    import batch_main
+    import main as cli
+
+    w, _ = ckpt
+    words = [f"w{i}" for i in range(TINY_CFG["vocab_size"] - 2)]
+    path = str(write_checkpoint(tmp_path / "ckpt", TINY_CFG, w, vocab_words=words))
+    base = ["--model", path, "--prompt", "w5 w17 w400 w3", "--raw-prompt", "--max-new-tokens", "10"]
+    greedy = cli.main(base)
+    assert isinstance(greedy, str) and len(greedy.split()) <= 10
+    spec = cli.main(base + ["--draft-model", path, "--proposal-length", "3"])
+    assert spec.split()[:3] == greedy.split()[:3]
+    sampled = cli.main(base + ["--sampler-temp", "0.8", "--sampler-top-k", "20", "--sampler-top-p", "0.9"])
+    assert isinstance(sampled, str)
+    ops = cli.main(base + ["--solution", "ops"])
+    assert ops.split()[:3] == greedy.split()[:3]
+    chat = cli.main(["--model", path, "--prompt", "w5 w6", "--max-new-tokens", "4"])  # through the chat template
+    assert isinstance(chat, str)
+    prompts = tmp_path / "prompts.txt"
+    prompts.write_text("w5 w6 w7\nw8 w9\nw10 w11 w12 w13\n")
+    done = batch_main.main(["--model", path, "--batch-size", "2", "--prefill-step", "16", "--max-seq-len", "24",
+                            "--raw-prompts", "--prompts-file", str(prompts)])
+    assert sorted(i for i, _ in done) == [0, 1, 2]
+    capsys.readouterr()
