@@ -101,6 +101,14 @@ int tl_decode_attention(const void *q, const void *k, const void *v, const float
                         int S, int D, int num_heads, int num_kv_heads, float scale, int is_causal, int has_mask,
                         tl_dtype dtype, void *stream);
 
+/* ---- replaces mx.gather_qmm as the reference uses it (grouped_expert_linear, src/tiny_llm_ref/moe.py:7-36;
+ * SURVEY.md §8f row 3): out[m,:] = a[m,:] @ dequant(b[expert_ids[m]])^T, one expert per activation row.
+ * b [E,K,N/8] u32, scales,biases [E,K,N/128], a [M,N], expert_ids [M] int32 ON THE DEVICE (ids outside [0,E) are
+ * clamped), out [M,K].  group_size 128, bits 4, f16/bf16 like tl_quantized_matmul. */
+int tl_gather_quantized_matvec(const void *scales, const void *biases, const void *a, const uint32_t *b,
+                               const int32_t *expert_ids, void *out, int M, int N, int K, int num_experts,
+                               int group_size, int bits, tl_dtype dtype, void *stream);
+
 /* ---- replaces paged_cache_update (paged_attention.cpp:14-70) ---------------
  * pages [P,H,page_size,D] (written IN PLACE), values [1,H,length,D]. */
 int tl_paged_cache_update(void *pages, const void *values, int num_pages, int heads, int page_size, int head_dim,

@@ -370,3 +370,74 @@ def test_paged_attention_validation(ext):
     with pytest.raises(RuntimeError, match="must be int32"):
         ext.paged_attention(q[:, :1], dev(kp, "bf16"), dev(vp, "bf16"), torch.from_numpy(table).to(DEV).long(),
                             torch.from_numpy(ctx).to(DEV), 1.0, True, num_kv_heads=2, num_heads=4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# grouped-expert W4 product and the MoE block (reference moe.py:7-89, test_week_3_day_6.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def _expert_stack(rng, E, K, N, dtype, sigma=0.05):
+    packed, scales, biases = [], [], []
+    for _ in range(E):
+        p, s, b = O.quantize_affine(rng.standard_normal((K, N)).astype(np.float32) * sigma, dtype=dtype)
+        packed.append(p), scales.append(s), biases.append(b)
+    return np.stack(packed), np.stack(scales), np.stack(biases)
+
+
+def _qw(triple, dtype):
+    from tiny_llm_hip import QuantizedWeights
+
+    packed, scales, biases = triple
+    return QuantizedWeights(dev(scales, dtype), dev(biases, dtype), 128, 4,
+                            torch.from_numpy(np.ascontiguousarray(packed).view(np.int32)).to(DEV))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("M,E,K,N", [(1, 4, 64, 128), (5, 8, 200, 256), (16, 8, 256, 512), (40, 3, 96, 1024)])
+def test_gather_quantized_matvec(ext, dtype, M, E, K, N):
+    """One GEMV launch, an expert index per activation row (mx.gather_qmm as grouped_expert_linear uses it); repeated and
+    out-of-range ids (clamped) included."""
+    rng = np.random.default_rng(M * 100 + E)
+    packed, scales, biases = _expert_stack(rng, E, K, N, dtype)
+    a = O.cast(rng.standard_normal((M, N)).astype(np.float32), dtype)
+    ids = rng.integers(0, E, size=M).astype(np.int32)
+    want = O.gather_quantized_matvec(scales, biases, a, packed, ids, dtype)
+    got = ext.gather_quantized_matvec(dev(scales, dtype), dev(biases, dtype), 128, 4, dev(a, dtype),
+                                      torch.from_numpy(packed.view(np.int32)).to(DEV), torch.from_numpy(ids).to(DEV))
+    close(host(got), want, dtype)
+    wild = ids.copy()
+    wild[0] = E + 5
+    clamped = ext.gather_quantized_matvec(dev(scales, dtype), dev(biases, dtype), 128, 4, dev(a, dtype),
+                                          torch.from_numpy(packed.view(np.int32)).to(DEV), torch.from_numpy(wild).to(DEV))
+    want0 = O.gather_quantized_matvec(scales, biases, a[:1], packed, np.array([E - 1]), dtype)
+    close(host(clamped)[:1], want0, dtype)
+    with pytest.raises(RuntimeError, match="one entry per row"):
+        ext.gather_quantized_matvec(dev(scales, dtype), dev(biases, dtype), 128, 4, dev(a, dtype),
+                                    torch.from_numpy(packed.view(np.int32)).to(DEV), torch.from_numpy(ids[:-1].copy()).to(DEV) if M > 1 else torch.zeros(2, dtype=torch.int32, device=DEV))
+
+
+@pytest.mark.parametrize("norm_topk", [False, True])
+def test_moe_block_matches_oracle(ext, norm_topk):
+    """Router + top-k + SwiGLU experts + weighted sum (Qwen3-MoE MLP) against the numpy restatement; the oracle is given
+    the selection the device made, so a tie between two experts' bf16 probabilities cannot fail the comparison."""
+    from tiny_llm_hip import Moe, route_topk
+
+    rng = np.random.default_rng(7 + norm_topk)
+    E, D, H, k, B, L = 8, 256, 384, 2, 2, 3
+    router = O.quantize_affine(rng.standard_normal((E, D)).astype(np.float32) * 0.3, dtype="bf16")
+    gate, up = _expert_stack(rng, E, H, D, "bf16"), _expert_stack(rng, E, H, D, "bf16")
+    down = _expert_stack(rng, E, D, H, "bf16")
+    x = O.bf16(rng.standard_normal((B * L, D)).astype(np.float32))
+    moe = Moe(_qw(router, "bf16"), _qw(gate, "bf16"), _qw(up, "bf16"), _qw(down, "bf16"), k, norm_topk_prob=norm_topk)
+    xt = dev(x, "bf16").reshape(B, L, D)
+    probs, ids, scores = route_topk(xt, moe.w_router, k, norm_topk)
+    got = moe(xt)
+    ids_np = ids.reshape(-1, k).cpu().numpy()
+    want, _, want_scores = O.moe_block(x, router, gate, up, down, k, norm_topk, "bf16", ids=ids_np)
+    # the selection is a valid top-k of the oracle's router probabilities
+    logits = O.quantized_matmul(router[1], router[2], x, router[0])
+    ref_probs = O.softmax(logits.astype(np.float32))
+    kth = np.sort(ref_probs, axis=-1)[:, -k]
+    assert np.all(np.take_along_axis(ref_probs, ids_np, axis=-1) >= kth[:, None] - 4e-3)
+    np.testing.assert_allclose(host(scores).reshape(-1, k), want_scores, atol=8e-3, rtol=2e-2)
+    np.testing.assert_allclose(host(got).reshape(-1, D), want, atol=3e-2, rtol=3e-2)
+    assert abs(float(host(probs).reshape(-1, E).sum(axis=-1).mean()) - 1.0) < 2e-2

@@ -303,9 +303,59 @@ static int run_qmm(const void *scales, const void *biases, const void *a, const 
     return TL_OK;
 }
 
+// one GEMV per activation row, each against the weights of its own expert (grid.y = rows)
+template <typename TT>
+static int run_gather_qmv(const void *scales, const void *biases, const void *a, const uint32_t *b, const int32_t *expert_ids,
+                          void *out, int M, int N, int K, int num_experts, hipStream_t st) {
+    QmvArgs args{};
+    args.scales = (const uint16_t *)scales;
+    args.biases = (const uint16_t *)biases;
+    args.a = (const uint16_t *)a;
+    args.b = b;
+    args.out = (uint16_t *)out;
+    args.M = 1;
+    args.N = N;
+    args.K = K;
+    args.expert_ids = expert_ids;
+    args.num_experts = num_experts;
+    const QmvPlan pl = qmv_plan(1, N, K);
+    if (pl.lds > 150 * 1024) return fail(TL_ERR_UNSUPPORTED, "gather_quantized_matvec: reduction dimension too large");
+    const dim3 grid(pl.blocks, M), block(256);
+#define GQ_CASE(WNv, RPLv)                                                                                          \
+    if (pl.WN == WNv && pl.RPL == RPLv) {                                                                           \
+        auto kern = qmv_kernel<TT, 1, WNv, RPLv, PRO_NONE, EPI_STORE>;                                              \
+        if (pl.lds > 64 * 1024)                                                                                     \
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
+        hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                                    \
+        return TL_OK;                                                                                               \
+    }
+    GQ_CASE(1, 2) GQ_CASE(1, 1) GQ_CASE(2, 1) GQ_CASE(4, 1)
+#undef GQ_CASE
+    return fail(TL_ERR_UNSUPPORTED, "gather_quantized_matvec: no GEMV configuration for this shape");
+}
+
 }  // namespace tl
 
 using namespace tl;
+
+extern "C" int tl_gather_quantized_matvec(const void *scales, const void *biases, const void *a, const uint32_t *b,
+                                          const int32_t *expert_ids, void *out, int M, int N, int K, int num_experts,
+                                          int group_size, int bits, tl_dtype dtype, void *stream) {
+    TL_REQUIRE(dtype == TL_F16 || dtype == TL_BF16, "gather_quantized_matvec: scales must be float16 or bfloat16");
+    TL_REQUIRE(bits == 4, "gather_quantized_matvec: bits must be 4");
+    TL_REQUIRE(group_size == 128, "gather_quantized_matvec: group_size must be 128");
+    TL_REQUIRE(scales && biases && a && b && expert_ids && out, "gather_quantized_matvec: null pointer");
+    TL_REQUIRE(M >= 0 && K >= 0 && N > 0 && num_experts > 0, "gather_quantized_matvec: bad shape");
+    TL_REQUIRE(N % 128 == 0, "gather_quantized_matvec: N must be divisible by group_size");
+    TL_REQUIRE(M <= 65535, "gather_quantized_matvec: at most 65535 rows per call");
+    if (M == 0 || K == 0) return TL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dtype == TL_F16 ? run_gather_qmv<F16>(scales, biases, a, b, expert_ids, out, M, N, K, num_experts, st)
+                                   : run_gather_qmv<BF16>(scales, biases, a, b, expert_ids, out, M, N, K, num_experts, st);
+    if (rc != TL_OK) return rc;
+    TL_CHECK_LAUNCH("gather_quantized_matvec");
+    return TL_OK;
+}
 
 extern "C" int tl_quantized_matmul_split_k(int M, int N, int K, int use_simdgroup, int use_split_k) {
     if (!use_simdgroup || !use_split_k || M <= 8 || N < 128) return 1;

@@ -47,6 +47,11 @@ struct QmvArgs {
     int M, N, K;
     prof_t *prof;   // nullptr except during an engine profile step
     prof_t *trace;  // lab-only phase stamps (QMV2_TRACE builds)
+    // grouped-expert mode (tl_gather_quantized_matvec; reference mx.gather_qmm in moe.py:7-36): when expert_ids is set the
+    // launch has gridDim.y = rows, and row m multiplies with the weights of expert expert_ids[m]: b [E, K, N/8],
+    // scales / biases [E, K, N/128].  The kernel then runs as M = 1 on that row.
+    const int32_t *expert_ids;
+    int num_experts;
 };
 
 template <typename TT>
@@ -86,8 +91,19 @@ __host__ __device__ inline size_t qmv_lds_bytes(int MR, int N, int WN, int RPL) 
 }
 
 template <typename TT, int MR, int WN, int RPL, int PRO, int EPI>
-__global__ __launch_bounds__(256) void qmv_kernel(const QmvArgs p) {
+__global__ __launch_bounds__(256) void qmv_kernel(const QmvArgs p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    QmvArgs p = p_in;
+    if (p.expert_ids) {  // uniform: one activation row and one expert per blockIdx.y
+        const int m = blockIdx.y;
+        const long e = min(max(p.expert_ids[m], 0), p.num_experts - 1);
+        p.b += e * (long)p.K * (p.N >> 3);
+        p.scales += e * (long)p.K * (p.N >> 7);
+        p.biases += e * (long)p.K * (p.N >> 7);
+        p.a += (long)m * p.N;
+        p.out += (long)m * p.K;
+        p.M = 1;
+    }
     constexpr int WR = 4 / WN;
     constexpr int RB = 4 * WR * RPL;
     using D2 = Dot2<TT>;

@@ -49,6 +49,7 @@ _SIGNATURES = {
         [_c_void_p] * 5 + [_c_int] * 5 + [_c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p],
     ),
     "tl_quantized_matmul_workspace_bytes": (_c_size_t, [_c_int] * 6),
+    "tl_gather_quantized_matvec": (_c_int, [_c_void_p] * 6 + [_c_int] * 7 + [_c_void_p]),
     "tl_quantized_matmul_split_k": (_c_int, [_c_int] * 5),
     "tl_quantized_embedding": (_c_int, [_c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p]),
     "tl_rms_norm": (_c_int, [_c_void_p] * 3 + [_c_int, _c_int, _c_float, _c_int, _c_void_p]),
@@ -253,6 +254,37 @@ def quantized_matmul(
             ws.numel() if ws is not None else 0, _stream(),
         )
     )
+    return out
+
+
+def gather_quantized_matvec(scales: torch.Tensor, biases: torch.Tensor, group_size: int, bits: int, a: torch.Tensor,
+                            b: torch.Tensor, expert_ids: torch.Tensor, stream=None) -> torch.Tensor:
+    """Grouped-expert W4A16 product ``out[m] = a[m] @ dequant(b[expert_ids[m]]).T`` (what the reference gets from
+    ``mx.gather_qmm`` in grouped_expert_linear, src/tiny_llm_ref/moe.py:7-36).  b [E,K,N/8], scales/biases [E,K,N/128],
+    a [M,N], expert_ids [M] int32 on the device."""
+    if scales.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("gather_quantized_matvec: scales must be float16 or bfloat16")
+    if scales.dtype != biases.dtype or a.dtype != scales.dtype:
+        raise RuntimeError("gather_quantized_matvec: scales, biases and a must share one dtype")
+    if b.dtype not in (torch.uint32, torch.int32):
+        raise RuntimeError("gather_quantized_matvec: b must be uint32")
+    if bits != 4 or group_size != 128:
+        raise RuntimeError("gather_quantized_matvec: only 4-bit weights in groups of 128 are supported")
+    if a.dim() != 2 or b.dim() != 3 or scales.dim() != 3 or scales.shape != biases.shape:
+        raise RuntimeError("gather_quantized_matvec: expected a [M,N], b [E,K,N/8], scales/biases [E,K,N/128]")
+    M, N = a.shape
+    E, K = b.shape[0], b.shape[1]
+    if N % group_size != 0 or b.shape[2] != N // 8 or tuple(scales.shape) != (E, K, N // group_size):
+        raise RuntimeError("gather_quantized_matvec: shapes of a, b and scales do not describe one [E,K,N] weight stack")
+    if expert_ids.dtype != torch.int32 or tuple(expert_ids.shape) != (M,):
+        raise RuntimeError("gather_quantized_matvec: expert_ids must be int32 with one entry per row of a")
+    _require_gpu("gather_quantized_matvec", scales, biases, a, b, expert_ids)
+    for name, t in (("a", a), ("b", b), ("scales", scales), ("biases", biases), ("expert_ids", expert_ids)):
+        if not t.is_contiguous():
+            raise RuntimeError(f"gather_quantized_matvec: {name} must be contiguous")
+    out = torch.empty((M, K), dtype=a.dtype, device=a.device)
+    _check(_lib.tl_gather_quantized_matvec(_ptr(scales), _ptr(biases), _ptr(a), _ptr(b), _ptr(expert_ids), _ptr(out), M, N,
+                                           K, E, int(group_size), int(bits), _DTYPES[a.dtype], _stream()))
     return out
 
 
@@ -483,6 +515,7 @@ def paged_attention(
 __all__ = [
     "load_library",
     "quantized_matmul",
+    "gather_quantized_matvec",
     "quantized_embedding",
     "rms_norm",
     "rope",

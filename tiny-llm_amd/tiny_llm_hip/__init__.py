@@ -19,5 +19,6 @@ from .qwen3_week3 import Qwen3ModelWeek3  # noqa: F401
 from .sampler import *  # noqa: F401,F403
 from .batch import *  # noqa: F401,F403
 from .models import *  # noqa: F401,F403
+from .moe import *  # noqa: F401,F403
 from .loader import load, load_weights, TokenizerWrapper  # noqa: F401
 from .week2_kernels import *  # noqa: F401,F403
