@@ -125,6 +125,12 @@ int tl_engine_move(tl_engine *e, int src, int dst);
  * the slot's pending input token for the next decode step.  n <= max_prefill_rows. */
 int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, int n, int want_logits);
 
+/* Prefix sharing (reference KvPrefixGenerator fork/restore, agent/branching.py:42-208): make the
+ * free slot `dst` a second sequence with the same tokens as the live slot `src`.  Full KV pages are shared (reference
+ * counted, never rewritten), a partially filled tail page is copied; the pending input token is copied too.  Afterwards
+ * both slots decode, rewind and release independently. */
+int tl_engine_fork(tl_engine *e, int src, int dst);
+
 /* Speculative verification (reference speculative_generate, generate.py:84-322: one target call over the pending token
  * plus the draft's proposals, logits_to_keep = all rows).  Appends n (1..8) tokens to the slot exactly like a prefill chunk
  * and returns in out_ids[i] the greedy token that follows tokens[0..i].  Nothing is recorded as generated; the caller

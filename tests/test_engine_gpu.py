@@ -454,3 +454,71 @@ def test_cli_entry_points_on_a_written_checkpoint(ckpt, tmp_path, capsys):
                             "--raw-prompts", "--prompts-file", str(prompts)])
     assert sorted(i for i, _ in done) == [0, 1, 2]
     capsys.readouterr()
+
+
+def test_fork_shares_prefix_pages_and_branches_decode_independently(ckpt):
+    """tl_engine_fork: a forked slot continues exactly like its source (same logits), full pages are shared and a partial
+    tail page is copied (page accounting), the two branches then take different tokens without disturbing each other
+    (each checked against a sequence that was prefilled from scratch), rewinding into a shared page copies it first, and
+    releasing in either order returns every page."""
+    from tiny_llm_hip.engine import DecodeEngine
+
+    w, model = ckpt
+    eng = DecodeEngine(model, page_size=16, num_pages=32, max_batch=3, max_prefill_rows=64)
+    try:
+        prompt = prompt_ids(37, seed=41)          # 2 full pages + 5 tokens
+        eng.begin(0)
+        eng.prefill(0, prompt)
+        base_pages = eng.stats()["pages_in_use"]
+        assert base_pages == 3
+        eng.fork(0, 1)
+        assert eng.stats()["pages_in_use"] == base_pages + 1 and eng.context_len(1) == len(prompt)
+        eng.decode(1, batch=2)                    # both consume the same pending token
+        both = eng.logits(2)
+        assert torch.equal(both[0], both[1])
+        first = eng.read_tokens(0, 2)             # [token after the prompt, token after that]
+        # branch: slot 0 keeps its own continuation, slot 1 is forced onto another token
+        other = (first[1] + 17) % TINY_CFG["vocab_size"]
+        eng.set_token(1, other)
+        eng.decode(4, batch=2)
+        branch0, branch1 = eng.read_tokens(0, 4), eng.read_tokens(1, 4)
+        fresh = DecodeEngine(model, page_size=16, num_pages=32, max_batch=1, max_prefill_rows=64)
+        try:
+            for history, got in ((prompt + first, branch0), (prompt + [first[0], other], branch1)):
+                fresh.begin(0)
+                fresh.prefill(0, history[:-1], want_logits=False)
+                fresh.set_token(0, history[-1])
+                fresh.decode(4, batch=1)
+                want = fresh.read_tokens(0, 4)
+                fresh.release(0)
+                assert got[:2] == want[:2], "a branch does not continue like an unshared sequence"
+        finally:
+            fresh.close()
+        # rewind slot 1 back into the shared second page: it must get a private copy before it appends again
+        ctx1 = eng.context_len(1)
+        eng.rewind(1, ctx1 - 20)
+        shared_before = eng.stats()["pages_in_use"]
+        eng.set_token(1, prompt[20])
+        eng.decode(1, batch=2)
+        solo = DecodeEngine(model, page_size=16, num_pages=32, max_batch=1, max_prefill_rows=64)
+        try:
+            solo.begin(0)
+            solo.prefill(0, prompt[:21])
+            assert torch.equal(solo.logits(1)[0], eng.logits(2)[1]) or np.allclose(
+                log_softmax(solo.logits(1)[0].float().cpu().numpy()),
+                log_softmax(eng.logits(2)[1].float().cpu().numpy()), atol=LOGPROB_ATOL)
+            solo.release(0)
+        finally:
+            solo.close()
+        assert eng.stats()["pages_in_use"] <= shared_before + 1
+        # slot 0 still decodes as before the rewind of slot 1 (its pages were not touched)
+        eng.release(1)
+        eng.fork(0, 2)
+        eng.release(0)                            # the source goes first: shared pages must survive for slot 2
+        eng.decode(2, batch=3)
+        assert eng.context_len(2) > len(prompt)
+        eng.release(2)
+        st = eng.stats()
+        assert st["pages_in_use"] == 0 and st["pages_free"] == 32
+    finally:
+        eng.close()

@@ -83,6 +83,7 @@ struct tl_engine {
     std::vector<int> slot_produced;
     std::vector<int> free_pages;
     std::vector<char> page_was_used;
+    std::vector<int> page_refs;  // sequences holding each page (prefix sharing after tl_engine_fork); 0 = free
     tl_engine_stats stats{};
 
     bool warmed = false;
@@ -418,6 +419,38 @@ static void prof_after(tl_engine *e, ProfCtx *pc, int kind, int n_wg) {
     pc->kinds.push_back(kind);
 }
 
+// ---- page ownership: a page is shared by every sequence forked from a common prefix and returns to the free list when
+// the last holder lets go of it
+static int take_page(tl_engine *e) {
+    const int id = e->free_pages.back();
+    e->free_pages.pop_back();
+    e->page_refs[id] = 1;
+    e->stats.page_allocations++;
+    if (e->page_was_used[id]) e->stats.reused_page_allocations++;
+    e->page_was_used[id] = 1;
+    e->stats.pages_in_use++;
+    e->stats.peak_pages_in_use = std::max(e->stats.peak_pages_in_use, e->stats.pages_in_use);
+    return id;
+}
+static void drop_page(tl_engine *e, int id) {
+    if (--e->page_refs[id] == 0) {
+        e->free_pages.push_back(id);
+        e->stats.pages_in_use--;
+    }
+}
+// K and V rows of one page, every layer (device to device, stream ordered)
+static int copy_page(tl_engine *e, int from, int to) {
+    const tl_engine_config &c = e->cfg;
+    const size_t page_elems = (size_t)c.num_kv_heads * c.page_size * c.head_dim;
+    for (int l = 0; l < c.num_layers; ++l) {
+        TL_HIP(hipMemcpyAsync(e->layer_k(l) + (size_t)to * page_elems, e->layer_k(l) + (size_t)from * page_elems,
+                              page_elems * 2, hipMemcpyDeviceToDevice, e->stream));
+        TL_HIP(hipMemcpyAsync(e->layer_v(l) + (size_t)to * page_elems, e->layer_v(l) + (size_t)from * page_elems,
+                              page_elems * 2, hipMemcpyDeviceToDevice, e->stream));
+    }
+    return TL_OK;
+}
+
 static int reserve_locked(tl_engine *e, int slot, int total_tokens,
                           std::vector<std::pair<int32_t *, int32_t>> &pokes) {
     const tl_engine_config &c = e->cfg;
@@ -430,16 +463,10 @@ static int reserve_locked(tl_engine *e, int slot, int total_tokens,
     if (need - have > (int)e->free_pages.size())
         return fail(TL_ERR_INVALID, "engine: KV page pool exhausted");
     for (int j = have; j < need; ++j) {
-        const int id = e->free_pages.back();
-        e->free_pages.pop_back();
+        const int id = take_page(e);
         pages.push_back(id);
         pokes.emplace_back(e->block_table + (size_t)slot * c.max_pages_per_seq + j, id);
-        e->stats.page_allocations++;
-        if (e->page_was_used[id]) e->stats.reused_page_allocations++;
-        e->page_was_used[id] = 1;
     }
-    e->stats.pages_in_use += need - have;
-    e->stats.peak_pages_in_use = std::max(e->stats.peak_pages_in_use, e->stats.pages_in_use);
     return TL_OK;
 }
 
@@ -664,6 +691,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->free_pages.resize(c.num_pages);
     for (int i = 0; i < c.num_pages; ++i) e->free_pages[i] = c.num_pages - 1 - i;  // pop_back hands out 0,1,2,...
     e->page_was_used.assign(c.num_pages, 0);
+    e->page_refs.assign(c.num_pages, 0);
     e->stats.pages_free = c.num_pages;
     e->stats.kv_bytes = e->kv_bytes;
     e->stats.workspace_bytes = e->arena_bytes + e->tiled_bytes;
@@ -723,10 +751,9 @@ extern "C" int tl_engine_release(tl_engine *e, int slot) {
     std::vector<std::pair<int32_t *, int32_t>> pk;
     auto &pages = e->slot_pages[slot];
     for (size_t j = 0; j < pages.size(); ++j) {
-        e->free_pages.push_back(pages[j]);
+        drop_page(e, pages[j]);
         pk.emplace_back(e->block_table + (size_t)slot * e->cfg.max_pages_per_seq + j, -1);
     }
-    e->stats.pages_in_use -= (int)pages.size();
     pages.clear();
     e->slot_live[slot] = 0;
     e->slot_ctx[slot] = 0;
@@ -745,15 +772,65 @@ extern "C" int tl_engine_rewind(tl_engine *e, int slot, int n) {
     std::vector<std::pair<int32_t *, int32_t>> pk;
     auto &pages = e->slot_pages[slot];
     while ((int)pages.size() > keep) {
-        e->free_pages.push_back(pages.back());
+        drop_page(e, pages.back());
         pk.emplace_back(e->block_table + (size_t)slot * e->cfg.max_pages_per_seq + (pages.size() - 1), -1);
         pages.pop_back();
-        e->stats.pages_in_use--;
+    }
+    // the next append lands in the tail page: if a fork shares it, give this sequence its own copy first
+    if (keep > 0 && ctx % e->cfg.page_size != 0 && e->page_refs[pages[keep - 1]] > 1) {
+        TL_REQUIRE(!e->free_pages.empty(), "engine_rewind: KV page pool exhausted (copy of a shared tail page)");
+        const int old_id = pages[keep - 1];
+        const int fresh = take_page(e);
+        TL_TRY(copy_page(e, old_id, fresh));
+        drop_page(e, old_id);
+        pages[keep - 1] = fresh;
+        pk.emplace_back(e->block_table + (size_t)slot * e->cfg.max_pages_per_seq + (keep - 1), fresh);
     }
     e->slot_ctx[slot] = ctx;
     pk.emplace_back(e->context_lens + slot, ctx);
     e->stats.pages_free = (int)e->free_pages.size();
     return poke(e, pk);
+}
+
+// Fork: slot `dst` becomes a second sequence with the same prefix as `src` (reference KvPrefixGenerator fork / restore on
+// dense caches, agent/branching.py:42-208; here on the page pool).  Full pages are shared by reference count -- they are
+// never written again -- and a partially filled tail page is copied, so both sequences can append independently.
+extern "C" int tl_engine_fork(tl_engine *e, int src, int dst) {
+    TL_TRY(slot_check(e, src, true));
+    TL_TRY(slot_check(e, dst, false));
+    TL_REQUIRE(src != dst, "engine_fork: source and destination are the same slot");
+    TL_REQUIRE(!e->slot_live[dst], "engine_fork: destination slot already holds a sequence");
+    const tl_engine_config &c = e->cfg;
+    const int ctx = e->slot_ctx[src];
+    const int full = ctx / c.page_size;
+    const bool partial = ctx % c.page_size != 0;
+    TL_REQUIRE(!partial || !e->free_pages.empty(), "engine_fork: KV page pool exhausted");
+    const auto &from = e->slot_pages[src];
+    auto &to = e->slot_pages[dst];
+    to.clear();
+    std::vector<std::pair<int32_t *, int32_t>> pk;
+    for (int j = 0; j < full; ++j) {
+        e->page_refs[from[j]]++;
+        to.push_back(from[j]);
+        pk.emplace_back(e->block_table + (size_t)dst * c.max_pages_per_seq + j, from[j]);
+    }
+    if (partial) {
+        const int fresh = take_page(e);
+        TL_TRY(copy_page(e, from[full], fresh));
+        to.push_back(fresh);
+        pk.emplace_back(e->block_table + (size_t)dst * c.max_pages_per_seq + full, fresh);
+    }
+    e->slot_live[dst] = 1;
+    e->slot_ctx[dst] = ctx;
+    e->slot_produced[dst] = 0;
+    pk.emplace_back(e->live + dst, 1);
+    pk.emplace_back(e->context_lens + dst, ctx);
+    pk.emplace_back(e->produced + dst, 0);
+    TL_TRY(poke(e, pk));
+    // the pending input token travels on the device
+    TL_HIP(hipMemcpyAsync(e->tokens + dst, e->tokens + src, sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream));
+    e->stats.pages_free = (int)e->free_pages.size();
+    return TL_OK;
 }
 
 // Move a (prefilled) sequence from slot `src` to the free slot `dst`: the reference prefills a request in its own

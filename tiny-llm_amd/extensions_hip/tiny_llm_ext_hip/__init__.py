@@ -111,6 +111,7 @@ _SIGNATURES.update({
     "tl_engine_rewind": (_c_int, [_c_void_p, _c_int, _c_int]),
     "tl_engine_context_len": (_c_int, [_c_void_p, _c_int]),
     "tl_engine_move": (_c_int, [_c_void_p, _c_int, _c_int]),
+    "tl_engine_fork": (_c_int, [_c_void_p, _c_int, _c_int]),
     "tl_engine_read_pending": (_c_int, [_c_void_p, _c_int, _P(ctypes.c_int32)]),
     "tl_engine_prefill": (_c_int, [_c_void_p, _c_int, _P(ctypes.c_int32), _c_int, _c_int]),
     "tl_engine_verify": (_c_int, [_c_void_p, _c_int, _P(ctypes.c_int32), _c_int, _P(ctypes.c_int32)]),

@@ -134,6 +134,10 @@ class DecodeEngine:
     def move(self, src: int, dst: int) -> None:
         _ext.check(_lib.tl_engine_move(self._h, src, dst))
 
+    def fork(self, src: int, dst: int) -> None:
+        """Make free slot ``dst`` a copy-on-write twin of ``src`` (shared prefix pages, own tail page)."""
+        _ext.check(_lib.tl_engine_fork(self._h, src, dst))
+
     def read_pending(self, count: int | None = None) -> list[int]:
         """Pending (= most recently generated) token id of slots [0, count); synchronises."""
         count = count or self.max_batch
