@@ -18,7 +18,7 @@ def load(path):
 fetch = load(src / "fetch" / "lab_counter_collection.csv")
 write = load(src / "write" / "lab_counter_collection.csv")
 shapes = {"qkv": (6144, 2560, "tl::qmv3_kernel<1, 2, 4, 1, 0, 10>", 192 * 256), "o": (2560, 4096, "tl::qmv3_kernel<1, 4, 4, 0, 1, 8>", 160 * 256),
-          "gate_up": (19456, 2560, "tl::qmv3_kernel<1, 2, 4, 1, 2, 10>", 608 * 256), "down": (2560, 9728, "tl::qmv3_kernel<1, 8, 8, 0, 1, 10>", 160 * 512),
+          "gate_up": (19456, 2560, "tl::qmv3_kernel<1, 4, 4, 1, 2, 5>", 1216 * 256), "down": (2560, 9728, "tl::qmv3_kernel<1, 8, 8, 0, 1, 10>", 160 * 512),
           "lm_head": (151936, 2560, "tl::qmv3_kernel<1, 2, 4, 1, 0, 10>", 4748 * 256)}
 # calibration: lm_head-sized stream (the largest stream_kernel dispatch set is a mix of shapes; use the qmv3 lm_head
 # plain variant against its known weight bytes as the wide-stream reference)
