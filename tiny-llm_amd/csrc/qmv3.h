@@ -16,13 +16,15 @@
 //    yields the bf16 pair (128+q_2i, 128+q_2i+1): weights unpack straight into natural k order and the activations
 //    need no permutation.  Scales and biases ride along as one dword (s | beta << 16) per (tile, g, row).
 //  * MATRIX CORES: D[act row][weight row] += A[act rows x 32 k] * B[32 k x 16 weight rows] with
-//    v_mfma_f32_16x16x32_bf16; a second MFMA against an all-ones B yields sum_k a for the bias term, so the VALU
-//    only unpacks nibbles (7 ops per 8 weights).  The 16 A rows are the decode batch (M <= 8; rows >= M repeat).
-//  * WAVE SPECIALISATION: the CW compute waves do nothing but put their whole weight slice in flight and wait at
-//    a barrier; one extra STAGER wave loads the activation rows (its own vmcnt queue), applies the fused RMSNorm,
-//    and writes bf16 rows to LDS.  Activation latency hides under the weight stream.
+//    v_mfma_f32_16x16x32_bf16; the VALU only unpacks nibbles (7 ops per 8 weights) and applies the per-group scale /
+//    bias term, acc += s * D + (beta - 128 s) * sum_k a, with sum_k a taken once per workgroup while the activations
+//    are staged.  The 16 A rows are the decode batch (M <= 8; rows >= M repeat).
+//  * COOPERATIVE STAGING: every wave first puts its whole weight slice in flight (LM 1-KiB blocks in registers), then
+//    all waves together load the activation rows, apply the fused RMSNorm and write bf16 rows to LDS.  The
+//    activation loads are issued BEFORE the weight loads (vmcnt retires in order and they are needed first); a
+//    dedicated stager wave was measured 1.6-2.6x slower (profiles/README.md).
 //  * every load is unconditional from a clamped address (a divergent branch around a load makes hipcc wait for it
-//    at the join), and every compute wave runs a fixed Q3_LMAX-group body (surplus groups carry a zero scale).
+//    at the join), and every compute wave runs a fixed LM-group body (surplus groups carry a zero scale).
 #pragma once
 #include "common.h"
 #include "qmv.h"
@@ -43,7 +45,7 @@ struct Qmv3Args {
     int M, N, K;
     prof_t *prof;
 #ifdef QMV3_LAB
-    int ablate;  // lab only: 1 = skip MFMA math, 2 = skip the activation barrier wait, 4 = stager does nothing
+    int ablate;  // lab only: 1 = skip MFMA math, 2 = skip the staging arithmetic / LDS stores, 4 = skip the activation loads
 #endif
 };
 
@@ -131,6 +133,10 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
             const bool ok = okc && m < p.M;
+            if (Q3_ABL(4)) {
+                xv[k][m] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                continue;
+            }
             xv[k][m] = *reinterpret_cast<const u32x4 *>(p.a + (ok ? (size_t)m * N + coff : 0));
             if (!ok) xv[k][m] = u32x4{0u, 0u, 0u, 0u};
         }
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
             inv[m] = rsqrtf(tot / (float)N + p.eps);
         }
     }
-    if (reg_path) {
+    if (reg_path && !Q3_ABL(2)) {
 #pragma unroll
         for (int k = 0; k < CCU; ++k) {
             const int cc = tid + k * T;
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
                 for (int m = 0; m < MR; ++m) finish_chunk(m, cc, xv[k][m], nwv[k], inv[m]);
             }
         }
-    } else {
+    } else if (!reg_path) {
         for (int cc = tid; cc < cpr; cc += T) {  // each thread revisits exactly the chunks it parked
             u32x4 g = u32x4{0u, 0u, 0u, 0u};
             if constexpr (PRO == PRO_RMSNORM) g = *reinterpret_cast<const u32x4 *>(p.norm_w + (size_t)cc * 8);
