@@ -326,6 +326,9 @@ __global__ __launch_bounds__(128) void paged_merge_kernel(const float *__restric
 //   fp32 scores/softmax, P rounded to bf16 before PV, causal tile skipping and
 //   zero output for empty rows, as the reference.
 // ---------------------------------------------------------------------------
+#ifndef FA_ABL
+#define FA_ABL 0  // tools/lab/fa_lab only: 1 no softmax arithmetic, 2 no PV MFMA, 4 no QK MFMA, 8 no LDS staging stores, 16 no K/V reloads
+#endif
 constexpr int FA_BK = 64;            // tokens staged per barrier phase (two 32-token MFMA sub-tiles)
 constexpr int FA_SUB = FA_BK / 32;
 constexpr int FA_CPT = FA_BK / 16;    // 16-byte K (and V) chunks per thread and stage
@@ -491,9 +494,9 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     }
     for (int stage = stage_begin; stage < stage_end; ++stage) {
         __syncthreads();  // previous stage's LDS reads are complete
-        stage_store();
+        if (!(FA_ABL & 8) || stage == stage_begin) stage_store();
         __syncthreads();
-        if (stage + 1 < stage_end) {
+        if (stage + 1 < stage_end && !(FA_ABL & 16)) {
             stage_load(stage + 1);
             if (stage + 2 < stage_end) load_pids(stage + 2);
         }
@@ -511,6 +514,8 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
         for (int s = 0; s < 8; ++s) {
             const int ch = (2 * s + h) ^ (l32 & 15);
             const u32x4 kf = *reinterpret_cast<const u32x4 *>(&ks[(tb + l32) * D + ch * 8]);
+            if constexpr (FA_ABL & 4) sacc[s] += __uint_as_float((kf[0] ^ qf[s][1]) & 0x3f800000u);
+            else
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
                                                            __builtin_bit_cast(bf16x8_t, qf[s]), sacc, 0, 0, 0);
         }
@@ -524,6 +529,9 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
             sacc[r] = valid ? sacc[r] * scale_log2 : -INFINITY;
             tmax = fmaxf(tmax, sacc[r]);
         }
+        if constexpr (FA_ABL & 1) {
+            run_sum += sacc[0];
+        } else {
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float new_max = fmaxf(run_max, tmax);
         const bool finite_row = q_valid && new_max != -INFINITY;
@@ -544,6 +552,7 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[db][r] *= prev_scale;
         }
+        }  // FA_ABL & 1
 
         // P^T fragments (B operand), step s uses regs 8s..8s+7
         u32x4 pf[2];
@@ -561,6 +570,8 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
                 const u32x2 lo = *reinterpret_cast<const u32x2 *>(&vt[d * FA_LDV + tb + 16 * s + 4 * h]);
                 const u32x2 hi = *reinterpret_cast<const u32x2 *>(&vt[d * FA_LDV + tb + 16 * s + 4 * h + 8]);
                 const u32x4 vf = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                if constexpr (FA_ABL & 2) o[db][s] += __uint_as_float((vf[0] ^ pf[s][1]) & 0x3f800000u);
+                else
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
                                                                 __builtin_bit_cast(bf16x8_t, pf[s]), o[db], 0, 0, 0);
             }
