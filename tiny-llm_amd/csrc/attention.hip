@@ -519,29 +519,50 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
                                                            __builtin_bit_cast(bf16x8_t, qf[s]), sacc, 0, 0, 0);
         }
-        // mask + scale ; lane holds tokens (r&3)+8(r>>2)+4h of query row qrow
+        // mask + scale ; lane holds tokens (r&3)+8(r>>2)+4h of query row qrow.
+        // Interior tiles (wave-uniform test: every token is inside the context, on one live page, and at or below the causal
+        // diagonal of the block's FIRST query row) need no per-element test: most tiles of a long context are interior.
         float tmax = -INFINITY;
+        const bool interior = page_shift >= 5 && tile * 32 + 31 < ctx && tile_page[stage & 1][tb] >= 0 &&
+                              (!is_causal || tile * 32 + 31 <= qb * 32 + (ctx - L));
+        if (interior) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tok = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            bool valid = q_valid && tok < ctx && tile_page[stage & 1][tb + (r & 3) + 8 * (r >> 2) + 4 * h] >= 0;
-            if (is_causal) valid = valid && tok <= qrow + (ctx - L);
-            sacc[r] = valid ? sacc[r] * scale_log2 : -INFINITY;
-            tmax = fmaxf(tmax, sacc[r]);
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] *= scale_log2;
+                tmax = fmaxf(tmax, sacc[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tok = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                bool valid = q_valid && tok < ctx && tile_page[stage & 1][tb + (r & 3) + 8 * (r >> 2) + 4 * h] >= 0;
+                if (is_causal) valid = valid && tok <= qrow + (ctx - L);
+                sacc[r] = valid ? sacc[r] * scale_log2 : -INFINITY;
+                tmax = fmaxf(tmax, sacc[r]);
+            }
         }
         if constexpr (FA_ABL & 1) {
             run_sum += sacc[0];
         } else {
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float new_max = fmaxf(run_max, tmax);
-        const bool finite_row = q_valid && new_max != -INFINITY;
-        const float prev_scale = (run_max == -INFINITY || !finite_row) ? 0.f : exp2f(run_max - new_max);
-        float tsum = 0.f;
+        float prev_scale, tsum = 0.f;
+        if (interior) {  // every score is finite: exp2f(-inf) of the first tile's running maximum is the wanted 0
+            prev_scale = exp2f(run_max - new_max);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = (sacc[r] == -INFINITY || !finite_row) ? 0.f : exp2f(sacc[r] - new_max);
-            sacc[r] = p;
-            tsum += p;
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = exp2f(sacc[r] - new_max);
+                tsum += sacc[r];
+            }
+        } else {
+            const bool finite_row = q_valid && new_max != -INFINITY;
+            prev_scale = (run_max == -INFINITY || !finite_row) ? 0.f : exp2f(run_max - new_max);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = (sacc[r] == -INFINITY || !finite_row) ? 0.f : exp2f(sacc[r] - new_max);
+                sacc[r] = p;
+                tsum += p;
+            }
         }
         tsum += __shfl_xor(tsum, 32, 64);
         run_max = new_max;
