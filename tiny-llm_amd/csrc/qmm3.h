@@ -24,6 +24,9 @@
 
 namespace tl {
 
+#ifndef QMM3_ABL
+#define QMM3_ABL 0  // tools/lab/qmm3_lab only: 1 no MFMA, 2 no activation staging, 4 no partial stores
+#endif
 constexpr int QM3_WAVES = 8;
 constexpr int QM3_PAD = 8;  // bf16 elements of padding per staged activation row
 
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {  // CHUNKS is a multiple of 64: whole waves drop out, a 16-lane group stays in one row/group
             const int ch = tid + it * T;
-            if (ch >= CHUNKS) break;
+            if (ch >= CHUNKS || (QMM3_ABL & 2)) break;
             const int row = ch / CPR;
             const int cc = ch - row * CPR;
             const int g = cc >> 4;
@@ -132,9 +135,12 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
             for (int mb = 0; mb < MB; ++mb) {
                 const u32x4 ax = *reinterpret_cast<const u32x4 *>(xbase + (size_t)mb * 16 * XS + i * 128 + 8 * t);
 #pragma unroll
-                for (int tw = 0; tw < TW; ++tw)
+                for (int tw = 0; tw < TW; ++tw) {
+                    if constexpr (QMM3_ABL & 1) d[tw][mb][t] += __uint_as_float((ax[0] ^ bq[tw][1]) & 0x3f800000u);
+                    else
                     d[tw][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax),
                                                                         __builtin_bit_cast(bf16x8_t, bq[tw]), d[tw][mb], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = mb * 16 + 4 * c + j;
-                if (row < p.M) p.partial[((size_t)slice * p.M + row) * K + ocol] = acc[tw][mb][j];
+                if (row < p.M && (!(QMM3_ABL & 4) || acc[tw][mb][j] == 123.f)) p.partial[((size_t)slice * p.M + row) * K + ocol] = acc[tw][mb][j];
             }
     }
     prof_end(p.prof, prof_t0);
