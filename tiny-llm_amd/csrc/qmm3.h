@@ -25,7 +25,7 @@
 namespace tl {
 
 #ifndef QMM3_ABL
-#define QMM3_ABL 0  // tools/lab/qmm3_lab only: 1 no MFMA, 2 no activation staging, 4 no partial stores
+#define QMM3_ABL 0  // tools/lab/qmm3_lab only: 1 no MFMA, 2 no activation staging, 4 no partial stores, 8 no group-sum arithmetic
 #endif
 constexpr int QM3_WAVES = 8;
 constexpr int QM3_PAD = 8;  // bf16 elements of padding per staged activation row
@@ -101,6 +101,10 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
             for (int e = 0; e < 4; ++e) {
                 f[2 * e] = BF16::to_float((uint16_t)(v[e] & 0xffffu));
                 f[2 * e + 1] = BF16::to_float((uint16_t)(v[e] >> 16));
+            }
+            if constexpr (QMM3_ABL & 8) {
+                if ((cc & 15) == 0) xsum[g * ROWS + row] = f[0];
+                continue;
             }
             float sum = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
             sum = group16_sum(sum);
