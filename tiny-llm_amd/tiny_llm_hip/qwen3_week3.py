@@ -7,6 +7,7 @@ import torch
 from .attention import paged_attention
 from .embedding import QuantizedEmbedding
 from .kv_cache import TinyKvCache
+from .moe import Moe
 from .paged_kv_cache import TinyKvPagedCache, TinyKvPagedPool
 from .quantize import QuantizedWeights, quantized_linear
 from .week2_kernels import FastRMSNorm, FastRoPE, decode_attention_custom, scaled_dot_product_attention, swiglu
@@ -92,7 +93,7 @@ def is_qwen3_moe_sparse_layer(args: Any, layer_idx: int) -> bool:
 
 class Qwen3ModelWeek3:
     """Every layer owns one page pool; a request gets one ``TinyKvPagedCache`` per layer on it
-    (reference qwen3_week3.py:218-338).  Dense Qwen3 only: the optional MoE chapter is out of scope."""
+    (reference qwen3_week3.py:218-338).  Sparse (Qwen3-MoE) layers use the grouped-expert block of moe.py."""
 
     def __init__(self, mlx_model: Any, page_size: int = 128, enable_paged_attention: bool = True):
         args = mlx_model.args
@@ -110,9 +111,16 @@ class Qwen3ModelWeek3:
             self.vocab_size, self.hidden_size, w4(mlx_model.model.embed_tokens), use_custom_kernel=True)
         self.layers_inner = []
         for index, layer in enumerate(mlx_model.model.layers):
-            if is_qwen3_moe_sparse_layer(args, index):
-                raise NotImplementedError("Qwen3-MoE layers are outside the W4 dense decode path")
             attn, mlp = layer.self_attn, layer.mlp
+            if is_qwen3_moe_sparse_layer(args, index):
+                # Qwen3-MoE: router + grouped-expert SwiGLU (reference qwen3_week3.py:258-272, moe.py:39-89)
+                mlp_block = Moe(w_router=w4(mlp.gate), w_gate=w4(mlp.switch_mlp.gate_proj),
+                                w_up=w4(mlp.switch_mlp.up_proj), w_down=w4(mlp.switch_mlp.down_proj),
+                                num_experts_per_tok=args.num_experts_per_tok,
+                                norm_topk_prob=getattr(args, "norm_topk_prob", False))
+            else:
+                mlp_block = Qwen3MLP(args.hidden_size, args.intermediate_size, w4(mlp.gate_proj), w4(mlp.up_proj),
+                                     w4(mlp.down_proj))
             self.layers_inner.append(Qwen3TransformerBlock(
                 num_attention_heads=args.num_attention_heads, num_kv_heads=args.num_key_value_heads,
                 hidden_size=args.hidden_size, head_dim=args.head_dim, rms_norm_eps=args.rms_norm_eps,
@@ -120,8 +128,7 @@ class Qwen3ModelWeek3:
                 q_norm=attn.q_norm.weight, k_norm=attn.k_norm.weight,
                 w_input_layernorm=layer.input_layernorm.weight,
                 w_post_attention_layernorm=layer.post_attention_layernorm.weight,
-                mlp=Qwen3MLP(args.hidden_size, args.intermediate_size, w4(mlp.gate_proj), w4(mlp.up_proj),
-                             w4(mlp.down_proj)),
+                mlp=mlp_block,
                 max_seq_len=args.max_position_embeddings, theta=args.rope_theta,
                 use_paged_attention=enable_paged_attention))
         self.norm = FastRMSNorm(args.hidden_size, weight=mlx_model.model.norm.weight, eps=args.rms_norm_eps)
