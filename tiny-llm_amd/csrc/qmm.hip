@@ -93,8 +93,11 @@ __device__ __forceinline__ u32x4 dequant_word(uint32_t w, float s, float beta) {
 #ifndef QMM_ABL
 #define QMM_ABL 0  // tools/lab/gemm_lab only: 1 = no dequant arithmetic, 2 = no MFMA, 4 = no activation re-staging
 #endif
+#ifndef QMM_OCC
+#define QMM_OCC 3  // waves per SIMD the register allocation aims for (136 registers fit 3; 4 costs 5 spilled VGPRs)
+#endif
 template <typename TT, int MT>
-__global__ __launch_bounds__(256) void qmm_mfma_kernel(const uint16_t *__restrict__ scales,
+__global__ __launch_bounds__(256, QMM_OCC) void qmm_mfma_kernel(const uint16_t *__restrict__ scales,
                                                        const uint16_t *__restrict__ biases,
                                                        const uint16_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                        uint16_t *__restrict__ out, int M, int N, int K,
