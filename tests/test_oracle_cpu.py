@@ -137,3 +137,39 @@ def test_c_port_matches_numpy_oracle(built_libs):
         if top2[1] - top2[0] > 0.1:
             assert tid == int(np.argmax(want))
     port.close()
+
+
+def test_moe_oracle_against_a_dense_fp32_formulation():
+    """oracle.moe_block / gather_quantized_matvec (the checkers of the grouped-expert GPU tests) against a plain fp32
+    evaluation over dequantised expert weights: same routing, outputs within bf16 rounding of each other."""
+    rng = np.random.default_rng(11)
+    E, D, H, k, T = 4, 128, 256, 2, 5
+
+    def stack(rows, cols):
+        triples = [O.quantize_affine(rng.standard_normal((rows, cols)).astype(np.float32) * 0.05) for _ in range(E)]
+        return tuple(np.stack([t[i] for t in triples]) for i in range(3))
+
+    router = O.quantize_affine(rng.standard_normal((E, D)).astype(np.float32) * 0.3)
+    gate, up, down = stack(H, D), stack(H, D), stack(D, H)
+    x = O.bf16(rng.standard_normal((T, D)).astype(np.float32))
+    out, ids, scores = O.moe_block(x, router, gate, up, down, k, norm_topk_prob=True)
+    assert ids.shape == (T, k) and np.allclose(scores.sum(axis=-1), 1.0, atol=2e-2)
+
+    def dense(triple, e):
+        return O.dequantize_weights(triple[0][e], triple[1][e], triple[2][e]).astype(np.float32)
+
+    logits = x @ O.dequantize_weights(*router).astype(np.float32).T
+    probs = O.softmax(logits)
+    want_ids = np.argsort(-probs, axis=-1)[:, :k]
+    assert all(set(a) == set(b) for a, b in zip(ids.tolist(), want_ids.tolist()))
+    ref = np.zeros((T, D), np.float32)
+    for t in range(T):
+        p = probs[t, ids[t]]
+        p = p / p.sum()
+        for j, e in enumerate(ids[t]):
+            g, u = x[t] @ dense(gate, e).T, x[t] @ dense(up, e).T
+            ref[t] += p[j] * ((O.silu(g) * u) @ dense(down, e).T)
+    np.testing.assert_allclose(out, ref, atol=2e-2 * np.abs(ref).max(), rtol=5e-2)
+    row = O.gather_quantized_matvec(gate[1], gate[2], x, gate[0], np.array([1, 0, 3, 3, 2]))
+    for t, e in enumerate([1, 0, 3, 3, 2]):
+        np.testing.assert_allclose(row[t], O.bf16(x[t] @ dense(gate, e).T), atol=2e-2, rtol=2e-2)
