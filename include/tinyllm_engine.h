@@ -189,6 +189,53 @@ typedef struct tl_step_profile {
 } tl_step_profile;
 int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *out);
 
+/* ===== kernel-level entry points of the decode path ===========================================
+ * The launch code the engine runs per projection and per layer, on caller-owned device buffers: what the operator
+ * microbenches time (reference benches/bench_week2_operators.py:355-358, bench_week3_attention.py:74-77) and what the
+ * parity tests drive at the real Qwen3-4B shapes (tests/test_decode_kernels_gpu.py).  Not used by the engine itself. */
+
+/* A W4 matrix re-packed into the decode layout ([rows/16][cols/128][64 lanes][4 words], csrc/qmv3.h).  `w` stays
+ * borrowed (the packed-dot fallback reads the checkpoint layout); rows % 16 == 0, cols % 128 == 0.  Stream ordered. */
+typedef struct tl_tiled_w4 tl_tiled_w4;
+int tl_tiled_w4_create(const tl_w4 *w, void *stream, tl_tiled_w4 **out);
+void tl_tiled_w4_destroy(tl_tiled_w4 *t);
+
+/* Which kernel a projection ran: 1 = fused MFMA GEMV (qmv3: p = MR, KS, CW, LM, workgroups), 2 = skinny MFMA matmul +
+ * slice reduction (qmm3: p = MB, TW, LM, slices, tile groups), 3 = packed-dot GEMV fallback, 4 = prefill GEMM path. */
+typedef struct tl_linear_info {
+    int kernel;
+    int launches;
+    int rows_per_pass; /* activation rows per launch (the GEMV splits M when the staged rows exceed LDS) */
+    int p[5];
+} tl_linear_info;
+
+/* out = epilogue(prologue(a) @ W^T) over M (1..64) bf16 rows, exactly as one projection of a decode step:
+ *   prologue 0 none | 1 RMSNorm(a, norm_w, eps) rounded to bf16;  epilogue 0 store | 1 residual + bf16(acc) |
+ *   2 SwiGLU over interleaved (gate_i, up_i) rows -> out [M, rows/2].
+ *   kernel 0 = the engine's routing by M and matrix size, 1 = force the fused GEMV (M <= 8), 2 = force the skinny matmul.
+ * The engine uses the pairs (1,0) qkv / lm_head, (0,1) wo / w_down, (1,2) gate|up, (0,0). */
+size_t tl_decode_linear_workspace_bytes(int M, int rows, int cols);
+int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
+                     const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,
+                     size_t workspace_bytes, void *stream, tl_linear_info *info);
+
+/* The attention launch of one decode layer: q/k-RMSNorm + RoPE at position context_lens[b] + append of the new K/V row to
+ * the pages (IN PLACE) + GQA attention over context_lens[b] + 1 tokens (+ the merge launch when the context is split).
+ *   qkv [batch, (Hq + 2 Hkv) D] bf16, pages [P, Hkv, page_size, D] bf16, block_table [batch, max_pages] int32,
+ *   context_lens [batch] int32 (tokens already cached), out [batch, Hq D] bf16.
+ * max_context: host upper bound of context_lens (sizes the context split exactly as tl_engine_decode does). */
+typedef struct tl_attention_info {
+    int n_splits, tokens_per_split, heads_per_workgroup;
+    int wide_waves, wide_rows_in_flight, scalar_page_ids; /* wide one-head kernel: waves, K/V rows in flight per group, page ids by s_load */
+    int launches;
+} tl_attention_info;
+size_t tl_decode_attention_fused_workspace_bytes(int batch, int num_heads, int head_dim);
+int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev, void *key_pages_dev,
+                              void *value_pages_dev, const int32_t *block_table_dev, const int32_t *context_lens_dev,
+                              void *out_dev, int batch, int num_heads, int num_kv_heads, int head_dim, int page_size,
+                              int max_pages, float rope_theta, float eps, int max_context, void *workspace_dev,
+                              size_t workspace_bytes, void *stream, tl_attention_info *info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,13 @@ def _load():
     lib.oq_decode_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.oq_weight_bytes.restype = ctypes.c_double
     lib.oq_weight_bytes.argtypes = [ctypes.c_void_p]
+    # float64 ground truth (qwen3_truth.c): same struct layouts
+    lib.ot_create.restype = ctypes.c_void_p
+    lib.ot_create.argtypes = lib.oq_create.argtypes
+    lib.ot_destroy.argtypes = [ctypes.c_void_p]
+    lib.ot_reset.argtypes = [ctypes.c_void_p]
+    lib.ot_decode_step.restype = ctypes.c_int
+    lib.ot_decode_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     return lib
 
 
@@ -57,6 +64,9 @@ def _bf16_bits(a) -> np.ndarray:
 class COracleQwen3:
     """weights: the dict layout of tiny_oracle.make_qwen3_weights (scales/biases as bf16-representable float32 or
     raw uint16 bf16 bits)."""
+
+    _PREFIX = "oq"
+    _LOGIT_DTYPE = np.float32
 
     def __init__(self, cfg: dict, weights: dict, max_ctx: int = 512, threads: int | None = None):
         if threads:
@@ -87,16 +97,18 @@ class COracleQwen3:
         c = _Config(cfg["hidden_size"], cfg["num_hidden_layers"], cfg["num_attention_heads"],
                     cfg["num_key_value_heads"], cfg["head_dim"], cfg["intermediate_size"], cfg["vocab_size"], max_ctx,
                     float(cfg["rope_theta"]), float(cfg["rms_norm_eps"]))
-        self.h = self.lib.oq_create(ctypes.byref(c), layers, ctypes.byref(embed),
-                                    ctypes.byref(head) if head is not None else None, norm(weights["norm"]))
-        self._logits = np.zeros(cfg["vocab_size"], dtype=np.float32)
+        create = getattr(self.lib, self._PREFIX + "_create")
+        self.h = create(ctypes.byref(c), layers, ctypes.byref(embed),
+                        ctypes.byref(head) if head is not None else None, norm(weights["norm"]))
+        self._logits = np.zeros(cfg["vocab_size"], dtype=self._LOGIT_DTYPE)
 
     def reset(self) -> None:
-        self.lib.oq_reset(self.h)
+        getattr(self.lib, self._PREFIX + "_reset")(self.h)
 
     def step(self, token: int):
-        """Feed one token; returns (argmax id, logits[vocab] float32 with bf16-representable values)."""
-        tid = self.lib.oq_decode_step(self.h, int(token), self._logits.ctypes.data)
+        """Feed one token; returns (argmax id, logits[vocab]) — float32 with bf16-representable values for the bf16 port,
+        unrounded float64 for the ground truth."""
+        tid = getattr(self.lib, self._PREFIX + "_decode_step")(self.h, int(token), self._logits.ctypes.data)
         if tid < 0:
             raise RuntimeError("c oracle: cache full or token out of range")
         return tid, self._logits.copy()
@@ -106,7 +118,7 @@ class COracleQwen3:
 
     def close(self) -> None:
         if getattr(self, "h", None):
-            self.lib.oq_destroy(self.h)
+            getattr(self.lib, self._PREFIX + "_destroy")(self.h)
             self.h = None
 
     def __del__(self):
@@ -114,3 +126,14 @@ class COracleQwen3:
             self.close()
         except Exception:
             pass
+
+
+class CTruthQwen3(COracleQwen3):
+    """oracle/qwen3_truth.c: the same decode step in float64 with NO intermediate rounding — the ground truth the
+    model-level tolerances are derived from (|HIP - truth| against |bf16 oracle - truth|)."""
+
+    _PREFIX = "ot"
+    _LOGIT_DTYPE = np.float64
+
+    def weight_bytes(self) -> float:
+        raise NotImplementedError

@@ -46,3 +46,91 @@ def log_softmax(x: np.ndarray) -> np.ndarray:
     x = np.asarray(x, dtype=np.float64)
     m = x.max(axis=-1, keepdims=True)
     return (x - m - np.log(np.exp(x - m).sum(axis=-1, keepdims=True))).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Real Qwen3-4B shapes (pinned in the reference's benchmark JSON) and ground-truth based tolerances
+# ---------------------------------------------------------------------------------------------------------------------
+QWEN4B_CFG = dict(hidden_size=2560, num_hidden_layers=36, num_attention_heads=32, num_key_value_heads=8, head_dim=128,
+                  intermediate_size=9728, vocab_size=151936, rope_theta=1000000, rms_norm_eps=1e-6,
+                  max_position_embeddings=40960, tie_word_embeddings=True)
+
+# A model-level parity test bounds the HIP path's distance from the float64 ground truth (oracle.TruthQwen3 /
+# c_oracle.CTruthQwen3) by this multiple of the bf16 oracle's own distance from it, plus one bf16 ulp of the largest
+# logit (both sides are bf16-rounded, so each max-error is itself quantised to half an ulp).
+TRUTH_FACTOR = 1.5
+
+
+def bf16_ulp(x) -> np.ndarray:
+    """Spacing of bfloat16 at |x| (8 significant bits)."""
+    x = np.maximum(np.abs(np.asarray(x, dtype=np.float64)), 2.0 ** -126)
+    return 2.0 ** (np.floor(np.log2(x)) - 7)
+
+
+def assert_bf16_close(got, want, ulps: float = 2.0, abs_floor: float = 0.0, what: str = ""):
+    """|got - want| <= ulps * ulp_bf16(want) + abs_floor elementwise.  `want` is the oracle's bf16 result (float64
+    accumulation, one rounding); a kernel that accumulates in fp32 in another order lands within one ulp of it except
+    where the value is small against its own partial sums, which `abs_floor` (stated by the caller) covers."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    allowed = ulps * bf16_ulp(want) + abs_floor
+    bad = np.abs(got - want) > allowed
+    if bad.any():
+        i = np.unravel_index(np.argmax(np.abs(got - want) - allowed), got.shape)
+        raise AssertionError(f"{what}: {int(bad.sum())} of {got.size} elements outside {ulps} bf16 ulp + {abs_floor:g}; "
+                             f"worst at {i}: got {got[i]!r}, want {want[i]!r}")
+
+
+def log_parity(record: dict) -> None:
+    """Append one measured-parity record to gpurun_out/parity_numbers.jsonl (scratch; summaries are copied to profiles/)."""
+    import json
+    from pathlib import Path
+
+    out = Path(__file__).resolve().parent.parent / "gpurun_out"
+    try:
+        out.mkdir(exist_ok=True)
+        with open(out / "parity_numbers.jsonl", "a") as f:
+            f.write(json.dumps(record) + "\n")
+    except OSError:
+        pass
+
+
+def check_against_truth(got, oracle, truth, what: str, factor: float = TRUTH_FACTOR) -> dict:
+    """got / oracle: bf16 logits [steps, vocab] of the HIP path and of the bf16 oracle; truth: float64 logits.
+    Asserts max|got - truth| <= factor * max|oracle - truth| + one bf16 ulp of the largest logit, logs the numbers."""
+    got, oracle, truth = (np.asarray(a, dtype=np.float64) for a in (got, oracle, truth))
+    e_hip = float(np.abs(got - truth).max())
+    e_orc = float(np.abs(oracle - truth).max())
+    rms_hip = float(np.sqrt(np.mean((got - truth) ** 2)))
+    rms_orc = float(np.sqrt(np.mean((oracle - truth) ** 2)))
+    ulp = float(bf16_ulp(np.abs(truth).max()))
+    rec = {"what": what, "max_abs_hip_vs_truth": e_hip, "max_abs_oracle_vs_truth": e_orc,
+           "max_abs_hip_vs_oracle": float(np.abs(got - oracle).max()), "rms_hip_vs_truth": rms_hip,
+           "rms_oracle_vs_truth": rms_orc, "max_abs_logit": float(np.abs(truth).max()), "bf16_ulp_at_max": ulp}
+    log_parity(rec)
+    assert e_hip <= factor * e_orc + ulp, f"{what}: HIP is {e_hip:.4g} from the float64 truth, the bf16 oracle {e_orc:.4g}"
+    assert rms_hip <= factor * rms_orc + 1e-6, f"{what}: rms error {rms_hip:.4g} (HIP) vs {rms_orc:.4g} (oracle)"
+    return rec
+
+
+def oracle_weights_from_model(model) -> dict:
+    """mlx_lm-shaped torch model (any device) -> the oracle's weight dict with raw uint16 bf16 bits (c_oracle accepts
+    those directly; tiny_oracle functions need from_bf16_bits first)."""
+    def w4(layer):
+        return (layer.weight.cpu().numpy().view(np.uint32), layer.scales.view(torch.int16).cpu().numpy().view(np.uint16),
+                layer.biases.view(torch.int16).cpu().numpy().view(np.uint16))
+
+    def norm(t):
+        return t.to(torch.bfloat16).view(torch.int16).cpu().numpy().view(np.uint16)
+
+    layers = []
+    for layer in model.model.layers:
+        a, m = layer.self_attn, layer.mlp
+        layers.append(dict(q=w4(a.q_proj), k=w4(a.k_proj), v=w4(a.v_proj), o=w4(a.o_proj), gate=w4(m.gate_proj),
+                           up=w4(m.up_proj), down=w4(m.down_proj), q_norm=norm(a.q_norm.weight),
+                           k_norm=norm(a.k_norm.weight), input_norm=norm(layer.input_layernorm.weight),
+                           post_norm=norm(layer.post_attention_layernorm.weight)))
+    out = dict(embed=w4(model.model.embed_tokens), layers=layers, norm=norm(model.model.norm.weight))
+    if hasattr(model, "lm_head"):
+        out["lm_head"] = w4(model.lm_head)
+    return out

@@ -1,0 +1,352 @@
+"""GPU parity of the kernels the decode engine ACTUALLY launches, at the real Qwen3-4B shapes and BASELINE contexts.
+
+The operator tests (test_ops_gpu.py) drive the public reference API; the engine, however, decodes through its own
+kernels: `qmv3_kernel` (fused MFMA GEMV over the tiled weights), `qmm3_kernel` + slice reduction (5..64 rows) and
+`attn_decode_wide_kernel` / `attn_decode_fused_kernel` (+ merge).  These tests call exactly that launch code through the
+kernel-level C entry points (`tl_decode_linear`, `tl_decode_attention_fused`, include/tinyllm_engine.h) and compare with
+the numpy oracle on the same seeded inputs:
+
+  * the five Qwen3-4B projections (6144x2560 qkv, 2560x4096 wo, 19456x2560 interleaved gate|up, 2560x9728 w_down,
+    151936x2560 lm_head) x rows {1,2,4,8} (GEMV) and {5,9,16,33,64} (skinny matmul) x the fused variant the engine uses for
+    that projection (RMSNorm prologue, residual / SwiGLU epilogue) and the plain one, asserting WHICH kernel and which
+    template instantiation ran (no silent fallback to the packed-dot GEMV);
+  * decode attention at contexts 1 .. 32,768, page 128, Hq32/Hkv8/D128 (the reference's bench_week3_attention.py:74-77
+    shape), 1 and 4 sequences, the wide one-head kernel, the split kernel + merge, and the >64-split merge;
+  * the MFMA FlashAttention operator at a 2048-row chunk over an 8k cached context (sampled query rows).
+
+Reference tests mirrored: tests_refsol/test_week_2_day_3.py:89-118 (per-shape matvec vs the dequantised product),
+test_week_3_day_4.py:118-245 (paged decode), test_week_3_day_5.py:23-61 (paged FlashAttention).
+Tolerance (stated per assert): outputs are bf16; the oracle accumulates in float64 and rounds once, the kernels
+accumulate in fp32 in another order, so a value may land on the neighbouring bf16 (1 ulp); an op with two roundings
+(residual, SwiGLU) may move 2.  `abs_floor` covers outputs that are small against their own partial sums.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tiny_oracle as O
+from helpers import assert_bf16_close, log_parity
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+EPS = 1e-6
+
+PRO_NONE, PRO_RMSNORM = 0, 1
+EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2
+
+# name: (weight rows K, reduction N, prologue, epilogue) -- the fused pair the engine uses for that projection
+PROJECTIONS = {
+    "qkv": (6144, 2560, PRO_RMSNORM, EPI_STORE),
+    "wo": (2560, 4096, PRO_NONE, EPI_RESIDUAL),
+    "gate_up": (19456, 2560, PRO_RMSNORM, EPI_SWIGLU),
+    "down": (2560, 9728, PRO_NONE, EPI_RESIDUAL),
+    "lm_head": (151936, 2560, PRO_RMSNORM, EPI_STORE),
+}
+# qmv3 template parameters the planner picks at ONE row (MR, KS, CW, LM): what bench.py's roofline kernel is
+GEMV_PLAN_M1 = {"qkv": (1, 2, 4, 10), "wo": (1, 4, 4, 8), "gate_up": (1, 4, 4, 5), "down": (1, 8, 8, 10),
+                "lm_head": (1, 2, 4, 10)}
+MAX_ROWS = 64
+
+
+@pytest.fixture(scope="module")
+def ext():
+    import tiny_llm_ext_hip
+
+    tiny_llm_ext_hip.load_library(".")
+    return tiny_llm_ext_hip
+
+
+def _bf16_host(t: torch.Tensor) -> np.ndarray:
+    return t.float().cpu().numpy()
+
+
+class _Projection:
+    """Seeded W4 matrix of one Qwen3-4B projection (product quantiser on N(0, 0.02) weights, built on the GPU), the
+    activation / residual rows, and the oracle's results for every fused variant (all MAX_ROWS rows, computed once)."""
+
+    def __init__(self, ext, name):
+        from tiny_llm_hip.synthetic import quantize
+
+        K, N, pro, epi = PROJECTIONS[name]
+        self.name, self.K, self.N, self.pro, self.epi = name, K, N, pro, epi
+        gen = torch.Generator(device=DEV)
+        gen.manual_seed(1000 + len(name) * 7 + K % 97)
+        w = (torch.randn((K, N), generator=gen, device=DEV, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+        packed, scales, biases = quantize(w)
+        del w
+        self.a = torch.randn((MAX_ROWS, N), generator=gen, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+        self.norm_w = (1.0 + 0.05 * torch.randn((N,), generator=gen, device=DEV, dtype=torch.float32)).to(torch.bfloat16)
+        self.residual = torch.randn((MAX_ROWS, K), generator=gen, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+        self.tiled = ext.TiledW4(packed, scales, biases)
+        # oracle, float64 accumulation, one rounding per reference op
+        hp = packed.cpu().numpy().view(np.uint32)
+        hs, hb = _bf16_host(scales), _bf16_host(biases)
+        a, nw, res = _bf16_host(self.a), _bf16_host(self.norm_w), _bf16_host(self.residual)
+        # one pass over the weights for both activation sets (unpacking 389 M nibbles dominates the lm_head oracle)
+        stacked = np.concatenate([a, O.rms_norm_fast(a, nw, EPS)], axis=0) if pro == PRO_RMSNORM else a
+        both = O.quantized_matmul(hs, hb, stacked, hp, "bf16")
+        plain = both[:MAX_ROWS]
+        self.want = {(PRO_NONE, EPI_STORE): plain}
+        if pro == PRO_RMSNORM:
+            normed = both[MAX_ROWS:]
+            if epi == EPI_SWIGLU:  # rows interleaved: even = gate_i, odd = up_i (the engine's fused gate|up weight)
+                self.want[(pro, epi)] = O.swiglu(normed[:, 0::2], normed[:, 1::2])
+            else:
+                self.want[(pro, epi)] = normed
+        else:
+            self.want[(pro, epi)] = O.bf16(res + plain)
+        self.scale = float(np.sqrt(np.mean(plain.astype(np.float64) ** 2)))
+
+    def run(self, ext, M, variant, kernel):
+        pro, epi = variant
+        return ext.decode_linear(self.tiled, self.a[:M].contiguous(), prologue=pro, epilogue=epi,
+                                 norm_weight=self.norm_w if pro == PRO_RMSNORM else None,
+                                 residual=self.residual[:M].contiguous() if epi == EPI_RESIDUAL else None, eps=EPS,
+                                 kernel=kernel)
+
+
+_cache = {}
+
+
+@pytest.fixture()
+def projection(ext, request):
+    name = request.param
+    if name not in _cache:  # built once per session: the lm_head oracle alone unpacks 389 M nibbles
+        _cache[name] = _Projection(ext, name)
+    return _cache[name]
+
+
+def _variants(p):
+    return [(PRO_NONE, EPI_STORE), (p.pro, p.epi)]
+
+
+def _check(p, got, M, variant, what):
+    want = p.want[variant][:M]
+    two_roundings = variant[1] != EPI_STORE
+    # abs_floor: fp32 accumulation over N terms of size ~rms/sqrt(N) each, on outputs of rms `scale`
+    assert_bf16_close(_bf16_host(got), want, ulps=2.0 if two_roundings else 1.0, abs_floor=2e-4 * max(1.0, p.scale), what=what)
+
+
+@pytest.mark.parametrize("M", [1, 2, 4, 8])
+@pytest.mark.parametrize("projection", list(PROJECTIONS), indirect=True)
+def test_fused_gemv_at_qwen3_4b_shapes(ext, projection, M):
+    """qmv3_kernel, the kernel bench.py's roofline names, on every 4B projection: plain and with the engine's fused
+    prologue / epilogue; the MFMA kernel itself must have run, with the planner's documented instantiation at one row."""
+    p = projection
+    for variant in _variants(p):
+        got, info = p.run(ext, M, variant, kernel=1)
+        what = f"qmv3 {p.name} M={M} variant={variant} {info}"
+        assert info["kernel"] == 1, f"{what}: fell back to {info['kernel_name']}"
+        if M == 1:
+            assert tuple(info["p"][:4]) == GEMV_PLAN_M1[p.name], what
+        if info["rows_per_pass"] == M:
+            assert info["launches"] == 1, what
+        _check(p, got, M, variant, what)
+
+
+@pytest.mark.parametrize("M", [5, 9, 16, 33, 64])
+@pytest.mark.parametrize("projection", list(PROJECTIONS), indirect=True)
+def test_skinny_matmul_at_qwen3_4b_shapes(ext, projection, M):
+    """qmm3_kernel + qmm3_reduce_kernel (batched decode, 5..64 rows): fp32 slice partials summed in slice order, the
+    engine's epilogues applied by the reduction; includes the 64-row lm_head whose partials are the largest workspace."""
+    p = projection
+    for variant in _variants(p):
+        got, info = p.run(ext, M, variant, kernel=2)
+        what = f"qmm3 {p.name} M={M} variant={variant} {info}"
+        assert info["kernel"] == 2, what
+        _check(p, got, M, variant, what)
+    if M > 8:  # the engine's own routing sends more than 8 rows here as well
+        _, info = p.run(ext, M, (p.pro, p.epi), kernel=0)
+        assert info["kernel"] == 2, f"routing at M={M}: {info}"
+
+
+@pytest.mark.parametrize("projection", list(PROJECTIONS), indirect=True)
+def test_engine_routing_between_gemv_and_skinny_matmul(ext, projection):
+    """1..4 rows: fused GEMV everywhere.  5..8 rows: GEMV for the small projections, skinny matmul for w_down / lm_head
+    (csrc/engine.hip engine_linear); results of both kernels agree with the oracle at 8 rows."""
+    p = projection
+    variant = (p.pro, p.epi)
+    for M in (1, 3, 4):
+        _, info = p.run(ext, M, variant, kernel=0)
+        assert info["kernel"] == 1, f"{p.name} M={M}: {info}"
+    got, info = p.run(ext, 8, variant, kernel=0)
+    assert info["kernel"] == (2 if p.name in ("down", "lm_head") else 1), f"{p.name} M=8: {info}"
+    _check(p, got, 8, variant, f"routing {p.name} M=8")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# decode attention of the engine (q/k-norm + RoPE + KV append + paged GQA attention) at BASELINE contexts
+# ---------------------------------------------------------------------------------------------------------------------
+HQ, HKV, D, PAGE = 32, 8, 128, 128
+THETA = 1e6
+
+
+def _attention_case(rng, ctxs, extra_pages=2):
+    """Scattered physical pages (reference construction test_week_3_day_5.py:25-37), random bf16 K/V, one qkv row per
+    sequence; ctx = tokens already cached (an idle slot has ctx 0 and an all -1 block-table row)."""
+    B = len(ctxs)
+    need = [(c + 1 + PAGE - 1) // PAGE if c >= 0 else 0 for c in ctxs]
+    P = sum(need) + extra_pages
+    ids = list(rng.permutation(P))
+    max_pages = max(max(need), 1) + 1
+    table = -np.ones((B, max_pages), dtype=np.int32)
+    for b in range(B):
+        for j in range(need[b]):
+            table[b, j] = ids.pop()
+    kp = O.bf16(rng.standard_normal((P, HKV, PAGE, D), dtype=np.float32))
+    vp = O.bf16(rng.standard_normal((P, HKV, PAGE, D), dtype=np.float32))
+    qkv = O.bf16(rng.standard_normal((B, (HQ + 2 * HKV) * D), dtype=np.float32))
+    qn = O.bf16(1.0 + 0.1 * rng.standard_normal((D,), dtype=np.float32))
+    kn = O.bf16(1.0 + 0.1 * rng.standard_normal((D,), dtype=np.float32))
+    return kp, vp, table, np.asarray([max(c, 0) for c in ctxs], dtype=np.int32), qkv, qn, kn
+
+
+def _attention_oracle(kp, vp, table, ctx, qkv, qn, kn, idle):
+    """Reference op order (qwen3_week3.py:63-86): q/k RMSNorm -> RoPE at offset ctx -> paged_cache_update -> paged_attention
+    over ctx + 1 tokens."""
+    B = len(ctx)
+    kp, vp = kp.copy(), vp.copy()
+    rows = qkv.reshape(B, HQ + 2 * HKV, D)
+    q = O.rms_norm_fast(rows[:, :HQ], qn, EPS)[:, None]             # [B, L=1, Hq, D]
+    k = O.rms_norm_fast(rows[:, HQ:HQ + HKV], kn, EPS)[:, None]
+    v = rows[:, HQ + HKV:][:, None]
+    q = O.rope(q, ctx, D, THETA, False, "bf16")
+    k = O.rope(k, ctx, D, THETA, False, "bf16")
+    lens = ctx.copy()
+    for b in range(B):
+        if idle[b]:
+            lens[b] = 0
+            continue
+        pid, slot = int(table[b, ctx[b] // PAGE]), int(ctx[b] % PAGE)
+        kp[pid, :, slot, :] = k[b, 0]
+        vp[pid, :, slot, :] = v[b, 0]
+        lens[b] = ctx[b] + 1
+    out = O.paged_attention(q.transpose(0, 2, 1, 3).reshape(B * HQ, 1, D), kp, vp, table, lens, D ** -0.5, True, HKV, HQ)
+    return out.reshape(B, HQ * D), kp, vp
+
+
+def _run_attention(ext, case, max_context):
+    kp, vp, table, ctx, qkv, qn, kn = case
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV, torch.bfloat16)
+    kpd, vpd = t(kp), t(vp)
+    out, info = ext.decode_attention_fused(t(qkv), t(qn), t(kn), kpd, vpd, torch.from_numpy(table).to(DEV),
+                                           torch.from_numpy(ctx).to(DEV), num_heads=HQ, num_kv_heads=HKV, rope_theta=THETA,
+                                           eps=EPS, max_context=max_context)
+    torch.cuda.synchronize()
+    return _bf16_host(out), _bf16_host(kpd), _bf16_host(vpd), info
+
+
+def _check_attention(case, got, kp_after, vp_after, idle, what):
+    want, kp_want, vp_want = _attention_oracle(*case, idle)
+    # outputs are softmax-weighted means of N(0,1) values (|out| ~ 0.05 .. 1): 1 bf16 ulp + fp32 / exp2 accumulation noise
+    assert_bf16_close(got, want, ulps=1.0, abs_floor=1.5e-3, what=what)
+    for b, is_idle in enumerate(idle):
+        if is_idle:
+            assert not got[b].any(), f"{what}: idle slot {b} must produce zeros"
+    np.testing.assert_array_equal(vp_after, vp_want, err_msg=f"{what}: value pages (appended V row, nothing else touched)")
+    kp_before, table, ctx = case[0], case[2], case[3]
+    touched = np.zeros(kp_before.shape[:3], dtype=bool)  # [P, Hkv, slot]
+    for b, is_idle in enumerate(idle):
+        if not is_idle:
+            touched[int(table[b, ctx[b] // PAGE]), :, int(ctx[b] % PAGE)] = True
+    np.testing.assert_array_equal(kp_after[~touched], kp_before[~touched], err_msg=f"{what}: key pages outside the appended rows")
+    # the appended K row went through RMSNorm and RoPE in fp32 on both sides (two bf16 roundings): a one-ulp difference of a
+    # normalised value moves the rotated pair by up to 2^-8 of the LARGER partner, whatever the size of the result
+    assert_bf16_close(kp_after[touched], kp_want[touched], ulps=1.0, abs_floor=2.0 ** -6, what=f"{what}: appended K row (norm + RoPE)")
+
+
+@pytest.mark.parametrize("ctx", [0, 1, 63, 64, 127, 128, 255, 256, 300, 511, 512, 1000, 3000, 4095])
+def test_decode_attention_contexts_up_to_4k(ext, ctx, monkeypatch):
+    """One sequence, the plan the engine picks for it: the wide one-head kernel (no merge launch up to 511 cached tokens,
+    then 256/512-token windows + merge)."""
+    for name in ("TL_ATTN_WIDE_MAX", "TL_ATTN_NW", "TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_VECTOR_IDS"):
+        monkeypatch.delenv(name, raising=False)
+    rng = np.random.default_rng(1000 + ctx)
+    case = _attention_case(rng, [ctx])
+    got, kpa, vpa, info = _run_attention(ext, case, ctx)
+    what = f"ctx={ctx} {info}"
+    assert info["wide_waves"] > 0 and info["heads_per_workgroup"] == 1, what
+    assert info["n_splits"] * info["tokens_per_split"] >= ctx + 1, what
+    if ctx + 1 <= 512:
+        assert info["n_splits"] == 1 and info["launches"] == 1, f"{what}: contexts up to 512 need no merge launch"
+        assert info["scalar_page_ids"] in (1, 2, 4), f"{what}: page 128 windows take their page ids through s_load"
+    _check_attention(case, got, kpa, vpa, [False], what)
+    log_parity({"what": "decode_attention", "ctx": ctx, **info})
+
+
+@pytest.mark.parametrize("nw", [4, 8, 16])
+@pytest.mark.parametrize("ctx", [200, 400])
+@pytest.mark.parametrize("vector_ids", [False, True])
+def test_decode_attention_wide_variants(ext, ctx, nw, vector_ids, monkeypatch):
+    """Every (waves, rows-in-flight) instantiation of the wide kernel that TL_ATTN_NW can select, with scalar and vector
+    page-id loads."""
+    monkeypatch.setenv("TL_ATTN_NW", str(nw))
+    if vector_ids:
+        monkeypatch.setenv("TL_ATTN_VECTOR_IDS", "1")
+    else:
+        monkeypatch.delenv("TL_ATTN_VECTOR_IDS", raising=False)
+    rng = np.random.default_rng(ctx * 31 + nw)
+    case = _attention_case(rng, [ctx, 17])
+    got, kpa, vpa, info = _run_attention(ext, case, ctx)
+    what = f"ctx={ctx} nw={nw} vector_ids={vector_ids} {info}"
+    assert info["wide_waves"] > 0 and (info["scalar_page_ids"] == 0) == vector_ids, what
+    _check_attention(case, got, kpa, vpa, [False, False], what)
+
+
+@pytest.mark.parametrize("ctxs", [[8191], [8192, 5000, 129, -1], [32767], [32768, 1, 700, 20000]])
+@pytest.mark.parametrize("mode", ["default", "one_head_wide", "splits256", "legacy_rq1"])
+def test_decode_attention_long_contexts(ext, ctxs, mode, monkeypatch):
+    """BASELINE configs 3 and 5 (8k and 32k cached tokens, page 128), 1 and 4 sequences (ragged, one idle slot written as
+    -1): the default plan (one workgroup per GQA group walking 64-token stages, split + merge), the one-head wide kernel
+    forced onto long contexts, 256 context splits (attn_merge_many_kernel), and the one-head split kernel."""
+    for name in ("TL_ATTN_WIDE_MAX", "TL_ATTN_NW", "TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_RQ1_CTX"):
+        monkeypatch.delenv(name, raising=False)
+    if mode == "one_head_wide":
+        monkeypatch.setenv("TL_ATTN_RQ1_CTX", "65536")
+        monkeypatch.setenv("TL_ATTN_MAX_SPLITS", "256")
+    elif mode == "splits256":
+        monkeypatch.setenv("TL_ATTN_MAX_SPLITS", "256")
+        monkeypatch.setenv("TL_ATTN_WIDE_MAX", "0")
+    elif mode == "legacy_rq1":
+        monkeypatch.setenv("TL_ATTN_RQ", "1")
+        monkeypatch.setenv("TL_ATTN_WIDE_MAX", "0")
+    idle = [c < 0 for c in ctxs]
+    rng = np.random.default_rng(abs(sum(ctxs)) + len(mode))
+    case = _attention_case(rng, ctxs)
+    got, kpa, vpa, info = _run_attention(ext, case, max(ctxs))
+    what = f"ctxs={ctxs} mode={mode} {info}"
+    if mode == "one_head_wide":
+        assert info["wide_waves"] > 0, what
+    if mode == "splits256" and max(ctxs) >= 32767 and len(ctxs) == 1:
+        assert info["n_splits"] > 64, f"{what}: expected the many-split merge"
+    if mode in ("splits256", "legacy_rq1"):
+        assert info["wide_waves"] == 0, what
+    _check_attention(case, got, kpa, vpa, idle, what)
+    log_parity({"what": "decode_attention_long", "ctxs": ctxs, "mode": mode, **info})
+
+
+def test_flash_attention_2048_row_chunk_over_8k_context(ext):
+    """The paged MFMA FlashAttention operator as chunked prefill uses it at BASELINE config 3: the last 2048-row chunk of an
+    8,192-token prompt (context 8,192 incl. the chunk), 32/8 heads, page 128.  Sampled query rows (first / last rows,
+    32- and 64-row tile edges, random interior rows), every head, against the oracle with P rounded to bf16 before PV
+    (paged_attention.metal:439-444)."""
+    rng = np.random.default_rng(2048)
+    L, ctx = 2048, 8192
+    need = ctx // PAGE
+    P = need + 3
+    table = np.asarray([rng.permutation(P)[:need]], dtype=np.int32)
+    kp = O.bf16(rng.standard_normal((P, HKV, PAGE, D), dtype=np.float32))
+    vp = O.bf16(rng.standard_normal((P, HKV, PAGE, D), dtype=np.float32))
+    q = O.bf16(rng.standard_normal((HQ, L, D), dtype=np.float32))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV, torch.bfloat16)
+    got = ext.paged_attention(t(q), t(kp), t(vp), torch.from_numpy(table).to(DEV),
+                              torch.tensor([ctx], dtype=torch.int32, device=DEV), D ** -0.5, True, num_kv_heads=HKV,
+                              num_heads=HQ, max_context_hint=ctx)
+    got = _bf16_host(got)
+    rows = sorted({0, 1, 31, 32, 33, 63, 64, 65, 127, 128, 1023, 1024, 2046, 2047, *rng.integers(0, L, size=10).tolist()})
+    for r in rows:
+        vis = ctx - L + r + 1  # causal visibility of chunk row r (paged_attention.metal:158-160)
+        want = O.paged_attention(q[:, r:r + 1], kp, vp, table, np.asarray([vis], dtype=np.int32), D ** -0.5, True, HKV, HQ,
+                                 "bf16", round_p=True)
+        assert_bf16_close(got[:, r], want[:, 0], ulps=1.0, abs_floor=1.5e-3, what=f"FA row {r} (sees {vis} tokens)")

@@ -5,10 +5,16 @@ on a seeded 2-layer Qwen3-shaped W4 checkpoint, mirroring the reference's model-
 (tests_refsol/test_week_3_day_3.py:386-402: Week3 vs Week2 log-probs, rtol=atol=1e-3 on a fake model;
 tests_refsol/test_week_2_day_6.py:92-109: full-model log-probs vs mlx_lm, rtol 0.1 / atol 2.0).
 
-Tolerance used here: log-probs (fp32 log-softmax of bf16 logits) within 6e-2 absolute.  Rationale: logits of
-this model are O(1..4) in bf16 (ulp 0.0078..0.0156); the fused kernels keep every reference rounding point
-but sum in a different fp32 order, so a handful of values flip by one bf16 ulp per op and that propagates
-through 2 layers.  Greedy tokens must match exactly whenever the oracle's top-2 margin exceeds that band.
+Tolerances are DERIVED, not chosen: the bf16 oracle and the HIP engine both round activations to bfloat16 at every
+reference op boundary, in different fp32 summation orders, so neither is "right" -- both approximate the real-valued
+function that oracle.TruthQwen3 evaluates in float64 with no intermediate rounding.  Wherever a truth is available a
+test asserts  max|HIP - truth| <= 1.5 * max|oracle - truth| + 1 bf16 ulp  on the raw logits (helpers.check_against_truth;
+the measured numbers go to gpurun_out/parity_numbers.jsonl).  Comparisons between two rounded paths use bands that follow
+from that by the triangle inequality, with E = the oracle's measured distance from the truth on this checkpoint (fixture
+`err`): HIP vs oracle 2.5 E, HIP vs HIP (solo vs batch, chunked vs one-shot) 3 E.  A greedy token may differ from a
+reference path's only where the reference's own margin to that token is inside the band (a provable near-tie).
+North-star "1e-3" is the reference's tolerance between two MLX paths on a FAKE tiny model (test_week_3_day_3.py:386-402);
+on this checkpoint the bf16 oracle itself sits E ~ 2e-2 from the truth, so no bf16 pipeline can meet 1e-3 against another.
 """
 
 import numpy as np
@@ -16,10 +22,9 @@ import pytest
 import torch
 
 from oracle import tiny_oracle as O
-from helpers import TINY_CFG, log_softmax, to_mlx_shaped
+from helpers import TINY_CFG, bf16_ulp, check_against_truth, log_parity, to_mlx_shaped
 
 pytestmark = pytest.mark.gpu
-LOGPROB_ATOL = 6e-2
 
 
 @pytest.fixture(scope="module")
@@ -37,36 +42,63 @@ def engine(ckpt):
     eng.close()
 
 
+@pytest.fixture(scope="module")
+def err(ckpt):
+    """E: the bf16 oracle's distance (max abs logit error) from the float64 truth on this checkpoint, measured over the
+    prompts the tests use; and the bands derived from it.  CPU only."""
+    w, _ = ckpt
+    worst, worst_gemm, top = 0.0, 0.0, 0.0
+    for n in (5, 37, 150):
+        prompt = prompt_ids(n, seed=n)
+        truth, orc, gemm = O.TruthQwen3(TINY_CFG, w), O.OracleQwen3(TINY_CFG, w), O.OracleQwen3(TINY_CFG, w, gemm_rows_threshold=0)
+        lt, lo, lg = truth.forward(prompt)[0, -1], orc.forward(prompt)[0, -1], gemm.forward(prompt)[0, -1]
+        for _ in range(4):
+            tok = [int(np.argmax(lo))]
+            lt, lo, lg = truth.forward(tok)[0, -1], orc.forward(tok)[0, -1], gemm.forward(tok)[0, -1]
+            worst = max(worst, float(np.abs(lo - lt).max()))
+            worst_gemm = max(worst_gemm, float(np.abs(lg - lt).max()))
+            top = max(top, float(np.abs(lt).max()))
+    ulp = float(bf16_ulp(top))
+    out = {"E": worst, "E_gemm": worst_gemm, "ulp": ulp, "hip_vs_oracle": 2.5 * worst + ulp, "hip_vs_hip": 3.0 * worst + ulp,
+           "gemv_vs_gemm": 1.5 * (worst + worst_gemm) + ulp}
+    log_parity({"what": "engine test bands (TINY checkpoint)", **out})
+    return out
+
+
+def assert_near_greedy(logits_row, token, band, what):
+    """`token` must be the argmax of `logits_row`, or so close to it that the two paths' rounding can explain the choice."""
+    row = np.asarray(logits_row, dtype=np.float64)
+    gap = float(row.max() - row[token])
+    assert gap <= band, f"{what}: token {token} is {gap:.4f} below the best logit (band {band:.4f})"
+
+
 def prompt_ids(n, seed=0):
     rng = np.random.default_rng(seed)
     return [int(t) for t in rng.integers(1, TINY_CFG["vocab_size"], size=n)]
 
 
-def oracle_run(w, prompt, steps):
-    """Greedy decode with the oracle; returns per-step logits (first from prefill) and ids."""
-    model = O.OracleQwen3(TINY_CFG, w)
-    logits = [model.forward(prompt)[0, -1]]
+def oracle_run(w, prompt, steps, cfg=TINY_CFG):
+    """Greedy decode with the bf16 oracle, and the float64 truth teacher-forced on the same ids; returns per-step logits
+    (first from prefill) of both, and the oracle's ids."""
+    model, truth = O.OracleQwen3(cfg, w), O.TruthQwen3(cfg, w)
+    logits, exact = [model.forward(prompt)[0, -1]], [truth.forward(prompt)[0, -1]]
     ids = [int(np.argmax(logits[-1]))]
     for _ in range(steps):
         logits.append(model.forward([ids[-1]])[0, -1])
+        exact.append(truth.forward([ids[-1]])[0, -1])
         ids.append(int(np.argmax(logits[-1])))
-    return np.stack(logits), ids
-
-
-def margin_ok(logits_row, band=LOGPROB_ATOL * 2):
-    top2 = np.sort(logits_row)[-2:]
-    return (top2[1] - top2[0]) > band
+    return np.stack(logits), ids, np.stack(exact)
 
 
 @pytest.mark.parametrize("n_prompt", [1, 5, 20, 37, 90, 150, 300])
-def test_engine_matches_oracle(ckpt, engine, n_prompt):
+def test_engine_matches_oracle(ckpt, engine, err, n_prompt):
     """prefill (GEMV path for <=8 rows, MFMA GEMM + paged FlashAttention above) then 12 fused decode steps,
-    crossing page boundaries (page_size 16).  Contexts above 64 tokens split the decode attention over 2/4/8
-    workgroups per head, merged by a second launch."""
+    crossing page boundaries (page_size 16); the decode attention window grows 64 -> 512 tokens in one workgroup, beyond
+    that it is split and merged by a second launch.  HIP must sit as close to the float64 truth as the bf16 oracle does."""
     w, _ = ckpt
     prompt = prompt_ids(n_prompt, seed=n_prompt)
     steps = 12
-    want_logits, want_ids = oracle_run(w, prompt, steps)
+    want_logits, want_ids, truth_logits = oracle_run(w, prompt, steps)
     engine.begin(0)
     engine.prefill(0, prompt, chunk=64)
     got = [engine.logits(1)[0].float().cpu().numpy()]
@@ -79,10 +111,11 @@ def test_engine_matches_oracle(ckpt, engine, n_prompt):
         ids.append(engine.read_tokens(0, 1)[0])
     engine.release(0)
     got = np.stack(got)
-    np.testing.assert_allclose(log_softmax(got), log_softmax(want_logits), atol=LOGPROB_ATOL, rtol=0)
+    # prompts above 8 rows prefill through the tile GEMM (weights rounded to bf16 first, reference quantize.py:54-65), as the
+    # oracle does; the decode steps are GEMV on both sides
+    check_against_truth(got, want_logits, truth_logits, what=f"engine vs oracle vs truth, TINY, prompt {n_prompt}")
     for s in range(steps + 1):
-        if margin_ok(want_logits[s]):
-            assert ids[s] == want_ids[s], f"greedy token differs at step {s}"
+        assert_near_greedy(want_logits[s], ids[s], err["hip_vs_oracle"], f"greedy token at step {s}")
 
 
 def test_engine_graph_equals_eager_and_free_running(ckpt, engine):
@@ -103,7 +136,7 @@ def test_engine_graph_equals_eager_and_free_running(ckpt, engine):
     assert st["pages_in_use"] == 0 and st["pages_free"] == 64
 
 
-def test_engine_matches_op_by_op_model(ckpt, engine):
+def test_engine_matches_op_by_op_model(ckpt, engine, err):
     """Same checkpoint through tiny_llm_hip.Qwen3ModelWeek3 (one HIP operator per reference op)."""
     from tiny_llm_hip import Qwen3ModelWeek3
 
@@ -132,7 +165,8 @@ def test_engine_matches_op_by_op_model(ckpt, engine):
         engine.decode(1, batch=1)
         got.append(engine.logits(1)[0].float().cpu().numpy())
     engine.release(0)
-    np.testing.assert_allclose(log_softmax(np.stack(got)), log_softmax(np.stack(ref)), atol=LOGPROB_ATOL, rtol=0)
+    # two HIP paths (fused engine vs one operator per reference op), each within 1.5 E of the truth
+    assert float(np.abs(np.stack(got) - np.stack(ref)).max()) <= err["hip_vs_hip"]
 
 
 def test_engine_batch_slots_are_independent(ckpt, engine):
@@ -161,10 +195,10 @@ def test_engine_batch_slots_are_independent(ckpt, engine):
     assert tail[:11] == solo[1]
 
 
-def test_engine_rewind_and_chunked_prefill(ckpt, engine):
+def test_engine_rewind_and_chunked_prefill(ckpt, engine, err):
     """rewind(n) then re-decoding reproduces the same ids (reference rewind, paged_kv_cache.py:414-434);
     chunked prefill (chunks of 8 -> GEMV/decode-attention path, 16 -> MFMA path) matches one-shot prefill
-    within the log-prob band."""
+    within the band of two HIP paths of which one runs the tile GEMM (weights rounded to bf16 first)."""
     prompt = prompt_ids(40, seed=9)
     engine.begin(0)
     engine.prefill(0, prompt)
@@ -187,7 +221,7 @@ def test_engine_rewind_and_chunked_prefill(ckpt, engine):
             engine.decode(1, batch=1)
         got = engine.logits(1)[0].float().cpu().numpy()
         engine.release(0)
-        np.testing.assert_allclose(log_softmax(got), log_softmax(one_shot), atol=LOGPROB_ATOL, rtol=0)
+        assert float(np.abs(got - one_shot).max()) <= err["gemv_vs_gemm"], f"chunk {chunk}"
 
 
 def test_engine_errors(ckpt, engine):
@@ -206,30 +240,45 @@ def test_engine_errors(ckpt, engine):
     engine.release(0)
 
 
-def test_continuous_batching_matches_solo_generation(ckpt):
+def _solo_rows(eng, prompt, ids, chunk):
+    """Logits row that chose ids[j], for every j, when the request is served ALONE and fed exactly `ids`."""
+    eng.begin(0)
+    try:
+        eng.prefill(0, prompt, chunk=chunk)
+        rows = [eng.logits(1)[0].float().cpu().numpy()]
+        for tok in ids[:-1]:
+            eng.set_token(0, tok)
+            eng.decode(1, batch=1)
+            rows.append(eng.logits(1)[0].float().cpu().numpy())
+    finally:
+        eng.release(0)
+    return rows
+
+
+def test_continuous_batching_matches_solo_generation(ckpt, err):
     """batch_generate_ids (reference batch.py:136-285 schedule: one prefill chunk + one batched decode step per turn,
-    staging slot -> decode slot hand-over) must give every request exactly the ids it gets when served alone, and
-    return every page."""
+    staging slot -> decode slot hand-over).  EVERY id of EVERY request is checked: served alone and fed the same history,
+    the engine must rank that id first, or within the band two HIP paths can differ by (rows of a batch see another
+    attention window split and another RMSNorm grouping than a solo row, so a provable near-tie may go the other way --
+    nothing else is accepted).  All pages come back."""
     from tiny_llm_hip.engine import DecodeEngine, batch_generate_ids
 
     eng = DecodeEngine(ckpt[1], page_size=16, num_pages=96, max_batch=4, max_prefill_rows=64)
     try:
         prompts = [prompt_ids(n, seed=100 + n) for n in (5, 23, 9, 40, 17, 3)]
         limits = [26, 29, 24, 27, 1, 28]
-        solo = []
-        for p, n in zip(prompts, limits):
-            solo.append(eng.generate(p, n, slot=0, chunk=16))
         active_counts = []
         got = batch_generate_ids(eng, prompts, limits, batch_size=3, prefill_step=16, on_step=active_counts.append)
         assert sorted(i for i, _ in got) == list(range(len(prompts)))
-        # Rows of a batched GEMV see the same weights but a different fp32 grouping of the RMSNorm sum of squares
-        # than a solo row, so a near-tie can flip one greedy id and the continuation then legitimately diverges:
-        # require identical lengths and first ids everywhere and identical sequences for most requests.
-        exact = 0
+        total, first_choice = 0, 0
         for idx, ids in got:
-            assert len(ids) == limits[idx] and ids[0] == solo[idx][0], f"request {idx}"
-            exact += int(ids == solo[idx])
-        assert exact >= len(prompts) - 2, f"only {exact} of {len(prompts)} requests reproduce solo decoding"
+            assert len(ids) == limits[idx], f"request {idx}"
+            rows = _solo_rows(eng, prompts[idx], ids, chunk=16)
+            for j, tok in enumerate(ids):
+                assert_near_greedy(rows[j], tok, err["hip_vs_hip"], f"request {idx}, generated position {j}")
+                first_choice += int(tok == int(np.argmax(rows[j])))
+                total += 1
+        assert first_choice >= 0.95 * total, f"only {first_choice} of {total} ids are the solo path's first choice"
         assert max(active_counts) == 3, "the decode batch should fill up"
         st = eng.stats()
         assert st["pages_in_use"] == 0 and st["pages_free"] == 96
@@ -237,8 +286,10 @@ def test_continuous_batching_matches_solo_generation(ckpt):
         eng.close()
 
 
-def _solo_vs_batch(model, n_seq, steps=3, page_size=16, env_pages=None):
-    """Logits of every sequence decoded alone (slot 0, fused GEMV) and decoded together (one batch of n_seq rows)."""
+def _solo_vs_batch(model, n_seq, steps=3, page_size=16, env_pages=None, return_ids=False):
+    """Logits of every sequence decoded alone (slot 0, fused GEMV) and decoded together (one batch of n_seq rows).  The batch
+    is teacher-forced on the ids of the solo runs, so both paths see the same history even where a near-tie would let their
+    greedy choices differ."""
     from tiny_llm_hip.engine import DecodeEngine
 
     vocab = model.args.vocab_size if hasattr(model, "args") else TINY_CFG["vocab_size"]
@@ -247,43 +298,49 @@ def _solo_vs_batch(model, n_seq, steps=3, page_size=16, env_pages=None):
     try:
         rng = np.random.default_rng(77)
         prompts = [[int(t) for t in rng.integers(1, vocab, size=4 + (3 * i) % 23)] for i in range(n_seq)]
-        solo = []
+        solo, fed = [], []
         for p in prompts:
             eng.begin(0)
             eng.prefill(0, p)
             eng.decode(steps, batch=1)
             solo.append(eng.logits(1)[0].float().cpu().numpy())
+            fed.append(eng.read_tokens(0, steps + 1)[:-1])  # the token each decode step consumed
             eng.release(0)
         for i, p in enumerate(prompts):
             eng.begin(i)
             eng.prefill(i, p)
-        eng.decode(steps, batch=n_seq)
+        for k in range(steps):
+            for i in range(n_seq):
+                eng.set_token(i, fed[i][k])
+            eng.decode(1, batch=n_seq)
         got = eng.logits(n_seq).float().cpu().numpy()
         for i in range(n_seq):
             eng.release(i)
         assert eng.stats()["pages_in_use"] == 0
+        if return_ids:
+            return got, np.stack(solo), prompts, fed
         return got, np.stack(solo)
     finally:
         eng.close()
 
 
 @pytest.mark.parametrize("n_seq", [9, 12, 24, 40, 64])
-def test_batched_decode_skinny_matmul_matches_solo(ckpt, monkeypatch, n_seq):
+def test_batched_decode_skinny_matmul_matches_solo(ckpt, err, monkeypatch, n_seq):
     """9..64 decode rows run the K-sliced skinny MFMA matmul (csrc/qmm3.h): the GEMV's algebraic form (reference
     quantized_matmul.metal:510-521) with the slices summed in fp32, so a sequence must decode to (nearly) the same
-    logits alone and in a batch -- same band as the oracle comparison."""
+    logits alone and in a batch -- the band of two HIP paths that share every rounding point."""
     monkeypatch.delenv("TL_NO_QMM3", raising=False)
     got, solo = _solo_vs_batch(ckpt[1], n_seq)
-    np.testing.assert_allclose(log_softmax(got), log_softmax(solo), atol=LOGPROB_ATOL, rtol=0)
+    assert float(np.abs(got - solo).max()) <= err["hip_vs_hip"]
 
 
-def test_batched_decode_reference_gemm_path(ckpt, monkeypatch):
+def test_batched_decode_reference_gemm_path(ckpt, err, monkeypatch):
     """TL_NO_QMM3=1: more than 8 decode rows go through RMSNorm + W4 MFMA GEMM + SwiGLU/residual kernels (reference
-    quantize.py:54-65 sends rows > 8 to the matmul path, whose weights are rounded to bf16 first): log-probs within
-    the model-level band of solo decoding."""
+    quantize.py:54-65 sends rows > 8 to the matmul path, whose weights are rounded to bf16 first): logits within
+    1.5 x (E of the GEMV oracle + E of the all-GEMM oracle) of solo decoding, both E measured against the float64 truth."""
     monkeypatch.setenv("TL_NO_QMM3", "1")
     got, solo = _solo_vs_batch(ckpt[1], 12)
-    np.testing.assert_allclose(log_softmax(got), log_softmax(solo), atol=0.15, rtol=0)
+    assert float(np.abs(got - solo).max()) <= err["gemv_vs_gemm"]
 
 
 WIDE_CFG = dict(hidden_size=1280, num_hidden_layers=1, num_attention_heads=10, num_key_value_heads=2, head_dim=128,
@@ -294,20 +351,21 @@ WIDE_CFG = dict(hidden_size=1280, num_hidden_layers=1, num_attention_heads=10, n
 @pytest.mark.parametrize("n_seq", [16, 32, 64])
 def test_skinny_matmul_wide_shapes(n_seq):
     """Reduction dims of 10 / 20 quantisation groups (hidden 1280, intermediate 2560) reach the 10-, 8- and 5-group slice
-    variants and several slices per row; batch rows vs the same rows decoded alone, and one row against the oracle."""
+    variants and several slices per row.  Batch rows vs the same rows decoded alone (3 E), and two rows of the batch against
+    the bf16 oracle and the float64 truth fed the same tokens (HIP error <= 1.5 x oracle error)."""
     w = O.make_qwen3_weights(WIDE_CFG, seed=5, sigma=0.03)
     model = to_mlx_shaped(WIDE_CFG, w)
-    got, solo = _solo_vs_batch(model, n_seq, steps=2, page_size=16)
-    np.testing.assert_allclose(log_softmax(got), log_softmax(solo), atol=LOGPROB_ATOL, rtol=0)
-    # row 0 against the oracle: prompt of 4 tokens, 2 greedy steps
-    rng = np.random.default_rng(77)
-    prompt = [int(t) for t in rng.integers(1, WIDE_CFG["vocab_size"], size=4)]
-    orc = O.OracleQwen3(WIDE_CFG, w)
-    logits = orc.forward(prompt)[0, -1]
-    for _ in range(2):
-        logits = orc.forward([int(np.argmax(logits))])[0, -1]
-    if margin_ok(logits):
-        np.testing.assert_allclose(log_softmax(got[0]), log_softmax(logits), atol=LOGPROB_ATOL, rtol=0)
+    got, solo, prompts, fed = _solo_vs_batch(model, n_seq, steps=2, page_size=16, return_ids=True)
+    worst = 0.0
+    for row in (0, n_seq - 1):
+        orc, truth = O.OracleQwen3(WIDE_CFG, w), O.TruthQwen3(WIDE_CFG, w)
+        lo, lt = orc.forward(prompts[row])[0, -1], truth.forward(prompts[row])[0, -1]
+        for tok in fed[row]:
+            lo, lt = orc.forward([tok])[0, -1], truth.forward([tok])[0, -1]
+        rec = check_against_truth(got[row][None], lo[None], lt[None], what=f"WIDE batch of {n_seq}, row {row} (skinny matmul)")
+        worst = max(worst, rec["max_abs_oracle_vs_truth"])
+    band = 3.0 * worst + float(bf16_ulp(np.abs(solo).max()))
+    assert float(np.abs(got - solo).max()) <= band, "batch rows vs the same rows decoded alone"
 
 
 def _prefill_logits(model, prompt, rows):
@@ -329,7 +387,7 @@ def _prefill_logits(model, prompt, rows):
 def test_prefill_long_chunks(ckpt, wide, n_prompt, rows):
     """Chunks of 80 .. 256 rows: W4 MFMA GEMM (row tiles of 32 / 64 / 128, split-K where the tiles alone cannot fill the
     chip), paged FlashAttention with ragged last query blocks and -- for the later chunks of the 300-token prompt -- a
-    non-empty cached context.  Checked against the oracle forward in the same band as the decode tests."""
+    non-empty cached context.  HIP must sit as close to the float64 truth as the bf16 oracle (tile-GEMM semantics) does."""
     if wide:
         cfg, w = WIDE_CFG, O.make_qwen3_weights(WIDE_CFG, seed=5, sigma=0.03)
         model = to_mlx_shaped(WIDE_CFG, w)
@@ -338,10 +396,11 @@ def test_prefill_long_chunks(ckpt, wide, n_prompt, rows):
     prompt = [int(t) for t in np.random.default_rng(n_prompt).integers(1, cfg["vocab_size"], size=n_prompt)]
     got = _prefill_logits(model, prompt, rows)
     want = O.OracleQwen3(cfg, w).forward(prompt)[0, -1]
-    np.testing.assert_allclose(log_softmax(got), log_softmax(want), atol=LOGPROB_ATOL, rtol=0)
+    truth = O.TruthQwen3(cfg, w).forward(prompt)[0, -1]
+    check_against_truth(got[None], want[None], truth[None], what=f"prefill {'WIDE' if wide else 'TINY'} {n_prompt} tokens, chunks of {rows}")
 
 
-def test_engine_verify_matches_oracle_rows(ckpt, engine):
+def test_engine_verify_matches_oracle_rows(ckpt, engine, err):
     """tl_engine_verify: rows of one multi-token call (L <= 8 through the paged decode kernel) give the oracle's greedy
     continuation at every position, and rewinding the rejected suffix restores the cache for normal decoding."""
     w, _ = ckpt
@@ -353,10 +412,8 @@ def test_engine_verify_matches_oracle_rows(ckpt, engine):
     engine.prefill(0, prompt)
     got = engine.verify(0, extra)
     assert engine.context_len(0) == len(prompt) + len(extra)
-    for i in range(len(extra)):
-        row = want[len(prompt) + i]
-        if margin_ok(row):
-            assert got[i] == int(np.argmax(row)), f"row {i}"
+    for i in range(len(extra)):  # every row's greedy id: the oracle's argmax, or a provable near-tie with it
+        assert_near_greedy(want[len(prompt) + i], got[i], err["hip_vs_oracle"], f"verify row {i}")
     # drop the last 3 verified tokens again and decode on: same result as a sequence that never saw them
     engine.rewind(0, 3)
     engine.set_token(0, extra[2])
@@ -364,11 +421,12 @@ def test_engine_verify_matches_oracle_rows(ckpt, engine):
     after = engine.logits(1)[0].float().cpu().numpy()
     engine.release(0)
     ref = O.OracleQwen3(TINY_CFG, w).forward(prompt + extra[:3])[0, -1]
-    np.testing.assert_allclose(log_softmax(after), log_softmax(ref), atol=LOGPROB_ATOL, rtol=0)
+    truth = O.TruthQwen3(TINY_CFG, w).forward(prompt + extra[:3])[0, -1]
+    check_against_truth(after[None], ref[None], truth[None], what="decode after verify + rewind, TINY")
 
 
 @pytest.mark.parametrize("same_draft", [True, False])
-def test_speculative_decoding_over_two_engines(ckpt, same_draft):
+def test_speculative_decoding_over_two_engines(ckpt, err, same_draft):
     """speculative_generate_ids: the result is a greedy continuation of the TARGET whatever the draft proposes, checked id
     by id against the oracle forward of the emitted sequence; an identical draft is accepted almost always, a different one
     rarely."""
@@ -387,15 +445,14 @@ def test_speculative_decoding_over_two_engines(ckpt, same_draft):
             assert len(spec) == 28 and stats["target_calls"] <= 29
             accepted += stats["accepted"]
             proposed += stats["proposed"]
-            # every emitted id must be the oracle's greedy choice given the ids emitted before it (positions whose top-2
-            # logit margin is inside the comparison band may legitimately go either way and are skipped)
+            # every emitted id must be the oracle's greedy choice given the ids emitted before it, or a provable near-tie
+            # with it (the oracle's own margin to that id inside the HIP-vs-oracle band)
             rows = O.OracleQwen3(TINY_CFG, w).forward(p + spec, logits_to_keep=None)[0]
             for j, tok in enumerate(spec):
                 row = rows[len(p) - 1 + j]
-                if margin_ok(row):
-                    assert tok == int(np.argmax(row)), f"prompt of {len(p)} tokens, generated position {j}"
-                    checked += 1
-        assert checked > 60, "too few clear-margin positions to call this a test"
+                assert_near_greedy(row, tok, err["hip_vs_oracle"], f"prompt of {len(p)} tokens, generated position {j}")
+                checked += int(tok == int(np.argmax(row)))
+        assert checked > 100, "most positions should simply be the oracle's argmax"
         rate = accepted / max(proposed, 1)
         assert (rate > 0.8) if same_draft else (rate < 0.5), f"acceptance rate {rate:.2f}"
         assert target.stats()["pages_in_use"] == 0 and draft.stats()["pages_in_use"] == 0
@@ -456,7 +513,7 @@ def test_cli_entry_points_on_a_written_checkpoint(ckpt, tmp_path, capsys):
     capsys.readouterr()
 
 
-def test_fork_shares_prefix_pages_and_branches_decode_independently(ckpt):
+def test_fork_shares_prefix_pages_and_branches_decode_independently(ckpt, err):
     """tl_engine_fork: a forked slot continues exactly like its source (same logits), full pages are shared and a partial
     tail page is copied (page accounting), the two branches then take different tokens without disturbing each other
     (each checked against a sequence that was prefilled from scratch), rewinding into a shared page copies it first, and
@@ -484,14 +541,18 @@ def test_fork_shares_prefix_pages_and_branches_decode_independently(ckpt):
         branch0, branch1 = eng.read_tokens(0, 4), eng.read_tokens(1, 4)
         fresh = DecodeEngine(model, page_size=16, num_pages=32, max_batch=1, max_prefill_rows=64)
         try:
+            # all 4 ids of both branches: an unshared sequence with the same history must make the same choice (or hold a
+            # provable near-tie with it: the forked batch of 2 rows runs another GEMV instantiation than the solo row)
             for history, got in ((prompt + first, branch0), (prompt + [first[0], other], branch1)):
                 fresh.begin(0)
                 fresh.prefill(0, history[:-1], want_logits=False)
-                fresh.set_token(0, history[-1])
-                fresh.decode(4, batch=1)
-                want = fresh.read_tokens(0, 4)
+                fed = [history[-1]] + got[:-1]
+                for j, tok in enumerate(got):
+                    fresh.set_token(0, fed[j])
+                    fresh.decode(1, batch=1)
+                    row = fresh.logits(1)[0].float().cpu().numpy()
+                    assert_near_greedy(row, tok, err["hip_vs_hip"], f"branch id {j} vs an unshared sequence")
                 fresh.release(0)
-                assert got[:2] == want[:2], "a branch does not continue like an unshared sequence"
         finally:
             fresh.close()
         # rewind slot 1 back into the shared second page: it must get a private copy before it appends again
@@ -504,9 +565,10 @@ def test_fork_shares_prefix_pages_and_branches_decode_independently(ckpt):
         try:
             solo.begin(0)
             solo.prefill(0, prompt[:21])
-            assert torch.equal(solo.logits(1)[0], eng.logits(2)[1]) or np.allclose(
-                log_softmax(solo.logits(1)[0].float().cpu().numpy()),
-                log_softmax(eng.logits(2)[1].float().cpu().numpy()), atol=LOGPROB_ATOL)
+            # the copied page must hold the same K/V as a from-scratch prefill: two HIP paths (decode step in a batch of 2
+            # vs the last row of a prefill), band 3 E
+            delta = np.abs(solo.logits(1)[0].float().cpu().numpy() - eng.logits(2)[1].float().cpu().numpy()).max()
+            assert float(delta) <= err["gemv_vs_gemm"], f"logits after the copy-on-write rewind differ by {delta}"
             solo.release(0)
         finally:
             solo.close()

@@ -67,6 +67,20 @@ def test_load_reproduces_every_tensor(tmp_path, weights, shards):
     prompt = tok.apply_chat_template([{"role": "user", "content": "hello"}], tokenize=False, add_generation_prompt=True)
     assert prompt.startswith("user hello") and prompt.endswith("assistant")
 
+    # the scheduler builds a private detokenizer per request exactly like the reference
+    # (batch.py:23: tokenizer.detokenizer.__class__(tokenizer._tokenizer)): the loader's wrapper must carry both
+    from types import SimpleNamespace
+
+    from tiny_llm_hip.batch import Request
+
+    fake_model = SimpleNamespace(create_kv_cache=lambda: [])
+    req = Request(fake_model, tok, "hello tiny llm", prefill_max_step=2, device="cpu")
+    assert req.prefill_tokens.tolist() == [2, 4, 5] and req.eos_token_id == 0
+    assert req.detokenizer is not tok.detokenizer
+    for t in ids:
+        req.detokenizer.add_token(t)
+    assert req.detokenizer.text == tok.decode(ids)
+
 
 @pytest.mark.parametrize("mutate,message", [
     (lambda cfg, path: cfg["quantization"].update(group_size=64), "group_size=64"),

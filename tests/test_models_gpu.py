@@ -3,9 +3,13 @@
 test_week_3_day_4.py:325-345): every Week-2 checkpoint of the kernel ladder, the Week-3 paged model and the Week-1
 dense model must agree on log-probs for the same seeded W4 checkpoint, and all of them with the numpy oracle.
 
-Tolerance: log-softmax within 8e-2 absolute (reference: rtol 0.1 / atol 2.0 on full models, 1e-3 between two paths
-that share every kernel).  Paths here differ in kernel family and rounding points (e.g. the readable RMSNorm rounds
-twice, Week-1 uses dense bf16 weights), so single-ulp bf16 flips propagate through the two layers.
+Tolerance (derived, see test_engine_gpu.py's docstring): every path is teacher-forced on the bf16 oracle's greedy ids and
+its RAW logits are compared with the float64 no-rounding truth (oracle.TruthQwen3):  max|path - truth| must stay within
+`factor` x the bf16 oracle's own max distance from the truth + 1 bf16 ulp.  factor = 1.5 for paths with the oracle's rounding
+points (Week 3, Week-2 checkpoints from "rmsnorm" on), 2.5 for the early Week-2 checkpoints and Week 1, whose reference
+semantics round MORE often (readable RMSNorm rounds twice, layer_norm.py:10-15; "kv-cache" and Week 1 also round every
+dequantised weight to bf16, quantize.py:93-100).  Reference bars for comparison: rtol 0.1 / atol 2.0 on full models
+(test_week_2_day_6.py:92-109), 1e-3 between two paths that share every kernel on a fake model (test_week_3_day_3.py:386-402).
 """
 
 import numpy as np
@@ -13,10 +17,9 @@ import pytest
 import torch
 
 from oracle import tiny_oracle as O
-from helpers import TINY_CFG, log_softmax, to_mlx_shaped
+from helpers import TINY_CFG, check_against_truth, to_mlx_shaped
 
 pytestmark = pytest.mark.gpu
-ATOL = 8e-2
 
 
 @pytest.fixture(scope="module")
@@ -25,15 +28,17 @@ def ckpt():
     return w, to_mlx_shaped(TINY_CFG, w)
 
 
-def run_cached(model, prompt, steps):
-    """prefill + greedy decode through a KV-cached model; returns per-step last-row logits."""
+def run_cached(model, prompt, steps, forced=None):
+    """prefill + decode through a KV-cached model; returns per-step last-row logits.  `forced`: the ids to feed (teacher
+    forcing); otherwise the model's own greedy ids."""
     cache = model.create_kv_cache()
     try:
         toks = torch.tensor([prompt], dtype=torch.int32, device="cuda")
         out = [model(toks, 0, cache, logits_to_keep=1)[0, -1].float().cpu().numpy()]
         offset = len(prompt)
-        for _ in range(steps):
-            t = torch.tensor([[int(np.argmax(out[-1]))]], dtype=torch.int32, device="cuda")
+        for i in range(steps):
+            tok = forced[i] if forced is not None else int(np.argmax(out[-1]))
+            t = torch.tensor([[tok]], dtype=torch.int32, device="cuda")
             out.append(model(t, offset, cache, logits_to_keep=1)[0, -1].float().cpu().numpy())
             offset += 1
         return np.stack(out)
@@ -48,28 +53,34 @@ def test_week2_ladder_week3_and_oracle_agree(ckpt):
 
     w, mlx_model = ckpt
     prompt = [7, 300, 12, 901, 44, 5, 610, 73, 250, 18, 999]  # 11 tokens: the prefill takes the GEMM path
-    ref = O.OracleQwen3(TINY_CFG, w)
-    want = [ref.forward(prompt)[0, -1]]
+    ref, exact = O.OracleQwen3(TINY_CFG, w), O.TruthQwen3(TINY_CFG, w)
+    want, truth, ids = [ref.forward(prompt)[0, -1]], [exact.forward(prompt)[0, -1]], []
     for _ in range(4):
-        want.append(ref.forward([int(np.argmax(want[-1]))])[0, -1])
-    want = log_softmax(np.stack(want))
-    week3 = log_softmax(run_cached(Qwen3ModelWeek3(mlx_model, page_size=4), prompt, 4))
-    np.testing.assert_allclose(week3, want, atol=ATOL, rtol=0)
+        ids.append(int(np.argmax(want[-1])))
+        want.append(ref.forward([ids[-1]])[0, -1])
+        truth.append(exact.forward([ids[-1]])[0, -1])
+    want, truth = np.stack(want), np.stack(truth)
+    week3 = run_cached(Qwen3ModelWeek3(mlx_model, page_size=4), prompt, 4, forced=ids)
+    check_against_truth(week3, want, truth, what="Qwen3ModelWeek3 op by op, TINY")
     for name in WEEK2_CHECKPOINTS:
-        got = log_softmax(run_cached(Qwen3ModelWeek2(mlx_model, checkpoint=name), prompt, 4))
-        np.testing.assert_allclose(got, want, atol=ATOL, rtol=0, err_msg=f"Week-2 checkpoint {name}")
+        got = run_cached(Qwen3ModelWeek2(mlx_model, checkpoint=name), prompt, 4, forced=ids)
+        more_roundings = WEEK2_CHECKPOINTS.index(name) < WEEK2_CHECKPOINTS.index("rmsnorm")
+        check_against_truth(got, want, truth, what=f"Qwen3ModelWeek2 checkpoint {name}, TINY", factor=2.5 if more_roundings else 1.5)
 
 
 def test_week1_dense_model_matches_cached_models(ckpt):
     """Week 1 re-runs the whole context without a cache, on dequantised bf16 weights (qwen3_week1.py:206-217)."""
     from tiny_llm_hip import Qwen3ModelWeek1, Qwen3ModelWeek3
 
-    _, mlx_model = ckpt
+    w, mlx_model = ckpt
     prompt = [9, 8, 700, 6, 55, 4]
     toks = torch.tensor([prompt], dtype=torch.int32, device="cuda")
     dense = Qwen3ModelWeek1(mlx_model)(toks)[0, -1].float().cpu().numpy()
     paged = run_cached(Qwen3ModelWeek3(mlx_model, page_size=4), prompt, 0)[0]
-    np.testing.assert_allclose(log_softmax(dense), log_softmax(paged), atol=ATOL, rtol=0)
+    want = O.OracleQwen3(TINY_CFG, w).forward(prompt)[0, -1]
+    truth = O.TruthQwen3(TINY_CFG, w).forward(prompt)[0, -1]
+    check_against_truth(paged[None], want[None], truth[None], what="Qwen3ModelWeek3 prefill, TINY")
+    check_against_truth(dense[None], want[None], truth[None], what="Qwen3ModelWeek1 (dense bf16 weights), TINY", factor=2.5)
 
 
 def test_week2_offset_mismatch_is_rejected(ckpt):
@@ -180,9 +191,15 @@ def test_week3_model_with_moe_layers():
             for c in cache:
                 c.release()
 
-    want = run(dense)
+    # every variant computes the dense model's function: all are held against ITS float64 truth (all 7 rows of the prompt)
+    ids = tokens[0].tolist()
+    oracle = O.OracleQwen3(TINY_CFG, w).forward(ids, logits_to_keep=None)[0]
+    truth = O.TruthQwen3(TINY_CFG, w).forward(ids, logits_to_keep=None)[0]
+    check_against_truth(run(dense)[0], oracle, truth, what="dense twin of the MoE model, TINY")
     got = run(moe_variant(1, 1))       # softmax over one expert = 1.0, renormalised top-1 = 1.0
-    np.testing.assert_allclose(log_softmax(got[0]), log_softmax(want[0]), atol=6e-2, rtol=0)
+    check_against_truth(got[0], oracle, truth, what="MoE 1 expert / top-1 == dense, TINY", factor=2.0)
     many = run(moe_variant(4, 2))      # identical experts, probabilities renormalised to sum to 1 -> the dense result again
     assert np.isfinite(many).all()
-    np.testing.assert_allclose(log_softmax(many[0]), log_softmax(want[0]), atol=8e-2, rtol=0)
+    # two experts' outputs are rounded to bf16, weighted by bf16 probabilities and summed in bf16 (moe.py:60-89): more
+    # rounding points than the dense MLP the oracle models
+    check_against_truth(many[0], oracle, truth, what="MoE 4 identical experts / top-2 == dense, TINY", factor=2.5)

@@ -72,6 +72,11 @@ struct tl_engine {
     int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup (TL_ATTN_RQ1_CTX)
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
     int attn_max_splits = 64;    // most context splits per sequence (TL_ATTN_MAX_SPLITS, a power of two <= 256)
+    int attn_wide_max = 512;     // largest window of the wide one-head kernel (TL_ATTN_WIDE_MAX: 0 = off, 64 .. 512)
+    int attn_wide_nw = 0;        // waves per wide workgroup (TL_ATTN_NW: 4, 8 or 16; 0 = by window)
+    bool attn_wide_vector_ids = false;  // TL_ATTN_VECTOR_IDS=1: page ids by vector loads even where scalar loads apply
+    tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
+    int force_linear = 0;               // kernel-level entry points: 1 = fused GEMV, 2 = skinny matmul
     size_t attn_ws_bytes = 0;
     int rows_cap = 0;
     int ring_cap = 4096;
@@ -182,26 +187,34 @@ static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
             if (launch_qmv3_bf16(a3, pro, epi, e->stream) != 0)
                 return fail(TL_ERR_UNSUPPORTED, "engine: MFMA GEMV launch failed");
             if (pc) prof_after(e, pc, kind, p3.blocks);
+            if (e->linfo) {
+                tl_linear_info &li = *e->linfo;
+                li.kernel = li.kernel == 0 || li.kernel == 1 ? 1 : li.kernel;
+                li.launches += 1;
+                li.rows_per_pass = step;
+                li.p[0] = p3.MR, li.p[1] = p3.KS, li.p[2] = p3.CW, li.p[3] = p3.LM, li.p[4] = p3.blocks;
+            }
             continue;
         }
         if (launch_qmv_fused_bf16(args, pro, epi, e->stream) != 0)
             return fail(TL_ERR_UNSUPPORTED, "engine: no GEMV configuration for this shape");
         if (pc) prof_after(e, pc, kind, qmv_plan(args.M, args.N, args.K).blocks);
+        if (e->linfo) {
+            e->linfo->kernel = 3;  // the packed-dot fallback ran (at least once)
+            e->linfo->launches += 1;
+            e->linfo->rows_per_pass = step;
+        }
     }
     TL_CHECK_LAUNCH("engine gemv");
     return TL_OK;
 }
 
+// The split-K / skinny-matmul workspace is sized ONCE in tl_engine_create for every shape the engine can launch
+// (instantiated graphs hold its address, and a capture cannot synchronise or allocate): a request beyond it is an error.
 static int ensure_splitk(tl_engine *e, size_t bytes) {
     if (bytes <= e->splitk_ws_bytes) return TL_OK;
-    TL_HIP(hipStreamSynchronize(e->stream));
-    if (e->splitk_ws) (void)hipFree(e->splitk_ws);
-    e->splitk_ws = nullptr;
-    e->splitk_ws_bytes = 0;
-    const size_t want = std::max(bytes, (size_t)64 << 20);
-    TL_HIP(hipMalloc(&e->splitk_ws, want));
-    e->splitk_ws_bytes = want;
-    return TL_OK;
+    return fail(TL_ERR_INVALID, "engine: matmul workspace too small for this shape (sized at tl_engine_create: " +
+                                    std::to_string(e->splitk_ws_bytes) + " bytes, need " + std::to_string(bytes) + ")");
 }
 
 // Reference-semantics GEMM over the checkpoint layout (weights rounded to bf16 first): tl_quantized_matmul.
@@ -236,11 +249,12 @@ static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
 // then SwiGLU / residual kernels.
 static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
                          const void *norm_w, const uint16_t *residual, ProfCtx *pc, int kind) {
-    if (M < e->qmm3_min_rows || (M <= 8 && !e->use_qmm3))
+    if (e->force_linear == 1) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
+    if (e->force_linear != 2 && (M < e->qmm3_min_rows || (M <= 8 && !e->use_qmm3)))
         return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
     // 5 .. 8 rows: the fused GEMV still wins on the small projections (one launch instead of norm + matmul + reduction)
     // as long as all rows fit its LDS in one pass; the big ones (down: 9728 columns, lm_head) go to the skinny matmul
-    if (M <= 8 && e->tiled.count(w.weight_dev) != 0 && qmv3_plan(M, w.cols, w.rows).ok &&
+    if (e->force_linear != 2 && M <= 8 && e->tiled.count(w.weight_dev) != 0 && qmv3_plan(M, w.cols, w.rows).ok &&
         (size_t)w.rows * w.cols <= e->qmm3_small_elems)
         return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
     const tl_engine_config &c = e->cfg;
@@ -270,33 +284,75 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
             return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul reduction launch failed");
         if (pc) prof_after(e, pc, kind, (int)(((long)M * (w.rows / (epi == EPI_SWIGLU ? 8 : 4)) + 255) / 256));
         TL_CHECK_LAUNCH("engine skinny matmul");
+        if (e->linfo) {
+            tl_linear_info &li = *e->linfo;
+            li.kernel = 2;
+            li.launches += 2 + (pro == PRO_RMSNORM ? 1 : 0);
+            li.rows_per_pass = M;
+            li.p[0] = p3.MB, li.p[1] = p3.TW, li.p[2] = p3.LM, li.p[3] = p3.slices, li.p[4] = p3.tile_groups;
+        }
         return TL_OK;
     }
+    if (e->force_linear == 2) return fail(TL_ERR_UNSUPPORTED, "engine: the skinny matmul does not cover this shape");
     if (M <= 8) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
     if (pro == PRO_RMSNORM) {
         TL_TRY(tl_rms_norm(a, norm_w, e->xn, M, w.cols, c.rms_norm_eps, TL_BF16, e->stream));
         in = e->xn;
     }
+    if (e->linfo) e->linfo->kernel = 4;
     return engine_gemm(e, w, in, out, M, epi, residual);
 }
 
 // Context split of the decode attention: power-of-two bucket >= context, fixed windows of C tokens per workgroup.
 struct SplitPlan {
     int n_splits, tokens_per_split;
-    int rq;  // query heads per workgroup
+    int rq;      // query heads per workgroup
+    int nw = 0;  // > 0: the wide kernel (attn_decode_wide_kernel) with nw waves, u rows in flight per 16-lane group ...
+    int u = 0;
+    int npw = 0;  // ... and npw scalar page ids per window (0 = page ids by vector loads)
+    long key() const {
+        return ((long)nw << 56) | ((long)u << 50) | ((long)npw << 46) | ((long)rq << 40) | ((long)n_splits << 24) | (long)tokens_per_split;
+    }
 };
-// Measured on MI355X (profiles/README.md): a decode-attention workgroup is bound by its dependent VALU chain, not by
-// bytes, so short contexts want the LEAST work per workgroup: one query head (rq = 1) and a window of attn_min_tokens
-// tokens.  Long contexts go back to one workgroup per GQA group so that the K/V window is read from HBM once.
+// Measured on MI355X (profiles/README.md): a decode-attention workgroup is bound by its dependent latency chain, not by
+// bytes.  Few sequences and short contexts: one query head per workgroup and the whole window in flight at once (the wide
+// kernel: up to 512 tokens per workgroup, so no merge launch up to that context).  Many sequences or long contexts: one
+// workgroup per GQA group walking 64-token stages, so that the K/V window is read from HBM once.
 static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
     const int rep = e->cfg.num_heads / e->cfg.num_kv_heads;
     int rq = e->attn_rq;
     if (rq <= 0) rq = (max_ctx <= e->attn_rq1_ctx && batch <= 4) ? 1 : AD_RQ;
     if (rq != 1) rq = AD_RQ;
-    const int chunks = (rep + rq - 1) / rq;
-    const int base = std::max(1, batch * e->cfg.num_kv_heads * chunks);
     int bucket = 64;
     while (bucket < max_ctx) bucket *= 2;
+    if (rq == 1 && e->attn_wide_max >= 64) {
+        int W = 64;
+        while (W < bucket && W < e->attn_wide_max) W *= 2;
+        const int n = bucket / W;
+        if (n <= e->attn_max_splits) {
+            SplitPlan sp{n, W, 1};
+            // waves per workgroup: TL_ATTN_NW, else 4 up to 256 tokens and 8 for 512 (rows in flight per group <= 16)
+            int nw = e->attn_wide_nw > 0 ? e->attn_wide_nw : (W <= 256 ? 4 : 8);
+            while (W / (4 * nw) > 16 && nw < 16) nw *= 2;
+            while (W / (4 * nw) < 4 && nw > 4) nw /= 2;
+            while (nw == 16 && W / (4 * nw) > 8) nw = 0;  // 16 waves hold at most 8 rows per group (128 VGPRs per lane)
+            const int u = nw > 0 ? W / (4 * nw) : 0;
+            if (nw > 0 && (u == 4 || u == 8 || u == 16)) {
+                sp.nw = nw;
+                sp.u = u;
+                const int ps = e->cfg.page_size;
+                const bool pow2 = ps > 0 && (ps & (ps - 1)) == 0;
+                if (e->cfg.head_dim == 128 && pow2 && ps >= 4 * nw && !e->attn_wide_vector_ids) {
+                    if (ps % W == 0) sp.npw = 1;
+                    else if (W % ps == 0 && (W / ps == 2 || W / ps == 4)) sp.npw = W / ps;
+                }
+                if (sp.nw == 16 && sp.u == 8 && sp.npw == 0) sp.nw = 8, sp.u = 16;  // that variant spills; same window on 8 waves
+                return sp;
+            }
+        }
+    }
+    const int chunks = (rep + rq - 1) / rq;
+    const int base = std::max(1, batch * e->cfg.num_kv_heads * chunks);
     int s = 1;
     const int min_tokens = e->attn_min_tokens;
     // few sequences: split for latency (up to 2048 short-lived workgroups); many sequences: the chip is already full, longer
@@ -319,67 +375,113 @@ static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t s
     else launch_attn_decode_sp<VD, false>(a, grid, st, rq);
 }
 
-// One fused decode step over slots [0, batch).
-static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nullptr) {
-    const int n_splits = sp.n_splits;
+template <int VD, int NW, int U>
+static bool launch_attn_wide_npw(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int npw) {
+    const size_t lds = (size_t)NW * (16 * VD + 2) * sizeof(float);
+    if (npw == 0) hipLaunchKernelGGL((attn_decode_wide_kernel<VD, NW, U, 0>), grid, dim3(NW * 64), lds, st, a);
+    else if constexpr (VD == 8) {
+        if (npw == 1) hipLaunchKernelGGL((attn_decode_wide_kernel<VD, NW, U, 1>), grid, dim3(NW * 64), lds, st, a);
+        else if (npw == 2) hipLaunchKernelGGL((attn_decode_wide_kernel<VD, NW, U, 2>), grid, dim3(NW * 64), lds, st, a);
+        else if (npw == 4) hipLaunchKernelGGL((attn_decode_wide_kernel<VD, NW, U, 4>), grid, dim3(NW * 64), lds, st, a);
+        else return false;
+    } else return false;
+    return true;
+}
+template <int VD>
+static bool launch_attn_wide(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, const SplitPlan &sp) {
+#define TL_WIDE(NWv, Uv) \
+    if (sp.nw == NWv && sp.u == Uv) return launch_attn_wide_npw<VD, NWv, Uv>(a, grid, st, sp.npw);
+    TL_WIDE(4, 4) TL_WIDE(4, 8) TL_WIDE(4, 16)
+    if constexpr (VD == 8) {
+        TL_WIDE(8, 4) TL_WIDE(8, 8) TL_WIDE(8, 16) TL_WIDE(16, 4) TL_WIDE(16, 8)
+    }
+#undef TL_WIDE
+    return false;
+}
+
+// q/k-norm + RoPE + KV append + decode attention of one layer over slots [0, batch) (+ the merge launch when the context
+// is split).  qkv [batch, (Hq + 2 Hkv) D] -> out [batch, Hq D]; partials in e->attn_ws.
+static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_norm, const void *k_norm, uint16_t *key_pages,
+                            uint16_t *value_pages, uint16_t *out, int batch, const SplitPlan &sp, ProfCtx *pc) {
     const tl_engine_config &c = e->cfg;
     const int D = c.head_dim;
+    const int n_splits = sp.n_splits;
     const int rep = c.num_heads / c.num_kv_heads;
     const int chunks = (rep + sp.rq - 1) / sp.rq;
-    for (int l = 0; l < c.num_layers; ++l) {
-        const tl_layer_weights &w = e->layers[l];
-        TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0));
-        AttnDecodeArgs a{};
-        a.qkv = e->qkv;
-        a.q_norm_w = (const uint16_t *)w.q_norm_dev;
-        a.k_norm_w = (const uint16_t *)w.k_norm_dev;
-        a.key_pages = e->layer_k(l);
-        a.value_pages = e->layer_v(l);
-        a.block_table = e->block_table;
-        a.context_lens = e->context_lens;
-        a.out = e->attn;
-        a.ws = e->attn_ws;
-        a.page_size = c.page_size;
-        a.max_pages = c.max_pages_per_seq;
-        a.num_heads = c.num_heads;
-        a.num_kv_heads = c.num_kv_heads;
-        a.scale = 1.0f / sqrtf((float)D);
-        a.eps = c.rms_norm_eps;
-        a.rope_base = c.rope_theta;
-        a.n_splits = n_splits;
-        a.n_row_chunks = chunks;
-        a.tokens_per_split = sp.tokens_per_split;
-        a.split_shift = 0;
-        while ((1 << a.split_shift) < n_splits) ++a.split_shift;
-        a.rep = rep;
-        a.page_shift = -1;
-        for (int sh = 0; sh < 30; ++sh)
-            if ((1 << sh) == c.page_size) a.page_shift = sh;
-        a.rope_cur = e->rope_cur;
-        a.prof = pc ? pc->buf : nullptr;
-        const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
+    AttnDecodeArgs a{};
+    a.qkv = qkv;
+    a.q_norm_w = (const uint16_t *)q_norm;
+    a.k_norm_w = (const uint16_t *)k_norm;
+    a.key_pages = key_pages;
+    a.value_pages = value_pages;
+    a.block_table = e->block_table;
+    a.context_lens = e->context_lens;
+    a.out = out;
+    a.ws = e->attn_ws;
+    a.page_size = c.page_size;
+    a.max_pages = c.max_pages_per_seq;
+    a.num_heads = c.num_heads;
+    a.num_kv_heads = c.num_kv_heads;
+    a.scale = 1.0f / sqrtf((float)D);
+    a.eps = c.rms_norm_eps;
+    a.rope_base = c.rope_theta;
+    a.n_splits = n_splits;
+    a.n_row_chunks = chunks;
+    a.tokens_per_split = sp.tokens_per_split;
+    a.split_shift = 0;
+    while ((1 << a.split_shift) < n_splits) ++a.split_shift;
+    a.rep = rep;
+    a.page_shift = -1;
+    for (int sh = 0; sh < 30; ++sh)
+        if ((1 << sh) == c.page_size) a.page_shift = sh;
+    a.rope_cur = e->rope_cur;
+    a.prof = pc ? pc->buf : nullptr;
+    TL_REQUIRE((size_t)batch * c.num_heads * n_splits * (D + 2) * sizeof(float) <= e->attn_ws_bytes || n_splits == 1,
+               "engine: attention workspace too small for this split plan");
+    const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
+    if (sp.nw > 0) {
+        bool ok = false;
+        switch (D) {
+            case 128: ok = launch_attn_wide<8>(a, grid, e->stream, sp); break;
+            case 64: ok = launch_attn_wide<4>(a, grid, e->stream, sp); break;
+            case 32: ok = launch_attn_wide<2>(a, grid, e->stream, sp); break;
+            default: break;
+        }
+        if (!ok) return fail(TL_ERR_UNSUPPORTED, "engine: no wide decode-attention kernel for this plan");
+    } else {
         switch (D) {
             case 128: launch_attn_decode<8>(a, grid, e->stream, sp.rq); break;
             case 64: launch_attn_decode<4>(a, grid, e->stream, sp.rq); break;
             case 32: launch_attn_decode<2>(a, grid, e->stream, sp.rq); break;
             default: return fail(TL_ERR_UNSUPPORTED, "engine: head_dim must be 32, 64 or 128");
         }
-        if (pc) prof_after(e, pc, 5, (int)(grid.x * grid.y * grid.z));
-        if (n_splits > 1) {
-            const dim3 mg(batch * c.num_heads), mb(128);
-            prof_t *pb = pc ? pc->buf : nullptr;
-            switch (n_splits) {
-                case 2: hipLaunchKernelGGL(attn_merge_kernel<2>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
-                case 4: hipLaunchKernelGGL(attn_merge_kernel<4>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
-                case 8: hipLaunchKernelGGL(attn_merge_kernel<8>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
-                case 16: hipLaunchKernelGGL(attn_merge_kernel<16>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
-                case 32: hipLaunchKernelGGL(attn_merge_kernel<32>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
-                case 64: hipLaunchKernelGGL(attn_merge_kernel<64>, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, pb); break;
-                default: hipLaunchKernelGGL(attn_merge_many_kernel, mg, mb, 0, e->stream, e->attn_ws, e->attn, D, n_splits, pb); break;
-            }
-            if (pc) prof_after(e, pc, 6, batch * c.num_heads);
+    }
+    if (pc) prof_after(e, pc, 5, (int)(grid.x * grid.y * grid.z));
+    if (n_splits > 1) {
+        const dim3 mg(batch * c.num_heads), mb(128);
+        prof_t *pb = pc ? pc->buf : nullptr;
+        switch (n_splits) {
+            case 2: hipLaunchKernelGGL(attn_merge_kernel<2>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
+            case 4: hipLaunchKernelGGL(attn_merge_kernel<4>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
+            case 8: hipLaunchKernelGGL(attn_merge_kernel<8>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
+            case 16: hipLaunchKernelGGL(attn_merge_kernel<16>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
+            case 32: hipLaunchKernelGGL(attn_merge_kernel<32>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
+            case 64: hipLaunchKernelGGL(attn_merge_kernel<64>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
+            default: hipLaunchKernelGGL(attn_merge_many_kernel, mg, mb, 0, e->stream, e->attn_ws, out, D, n_splits, pb); break;
         }
-        TL_CHECK_LAUNCH("engine attention");
+        if (pc) prof_after(e, pc, 6, batch * c.num_heads);
+    }
+    TL_CHECK_LAUNCH("engine attention");
+    return TL_OK;
+}
+
+// One fused decode step over slots [0, batch).
+static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nullptr) {
+    const tl_engine_config &c = e->cfg;
+    for (int l = 0; l < c.num_layers; ++l) {
+        const tl_layer_weights &w = e->layers[l];
+        TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0));
+        TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc));
         TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1));
         TL_TRY(engine_linear(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2));
         TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3));
@@ -466,6 +568,28 @@ static int reserve_locked(tl_engine *e, int slot, int total_tokens,
         const int id = take_page(e);
         pages.push_back(id);
         pokes.emplace_back(e->block_table + (size_t)slot * c.max_pages_per_seq + j, id);
+    }
+    return TL_OK;
+}
+
+// Pages for ONE more token in every live slot of [0, batch): all or nothing.  The totals are checked before anything is
+// mutated, so a failing step leaves the host mirrors and the device block table exactly as they were (a half-applied
+// reservation would leave a slot that owns a page on the host and -1 on the device: silently dropped K/V).
+static int reserve_step_locked(tl_engine *e, int batch, std::vector<std::pair<int32_t *, int32_t>> &pokes, int *max_ctx) {
+    const tl_engine_config &c = e->cfg;
+    size_t extra = 0;
+    for (int b = 0; b < batch; ++b) {
+        if (!e->slot_live[b]) continue;
+        const int need = (e->slot_ctx[b] + 1 + c.page_size - 1) / c.page_size;
+        if (need > c.max_pages_per_seq)
+            return fail(TL_ERR_INVALID, "engine: sequence exceeds max_pages_per_seq * page_size tokens");
+        if (need > (int)e->slot_pages[b].size()) extra += (size_t)need - e->slot_pages[b].size();
+    }
+    if (extra > e->free_pages.size()) return fail(TL_ERR_INVALID, "engine: KV page pool exhausted");
+    for (int b = 0; b < batch; ++b) {
+        if (!e->slot_live[b]) continue;
+        TL_TRY(reserve_locked(e, b, e->slot_ctx[b] + 1, pokes));  // cannot fail after the checks above
+        *max_ctx = std::max(*max_ctx, e->slot_ctx[b] + 1);
     }
     return TL_OK;
 }
@@ -570,6 +694,11 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
         if (e->vpool) (void)hipFree(e->vpool);
         if (e->rope_table) (void)hipFree(e->rope_table);
         if (e->rope_cur) (void)hipFree(e->rope_cur);
+        if (e->splitk_ws) (void)hipFree(e->splitk_ws);
+        for (auto &kv : e->tiled) {
+            (void)hipFree(kv.second.wt);
+            (void)hipFree(kv.second.sbt);
+        }
         if (e->owns_stream) (void)hipStreamDestroy(e->stream);
         delete e;
         return fail(TL_ERR_HIP, msg);
@@ -615,6 +744,9 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e->attn_rq1_ctx = atoi(q);
     if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q));
+    if (const char *q = getenv("TL_ATTN_WIDE_MAX")) e->attn_wide_max = std::min(512, std::max(0, atoi(q)));
+    if (const char *q = getenv("TL_ATTN_NW")) e->attn_wide_nw = (atoi(q) == 4 || atoi(q) == 8 || atoi(q) == 16) ? atoi(q) : 0;
+    e->attn_wide_vector_ids = getenv("TL_ATTN_VECTOR_IDS") != nullptr;
 
     // state words: zero everything up to the activations, then the block table to -1
     if (hipMemsetAsync(e->arena, 0, o_x, e->stream) != hipSuccess) return cleanup_fail("engine_create: memset failed");
@@ -661,25 +793,25 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
         bool ok = true;
         for (const auto &l : e->layers) ok = ok && add_tiled(l.wqkv) && add_tiled(l.wo) && add_tiled(l.wgu) && add_tiled(l.wdown);
         ok = ok && add_tiled(e->head());
-        if (!ok) {
-            for (auto &kv : e->tiled) {
-                (void)hipFree(kv.second.wt);
-                (void)hipFree(kv.second.sbt);
-            }
-            return cleanup_fail("engine_create: hipMalloc(tiled weights) failed");
-        }
+        if (!ok) return cleanup_fail("engine_create: hipMalloc(tiled weights) failed");
     }
 
-    if (c.max_batch > 8) {
-        // batched decode goes through the W4 GEMM inside a captured graph: its split-K workspace must exist up front
+    {
+        // Workspace of every matmul the engine can launch, allocated once: fp32 slice partials of the skinny matmul
+        // (qmm3_min_rows .. 64 decode rows, any of the five matrices) and split-K partials of the prefill GEMM (9 ..
+        // rows_cap rows).  Graphs captured later hold this address, so it is never reallocated.
         size_t need = 0;
-        for (int M = 9; M <= c.max_batch; ++M) {
-            const tl_w4 *mats[5] = {&e->layers[0].wqkv, &e->layers[0].wo, &e->layers[0].wgu, &e->layers[0].wdown, &e->head()};
-            for (const tl_w4 *w : mats)
+        const tl_w4 *mats[5] = {&e->layers[0].wqkv, &e->layers[0].wo, &e->layers[0].wgu, &e->layers[0].wdown, &e->head()};
+        for (const tl_w4 *w : mats) {
+            for (int M = 1; M <= std::min(64, e->rows_cap); ++M) {
+                const Qmm3Plan p3 = qmm3_plan(M, w->cols, w->rows);
+                if (p3.ok) need = std::max(need, p3.partial_bytes);
+            }
+            for (int M = 9; M <= e->rows_cap; ++M)
                 need = std::max(need, tl_quantized_matmul_workspace_bytes(M, w->cols, w->rows, TL_BF16, 1, 1));
         }
         if (need > 0) {
-            if (hipMalloc(&e->splitk_ws, need) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(split-K workspace) failed");
+            if (hipMalloc(&e->splitk_ws, need) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(matmul workspace) failed");
             e->splitk_ws_bytes = need;
         }
     }
@@ -771,6 +903,14 @@ extern "C" int tl_engine_rewind(tl_engine *e, int slot, int n) {
     const int keep = (ctx + e->cfg.page_size - 1) / e->cfg.page_size;
     std::vector<std::pair<int32_t *, int32_t>> pk;
     auto &pages = e->slot_pages[slot];
+    {
+        // the copy of a shared tail page needs one free page; pages this rewind itself returns count.  Checked before
+        // anything is mutated, so a failing rewind leaves host mirrors and device tables untouched.
+        const bool cow = keep > 0 && ctx % e->cfg.page_size != 0 && keep <= (int)pages.size() && e->page_refs[pages[keep - 1]] > 1;
+        size_t will_free = 0;
+        for (int j = keep; j < (int)pages.size(); ++j) will_free += e->page_refs[pages[j]] == 1 ? 1 : 0;
+        TL_REQUIRE(!cow || e->free_pages.size() + will_free >= 1, "engine_rewind: KV page pool exhausted (copy of a shared tail page)");
+    }
     while ((int)pages.size() > keep) {
         drop_page(e, pages.back());
         pk.emplace_back(e->block_table + (size_t)slot * e->cfg.max_pages_per_seq + (pages.size() - 1), -1);
@@ -778,8 +918,7 @@ extern "C" int tl_engine_rewind(tl_engine *e, int slot, int n) {
     }
     // the next append lands in the tail page: if a fork shares it, give this sequence its own copy first
     if (keep > 0 && ctx % e->cfg.page_size != 0 && e->page_refs[pages[keep - 1]] > 1) {
-        TL_REQUIRE(!e->free_pages.empty(), "engine_rewind: KV page pool exhausted (copy of a shared tail page)");
-        const int old_id = pages[keep - 1];
+        const int old_id = pages[keep - 1];  // a free page exists: checked above
         const int fresh = take_page(e);
         TL_TRY(copy_page(e, old_id, fresh));
         drop_page(e, old_id);
@@ -1021,18 +1160,14 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
     std::vector<std::pair<int32_t *, int32_t>> pk;
     for (int s = 0; s < steps; ++s) {
         int max_ctx = 1;
-        for (int b = 0; b < batch; ++b) {
-            if (!e->slot_live[b]) continue;
-            TL_TRY(reserve_locked(e, b, e->slot_ctx[b] + 1, pk));
-            max_ctx = std::max(max_ctx, e->slot_ctx[b] + 1);
-        }
+        TL_TRY(reserve_step_locked(e, batch, pk, &max_ctx));
         if (!pk.empty()) {
             e->stats.pages_free = (int)e->free_pages.size();
             TL_TRY(poke(e, pk));
         }
         const SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
         if (use_graph && e->warmed) {
-            const auto key = std::make_pair(batch, ((long)sp.rq << 48) | ((long)sp.n_splits << 32) | (long)sp.tokens_per_split);
+            const auto key = std::make_pair(batch, sp.key());
             auto it = e->graphs.find(key);
             if (it == e->graphs.end()) {
                 hipGraph_t graph = nullptr;
@@ -1140,16 +1275,12 @@ extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *
                        c.vocab_size, e->context_lens, e->rope_table, e->rope_cur, e->rope_positions, c.head_dim / 2);
     std::vector<std::pair<int32_t *, int32_t>> pk;
     int max_ctx = 1;
-    for (int b = 0; b < batch; ++b) {
-        if (!e->slot_live[b]) continue;
-        const int rc = reserve_locked(e, b, e->slot_ctx[b] + 1, pk);
-        if (rc != TL_OK) {
-            cleanup();
-            return rc;
-        }
-        max_ctx = std::max(max_ctx, e->slot_ctx[b] + 1);
+    int rc = reserve_step_locked(e, batch, pk, &max_ctx);
+    if (rc != TL_OK) {
+        cleanup();
+        return rc;
     }
-    int rc = pk.empty() ? TL_OK : poke(e, pk);
+    rc = pk.empty() ? TL_OK : poke(e, pk);
     const SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
     const int n_splits = sp.n_splits;
     if (rc == TL_OK) rc = enqueue_step(e, batch, sp, &pc);
@@ -1195,4 +1326,170 @@ extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *
     }
     out->gemv_bytes[4] = w4_bytes(e->head());
     return TL_OK;
+}
+
+
+// ================================================================================================
+// Kernel-level entry points of the decode path (include/tinyllm_engine.h, last section): the SAME launch code the engine
+// runs per projection / per layer, on caller-owned buffers.  Used by the operator microbenches and by the parity tests at
+// the real Qwen3-4B shapes.
+struct tl_tiled_w4 {
+    tl_w4 w{};
+    tl_engine::Tiled t{};
+};
+
+extern "C" int tl_tiled_w4_create(const tl_w4 *w, void *stream, tl_tiled_w4 **out) {
+    TL_REQUIRE(w && out, "tiled_w4_create: null argument");
+    TL_TRY(check_w4(*w, w->rows, w->cols, "tiled_w4_create"));
+    TL_REQUIRE(w->rows > 0 && w->rows % 16 == 0 && w->cols > 0 && w->cols % 128 == 0,
+               "tiled_w4_create: rows must be a multiple of 16 and cols a multiple of 128");
+    auto *t = new tl_tiled_w4();
+    t->w = *w;
+    const size_t wbytes = (size_t)w->rows * w->cols / 2, sbytes = (size_t)w->rows * (w->cols / 128) * 4;
+    if (hipMalloc((void **)&t->t.wt, wbytes + 16384) != hipSuccess) {
+        delete t;
+        return fail(TL_ERR_HIP, "tiled_w4_create: hipMalloc failed");
+    }
+    if (hipMalloc((void **)&t->t.sbt, sbytes + 1024) != hipSuccess) {
+        (void)hipFree(t->t.wt);
+        delete t;
+        return fail(TL_ERR_HIP, "tiled_w4_create: hipMalloc failed");
+    }
+    if (repack_w4_tiled(w->weight_dev, (const uint16_t *)w->scales_dev, (const uint16_t *)w->biases_dev, t->t.wt, t->t.sbt, w->rows,
+                        w->cols, (hipStream_t)stream) != 0) {
+        (void)hipFree(t->t.wt);
+        (void)hipFree(t->t.sbt);
+        delete t;
+        return fail(TL_ERR_HIP, "tiled_w4_create: repack launch failed");
+    }
+    *out = t;
+    return TL_OK;
+}
+
+extern "C" void tl_tiled_w4_destroy(tl_tiled_w4 *t) {
+    if (!t) return;
+    (void)hipFree(t->t.wt);
+    (void)hipFree(t->t.sbt);
+    delete t;
+}
+
+extern "C" size_t tl_decode_linear_workspace_bytes(int M, int rows, int cols) {
+    if (M <= 0 || rows <= 0 || cols <= 0) return 0;
+    size_t need = align_up((size_t)M * cols * 2, 256);  // RMSNorm output ahead of the skinny matmul
+    const Qmm3Plan p3 = qmm3_plan(std::min(M, 64), cols, rows);
+    if (p3.ok) need += p3.partial_bytes;
+    return need;
+}
+
+extern "C" int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
+                                const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,
+                                size_t workspace_bytes, void *stream, tl_linear_info *info) {
+    TL_REQUIRE(w && a_dev && out_dev, "decode_linear: null argument");
+    TL_REQUIRE(M >= 1 && M <= 64, "decode_linear: between 1 and 64 activation rows");
+    TL_REQUIRE(prologue == PRO_NONE || prologue == PRO_RMSNORM, "decode_linear: prologue is 0 (none) or 1 (RMSNorm)");
+    TL_REQUIRE(epilogue == EPI_STORE || epilogue == EPI_RESIDUAL || epilogue == EPI_SWIGLU,
+               "decode_linear: epilogue is 0 (store), 1 (residual add) or 2 (SwiGLU over interleaved rows)");
+    TL_REQUIRE(prologue != PRO_RMSNORM || norm_w_dev, "decode_linear: the RMSNorm prologue needs its weight");
+    TL_REQUIRE(epilogue != EPI_RESIDUAL || residual_dev, "decode_linear: the residual epilogue needs the residual rows");
+    TL_REQUIRE(kernel >= 0 && kernel <= 2, "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV) or 2 (skinny matmul)");
+    TL_REQUIRE(epilogue != EPI_SWIGLU || w->w.rows % 2 == 0, "decode_linear: SwiGLU needs an even number of weight rows");
+    // the engine's own fused variants: RMSNorm+store (qkv, lm_head), residual (wo, w_down), RMSNorm+SwiGLU (gate|up), plain
+    TL_REQUIRE((prologue == PRO_NONE && epilogue != EPI_SWIGLU) || (prologue == PRO_RMSNORM && epilogue != EPI_RESIDUAL),
+               "decode_linear: no fused variant for this prologue / epilogue pair");
+    const size_t need = tl_decode_linear_workspace_bytes(M, w->w.rows, w->w.cols);
+    TL_REQUIRE(workspace_dev && workspace_bytes >= need, "decode_linear: workspace is missing or too small");
+    tl_engine e;  // only the fields the projection code reads
+    e.cfg.rms_norm_eps = eps;
+    e.stream = (hipStream_t)stream;
+    e.tiled[w->w.weight_dev] = w->t;
+    e.xn = (uint16_t *)workspace_dev;
+    const size_t xn_bytes = align_up((size_t)M * w->w.cols * 2, 256);
+    e.splitk_ws = (char *)workspace_dev + xn_bytes;
+    e.splitk_ws_bytes = workspace_bytes - xn_bytes;
+    e.force_linear = kernel;
+    tl_linear_info li{};
+    e.linfo = &li;
+    if (const char *q = getenv("TL_QMM3_MIN_M")) e.qmm3_min_rows = std::max(1, atoi(q));
+    if (const char *q = getenv("TL_QMM3_SMALL_ELEMS")) e.qmm3_small_elems = (size_t)atoll(q);
+    const int rc = engine_linear(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, prologue, epilogue, norm_w_dev,
+                                 (const uint16_t *)residual_dev, nullptr, 0);
+    e.splitk_ws = nullptr;  // borrowed
+    e.tiled.clear();
+    if (info) *info = li;
+    return rc;
+}
+
+// (cos, sin) of each row's position = its context length, the same expression as rope_table_kernel
+__global__ __launch_bounds__(64) void rope_rows_kernel(const int32_t *__restrict__ context_lens, float2 *__restrict__ rope_cur,
+                                                       int half, float base) {
+    const int b = blockIdx.x;
+    const int pos = context_lens[b];
+    for (int item = threadIdx.x; item < half; item += 64) {
+        const float fp = -(float)item / (float)half;
+        const float angle = (float)pos * exp2f(fp * log2f(base));
+        float sn, cs;
+        sincosf(angle, &sn, &cs);
+        rope_cur[(long)b * half + item] = make_float2(cs, sn);
+    }
+}
+
+extern "C" size_t tl_decode_attention_fused_workspace_bytes(int batch, int num_heads, int head_dim) {
+    if (batch <= 0 || num_heads <= 0 || head_dim <= 0) return 0;
+    return align_up((size_t)batch * (head_dim / 2) * sizeof(float2), 256) +
+           (size_t)batch * num_heads * 256 * (head_dim + 2) * sizeof(float);
+}
+
+extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,
+                                         void *key_pages_dev, void *value_pages_dev, const int32_t *block_table_dev,
+                                         const int32_t *context_lens_dev, void *out_dev, int batch, int num_heads,
+                                         int num_kv_heads, int head_dim, int page_size, int max_pages, float rope_theta,
+                                         float eps, int max_context, void *workspace_dev, size_t workspace_bytes,
+                                         void *stream, tl_attention_info *info) {
+    TL_REQUIRE(qkv_dev && q_norm_dev && k_norm_dev && key_pages_dev && value_pages_dev && block_table_dev && context_lens_dev &&
+                   out_dev, "decode_attention_fused: null pointer");
+    TL_REQUIRE(batch >= 1 && batch <= 256, "decode_attention_fused: between 1 and 256 sequences");
+    TL_REQUIRE(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
+               "decode_attention_fused: num_heads must be divisible by num_kv_heads");
+    TL_REQUIRE(head_dim == 32 || head_dim == 64 || head_dim == 128, "decode_attention_fused: head_dim must be 32, 64 or 128");
+    TL_REQUIRE(page_size > 0 && max_pages > 0 && max_context >= 0, "decode_attention_fused: bad page geometry");
+    const size_t need = tl_decode_attention_fused_workspace_bytes(batch, num_heads, head_dim);
+    TL_REQUIRE(workspace_dev && workspace_bytes >= need, "decode_attention_fused: workspace is missing or too small");
+    tl_engine e;
+    e.cfg.num_heads = num_heads;
+    e.cfg.num_kv_heads = num_kv_heads;
+    e.cfg.head_dim = head_dim;
+    e.cfg.page_size = page_size;
+    e.cfg.max_pages_per_seq = max_pages;
+    e.cfg.rope_theta = rope_theta;
+    e.cfg.rms_norm_eps = eps;
+    e.stream = (hipStream_t)stream;
+    e.block_table = const_cast<int32_t *>(block_table_dev);
+    e.context_lens = const_cast<int32_t *>(context_lens_dev);
+    e.rope_cur = (float2 *)workspace_dev;
+    const size_t rc_bytes = align_up((size_t)batch * (head_dim / 2) * sizeof(float2), 256);
+    e.attn_ws = (float *)((char *)workspace_dev + rc_bytes);
+    e.attn_ws_bytes = workspace_bytes - rc_bytes;
+    if (const char *q = getenv("TL_ATTN_RQ")) e.attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
+    if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e.attn_rq1_ctx = atoi(q);
+    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e.attn_max_splits = std::min(256, std::max(1, atoi(q)));
+    if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e.attn_min_tokens = std::max(64, atoi(q));
+    if (const char *q = getenv("TL_ATTN_WIDE_MAX")) e.attn_wide_max = std::min(512, std::max(0, atoi(q)));
+    if (const char *q = getenv("TL_ATTN_NW")) e.attn_wide_nw = (atoi(q) == 4 || atoi(q) == 8 || atoi(q) == 16) ? atoi(q) : 0;
+    e.attn_wide_vector_ids = getenv("TL_ATTN_VECTOR_IDS") != nullptr;
+    hipLaunchKernelGGL(rope_rows_kernel, dim3(batch), dim3(64), 0, e.stream, context_lens_dev, e.rope_cur, head_dim / 2, rope_theta);
+    TL_CHECK_LAUNCH("decode_attention_fused rope");
+    const SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
+    const int rc = engine_attention(&e, (const uint16_t *)qkv_dev, q_norm_dev, k_norm_dev, (uint16_t *)key_pages_dev,
+                                    (uint16_t *)value_pages_dev, (uint16_t *)out_dev, batch, sp, nullptr);
+    e.rope_cur = nullptr;  // borrowed
+    if (info) {
+        info->n_splits = sp.n_splits;
+        info->tokens_per_split = sp.tokens_per_split;
+        info->heads_per_workgroup = sp.rq;
+        info->wide_waves = sp.nw;
+        info->wide_rows_in_flight = sp.u;
+        info->scalar_page_ids = sp.npw;
+        info->launches = 1 + (sp.n_splits > 1 ? 1 : 0);
+    }
+    return rc;
 }

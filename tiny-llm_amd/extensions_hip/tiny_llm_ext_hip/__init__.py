@@ -98,8 +98,26 @@ class TlStepProfile(ctypes.Structure):
                 ("span_us", ctypes.c_double), ("clock_khz", _c_int), ("n_splits", _c_int)]
 
 
+class TlLinearInfo(ctypes.Structure):
+    _fields_ = [("kernel", _c_int), ("launches", _c_int), ("rows_per_pass", _c_int), ("p", _c_int * 5)]
+
+
+class TlAttentionInfo(ctypes.Structure):
+    _fields_ = [("n_splits", _c_int), ("tokens_per_split", _c_int), ("heads_per_workgroup", _c_int),
+                ("wide_waves", _c_int), ("wide_rows_in_flight", _c_int), ("scalar_page_ids", _c_int),
+                ("launches", _c_int)]
+
+
 _P = ctypes.POINTER
 _SIGNATURES.update({
+    "tl_tiled_w4_create": (_c_int, [_P(TlW4), _c_void_p, _P(_c_void_p)]),
+    "tl_tiled_w4_destroy": (None, [_c_void_p]),
+    "tl_decode_linear_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "tl_decode_linear": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_float,
+                                  _c_int, _c_void_p, _c_size_t, _c_void_p, _P(TlLinearInfo)]),
+    "tl_decode_attention_fused_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "tl_decode_attention_fused": (_c_int, [_c_void_p] * 8 + [_c_int] * 6 + [_c_float, _c_float, _c_int, _c_void_p, _c_size_t,
+                                                             _c_void_p, _P(TlAttentionInfo)]),
     "tl_engine_profile_step": (_c_int, [_c_void_p, _c_int, _P(TlStepProfile)]),
     "tl_engine_create": (_c_int, [_P(TlEngineConfig), _P(TlLayerWeights), _P(TlW4), _c_void_p, _P(TlW4), _c_void_p,
                                   _P(_c_void_p)]),
@@ -525,3 +543,100 @@ __all__ = [
     "paged_cache_update",
     "paged_attention",
 ]
+
+
+# ---- kernel-level entry points of the decode path (include/tinyllm_engine.h, last section) -------------------------
+PRO_NONE, PRO_RMSNORM = 0, 1
+EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2
+LINEAR_KERNELS = {1: "qmv3 (fused MFMA GEMV)", 2: "qmm3 (skinny MFMA matmul + slice reduction)",
+                  3: "qmv (packed-dot GEMV fallback)", 4: "prefill GEMM path"}
+
+
+class TiledW4:
+    """One W4 matrix re-packed into the decode engine's tiled layout (tl_tiled_w4).  Keeps the checkpoint tensors alive."""
+
+    def __init__(self, weight: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor):
+        _require_gpu("TiledW4", weight, scales, biases)
+        if weight.dtype not in (torch.int32, torch.uint32) or weight.dim() != 2:
+            raise RuntimeError("TiledW4: weight must be a 2-D uint32 tensor [rows, cols/8]")
+        if scales.dtype != torch.bfloat16 or biases.dtype != torch.bfloat16:
+            raise RuntimeError("TiledW4: the decode path is bfloat16")
+        self.weight, self.scales, self.biases = weight.contiguous(), scales.contiguous(), biases.contiguous()
+        self.rows, self.cols = int(weight.shape[0]), int(weight.shape[1]) * 8
+        if tuple(self.scales.shape) != (self.rows, self.cols // 128) or self.scales.shape != self.biases.shape:
+            raise RuntimeError("TiledW4: scales / biases must be [rows, cols/128]")
+        w4 = TlW4(_ptr(self.weight), _ptr(self.scales), _ptr(self.biases), self.rows, self.cols)
+        handle = _c_void_p()
+        _check(_lib.tl_tiled_w4_create(ctypes.byref(w4), _stream(), ctypes.byref(handle)))
+        self._h = handle
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize()
+            _lib.tl_tiled_w4_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_linear(w: TiledW4, a: torch.Tensor, *, prologue: int = PRO_NONE, epilogue: int = EPI_STORE,
+                  norm_weight: torch.Tensor | None = None, residual: torch.Tensor | None = None, eps: float = 1e-6,
+                  kernel: int = 0) -> tuple[torch.Tensor, dict]:
+    """One projection of a decode step over ``a`` [M <= 64, cols] bf16 (tl_decode_linear).  Returns (out, info) where info
+    names the kernel that ran and its launch parameters."""
+    _require_gpu("decode_linear", a)
+    if a.dtype != torch.bfloat16 or a.dim() != 2 or a.shape[1] != w.cols or not a.is_contiguous():
+        raise RuntimeError("decode_linear: a must be a contiguous bfloat16 [M, cols] tensor")
+    M = int(a.shape[0])
+    out_cols = w.rows // 2 if epilogue == EPI_SWIGLU else w.rows
+    out = torch.empty((M, out_cols), dtype=torch.bfloat16, device=a.device)
+    if residual is not None and (residual.dtype != torch.bfloat16 or tuple(residual.shape) != (M, w.rows)
+                                 or not residual.is_contiguous()):
+        raise RuntimeError("decode_linear: residual must be a contiguous bfloat16 [M, rows] tensor")
+    if norm_weight is not None and (norm_weight.dtype != torch.bfloat16 or tuple(norm_weight.shape) != (w.cols,)):
+        raise RuntimeError("decode_linear: norm_weight must be bfloat16 [cols]")
+    ws_bytes = _lib.tl_decode_linear_workspace_bytes(M, w.rows, w.cols)
+    ws = _workspace(ws_bytes, a.device)
+    info = TlLinearInfo()
+    _check(_lib.tl_decode_linear(w._h, _ptr(a), _ptr(out), M, int(prologue), int(epilogue),
+                                 _ptr(norm_weight) if norm_weight is not None else None,
+                                 _ptr(residual) if residual is not None else None, float(eps), int(kernel),
+                                 _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, _stream(),
+                                 ctypes.byref(info)))
+    return out, {"kernel": info.kernel, "kernel_name": LINEAR_KERNELS.get(info.kernel, "?"), "launches": info.launches,
+                 "rows_per_pass": info.rows_per_pass, "p": list(info.p)}
+
+
+def decode_attention_fused(qkv: torch.Tensor, q_norm: torch.Tensor, k_norm: torch.Tensor, key_pages: torch.Tensor,
+                           value_pages: torch.Tensor, block_table: torch.Tensor, context_lens: torch.Tensor, *,
+                           num_heads: int, num_kv_heads: int, rope_theta: float, eps: float,
+                           max_context: int) -> tuple[torch.Tensor, dict]:
+    """The attention launch of one decode layer (tl_decode_attention_fused): q/k-norm + RoPE + in-place KV append +
+    paged GQA attention over ``context_lens + 1`` tokens.  qkv [B, (Hq + 2 Hkv) D]; pages [P, Hkv, page, D] (modified)."""
+    _require_gpu("decode_attention_fused", qkv, q_norm, k_norm, key_pages, value_pages, block_table, context_lens)
+    B = int(qkv.shape[0])
+    P, Hkv, page, D = (int(x) for x in key_pages.shape)
+    if Hkv != num_kv_heads or tuple(value_pages.shape) != tuple(key_pages.shape):
+        raise RuntimeError("decode_attention_fused: page pools must be [P, num_kv_heads, page_size, D] and alike")
+    if qkv.dim() != 2 or qkv.shape[1] != (num_heads + 2 * num_kv_heads) * D:
+        raise RuntimeError("decode_attention_fused: qkv must be [batch, (Hq + 2 Hkv) * D]")
+    for name, t in (("qkv", qkv), ("key_pages", key_pages), ("value_pages", value_pages), ("q_norm", q_norm),
+                    ("k_norm", k_norm)):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous():
+            raise RuntimeError(f"decode_attention_fused: {name} must be contiguous bfloat16")
+    if block_table.dtype != torch.int32 or context_lens.dtype != torch.int32 or block_table.dim() != 2 \
+            or block_table.shape[0] != B or tuple(context_lens.shape) != (B,):
+        raise RuntimeError("decode_attention_fused: block_table [B, max_pages] and context_lens [B] must be int32")
+    out = torch.empty((B, num_heads * D), dtype=torch.bfloat16, device=qkv.device)
+    ws_bytes = _lib.tl_decode_attention_fused_workspace_bytes(B, num_heads, D)
+    ws = _workspace(ws_bytes, qkv.device)
+    info = TlAttentionInfo()
+    _check(_lib.tl_decode_attention_fused(_ptr(qkv), _ptr(q_norm), _ptr(k_norm), _ptr(key_pages), _ptr(value_pages),
+                                          _ptr(block_table.contiguous()), _ptr(context_lens), _ptr(out), B, num_heads,
+                                          num_kv_heads, D, page, int(block_table.shape[1]), float(rope_theta), float(eps),
+                                          int(max_context), _ptr(ws), ws.numel(), _stream(), ctypes.byref(info)))
+    return out, {name: getattr(info, name) for name, _ in info._fields_}

@@ -150,8 +150,14 @@ class _Detokenizer:
     """Incremental detokenizer with the mlx_lm surface the loops use: text so far, and the segment added since the last
     read (re-decodes the running id list; fine for a CLI, no hot path goes through it)."""
 
-    def __init__(self, decode):
-        self._decode = decode
+    def __init__(self, tokenizer_or_decode):
+        # mlx_lm builds its detokenizers from the tokenizer itself (reference batch.py:23:
+        # ``tokenizer.detokenizer.__class__(tokenizer._tokenizer)``); a bare decode callable is accepted too
+        if callable(tokenizer_or_decode) and not hasattr(tokenizer_or_decode, "decode"):
+            self._decode = tokenizer_or_decode
+        else:
+            tok = tokenizer_or_decode
+            self._decode = lambda ids: tok.decode(list(ids), skip_special_tokens=False)
         self.reset()
 
     def reset(self):
@@ -183,9 +189,10 @@ class TokenizerWrapper:
 
     def __init__(self, hf_tokenizer, eos_token_ids=None):
         self._tok = hf_tokenizer
+        self._tokenizer = hf_tokenizer  # the attribute name mlx_lm's wrapper exposes (read by reference batch.py:23)
         ids = eos_token_ids if eos_token_ids is not None else [hf_tokenizer.eos_token_id]
         self.eos_token_ids = {int(t) for t in (ids if isinstance(ids, (list, tuple, set)) else [ids]) if t is not None}
-        self._detok = _Detokenizer(lambda ids: self._tok.decode(ids, skip_special_tokens=False))
+        self._detok = _Detokenizer(hf_tokenizer)
 
     @property
     def eos_token_id(self):
