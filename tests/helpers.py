@@ -81,6 +81,19 @@ def assert_bf16_close(got, want, ulps: float = 2.0, abs_floor: float = 0.0, what
                              f"worst at {i}: got {got[i]!r}, want {want[i]!r}")
 
 
+def assert_within(got, want, allowed, what: str = ""):
+    """|got - want| <= allowed elementwise (allowed: an array derived by the caller from the magnitudes that were rounded)."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    allowed = np.broadcast_to(np.asarray(allowed, dtype=np.float64), want.shape)
+    excess = np.abs(got - want) - allowed
+    bad = ~(excess <= 0)  # NaN counts as bad
+    if bad.any():
+        i = np.unravel_index(np.nanargmax(np.where(np.isnan(excess), np.inf, excess)), got.shape)
+        raise AssertionError(f"{what}: {int(bad.sum())} of {got.size} elements outside the allowance; worst at {i}: "
+                             f"got {got[i]!r}, want {want[i]!r}, allowed {allowed[i]:.3g}")
+
+
 def log_parity(record: dict) -> None:
     """Append one measured-parity record to gpurun_out/parity_numbers.jsonl (scratch; summaries are copied to profiles/)."""
     import json

@@ -64,6 +64,8 @@ struct tl_engine {
     uint16_t *x = nullptr, *h = nullptr, *xn = nullptr, *qkv = nullptr, *q_t = nullptr, *attn_t = nullptr,
              *attn = nullptr, *gu = nullptr, *act = nullptr, *tmp = nullptr, *logits = nullptr;
     float *attn_ws = nullptr;
+    float *ss_x = nullptr, *ss_h = nullptr;  // [max_batch][QM3_SS] partial sums of squares of the rows of x / h (qmm3.h)
+    bool fuse_norm = true;                   // TL_QMM3_FUSED_NORM=0: RMSNorm ahead of a skinny matmul always as its own launch
     int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
     size_t qmm3_small_elems = (size_t)20 << 20;  // TL_QMM3_SMALL_ELEMS: see engine_linear
@@ -72,7 +74,10 @@ struct tl_engine {
     int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup (TL_ATTN_RQ1_CTX)
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
     int attn_max_splits = 64;    // most context splits per sequence (TL_ATTN_MAX_SPLITS, a power of two <= 256)
-    int attn_wide_max = 512;     // largest window of the wide one-head kernel (TL_ATTN_WIDE_MAX: 0 = off, 64 .. 512)
+    // largest window of the wide one-head kernel (TL_ATTN_WIDE_MAX: 0 = off, 64 .. 512).  Off by default: measured on the
+    // bench workload it costs 8.2 us per layer against 2.9 + 1.3 us for 64-token workgroups + merge (profiles/r02_labs):
+    // one CU keeps only ~32 KiB of L2 misses in flight (~16 GB/s), so a head's 128-256 KiB window has to be spread over CUs
+    int attn_wide_max = 0;
     int attn_wide_nw = 0;        // waves per wide workgroup (TL_ATTN_NW: 4, 8 or 16; 0 = by window)
     bool attn_wide_vector_ids = false;  // TL_ATTN_VECTOR_IDS=1: page ids by vector loads even where scalar loads apply
     tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
@@ -247,8 +252,12 @@ static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
 // RMSNorm / residual / SwiGLU inside).  5 .. 64 rows: the skinny matmul (qmm3.h).  More rows, or TL_NO_QMM3: the
 // reference's own op sequence -- RMSNorm kernel, W4 MFMA GEMM (quantize.py:54-65 routes rows > 8 to the matmul path),
 // then SwiGLU / residual kernels.
+// ss_in: partial sums of squares of the rows of `a` when its producer emitted them (fused RMSNorm of the skinny matmul),
+// else nullptr.  ss_out / *ss_emitted: where the slice reduction should leave the partials of `out`, and whether it did.
 static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
-                         const void *norm_w, const uint16_t *residual, ProfCtx *pc, int kind) {
+                         const void *norm_w, const uint16_t *residual, ProfCtx *pc, int kind, const float *ss_in = nullptr,
+                         float *ss_out = nullptr, bool *ss_emitted = nullptr) {
+    if (ss_emitted) *ss_emitted = false;
     if (e->force_linear == 1) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
     if (e->force_linear != 2 && (M < e->qmm3_min_rows || (M <= 8 && !e->use_qmm3)))
         return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
@@ -264,7 +273,8 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
     const auto tiled = e->tiled.find(w.weight_dev);
     const Qmm3Plan p3 = qmm3_plan(M, w.cols, w.rows);
     if (e->use_qmm3 && M <= 64 && tiled != e->tiled.end() && p3.ok) {
-        if (pro == PRO_RMSNORM) {
+        const bool fused_norm = pro == PRO_RMSNORM && ss_in != nullptr && e->fuse_norm;
+        if (pro == PRO_RMSNORM && !fused_norm) {
             TL_TRY(tl_rms_norm(a, norm_w, e->xn, M, w.cols, c.rms_norm_eps, TL_BF16, e->stream));
             in = e->xn;
         }
@@ -278,16 +288,23 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
         q.N = w.cols;
         q.K = w.rows;
         q.prof = pc ? pc->buf : nullptr;
-        if (launch_qmm3_bf16(q, e->stream) != 0) return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul launch failed");
+        q.norm_w = (const uint16_t *)norm_w;
+        q.ss = ss_in;
+        q.eps = c.rms_norm_eps;
+        if (launch_qmm3_bf16(q, e->stream, fused_norm ? PRO_RMSNORM : PRO_NONE) != 0)
+            return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul launch failed");
         if (pc) prof_after(e, pc, kind, p3.tile_groups * p3.slices);
-        if (launch_qmm3_reduce_bf16(q.partial, p3.slices, M, w.rows, epi, residual, out, q.prof, e->stream) != 0)
+        float *ss_dst = (ss_out && e->fuse_norm && qmm3_reduce_can_emit_ss(epi, w.rows)) ? ss_out : nullptr;
+        int reduce_wg = 0;
+        if (launch_qmm3_reduce_bf16(q.partial, p3.slices, M, w.rows, epi, residual, out, q.prof, e->stream, ss_dst, &reduce_wg) != 0)
             return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul reduction launch failed");
-        if (pc) prof_after(e, pc, kind, (int)(((long)M * (w.rows / (epi == EPI_SWIGLU ? 8 : 4)) + 255) / 256));
+        if (pc) prof_after(e, pc, kind, reduce_wg);
+        if (ss_emitted) *ss_emitted = ss_dst != nullptr;
         TL_CHECK_LAUNCH("engine skinny matmul");
         if (e->linfo) {
             tl_linear_info &li = *e->linfo;
             li.kernel = 2;
-            li.launches += 2 + (pro == PRO_RMSNORM ? 1 : 0);
+            li.launches += 2 + (pro == PRO_RMSNORM && !fused_norm ? 1 : 0);
             li.rows_per_pass = M;
             li.p[0] = p3.MB, li.p[1] = p3.TW, li.p[2] = p3.LM, li.p[3] = p3.slices, li.p[4] = p3.tile_groups;
         }
@@ -314,10 +331,12 @@ struct SplitPlan {
         return ((long)nw << 56) | ((long)u << 50) | ((long)npw << 46) | ((long)rq << 40) | ((long)n_splits << 24) | (long)tokens_per_split;
     }
 };
-// Measured on MI355X (profiles/README.md): a decode-attention workgroup is bound by its dependent latency chain, not by
-// bytes.  Few sequences and short contexts: one query head per workgroup and the whole window in flight at once (the wide
-// kernel: up to 512 tokens per workgroup, so no merge launch up to that context).  Many sequences or long contexts: one
-// workgroup per GQA group walking 64-token stages, so that the K/V window is read from HBM once.
+// Measured on MI355X (profiles/README.md, profiles/r02_labs): a decode-attention workgroup is bound by its dependent latency
+// chain and by how many L2 misses ONE CU keeps in flight (~32 KiB), not by chip bandwidth.  Few sequences and short
+// contexts: one query head and a 64-token window (32 KiB of K/V) per workgroup, partials merged by a second launch.  Many
+// sequences or long contexts: one workgroup per GQA group walking 64-token stages, so that the K/V window is read from HBM
+// once.  The wide one-head kernel (whole 64..512-token window in one workgroup, no merge launch) is kept behind
+// TL_ATTN_WIDE_MAX: it lost on every context it was meant for.
 static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
     const int rep = e->cfg.num_heads / e->cfg.num_kv_heads;
     int rq = e->attn_rq;
@@ -478,15 +497,22 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
 // One fused decode step over slots [0, batch).
 static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nullptr) {
     const tl_engine_config &c = e->cfg;
+    // x enters the step from the embedding gather (embed_slots_kernel / the previous step's step_end_kernel), which leaves the
+    // per-row partial sums of squares in ss_x; every slice reduction that rewrites x or h refreshes them (or says it did not)
+    bool x_ss = true;
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
-        TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0));
+        TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0,
+                             x_ss ? e->ss_x : nullptr));
         TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc));
-        TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1));
-        TL_TRY(engine_linear(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2));
-        TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3));
+        bool h_ss = false;
+        TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, &h_ss));
+        TL_TRY(engine_linear(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2,
+                             h_ss ? e->ss_h : nullptr));
+        TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, &x_ss));
     }
-    TL_TRY(engine_linear(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4));
+    TL_TRY(engine_linear(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4,
+                         x_ss ? e->ss_x : nullptr));
     StepEndArgs s{};
     s.logits = e->logits;
     s.vocab = c.vocab_size;
@@ -507,6 +533,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     s.rope_cur = e->rope_cur;
     s.rope_positions = e->rope_positions;
     s.rope_half = c.head_dim / 2;
+    s.ss_out = e->ss_x;
     s.prof = pc ? pc->buf : nullptr;
     hipLaunchKernelGGL(step_end_kernel, dim3(batch), dim3(1024), 0, e->stream, s);
     if (pc) prof_after(e, pc, 7, batch);
@@ -677,6 +704,8 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const size_t o_act = carve(R * c.intermediate_size * 2);
     const size_t o_log = carve((size_t)std::max(c.max_batch, 8) * c.vocab_size * 2);  // decode rows, or 8 verification rows
     const size_t o_vid = carve(8 * 4);
+    const size_t o_ssx = carve((size_t)c.max_batch * QM3_SS * 4);
+    const size_t o_ssh = carve((size_t)c.max_batch * QM3_SS * 4);
     // attention partials: decode (batch*Hq rows x 64 splits) or the L<=8 operator path during short prefills
     // decode partials: at most 64 splits per row with many sequences, at most 256 split-rows per head with few (pick_decode_splits)
     e->attn_ws_bytes = std::max((size_t)std::max(c.max_batch * 64, 4 * 256) * c.num_heads * (c.head_dim + 2) * 4,
@@ -737,6 +766,9 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->logits = (uint16_t *)(A + o_log);
     e->attn_ws = (float *)(A + o_ws);
     e->verify_ids = (int32_t *)(A + o_vid);
+    e->ss_x = (float *)(A + o_ssx);
+    e->ss_h = (float *)(A + o_ssh);
+    if (const char *q = getenv("TL_QMM3_FUSED_NORM")) e->fuse_norm = atoi(q) != 0;
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
     if (const char *q = getenv("TL_QMM3_SMALL_ELEMS")) e->qmm3_small_elems = (size_t)atoll(q);
@@ -1155,7 +1187,7 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
     // input activations of the first step come from the pending token ids
     hipLaunchKernelGGL(embed_slots_kernel, dim3(batch), dim3(256), 0, e->stream, e->tokens, e->embed.weight_dev,
                        (const uint16_t *)e->embed.scales_dev, (const uint16_t *)e->embed.biases_dev, e->x, c.hidden_size,
-                       c.vocab_size, e->context_lens, e->rope_table, e->rope_cur, e->rope_positions, c.head_dim / 2);
+                       c.vocab_size, e->context_lens, e->rope_table, e->rope_cur, e->rope_positions, c.head_dim / 2, e->ss_x);
     TL_CHECK_LAUNCH("engine embed");
     std::vector<std::pair<int32_t *, int32_t>> pk;
     for (int s = 0; s < steps; ++s) {
@@ -1272,7 +1304,7 @@ extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *
     }
     hipLaunchKernelGGL(embed_slots_kernel, dim3(batch), dim3(256), 0, e->stream, e->tokens, e->embed.weight_dev,
                        (const uint16_t *)e->embed.scales_dev, (const uint16_t *)e->embed.biases_dev, e->x, c.hidden_size,
-                       c.vocab_size, e->context_lens, e->rope_table, e->rope_cur, e->rope_positions, c.head_dim / 2);
+                       c.vocab_size, e->context_lens, e->rope_table, e->rope_cur, e->rope_positions, c.head_dim / 2, e->ss_x);
     std::vector<std::pair<int32_t *, int32_t>> pk;
     int max_ctx = 1;
     int rc = reserve_step_locked(e, batch, pk, &max_ctx);

@@ -778,6 +778,9 @@ struct StepEndArgs {
     const float2 *rope_table;
     float2 *rope_cur;
     int rope_positions, rope_half;
+    // optional: [max_batch][8] partial sums of squares of the embedded row (entry 0; the rest zero) for the fused RMSNorm of
+    // the next step's skinny QKV matmul (qmm3.h)
+    float *ss_out;
     prof_t *prof;
 };
 
@@ -854,14 +857,30 @@ __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
     const int token = s_token;
     const int words = p.hidden / 8;
     const int groups = p.hidden / 128;
+    float sumsq = 0.f;
     for (int w = threadIdx.x; w < words; w += 1024) {
         const uint32_t packed = p.emb_w[(long)token * words + w];
         const float scale = BF16::to_float(p.emb_s[(long)token * groups + w / 16]);
         const float bias = BF16::to_float(p.emb_b[(long)token * groups + w / 16]);
         uint16_t o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = BF16::from_float((float)((packed >> (4 * e)) & 0xfu) * scale + bias);
+        for (int e = 0; e < 8; ++e) {
+            o[e] = BF16::from_float((float)((packed >> (4 * e)) & 0xfu) * scale + bias);
+            const float v = BF16::to_float(o[e]);
+            sumsq += v * v;
+        }
         *reinterpret_cast<uint4 *>(p.x + (long)slot * p.hidden + w * 8) = *reinterpret_cast<const uint4 *>(o);
+    }
+    if (p.ss_out) {  // uniform.  s_val is free again: its last readers ran before the barrier above
+        const float ws = wave_sum(sumsq);
+        if ((threadIdx.x & 63) == 0) s_val[threadIdx.x >> 6] = ws;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+            for (int w = 0; w < 16; ++w) tot += s_val[w];
+            p.ss_out[(long)slot * 8] = tot;
+            for (int i = 1; i < 8; ++i) p.ss_out[(long)slot * 8 + i] = 0.f;
+        }
     }
     prof_end(p.prof, prof_t0);
 }
@@ -1037,20 +1056,35 @@ __global__ __launch_bounds__(256) void embed_slots_kernel(const int32_t *__restr
                                                           int hidden, int vocab, const int32_t *__restrict__ context_lens,
                                                           const float2 *__restrict__ rope_table,
                                                           float2 *__restrict__ rope_cur, int rope_positions,
-                                                          int rope_half) {
+                                                          int rope_half, float *__restrict__ ss_out) {
+    __shared__ float wave_ss[4];
     const int slot = blockIdx.x;
     int token = tokens[slot];
     token = token < 0 ? 0 : (token >= vocab ? vocab - 1 : token);
     const int words = hidden / 8;
     const int groups = hidden / 128;
+    float sumsq = 0.f;
     for (int w = threadIdx.x; w < words; w += 256) {
         const uint32_t packed = emb_w[(long)token * words + w];
         const float scale = BF16::to_float(emb_s[(long)token * groups + w / 16]);
         const float bias = BF16::to_float(emb_b[(long)token * groups + w / 16]);
         uint16_t o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = BF16::from_float((float)((packed >> (4 * e)) & 0xfu) * scale + bias);
+        for (int e = 0; e < 8; ++e) {
+            o[e] = BF16::from_float((float)((packed >> (4 * e)) & 0xfu) * scale + bias);
+            const float v = BF16::to_float(o[e]);
+            sumsq += v * v;
+        }
         *reinterpret_cast<uint4 *>(x + (long)slot * hidden + w * 8) = *reinterpret_cast<const uint4 *>(o);
+    }
+    if (ss_out) {  // partial sums of squares of the row for the fused RMSNorm of the skinny QKV matmul (entry 0; rest zero)
+        const float ws = wave_sum(sumsq);
+        if ((threadIdx.x & 63) == 0) wave_ss[threadIdx.x >> 6] = ws;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ss_out[(long)slot * 8] = (wave_ss[0] + wave_ss[1]) + (wave_ss[2] + wave_ss[3]);
+            for (int i = 1; i < 8; ++i) ss_out[(long)slot * 8 + i] = 0.f;
+        }
     }
     // whatever changed the slot's context on the host side (prefill, rewind, move), the step starts from fresh factors
     if ((int)threadIdx.x < rope_half) {

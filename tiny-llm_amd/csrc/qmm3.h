@@ -16,7 +16,10 @@
 //   Partial sums go to an fp32 workspace [slices][M][K]; qmm3_reduce_kernel adds the slices in a fixed order and applies
 //   the epilogue (store / residual add / SwiGLU over interleaved gate-up rows), so results do not depend on timing.
 //
-// RMSNorm is NOT fused here (a slice cannot see the whole row): the engine runs rms_norm once per projection (M rows).
+// RMSNorm: a slice cannot see the whole row, but the kernels that PRODUCE the row can -- the slice reduction of the previous
+// projection and the embedding gather emit deterministic per-row partial sums of squares ([row][QM3_SS] floats, summed here
+// in a fixed tree), and the staging pass normalises its slice with them (PRO_RMSNORM: bf16(x * inv * w), the reference's
+// rounding point).  Where no such partials exist (the producer was a GEMV) the engine runs rms_norm as its own launch.
 #pragma once
 #include "common.h"
 #include "qmv.h"
@@ -29,6 +32,7 @@ namespace tl {
 #endif
 constexpr int QM3_WAVES = 8;
 constexpr int QM3_PAD = 8;  // bf16 elements of padding per staged activation row
+constexpr int QM3_SS = 8;   // partial sums of squares kept per activation row (unused entries are zero)
 
 struct Qmm3Args {
     const uint32_t *wt;   // tiled packed weights [K/16][G][64][4]
@@ -37,13 +41,17 @@ struct Qmm3Args {
     float *partial;       // [slices][M][K] fp32
     int M, N, K;
     prof_t *prof;
+    // PRO_RMSNORM only: a holds the UN-normalised rows; ss [M][QM3_SS] partial sums of squares of each row
+    const uint16_t *norm_w;
+    const float *ss;
+    float eps;
 };
 
 __host__ __device__ inline size_t qmm3_lds_bytes(int MB, int LM) {
     return (size_t)MB * 16 * (LM * 128 + QM3_PAD) * 2 + (size_t)LM * MB * 16 * 4;
 }
 
-template <int MB, int TW, int LM>
+template <int MB, int TW, int LM, int PRO = PRO_NONE>
 __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = QM3_WAVES * 64;
@@ -95,13 +103,28 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
             const bool ok = row < p.M && g < gn;
             u32x4 v = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)row * N + (size_t)g0 * 128 + (size_t)cc * 8) : 0));
             if (!ok) v = u32x4{0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4 *>(xs + (size_t)row * XS + (size_t)cc * 8) = v;
             float f[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 f[2 * e] = BF16::to_float((uint16_t)(v[e] & 0xffffu));
                 f[2 * e + 1] = BF16::to_float((uint16_t)(v[e] >> 16));
             }
+            if constexpr (PRO == PRO_RMSNORM) {
+                // the row's sum of squares from its producers' partials (fixed summation tree), the weights of this chunk
+                const size_t rrow = ok ? (size_t)row : 0;
+                const f32x4 s0 = *reinterpret_cast<const f32x4 *>(p.ss + rrow * QM3_SS);
+                const f32x4 s1 = *reinterpret_cast<const f32x4 *>(p.ss + rrow * QM3_SS + 4);
+                const u32x4 gw = *reinterpret_cast<const u32x4 *>(p.norm_w + (ok ? ((size_t)g0 * 128 + (size_t)cc * 8) : 0));
+                const float tot = ((s0[0] + s0[1]) + (s0[2] + s0[3])) + ((s1[0] + s1[1]) + (s1[2] + s1[3]));
+                const float inv = rsqrtf(tot / (float)N + p.eps);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f[2 * e] = bf16_round(f[2 * e] * inv * BF16::to_float((uint16_t)(gw[e] & 0xffffu)));
+                    f[2 * e + 1] = bf16_round(f[2 * e + 1] * inv * BF16::to_float((uint16_t)(gw[e] >> 16)));
+                    v[e] = ok ? BF16::pack2(f[2 * e], f[2 * e + 1]) : 0u;
+                }
+            }
+            *reinterpret_cast<u32x4 *>(xs + (size_t)row * XS + (size_t)cc * 8) = v;
             if constexpr (QMM3_ABL & 8) {
                 if ((cc & 15) == 0) xsum[g * ROWS + row] = f[0];
                 continue;
@@ -206,8 +229,11 @@ inline Qmm3Plan qmm3_plan(int M, int N, int K) {
 }
 
 // qmm3.hip
-int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st);
-// out = epilogue(sum over slices); epi = EPI_STORE / EPI_RESIDUAL (residual [M,K]) / EPI_SWIGLU (out [M,K/2])
+int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro = PRO_NONE);
+// out = epilogue(sum over slices); epi = EPI_STORE / EPI_RESIDUAL (residual [M,K]) / EPI_SWIGLU (out [M,K/2]).
+// ss_out (optional, EPI_STORE / EPI_RESIDUAL with K <= QM3_SS * 1024): [M][QM3_SS] partial sums of squares of the bf16 output rows
+// for the next projection's fused RMSNorm; returns the number of workgroups launched through *n_wg.
 int launch_qmm3_reduce_bf16(const float *partial, int slices, int M, int K, int epi, const uint16_t *residual, uint16_t *out,
-                            prof_t *prof, hipStream_t st);
+                            prof_t *prof, hipStream_t st, float *ss_out = nullptr, int *n_wg = nullptr);
+inline bool qmm3_reduce_can_emit_ss(int epi, int K) { return epi != EPI_SWIGLU && K % 4 == 0 && (K / 4 + 255) / 256 <= QM3_SS; }
 }  // namespace tl

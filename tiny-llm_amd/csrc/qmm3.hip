@@ -3,30 +3,45 @@
 
 namespace tl {
 
-// partial [slices][M][K] fp32 -> out bf16.  One thread = 4 consecutive output columns of one row (EPI_SWIGLU: 4 columns of
-// the K/2-wide output = 8 interleaved gate/up columns).  Slices are added in index order: the result is deterministic.
-template <int EPI>
+// partial [slices][M][K] fp32 -> out bf16.  grid = (chunks of 256 threads, M rows); one thread = 4 consecutive output columns
+// of its row (EPI_SWIGLU: 4 columns of the K/2-wide output = 8 interleaved gate/up columns).  Slices are added in index order
+// (deterministic); the loads of 8 slices are in flight together (a dependent load per slice cost ~1 us each).
+// SS: the workgroup also writes the sum of squares of its (rounded) outputs to ss_out[row][blockIdx.x] -- partials of the
+// next projection's RMSNorm, reduced in a fixed order (wave shuffles, then the 4 waves in index order).
+template <int EPI, bool SS>
 __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restrict__ partial, int slices, int M, int K,
                                                           const uint16_t *__restrict__ residual,
-                                                          uint16_t *__restrict__ out, prof_t *prof) {
+                                                          uint16_t *__restrict__ out, float *__restrict__ ss_out, prof_t *prof) {
+    __shared__ float wave_ss[4];
     const prof_t prof_t0 = prof_begin(prof);
     constexpr int IN_PER = EPI == EPI_SWIGLU ? 8 : 4;
     const int per_row = K / IN_PER;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx < (long)M * per_row) {
-        const int m = (int)(idx / per_row);
-        const int q = (int)(idx - (long)m * per_row);
+    const int m = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    float sumsq = 0.f;
+    if (q < per_row) {
         const size_t in0 = (size_t)m * K + (size_t)q * IN_PER;
         const size_t slice_stride = (size_t)M * K;
         float acc[IN_PER];
 #pragma unroll
         for (int e = 0; e < IN_PER; ++e) acc[e] = 0.f;
-        for (int s = 0; s < slices; ++s) {
+        for (int s0 = 0; s0 < slices; s0 += 8) {
+            f32x4 x[8][IN_PER / 4];
 #pragma unroll
-            for (int v = 0; v < IN_PER / 4; ++v) {
-                const f32x4 x = *reinterpret_cast<const f32x4 *>(partial + (size_t)s * slice_stride + in0 + 4 * v);
+            for (int j = 0; j < 8; ++j) {
+                const size_t sidx = (size_t)min(s0 + j, slices - 1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * v + e] += x[e];
+                for (int v = 0; v < IN_PER / 4; ++v)
+                    x[j][v] = *reinterpret_cast<const f32x4 *>(partial + sidx * slice_stride + in0 + 4 * v);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (s0 + j < slices) {  // uniform; no load inside
+#pragma unroll
+                    for (int v = 0; v < IN_PER / 4; ++v)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[4 * v + e] += x[j][v][e];
+                }
             }
         }
         uint16_t o[4];
@@ -49,28 +64,50 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
             for (int e = 0; e < 4; ++e) o[e] = BF16::from_float(acc[e]);
             *reinterpret_cast<uint2 *>(out + in0) = *reinterpret_cast<const uint2 *>(o);
         }
+        if constexpr (SS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = BF16::to_float(o[e]);
+                sumsq += v * v;
+            }
+        }
+    }
+    if constexpr (SS) {
+        const float w = wave_sum(sumsq);
+        if ((threadIdx.x & 63) == 0) wave_ss[threadIdx.x >> 6] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ss_out[(size_t)m * QM3_SS + blockIdx.x] = (wave_ss[0] + wave_ss[1]) + (wave_ss[2] + wave_ss[3]);
+            if (blockIdx.x == 0)
+                for (int i = gridDim.x; i < QM3_SS; ++i) ss_out[(size_t)m * QM3_SS + i] = 0.f;
+        }
     }
     prof_end(prof, prof_t0);
 }
 
 int launch_qmm3_reduce_bf16(const float *partial, int slices, int M, int K, int epi, const uint16_t *residual, uint16_t *out,
-                            prof_t *prof, hipStream_t st) {
-    if (K % 8 != 0) return -1;
-    const long items = (long)M * (K / (epi == EPI_SWIGLU ? 8 : 4));
-    const dim3 grid((unsigned)((items + 255) / 256)), block(256);
-    if (epi == EPI_SWIGLU) hipLaunchKernelGGL(qmm3_reduce_kernel<EPI_SWIGLU>, grid, block, 0, st, partial, slices, M, K, residual, out, prof);
-    else if (epi == EPI_RESIDUAL) hipLaunchKernelGGL(qmm3_reduce_kernel<EPI_RESIDUAL>, grid, block, 0, st, partial, slices, M, K, residual, out, prof);
-    else hipLaunchKernelGGL(qmm3_reduce_kernel<EPI_STORE>, grid, block, 0, st, partial, slices, M, K, residual, out, prof);
+                            prof_t *prof, hipStream_t st, float *ss_out, int *n_wg) {
+    if (K % 8 != 0 || M < 1 || M > 65535) return -1;
+    const int per_row = K / (epi == EPI_SWIGLU ? 8 : 4);
+    const dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)M), block(256);
+    if (ss_out && !qmm3_reduce_can_emit_ss(epi, K)) return -1;
+    if (n_wg) *n_wg = (int)(grid.x * grid.y);
+    if (epi == EPI_SWIGLU) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_SWIGLU, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof);
+    else if (epi == EPI_RESIDUAL && ss_out) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_RESIDUAL, true>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof);
+    else if (epi == EPI_RESIDUAL) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_RESIDUAL, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof);
+    else if (ss_out) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_STORE, true>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof);
+    else hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_STORE, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st) {
+int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro) {
     const Qmm3Plan pl = qmm3_plan(args.M, args.N, args.K);
     if (!pl.ok) return -1;
+    if (pro == PRO_RMSNORM && (!args.ss || !args.norm_w)) return -1;
     const dim3 grid(pl.tile_groups, pl.slices), block(QM3_WAVES * 64);
 #define QM3_CASE(MBv, TWv, LMv)                                                                                     \
     if (pl.MB == MBv && pl.TW == TWv && pl.LM == LMv) {                                                             \
-        auto kern = qmm3_kernel<MBv, TWv, LMv>;                                                                     \
+        auto kern = pro == PRO_RMSNORM ? qmm3_kernel<MBv, TWv, LMv, PRO_RMSNORM> : qmm3_kernel<MBv, TWv, LMv, PRO_NONE>; \
         if (pl.lds > 64 * 1024)                                                                                     \
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
         hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                                    \
