@@ -7,7 +7,8 @@ benches/bench_course_progression.py:103-105).
     python -m benches.bench --model qwen3-4b --num-seqs 1 --min-input-len 128 --max-input-len 128 \
         --min-output-len 129 --max-output-len 129 --prefill-logits last          # reference acceptance shape
     python -m benches.bench --batch-decode --batch-size 64 --num-seqs 128 --min-input-len 128 --max-input-len 1024 \
-        --min-output-len 32 --max-output-len 128 --prefill-step 128             # serving trace (config 4, one GPU)
+        --min-output-len 32 --max-output-len 128 --prefill-step 128 --prefill-budget 2048   # serving trace (config 4, one GPU;
+                                                                  # benches/serve_replicas.py deals it over N GPUs)
 
 --solution engine (default): the fused decode engine (tinyllm_engine.h).  --solution ops: the op-by-op
 ``Qwen3ModelWeek3`` on the HIP operators, i.e. the reference's own call structure.  Weights are synthetic
@@ -20,7 +21,7 @@ import argparse
 import json
 import sys
 import time
-from dataclasses import dataclass, field
+from dataclasses import asdict, dataclass
 from pathlib import Path
 from random import Random
 
@@ -34,16 +35,6 @@ for p in (ROOT, ROOT / "tiny-llm_amd", ROOT / "tiny-llm_amd" / "extensions_hip")
 class BenchRequest:
     prompt_token_ids: list[int]
     max_new_tokens: int
-
-
-@dataclass
-class ServingMetrics:
-    """Counters of the reference's serving report (benches/bench.py:35-62) that exist on this path."""
-    peak_active_requests: int = 0
-    peak_live_pages: int = 0
-    peak_kv_bytes: int = 0
-    decode_steps: int = 0
-    decode_step_ms: list[float] = field(default_factory=list)
 
 
 def random_token_id(rng: Random, low: int, high: int, eos_token_id: int) -> int:
@@ -71,15 +62,6 @@ def build_requests(*, rng: Random, num_seqs: int, vocab_size: int, eos_token_id:
     return requests
 
 
-def percentile(values: list[float], q: float) -> float:
-    """Nearest-rank percentile (reference benches/bench.py:579-585)."""
-    if not values:
-        return 0.0
-    ordered = sorted(values)
-    rank = max(1, min(len(ordered), int(-(-q * len(ordered) // 1))))
-    return ordered[rank - 1]
-
-
 def safe_div(a: float, b: float) -> float:
     return a / b if b else 0.0
 
@@ -99,6 +81,9 @@ def parse_args(argv=None) -> argparse.Namespace:
     ap.add_argument("--batch-decode", action="store_true")
     ap.add_argument("--batch-size", type=int, default=5)
     ap.add_argument("--prefill-step", type=int, default=128)
+    ap.add_argument("--prefill-budget", type=int, default=None,
+                    help="prompt tokens a serving turn may spend on admission before its decode step (default: one "
+                         "--prefill-step chunk, the reference's schedule; config 4 uses 2048 so that 64 slots fill)")
     ap.add_argument("--page-size", type=int, default=128)
     ap.add_argument("--json-output", type=Path)
     args = ap.parse_args(argv)
@@ -128,82 +113,6 @@ def run_one_request_engine(engine, request: BenchRequest, prefill_step: int):
         return request.max_new_tokens, prefill_time, decode_time
     finally:
         engine.release(0)
-
-
-def run_batch_requests_engine(engine, requests: list[BenchRequest], batch_size: int, prefill_step: int,
-                              metrics: ServingMetrics):
-    """Reference run_batch_requests_serving: per loop turn one prefill chunk of the pending request (timed), adopt it
-    into a free slot when complete, one batched decode step over the occupied slots (timed), retire finished requests."""
-    from tiny_llm_hip.engine import _DECODE_ROW_BUCKETS
-
-    staging = batch_size
-    queue = list(range(len(requests)))
-    slots: list[dict | None] = [None] * batch_size
-    pending = None
-    generated = decode_tokens = 0
-    prefill_time = decode_time = 0.0
-    live: set[int] = set()
-    try:
-        while queue or pending is not None or any(s is not None for s in slots):
-            if queue and pending is None:
-                idx = queue.pop(0)
-                engine.begin(staging)
-                live.add(staging)
-                pending = {"idx": idx, "offset": 0, "count": 0}
-            if pending is not None:
-                tokens = requests[pending["idx"]].prompt_token_ids
-                if pending["offset"] < len(tokens):
-                    chunk = tokens[pending["offset"]:pending["offset"] + prefill_step]
-                    last = pending["offset"] + len(chunk) >= len(tokens)
-                    t0 = time.perf_counter()
-                    engine.prefill(staging, chunk, chunk=len(chunk), want_logits=last)
-                    engine.synchronize()
-                    prefill_time += time.perf_counter() - t0
-                    pending["offset"] += len(chunk)
-                    if last:
-                        pending["count"] = 1
-                        generated += 1
-                if pending["offset"] >= len(tokens):
-                    if pending["count"] >= requests[pending["idx"]].max_new_tokens:
-                        engine.release(staging)
-                        live.discard(staging)
-                        pending = None
-                    else:
-                        free = next((i for i, s in enumerate(slots) if s is None), None)
-                        if free is not None:
-                            engine.move(staging, free)
-                            live.discard(staging)
-                            live.add(free)
-                            slots[free] = pending
-                            pending = None
-            active = [i for i, s in enumerate(slots) if s is not None]
-            if active:
-                rows = min(next((b for b in _DECODE_ROW_BUCKETS if b >= active[-1] + 1), batch_size), batch_size)
-                t0 = time.perf_counter()
-                engine.decode(1, batch=rows)  # the occupied prefix of the slots (tiny_llm_hip.engine.batch_generate_ids)
-                engine.synchronize()
-                dt = time.perf_counter() - t0
-                decode_time += dt
-                metrics.decode_steps += 1
-                metrics.decode_step_ms.append(dt * 1e3)
-                metrics.peak_active_requests = max(metrics.peak_active_requests, len(active))
-                st = engine.stats()
-                metrics.peak_live_pages = max(metrics.peak_live_pages, st["pages_in_use"])
-                for i in active:
-                    slots[i]["count"] += 1
-                    generated += 1
-                    decode_tokens += 1
-                    if slots[i]["count"] >= requests[slots[i]["idx"]].max_new_tokens:
-                        engine.release(i)
-                        live.discard(i)
-                        slots[i] = None
-    finally:
-        for slot in list(live):
-            try:
-                engine.release(slot)
-            except RuntimeError:
-                pass
-    return generated, decode_tokens, prefill_time, decode_time
 
 
 # ------------------------------------------------------------------------------------------------ op-by-op runner
@@ -251,7 +160,7 @@ def main(argv=None) -> None:
                               min_output_len=args.min_output_len, max_output_len=args.max_output_len)
     total_prompt = sum(len(r.prompt_token_ids) for r in requests)
     longest = max(len(r.prompt_token_ids) + r.max_new_tokens for r in requests)
-    metrics = ServingMetrics() if args.batch_decode else None
+    metrics = None
 
     if args.solution == "engine":
         from tiny_llm_hip.engine import DecodeEngine
@@ -261,9 +170,17 @@ def main(argv=None) -> None:
         engine = DecodeEngine(mlx_model, page_size=args.page_size, num_pages=pages_per_seq * slots + 2, max_batch=slots,
                               max_pages_per_seq=pages_per_seq, max_prefill_rows=max(args.prefill_step, 8))
 
+        kv_page_bytes = 2 * cfg["num_hidden_layers"] * cfg["num_key_value_heads"] * args.page_size * cfg["head_dim"] * 2
+
         def run_all(reqs):
+            nonlocal metrics
             if args.batch_decode:
-                return run_batch_requests_engine(engine, reqs, args.batch_size, args.prefill_step, metrics)
+                from benches.serving import serve_requests
+
+                metrics = serve_requests(engine, reqs, batch_size=args.batch_size, prefill_step=args.prefill_step,
+                                         prefill_budget=args.prefill_budget, page_size=args.page_size,
+                                         kv_bytes_per_page=kv_page_bytes, capacity_pages=pages_per_seq * slots + 2)
+                return metrics.generated_tokens, metrics.decode_tokens, metrics.prefill_time, metrics.decode_time
             gen = dec = 0
             pt = dt = 0.0
             for r in reqs:
@@ -287,31 +204,28 @@ def main(argv=None) -> None:
 
     for _ in range(args.warmup):  # complete-request warmups, like the reference
         run_all(requests[: max(1, min(len(requests), args.batch_size if args.batch_decode else 1))])
-    if metrics is not None:  # the report covers the timed run only
-        metrics.__init__()
     t0 = time.perf_counter()
     generated, decode_tokens, prefill_time, decode_time = run_all(requests)
     total_time = time.perf_counter() - t0
 
-    print(f"Requests: {args.num_seqs}, Prompt tokens: {total_prompt}, Generated tokens: {generated}")
-    print(f"Time: {total_time:.2f}s, Output throughput: {safe_div(generated, total_time):.2f} tok/s")
-    print(f"Total throughput (prompt+output): {safe_div(total_prompt + generated, total_time):.2f} tok/s")
-    print(f"Prefill throughput: {safe_div(total_prompt, prefill_time):.2f} tok/s")
-    print(f"Decode throughput: {safe_div(decode_tokens, decode_time):.2f} tok/s")
     payload = {"config": vars(args) | {"json_output": str(args.json_output) if args.json_output else None},
                "metrics": {"requests": args.num_seqs, "prompt_tokens": total_prompt, "generated_tokens": generated,
                            "total_time_s": total_time, "output_tok_s": safe_div(generated, total_time),
                            "prefill_tok_s": safe_div(total_prompt, prefill_time),
                            "decode_tok_s": safe_div(decode_tokens, decode_time)}}
     if metrics is not None:
-        print(f"Request throughput: {safe_div(args.num_seqs, total_time):.2f} req/s")
-        print(f"Peak active requests: {metrics.peak_active_requests}")
-        print(f"Peak live KV pages: {metrics.peak_live_pages}")
-        p50, p95 = percentile(metrics.decode_step_ms, 0.5), percentile(metrics.decode_step_ms, 0.95)
-        print(f"Decode step p50/p95: {p50:.2f} / {p95:.2f} ms over {metrics.decode_steps} steps")
-        payload["metrics"] |= {"req_s": safe_div(args.num_seqs, total_time), "peak_active_requests": metrics.peak_active_requests,
-                               "peak_live_pages": metrics.peak_live_pages, "decode_step_p50_ms": p50,
-                               "decode_step_p95_ms": p95, "decode_steps": metrics.decode_steps}
+        from benches.serving import report_lines
+
+        print("\n".join(report_lines(args.num_seqs, total_prompt, total_time, metrics)))
+        serving = asdict(metrics)
+        serving.pop("decode_step_ms")
+        payload["metrics"] |= {"req_s": safe_div(args.num_seqs, total_time), **serving}
+    else:
+        print(f"Requests: {args.num_seqs}, Prompt tokens: {total_prompt}, Generated tokens: {generated}")
+        print(f"Time: {total_time:.2f}s, Output throughput: {safe_div(generated, total_time):.2f} tok/s")
+        print(f"Total throughput (prompt+output): {safe_div(total_prompt + generated, total_time):.2f} tok/s")
+        print(f"Prefill throughput: {safe_div(total_prompt, prefill_time):.2f} tok/s")
+        print(f"Decode throughput: {safe_div(decode_tokens, decode_time):.2f} tok/s")
     if args.json_output:
         args.json_output.parent.mkdir(parents=True, exist_ok=True)
         args.json_output.write_text(json.dumps(payload, indent=1, default=str))

@@ -1,0 +1,276 @@
+"""Continuous-batching serving loop over the decode engine, with the reference harness's report
+(reference: benches/bench.py:35-62 ServingMetrics, :351-572 run_batch_requests_serving, :787-830 report lines).
+
+One loop turn = (a) prefill work for the request being admitted, (b) hand it to a free decode slot once its prompt is
+in the cache, (c) ONE batched decode step over the occupied slots, (d) retire finished requests.  The reference does
+exactly one prefill chunk per turn; on an MI355X that makes admission the bottleneck of a 64-slot batch (a decode
+step takes ~4 ms, a 128-token chunk ~7 ms, and requests finish as fast as they are admitted: 21 of 64 slots busy).
+``prefill_budget`` therefore lets a turn spend up to that many prompt tokens on admission (default = one chunk, the
+reference's schedule), which is what lets config 4 ("64 concurrent requests") actually reach 64.
+
+The engine is duck-typed (begin / prefill / move / decode / release / synchronize / stats): ``ScheduleOnlyEngine``
+runs the same schedule against a cost model instead of a GPU (capacity planning, and the CPU tests of the scheduler
+and of the multi-replica dealer).
+"""
+
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+
+# decode row counts the engine keeps captured graphs for (tiny_llm_hip.engine._DECODE_ROW_BUCKETS)
+ROW_BUCKETS = (1, 2, 3, 4, 8, 16, 32, 48, 64, 96, 128, 192, 256)
+
+
+@dataclass
+class ServingMetrics:
+    """Field names are the reference's (benches/bench.py:35-62): drivers read them from the JSON payload.  Pages here are
+    ENGINE pages (one id spans every layer's K and V: kv_bytes_per_page bytes); the growth / copy counters are zero by
+    construction -- the pools are sized once, nothing is ever copied to grow (288 GB of HBM)."""
+    generated_tokens: int = 0
+    decode_tokens: int = 0
+    prefill_time: float = 0.0
+    decode_time: float = 0.0
+    peak_active_requests: int = 0
+    peak_live_pages: int = 0
+    peak_capacity_pages: int = 0
+    peak_tail_waste_slots: int = 0
+    peak_tail_waste_live_slots: int = 0
+    peak_tail_waste_bytes: int = 0
+    peak_tail_waste_fraction: float = 0.0
+    peak_kv_bytes: int = 0
+    decode_step_count: int = 0
+    decode_step_median_ms: float = 0.0
+    decode_step_p95_ms: float = 0.0
+    decode_step_max_ms: float = 0.0
+    decode_gap_count: int = 0
+    decode_gap_median_ms: float = 0.0
+    decode_gap_p95_ms: float = 0.0
+    decode_gap_max_ms: float = 0.0
+    reused_page_allocations: int = 0
+    storage_growths: int = 0
+    copied_pages_on_growth: int = 0
+    paged_growth_copy_bytes: int = 0
+    dense_growth_copy_bytes: int = 0
+    dense_staging_copy_bytes: int = 0
+    # not in the reference: what the scheduler did
+    prefill_chunks: int = 0
+    turns: int = 0
+    decode_step_ms: list = field(default_factory=list, repr=False)
+
+
+def nearest_rank(values, q: float) -> float:
+    """Nearest-rank percentile, the reference's definition (benches/bench.py:579-585)."""
+    if not values:
+        return 0.0
+    ordered = sorted(values)
+    rank = max(1, min(len(ordered), -int(-q * len(ordered) // 1)))
+    return ordered[rank - 1]
+
+
+def median(values) -> float:
+    if not values:
+        return 0.0
+    ordered = sorted(values)
+    mid = len(ordered) // 2
+    return ordered[mid] if len(ordered) % 2 else 0.5 * (ordered[mid - 1] + ordered[mid])
+
+
+def serve_requests(engine, requests, *, batch_size: int, prefill_step: int, prefill_budget: int | None = None,
+                   page_size: int = 128, kv_bytes_per_page: int = 0, capacity_pages: int = 0,
+                   clock=time.perf_counter) -> ServingMetrics:
+    """Serve ``requests`` (objects with prompt_token_ids, max_new_tokens) through ``engine`` with ``batch_size`` decode slots
+    and one staging slot (index batch_size).  Timers wrap a synchronised engine, like the reference's mx.eval inside them."""
+    if prefill_budget is None:
+        prefill_budget = prefill_step
+    m = ServingMetrics()
+    staging = batch_size
+    slots: list[dict | None] = [None] * batch_size
+    pending: dict | None = None
+    next_idx = 0
+    live: set[int] = set()
+    gaps_ms: list[float] = []
+    last_completion: float | None = None
+
+    def snapshot():
+        states = [s for s in slots if s is not None] + ([pending] if pending is not None else [])
+        m.peak_active_requests = max(m.peak_active_requests, len(states))
+        pages = sum((s["ctx"] + page_size - 1) // page_size for s in states)
+        waste = sum((-s["ctx"]) % page_size for s in states if s["ctx"] > 0)
+        m.peak_live_pages = max(m.peak_live_pages, pages)
+        m.peak_capacity_pages = max(m.peak_capacity_pages, capacity_pages)
+        m.peak_kv_bytes = max(m.peak_kv_bytes, capacity_pages * kv_bytes_per_page)
+        if waste > m.peak_tail_waste_slots:
+            m.peak_tail_waste_slots = waste
+            m.peak_tail_waste_live_slots = pages * page_size
+            m.peak_tail_waste_bytes = waste * (kv_bytes_per_page // page_size if page_size else 0)
+            m.peak_tail_waste_fraction = waste / (pages * page_size) if pages else 0.0
+
+    try:
+        while next_idx < len(requests) or pending is not None or any(s is not None for s in slots):
+            m.turns += 1
+            budget = prefill_budget
+            while budget > 0:
+                if pending is None:
+                    if next_idx >= len(requests):
+                        break
+                    engine.begin(staging)
+                    live.add(staging)
+                    pending = {"req": requests[next_idx], "offset": 0, "count": 0, "ctx": 0}
+                    next_idx += 1
+                tokens = pending["req"].prompt_token_ids
+                if pending["offset"] < len(tokens):
+                    chunk = tokens[pending["offset"]:pending["offset"] + prefill_step]
+                    last = pending["offset"] + len(chunk) >= len(tokens)
+                    t0 = clock()
+                    engine.prefill(staging, chunk, chunk=len(chunk), want_logits=last)
+                    engine.synchronize()
+                    m.prefill_time += clock() - t0
+                    m.prefill_chunks += 1
+                    budget -= len(chunk)
+                    pending["offset"] += len(chunk)
+                    pending["ctx"] += len(chunk)
+                    if last:
+                        pending["count"] = 1
+                        m.generated_tokens += 1
+                    snapshot()
+                if pending["offset"] < len(tokens):
+                    continue
+                if pending["count"] >= pending["req"].max_new_tokens:  # a one-token request never enters the batch
+                    engine.release(staging)
+                    live.discard(staging)
+                    pending = None
+                    continue
+                free = next((i for i, s in enumerate(slots) if s is None), None)
+                if free is None:
+                    break  # prefilled and waiting for a slot: admission stalls, decoding goes on
+                engine.move(staging, free)
+                live.discard(staging)
+                live.add(free)
+                slots[free] = pending
+                pending = None
+            active = [i for i, s in enumerate(slots) if s is not None]
+            if not active:
+                last_completion = None  # idle time without an active decode request is not a fairness gap
+                continue
+            rows = min(next((b for b in ROW_BUCKETS if b >= active[-1] + 1), batch_size), batch_size)
+            t0 = clock()
+            engine.decode(1, batch=rows)  # the occupied prefix of the slots; idle rows inside it produce nothing
+            engine.synchronize()
+            now = clock()
+            m.decode_time += now - t0
+            m.decode_step_ms.append((now - t0) * 1e3)
+            if last_completion is not None:
+                gaps_ms.append((now - last_completion) * 1e3)
+            last_completion = now
+            for i in active:
+                s = slots[i]
+                s["count"] += 1
+                s["ctx"] += 1
+                m.generated_tokens += 1
+                m.decode_tokens += 1
+            snapshot()
+            for i in active:
+                if slots[i]["count"] >= slots[i]["req"].max_new_tokens:
+                    engine.release(i)
+                    live.discard(i)
+                    slots[i] = None
+    finally:
+        for slot in list(live):
+            try:
+                engine.release(slot)
+            except RuntimeError:
+                pass
+    stats = engine.stats() if hasattr(engine, "stats") else {}
+    m.reused_page_allocations = int(stats.get("reused_page_allocations", 0))
+    m.decode_step_count = len(m.decode_step_ms)
+    m.decode_step_median_ms = median(m.decode_step_ms)
+    m.decode_step_p95_ms = nearest_rank(m.decode_step_ms, 0.95)
+    m.decode_step_max_ms = max(m.decode_step_ms, default=0.0)
+    m.decode_gap_count = len(gaps_ms)
+    m.decode_gap_median_ms = median(gaps_ms)
+    m.decode_gap_p95_ms = nearest_rank(gaps_ms, 0.95)
+    m.decode_gap_max_ms = max(gaps_ms, default=0.0)
+    return m
+
+
+def report_lines(num_seqs: int, prompt_tokens: int, total_time: float, m: ServingMetrics) -> list[str]:
+    """The report exactly as the reference prints it (benches/bench.py:765-830; drivers regex these lines,
+    benches/bench_course_progression.py:103-105)."""
+    def div(a, b):
+        return a / b if b else 0.0
+
+    gen = m.generated_tokens
+    return [
+        f"Requests: {num_seqs}, Prompt tokens: {prompt_tokens}, Generated tokens: {gen}",
+        f"Time: {total_time:.2f}s, Output throughput: {div(gen, total_time):.2f} tok/s",
+        f"Total throughput (prompt+output): {div(prompt_tokens + gen, total_time):.2f} tok/s",
+        f"Prefill throughput: {div(prompt_tokens, m.prefill_time):.2f} tok/s",
+        f"Decode throughput: {div(m.decode_tokens, m.decode_time):.2f} tok/s",
+        f"Request throughput: {div(num_seqs, total_time):.2f} req/s",
+        f"Peak active requests: {m.peak_active_requests}",
+        f"Peak KV bytes: {m.peak_kv_bytes}",
+        f"Peak live KV pages: {m.peak_live_pages}",
+        f"Peak KV capacity pages: {m.peak_capacity_pages}",
+        f"Peak tail waste slots: {m.peak_tail_waste_slots}",
+        f"Tail-waste snapshot live slots: {m.peak_tail_waste_live_slots}",
+        f"Tail-waste snapshot bytes: {m.peak_tail_waste_bytes}",
+        f"Tail-waste snapshot fraction: {m.peak_tail_waste_fraction:.6f}",
+        f"Decode step latency ms (median/p95/max): {m.decode_step_median_ms:.3f}/{m.decode_step_p95_ms:.3f}/{m.decode_step_max_ms:.3f}",
+        f"Decode completion gap ms (median/p95/max): {m.decode_gap_median_ms:.3f}/{m.decode_gap_p95_ms:.3f}/{m.decode_gap_max_ms:.3f}",
+        f"Reused page allocations: {m.reused_page_allocations}",
+        f"Page-pool growths: {m.storage_growths}",
+        f"Pages copied during pool growth: {m.copied_pages_on_growth}",
+        f"Dense KV bytes copied during growth: {m.dense_growth_copy_bytes}",
+        f"Dense KV bytes copied into batch tensors: {m.dense_staging_copy_bytes}",
+        f"Paged KV bytes copied during pool growth: {m.paged_growth_copy_bytes}",
+    ]
+
+
+class ScheduleOnlyEngine:
+    """The engine's slot interface against a COST MODEL instead of a GPU: a virtual clock advances by
+    ``prefill_ms_per_token`` per prompt token and ``decode_ms(rows)`` per batched step.  Enforces the slot protocol (a slot
+    is begun once, moved into a free slot, released once) so that scheduler bugs surface without hardware."""
+
+    def __init__(self, slots: int, prefill_ms_per_token: float = 0.055, decode_ms=lambda rows: 1.1 + 0.07 * rows):
+        self.slots = [None] * slots  # context length per live slot
+        self.now = 0.0
+        self.prefill_ms_per_token = prefill_ms_per_token
+        self.decode_ms = decode_ms
+        self.page_allocations = 0
+
+    def clock(self) -> float:
+        return self.now
+
+    def begin(self, slot):
+        if self.slots[slot] is not None:
+            raise RuntimeError("slot already holds a sequence")
+        self.slots[slot] = 0
+
+    def prefill(self, slot, tokens, chunk=None, want_logits=True):
+        if self.slots[slot] is None:
+            raise RuntimeError("slot holds no sequence")
+        self.slots[slot] += len(tokens)
+        self.now += len(tokens) * self.prefill_ms_per_token * 1e-3
+
+    def move(self, src, dst):
+        if self.slots[src] is None or self.slots[dst] is not None:
+            raise RuntimeError("bad move")
+        self.slots[dst], self.slots[src] = self.slots[src], None
+
+    def decode(self, steps, batch=None):
+        for i in range(batch):
+            if self.slots[i] is not None:
+                self.slots[i] += steps
+        self.now += steps * self.decode_ms(batch) * 1e-3
+
+    def release(self, slot):
+        if self.slots[slot] is None:
+            raise RuntimeError("slot holds no sequence")
+        self.slots[slot] = None
+
+    def synchronize(self):
+        pass
+
+    def stats(self):
+        return {"reused_page_allocations": 0, "pages_in_use": 0}

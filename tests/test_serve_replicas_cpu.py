@@ -1,0 +1,97 @@
+"""CPU tier: the serving scheduler (benches/serving.py) and the config-4 multi-replica dealer (benches/serve_replicas.py)
+against the schedule-only engine (a cost model; no kernel runs).  The world-size-2 case goes through
+torch.distributed.run with the gloo backend, exactly as the GPU launch does with one process per GPU."""
+
+import json
+import subprocess
+import sys
+from pathlib import Path
+from random import Random
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _trace(n, seed=0):
+    from benches.bench import build_requests
+
+    return build_requests(rng=Random(seed), num_seqs=n, vocab_size=151936, eos_token_id=151935, min_input_len=128,
+                          max_input_len=1024, min_output_len=32, max_output_len=128)
+
+
+def test_reference_schedule_starves_a_64_slot_batch_and_a_prefill_budget_fills_it():
+    """One 128-token chunk per turn (the reference's schedule, batch.py:136-285) admits requests about as fast as they
+    finish, so most of 64 slots stay empty (r01: 21 busy); 2048 prompt tokens of admission per turn fills all of them.
+    Every request is served exactly once either way, with exactly its token budget."""
+    from benches.serving import ScheduleOnlyEngine, serve_requests
+
+    reqs = _trace(160)
+    want_tokens = sum(r.max_new_tokens for r in reqs)
+    results = {}
+    for budget in (128, 2048):
+        eng = ScheduleOnlyEngine(65)
+        m = serve_requests(eng, reqs, batch_size=64, prefill_step=128, prefill_budget=budget, clock=eng.clock)
+        assert m.generated_tokens == want_tokens and all(s is None for s in eng.slots)
+        assert m.decode_tokens == want_tokens - len(reqs)  # the first token of a request comes out of its prefill
+        assert m.prefill_chunks == sum(-(-len(r.prompt_token_ids) // 128) for r in reqs)
+        results[budget] = (m.peak_active_requests, eng.now)
+    assert results[128][0] < 40, results
+    assert results[2048][0] >= 64, results
+    assert results[2048][1] < results[128][1], "filling the batch must shorten the virtual makespan"
+
+
+def test_report_lines_are_the_reference_strings():
+    """The strings the reference's drivers regex (benches/bench_course_progression.py:103-105) and its serving report
+    labels (benches/bench.py:787-830)."""
+    import re
+
+    from benches.serving import ScheduleOnlyEngine, report_lines, serve_requests
+
+    eng = ScheduleOnlyEngine(5)
+    reqs = _trace(6)
+    m = serve_requests(eng, reqs, batch_size=4, prefill_step=128, clock=eng.clock)
+    text = "\n".join(report_lines(len(reqs), sum(len(r.prompt_token_ids) for r in reqs), eng.now, m))
+    for label in ("Prefill", "Decode", "Output"):
+        assert re.search(rf"{label} throughput: ([0-9.]+) tok/s", text)
+    for label in ("Request throughput:", "Peak active requests:", "Peak KV bytes:", "Peak live KV pages:",
+                  "Peak KV capacity pages:", "Peak tail waste slots:", "Tail-waste snapshot live slots:",
+                  "Tail-waste snapshot bytes:", "Tail-waste snapshot fraction:", "Decode step latency ms (median/p95/max):",
+                  "Decode completion gap ms (median/p95/max):", "Reused page allocations:", "Page-pool growths:",
+                  "Pages copied during pool growth:", "Dense KV bytes copied during growth:",
+                  "Dense KV bytes copied into batch tensors:", "Paged KV bytes copied during pool growth:"):
+        assert label in text, label
+    assert m.peak_active_requests <= 5 and m.decode_step_count == len(m.decode_step_ms) > 0
+
+
+def test_dealer_and_aggregate_are_consistent():
+    from benches.serve_replicas import aggregate, deal
+
+    reqs = list(range(10))
+    assert deal(reqs, 0, 4) == [0, 4, 8] and deal(reqs, 3, 4) == [3, 7]
+    assert sorted(sum((deal(reqs, r, 4) for r in range(4)), [])) == reqs
+    reports = [{"rank": r, "requests": 2, "prompt_tokens": 100, "wall_s": 1.0 + r, "decode_step_ms": [1.0, 2.0 + r],
+                "metrics": {"generated_tokens": 50, "decode_tokens": 48, "decode_time": 0.5, "prefill_time": 0.25,
+                            "peak_active_requests": 2}} for r in range(2)]
+    out = aggregate(reports)
+    assert out["wall_s"] == 2.0 and out["output_tok_s"] == 100 / 2.0  # the job ends with its slowest replica
+    assert out["decode_tok_s"] == 2 * 48 / 0.5 and out["req_s"] == 4 / 2.0
+    assert out["decode_step_p95_ms"] == 3.0 and len(out["per_replica"]) == 2
+
+
+def test_two_replicas_over_gloo_match_one_replica_serving_everything(tmp_path):
+    """world size 2 through torch.distributed.run (gloo control plane): every request is served exactly once, the two
+    replicas split the trace by index, and the virtual job time is about half of the single-replica run."""
+    common = ["--solution", "schedule-only", "--num-seqs", "96", "--batch-size", "16", "--warmup-requests", "0"]
+    one = tmp_path / "one.json"
+    two = tmp_path / "two.json"
+    subprocess.run([sys.executable, str(ROOT / "benches" / "serve_replicas.py"), *common, "--json-output", str(one)],
+                   check=True, cwd=ROOT, timeout=300, capture_output=True)
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(ROOT / "benches" / "serve_replicas.py"),
+                           *common, "--json-output", str(two)], cwd=ROOT, timeout=600, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert "Replicas: 2" in proc.stdout and "GPU 1:" in proc.stdout
+    a, b = json.loads(one.read_text())["aggregate"], json.loads(two.read_text())["aggregate"]
+    assert a["replicas"] == 1 and b["replicas"] == 2
+    assert a["requests"] == b["requests"] == 96 and a["generated_tokens"] == b["generated_tokens"]
+    assert [r["requests"] for r in b["per_replica"]] == [48, 48]
+    assert 0.4 < b["wall_s"] / a["wall_s"] < 0.75

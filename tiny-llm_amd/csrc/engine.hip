@@ -479,16 +479,18 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
     if (n_splits > 1) {
         const dim3 mg(batch * c.num_heads), mb(128);
         prof_t *pb = pc ? pc->buf : nullptr;
+        int merge_wg = batch * c.num_heads;
         switch (n_splits) {
             case 2: hipLaunchKernelGGL(attn_merge_kernel<2>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
             case 4: hipLaunchKernelGGL(attn_merge_kernel<4>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
             case 8: hipLaunchKernelGGL(attn_merge_kernel<8>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
-            case 16: hipLaunchKernelGGL(attn_merge_kernel<16>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
-            case 32: hipLaunchKernelGGL(attn_merge_kernel<32>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
-            case 64: hipLaunchKernelGGL(attn_merge_kernel<64>, mg, mb, 0, e->stream, e->attn_ws, out, D, pb); break;
-            default: hipLaunchKernelGGL(attn_merge_many_kernel, mg, mb, 0, e->stream, e->attn_ws, out, D, n_splits, pb); break;
+            default:  // 16 and more splits: a row's partials spread over D / 32 workgroups x 8 split groups
+                merge_wg *= (D + 31) / 32;
+                hipLaunchKernelGGL(attn_merge_cols_kernel, dim3(batch * c.num_heads, (D + 31) / 32), dim3(256), 0, e->stream, e->attn_ws,
+                                   out, D, n_splits, pb);
+                break;
         }
-        if (pc) prof_after(e, pc, 6, batch * c.num_heads);
+        if (pc) prof_after(e, pc, 6, merge_wg);
     }
     TL_CHECK_LAUNCH("engine attention");
     return TL_OK;

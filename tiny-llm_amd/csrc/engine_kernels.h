@@ -715,40 +715,59 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict
     prof_end(prof, prof_t0);
 }
 
-// the same merge for more than 64 splits (long contexts): two passes over the partials, 32 loads in flight at a time
-__global__ __launch_bounds__(128) void attn_merge_many_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out,
-                                                              int D, int n_splits, prof_t *prof) {
+// The merge for 16 and more splits (contexts from ~1k tokens): grid = (rows, D / 32), block = 32 output columns x 8 split
+// groups.  One workgroup per row with every split's loads issued by 128 threads took 8 us at 64 splits (r02 bench, 8k and
+// 32k contexts: 288 us per step): only batch x heads CUs took part, each pulling 33 KB through its ~32 KiB-in-flight limit.
+// Here a row's partials are read by 4 workgroups x 8 split groups, 8 loads in flight per thread; every group folds its
+// splits (s = sg, sg + 8, ...) with the online-softmax update in index order, and the 8 groups meet in LDS in group order:
+// deterministic.
+__global__ __launch_bounds__(256) void attn_merge_cols_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out, int D,
+                                                              int n_splits, prof_t *prof) {
+    __shared__ float s_m[8][32], s_l[8][32], s_a[8][32];
     const prof_t prof_t0 = prof_begin(prof);
     const long orow = blockIdx.x;
+    const int c = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int d = min((int)blockIdx.y * 32 + c, D - 1);
     const int stride = D + 2;
     const float *base = ws + orow * n_splits * stride;
-    const int d = threadIdx.x < D ? threadIdx.x : 0;
-    float gm = -1e30f;
-    for (int s0 = 0; s0 < n_splits; s0 += 32) {
-        float ms[32];
+    float m = -1e30f, l = 0.f, acc = 0.f;
+    for (int s0 = sg; s0 < n_splits; s0 += 64) {
+        float ms[8], ls[8], vs[8];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) ms[j] = base[(size_t)min(s0 + j, n_splits - 1) * stride + D];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) gm = fmaxf(gm, ms[j]);
-    }
-    float gl = 0.f, acc = 0.f;
-    for (int s0 = 0; s0 < n_splits; s0 += 32) {
-        float ms[32], ls[32], vs[32];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const float *row = base + (size_t)min(s0 + j, n_splits - 1) * stride;
+        for (int j = 0; j < 8; ++j) {
+            const float *row = base + (size_t)min(s0 + 8 * j, n_splits - 1) * stride;
             ms[j] = row[D];
             ls[j] = row[D + 1];
             vs[j] = row[d];
         }
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const float f = s0 + j < n_splits ? exp2f(ms[j] - gm) : 0.f;
-            gl += ls[j] * f;
-            acc += vs[j] * f;
+        for (int j = 0; j < 8; ++j) {
+            if (s0 + 8 * j < n_splits) {  // uniform per split group; no load inside
+                const float nm = fmaxf(m, ms[j]);
+                const float f0 = exp2f(m - nm), f1 = exp2f(ms[j] - nm);
+                l = l * f0 + ls[j] * f1;
+                acc = acc * f0 + vs[j] * f1;
+                m = nm;
+            }
         }
     }
-    if ((int)threadIdx.x < D) out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : acc / gl);
+    s_m[sg][c] = m;
+    s_l[sg][c] = l;
+    s_a[sg][c] = acc;
+    __syncthreads();
+    if (sg == 0) {
+        float gm = s_m[0][c];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) gm = fmaxf(gm, s_m[j][c]);
+        float gl = 0.f, ga = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = exp2f(s_m[j][c] - gm);
+            gl += s_l[j][c] * f;
+            ga += s_a[j][c] * f;
+        }
+        if ((int)blockIdx.y * 32 + c < D) out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : ga / gl);
+    }
     prof_end(prof, prof_t0);
 }
 

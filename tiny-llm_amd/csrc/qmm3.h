@@ -143,8 +143,9 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[tw][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const uint16_t *xbase = xs + (size_t)r * XS + 32 * c;  // A operand: lane (row r of the block, k-block c)
-    const uint32_t nib_mask = 0x000f000fu;
+    uint32_t nib_mask = 0x000f000fu;
     uint32_t magic = 0x43004300u;
+    asm volatile("" : "+s"(nib_mask));  // opaque constants (qmv3.h unpack_w4_bf16): one v_and_or_b32 per unpacked pair
     asm volatile("" : "+v"(magic));
 #pragma unroll
     for (int i = 0; i < LM; ++i) {

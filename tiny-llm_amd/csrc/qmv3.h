@@ -69,23 +69,17 @@ __host__ __device__ inline size_t qmv3_lds_bytes(int MR, int N, int KS, int CW) 
     return qmv3_lds_red_off(MR, N) + red + (size_t)MR * CW * 4 + 64;  // + RMSNorm partial sums of squares
 }
 
-// 8 packed nibbles (n_i = q_2i, n_{i+4} = q_{2i+1}) -> four bf16 pairs (128+q_2i, 128+q_2i+1): 3 shifts + 4 v_bfi_b32
-// ((w & mask) | (magic & ~mask)).  hipcc emits v_and + v_or (11 ops) for the C expression because VOP3 on gfx9
-// cannot take two literals; here the mask sits in an SGPR and the magic in a VGPR.  The trailing s_nop covers the
-// VALU-write -> MFMA-read hazard that the compiler cannot see through an asm statement.
+// 8 packed nibbles (n_i = q_2i, n_{i+4} = q_{2i+1}) -> four bf16 pairs (128+q_2i, 128+q_2i+1): 3 shifts + 4 v_and_or_b32
+// ((w >> 4i) & mask | magic).  With literal constants hipcc emits v_and + v_or (11 ops: VOP3 cannot take two literals), so
+// the caller keeps the mask in an SGPR and the magic in a VGPR that are opaque to constant folding.
+// This is plain C on purpose.  Round 1 wrote these seven instructions as ONE inline-asm statement; the hazard recogniser
+// does not look inside asm, and in the <MR 2, KS 8, CW 8> instantiation the register allocator gave the statement's
+// outputs the registers a still-executing MFMA was reading as its accumulator input (XDL read SrcC -> VALU write, a WAR
+// hazard hipcc pads with s_nop for its own instructions): every output of that variant was garbage (found by
+// tests/test_decode_kernels_gpu.py at the real w_down shape with two activation rows).
 __device__ __forceinline__ u32x4 unpack_w4_bf16(uint32_t w, uint32_t mask_s, uint32_t magic_v) {
-    uint32_t o0, o1, o2, o3;
-    asm("v_bfi_b32 %0, %5, %4, %6\n\t"
-        "v_lshrrev_b32 %1, 4, %4\n\t"
-        "v_lshrrev_b32 %2, 8, %4\n\t"
-        "v_lshrrev_b32 %3, 12, %4\n\t"
-        "v_bfi_b32 %1, %5, %1, %6\n\t"
-        "v_bfi_b32 %2, %5, %2, %6\n\t"
-        "v_bfi_b32 %3, %5, %3, %6\n\t"
-        "s_nop 1"
-        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
-        : "v"(w), "s"(mask_s), "v"(magic_v));
-    return u32x4{o0, o1, o2, o3};
+    return u32x4{(w & mask_s) | magic_v, ((w >> 4) & mask_s) | magic_v, ((w >> 8) & mask_s) | magic_v,
+                 ((w >> 12) & mask_s) | magic_v};
 }
 
 // LM = groups per compute wave (the fixed-length body): the per-wave dependent chain (unpack + MFMA per group) is what
@@ -273,9 +267,10 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
     // LDS addresses: one VGPR base + compile-time offsets (rows >= MR of the A operand repeat row r % MR; never stored)
     const uint16_t *xbase = xs + (size_t)(r % MR) * xstride + 32 * c + (size_t)g0 * 128;
     const float *sbase = xsum + (size_t)g0 * 16 + 4 * c;
-    const uint32_t nib_mask = 0x000f000fu;
+    uint32_t nib_mask = 0x000f000fu;
     uint32_t magic = 0x43004300u;
-    asm volatile("" : "+v"(magic));  // keep the constant in a VGPR (VOP3 takes one scalar operand)
+    asm volatile("" : "+s"(nib_mask));  // opaque constants: the mask in an SGPR, the magic in a VGPR (VOP3 takes one scalar
+    asm volatile("" : "+v"(magic));     // operand and no second literal), so that every unpack is one v_and_or_b32
 #pragma unroll
     for (int i = 0; i < LM; ++i) {
         if (Q3_ABL(1)) {
