@@ -2,7 +2,8 @@
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch.  On gfx950 FETCH_SIZE counts a wide coalesced stream at
 exactly half its bytes (guides/MI355X_MICROARCH.md, HBM section): the factor is re-derived here from stream_kernel,
-whose byte count is known, and applied to the GEMV kernels."""
+whose byte count is known, and applied to the GEMV kernels (never from a GEMV kernel itself: that would make
+its own read/algorithmic ratio 1.000 by construction)."""
 import collections, csv, json, sys
 from pathlib import Path
 
@@ -20,11 +21,19 @@ write = load(src / "write" / "lab_counter_collection.csv")
 shapes = {"qkv": (6144, 2560, "tl::qmv3_kernel<1, 2, 4, 1, 0, 10>", 192 * 256), "o": (2560, 4096, "tl::qmv3_kernel<1, 4, 4, 0, 1, 8>", 160 * 256),
           "gate_up": (19456, 2560, "tl::qmv3_kernel<1, 4, 4, 1, 2, 5>", 1216 * 256), "down": (2560, 9728, "tl::qmv3_kernel<1, 8, 8, 0, 1, 10>", 160 * 512),
           "lm_head": (151936, 2560, "tl::qmv3_kernel<1, 2, 4, 1, 0, 10>", 4748 * 256)}
-# calibration: lm_head-sized stream (the largest stream_kernel dispatch set is a mix of shapes; use the qmv3 lm_head
-# plain variant against its known weight bytes as the wide-stream reference)
-k_lm = fetch[("tl::qmv3_kernel<1, 2, 4, 0, 0, 10>", 4748 * 256)] * 1024
-factor = (151936 * 2560 / 2 + 151936 * 20 * 4) / k_lm
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/lab/gemv_lab pmc (separate passes)", "fetch_size_correction": round(factor, 4),
+# calibration on stream_kernel<4, true> (tools/lab/gemv_lab.hip, pmc mode): a pure 16 B/lane non-temporal stream whose
+# byte count is known exactly -- per shape 2 grids x iters dispatches of K*N/2 bytes each (the lab's own loop bounds)
+known = 0.0
+for K, N in ((6144, 2560), (2560, 4096), (19456, 2560), (2560, 9728), (151936, 2560)):
+    wbytes = K * N // 2 + K * (N // 128) * 4
+    copies = max(1, min(40, (700 << 20) // wbytes + 1))
+    known += 2 * max(3 * copies, 60) * (K * N // 2)
+seen = 0.0
+for r in csv.DictReader(open(src / "fetch" / "lab_counter_collection.csv")):
+    if "stream_kernel" in r["Kernel_Name"]:
+        seen += float(r["Counter_Value"]) * 1024
+factor = known / seen
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/lab/gemv_lab pmc (separate passes)", "fetch_size_correction": round(factor, 4), "fetch_size_calibration": "stream_kernel<4, true>, %.3f GB of known reads" % (known / 1e9),
        "per_kind": {}}
 tot_bytes, tot_alg, launches = 0.0, 0.0, 0
 for name, (K, N, kern, grid) in shapes.items():
