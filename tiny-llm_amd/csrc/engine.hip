@@ -293,7 +293,7 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
         q.eps = c.rms_norm_eps;
         if (launch_qmm3_bf16(q, e->stream, fused_norm ? PRO_RMSNORM : PRO_NONE) != 0)
             return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul launch failed");
-        if (pc) prof_after(e, pc, kind, p3.tile_groups * p3.slices);
+        if (pc) prof_after(e, pc, kind, p3.grid_x * p3.slices);
         float *ss_dst = (ss_out && e->fuse_norm && qmm3_reduce_can_emit_ss(epi, w.rows)) ? ss_out : nullptr;
         int reduce_wg = 0;
         if (launch_qmm3_reduce_bf16(q.partial, p3.slices, M, w.rows, epi, residual, out, q.prof, e->stream, ss_dst, &reduce_wg) != 0)
@@ -378,7 +378,12 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // windows amortise the per-workgroup prologue and skip the merge launch (measured at 16 and 64 sequences)
     const int wg_cap = batch <= 4 ? 2048 : 512;
     while (s * 2 <= bucket / min_tokens && s * 2 * base <= wg_cap && s * 2 <= e->attn_max_splits) s *= 2;  // >= min_tokens per workgroup
-    return SplitPlan{s, bucket / s, rq};
+    // Windows sized to the context, not to its power-of-two bucket: a workgroup walks its whole window in 64-token stages
+    // whether or not the tokens exist, so a 33k context on a 64k bucket spent half of every window on masked loads (r02:
+    // 63 us per layer in the step against 44 us for the same kernel on an exactly filled bucket).  The split COUNT stays a
+    // power of two (the kernels decode blockIdx with shifts); the plan (and its captured graph) changes every 64 * s tokens.
+    const int per_split = ((max_ctx + s - 1) / s + 63) / 64 * 64;
+    return SplitPlan{s, std::max(64, std::min(per_split, bucket / s)), rq};
 }
 
 template <int VD, bool SP>

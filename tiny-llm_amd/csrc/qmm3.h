@@ -21,6 +21,7 @@
 // in a fixed tree), and the staging pass normalises its slice with them (PRO_RMSNORM: bf16(x * inv * w), the reference's
 // rounding point).  Where no such partials exist (the producer was a GEMV) the engine runs rms_norm as its own launch.
 #pragma once
+#include <algorithm>
 #include "common.h"
 #include "qmv.h"
 #include "qmv3.h"
@@ -64,145 +65,187 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
     const int r = lane & 15, c = lane >> 4;
     const int N = p.N, K = p.K, G = N >> 7;
     const int tiles = K >> 4;
+    const int tile_groups = (tiles + QM3_WAVES * TW - 1) / (QM3_WAVES * TW);
     const int slice = blockIdx.y;
     const int g0 = slice * LM;
     const int gn = min(LM, G - g0);  // groups this slice really has (the last slice may be short)
     uint16_t *xs = reinterpret_cast<uint16_t *>(smem);
     float *xsum = reinterpret_cast<float *>(smem + (size_t)ROWS * XS * 2);  // [LM][ROWS]
 
-    // ---- 1. weights of this wave's tiles: everything in flight before the staging ----------------------------------
+    // A workgroup stages its activation slice ONCE and then walks the tile groups tg = blockIdx.x, + gridDim.x, ...: at 33..64
+    // rows the slice (82 KB) is twice the weight bytes of one tile group, and pulling it through one CU's load path
+    // (~32 KiB of misses in flight) per tile group was what bounded the kernel (r02 lab: 608 workgroups x 82 KB for gate|up).
+    // ---- 1. weights of this wave's tiles of the FIRST tile group: in flight before the staging ------------------------
     u32x4 wq[TW][LM];
     uint32_t sq[TW][LM];
     int tile[TW];
+    auto load_weights = [&](int tg) {
 #pragma unroll
-    for (int tw = 0; tw < TW; ++tw) {
-        tile[tw] = (blockIdx.x * QM3_WAVES + wave) * TW + tw;
-        const int tc = min(tile[tw], tiles - 1);
-        const uint32_t *sp = p.sbt + (size_t)tc * G * 16 + r;
-        const u32x4 *wp = reinterpret_cast<const u32x4 *>(p.wt) + (size_t)tc * G * 64 + lane;
+        for (int tw = 0; tw < TW; ++tw) {
+            tile[tw] = (tg * QM3_WAVES + wave) * TW + tw;
+            const int tc = min(tile[tw], tiles - 1);
+            const uint32_t *sp = p.sbt + (size_t)tc * G * 16 + r;
+            const u32x4 *wp = reinterpret_cast<const u32x4 *>(p.wt) + (size_t)tc * G * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < LM; ++i) sq[tw][i] = sp[(size_t)min(g0 + i, G - 1) * 16];
+            for (int i = 0; i < LM; ++i) sq[tw][i] = sp[(size_t)min(g0 + i, G - 1) * 16];
 #pragma unroll
-        for (int i = 0; i < LM; ++i) wq[tw][i] = __builtin_nontemporal_load(wp + (size_t)min(g0 + i, G - 1) * 64);
-    }
+            for (int i = 0; i < LM; ++i) wq[tw][i] = __builtin_nontemporal_load(wp + (size_t)min(g0 + i, G - 1) * 64);
+        }
+    };
+    int tg = blockIdx.x;
+    load_weights(tg);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- 2. activation slice -> LDS, per-(group,row) sums ------------------------------------------------------------
-    // chunk = 8 consecutive elements; a row of the slice has LM*16 chunks; 16 consecutive lanes cover one group of one row
+    // chunk = 8 consecutive elements; a row of the slice has LM*16 chunks; 16 consecutive lanes cover one group of one row.
+    // The loads of SB chunks per thread are issued together (one dependent round trip per chunk cost ~1 us each).
     {
         constexpr int CPR = LM * 16;
         constexpr int CHUNKS = ROWS * CPR;
         constexpr int ITER = (CHUNKS + T - 1) / T;
+        constexpr int SB = ITER < 5 ? ITER : 5;
+        for (int it0 = 0; it0 < ITER; it0 += SB) {
+            u32x4 v[SB], gw[SB];
+            f32x4 s0[SB], s1[SB];
+            bool ok[SB];
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {  // CHUNKS is a multiple of 64: whole waves drop out, a 16-lane group stays in one row/group
-            const int ch = tid + it * T;
-            if (ch >= CHUNKS || (QMM3_ABL & 2)) break;
-            const int row = ch / CPR;
-            const int cc = ch - row * CPR;
-            const int g = cc >> 4;
-            const bool ok = row < p.M && g < gn;
-            u32x4 v = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)row * N + (size_t)g0 * 128 + (size_t)cc * 8) : 0));
-            if (!ok) v = u32x4{0u, 0u, 0u, 0u};
-            float f[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f[2 * e] = BF16::to_float((uint16_t)(v[e] & 0xffffu));
-                f[2 * e + 1] = BF16::to_float((uint16_t)(v[e] >> 16));
-            }
-            if constexpr (PRO == PRO_RMSNORM) {
-                // the row's sum of squares from its producers' partials (fixed summation tree), the weights of this chunk
-                const size_t rrow = ok ? (size_t)row : 0;
-                const f32x4 s0 = *reinterpret_cast<const f32x4 *>(p.ss + rrow * QM3_SS);
-                const f32x4 s1 = *reinterpret_cast<const f32x4 *>(p.ss + rrow * QM3_SS + 4);
-                const u32x4 gw = *reinterpret_cast<const u32x4 *>(p.norm_w + (ok ? ((size_t)g0 * 128 + (size_t)cc * 8) : 0));
-                const float tot = ((s0[0] + s0[1]) + (s0[2] + s0[3])) + ((s1[0] + s1[1]) + (s1[2] + s1[3]));
-                const float inv = rsqrtf(tot / (float)N + p.eps);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    f[2 * e] = bf16_round(f[2 * e] * inv * BF16::to_float((uint16_t)(gw[e] & 0xffffu)));
-                    f[2 * e + 1] = bf16_round(f[2 * e + 1] * inv * BF16::to_float((uint16_t)(gw[e] >> 16)));
-                    v[e] = ok ? BF16::pack2(f[2 * e], f[2 * e + 1]) : 0u;
+            for (int j = 0; j < SB; ++j) {
+                const int ch = min(tid + (it0 + j) * T, CHUNKS - 1);
+                const int row = ch / CPR;
+                const int cc = ch - row * CPR;
+                ok[j] = tid + (it0 + j) * T < CHUNKS && row < p.M && (cc >> 4) < gn && !(QMM3_ABL & 2);
+                v[j] = *reinterpret_cast<const u32x4 *>(p.a + (ok[j] ? ((size_t)row * N + (size_t)g0 * 128 + (size_t)cc * 8) : 0));
+                if constexpr (PRO == PRO_RMSNORM) {
+                    const size_t rrow = ok[j] ? (size_t)row : 0;
+                    s0[j] = *reinterpret_cast<const f32x4 *>(p.ss + rrow * QM3_SS);
+                    s1[j] = *reinterpret_cast<const f32x4 *>(p.ss + rrow * QM3_SS + 4);
+                    gw[j] = *reinterpret_cast<const u32x4 *>(p.norm_w + (ok[j] ? ((size_t)g0 * 128 + (size_t)cc * 8) : 0));
                 }
             }
-            *reinterpret_cast<u32x4 *>(xs + (size_t)row * XS + (size_t)cc * 8) = v;
-            if constexpr (QMM3_ABL & 8) {
-                if ((cc & 15) == 0) xsum[g * ROWS + row] = f[0];
-                continue;
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int chu = tid + (it0 + j) * T;
+                if (chu >= CHUNKS) break;  // CHUNKS is a multiple of 64: whole waves drop out, a 16-lane group stays in one row/group
+                const int row = chu / CPR;
+                const int cc = chu - row * CPR;
+                const int g = cc >> 4;
+                u32x4 x = ok[j] ? v[j] : u32x4{0u, 0u, 0u, 0u};
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f[2 * e] = BF16::to_float((uint16_t)(x[e] & 0xffffu));
+                    f[2 * e + 1] = BF16::to_float((uint16_t)(x[e] >> 16));
+                }
+                if constexpr (PRO == PRO_RMSNORM) {
+                    // the row's sum of squares from its producers' partials (fixed summation tree), the weights of this chunk
+                    const float tot = ((s0[j][0] + s0[j][1]) + (s0[j][2] + s0[j][3])) + ((s1[j][0] + s1[j][1]) + (s1[j][2] + s1[j][3]));
+                    const float inv = rsqrtf(tot / (float)N + p.eps);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f[2 * e] = bf16_round(f[2 * e] * inv * BF16::to_float((uint16_t)(gw[j][e] & 0xffffu)));
+                        f[2 * e + 1] = bf16_round(f[2 * e + 1] * inv * BF16::to_float((uint16_t)(gw[j][e] >> 16)));
+                        x[e] = ok[j] ? BF16::pack2(f[2 * e], f[2 * e + 1]) : 0u;
+                    }
+                }
+                *reinterpret_cast<u32x4 *>(xs + (size_t)row * XS + (size_t)cc * 8) = x;
+                if constexpr (QMM3_ABL & 8) {
+                    if ((cc & 15) == 0) xsum[g * ROWS + row] = f[0];
+                    continue;
+                }
+                float sum = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+                sum = group16_sum(sum);
+                if ((cc & 15) == 0) xsum[g * ROWS + row] = sum;
             }
-            float sum = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-            sum = group16_sum(sum);
-            if ((cc & 15) == 0) xsum[g * ROWS + row] = sum;
         }
     }
     __syncthreads();
 
-    // ---- 3. MFMA over the slice --------------------------------------------------------------------------------------
-    f32x4 acc[TW][MB];
-#pragma unroll
-    for (int tw = 0; tw < TW; ++tw)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) acc[tw][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const uint16_t *xbase = xs + (size_t)r * XS + 32 * c;  // A operand: lane (row r of the block, k-block c)
     uint32_t nib_mask = 0x000f000fu;
     uint32_t magic = 0x43004300u;
     asm volatile("" : "+s"(nib_mask));  // opaque constants (qmv3.h unpack_w4_bf16): one v_and_or_b32 per unpacked pair
     asm volatile("" : "+v"(magic));
-#pragma unroll
-    for (int i = 0; i < LM; ++i) {
-        f32x4 d[TW][MB];
+    for (;;) {
+        // ---- 3. MFMA over the slice for this tile group ---------------------------------------------------------------
+        // The staged slice does not change any more, so the compiler would hoist all MB * LM * 4 fragment reads out of this
+        // loop (320 VGPRs, spilled): the LDS addresses are laundered once per tile group.
+        const uint16_t *xb = xbase;
+        const float *xsm = xsum;
+        asm volatile("" : "+v"(xb), "+v"(xsm));
+        f32x4 acc[TW][MB];
 #pragma unroll
         for (int tw = 0; tw < TW; ++tw)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) d[tw][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int mb = 0; mb < MB; ++mb) acc[tw][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            u32x4 bq[TW];
+        for (int i = 0; i < LM; ++i) {
+            f32x4 d[TW][MB];
 #pragma unroll
-            for (int tw = 0; tw < TW; ++tw) bq[tw] = unpack_w4_bf16(wq[tw][i][t], nib_mask, magic);
+            for (int tw = 0; tw < TW; ++tw)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const u32x4 ax = *reinterpret_cast<const u32x4 *>(xbase + (size_t)mb * 16 * XS + i * 128 + 8 * t);
+                for (int mb = 0; mb < MB; ++mb) d[tw][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int tw = 0; tw < TW; ++tw) {
-                    if constexpr (QMM3_ABL & 1) d[tw][mb][t] += __uint_as_float((ax[0] ^ bq[tw][1]) & 0x3f800000u);
-                    else
-                    d[tw][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax),
-                                                                        __builtin_bit_cast(bf16x8_t, bq[tw]), d[tw][mb], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                u32x4 bq[TW];
+#pragma unroll
+                for (int tw = 0; tw < TW; ++tw) bq[tw] = unpack_w4_bf16(wq[tw][i][t], nib_mask, magic);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const u32x4 ax = *reinterpret_cast<const u32x4 *>(xb + (size_t)mb * 16 * XS + i * 128 + 8 * t);
+#pragma unroll
+                    for (int tw = 0; tw < TW; ++tw) {
+                        if constexpr (QMM3_ABL & 1) d[tw][mb][t] += __uint_as_float((ax[0] ^ bq[tw][1]) & 0x3f800000u);
+                        else
+                        d[tw][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax),
+                                                                            __builtin_bit_cast(bf16x8_t, bq[tw]), d[tw][mb], 0, 0, 0);
+                    }
                 }
             }
+#pragma unroll
+            for (int tw = 0; tw < TW; ++tw) {
+                const uint32_t sw = i < gn ? sq[tw][i] : 0u;  // groups past the end of the row contribute nothing
+                const float sc = __uint_as_float(sw << 16);
+                const float be = __uint_as_float(sw & 0xffff0000u) - 128.0f * sc;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const f32x4 xg = *reinterpret_cast<const f32x4 *>(xsm + i * ROWS + mb * 16 + 4 * c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[tw][mb][j] += sc * d[tw][mb][j] + be * xg[j];
+                }
+            }
+            // many row blocks: keep the scheduler from pulling the next groups' fragment reads (16 VGPRs per MFMA operand)
+            // ahead of this group's MFMAs -- it ran the kernel into scratch; the second wave of the SIMD covers the bubble
+            if constexpr (MB * TW >= 4 || (MB == 2 && LM >= 8)) __builtin_amdgcn_sched_barrier(0);
         }
+        int done_tile[TW];
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) done_tile[tw] = tile[tw];
+        // the next tile group's weights go out before this one's partial sums are stored
+        tg += gridDim.x;
+        const bool more = tg < tile_groups;  // uniform
+        if (more) load_weights(tg);
+
+        // ---- 4. partial sums: lane (weight row r, c) holds activation rows 16 mb + 4c + j ----------------------------
 #pragma unroll
         for (int tw = 0; tw < TW; ++tw) {
-            const uint32_t sw = i < gn ? sq[tw][i] : 0u;  // groups past the end of the row contribute nothing
-            const float sc = __uint_as_float(sw << 16);
-            const float be = __uint_as_float(sw & 0xffff0000u) - 128.0f * sc;
+            if (done_tile[tw] >= tiles) continue;
+            const int ocol = (done_tile[tw] << 4) + r;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const f32x4 xg = *reinterpret_cast<const f32x4 *>(xsum + i * ROWS + mb * 16 + 4 * c);
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[tw][mb][j] += sc * d[tw][mb][j] + be * xg[j];
-            }
+                for (int j = 0; j < 4; ++j) {
+                    const int row = mb * 16 + 4 * c + j;
+                    if (row < p.M && (!(QMM3_ABL & 4) || acc[tw][mb][j] == 123.f)) p.partial[((size_t)slice * p.M + row) * K + ocol] = acc[tw][mb][j];
+                }
         }
-    }
-
-    // ---- 4. partial sums: lane (weight row r, c) holds activation rows 16 mb + 4c + j --------------------------------
-#pragma unroll
-    for (int tw = 0; tw < TW; ++tw) {
-        if (tile[tw] >= tiles) continue;
-        const int ocol = (tile[tw] << 4) + r;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = mb * 16 + 4 * c + j;
-                if (row < p.M && (!(QMM3_ABL & 4) || acc[tw][mb][j] == 123.f)) p.partial[((size_t)slice * p.M + row) * K + ocol] = acc[tw][mb][j];
-            }
+        if (!more) break;
     }
     prof_end(p.prof, prof_t0);
 }
 
 struct Qmm3Plan {
     int MB, TW, LM, slices, tile_groups;
+    int grid_x;  // workgroups per slice: each walks tile groups grid_x apart (about one resident workgroup per CU in total)
     size_t lds, partial_bytes;
     bool ok;
 };
@@ -213,12 +256,13 @@ inline Qmm3Plan qmm3_plan(int M, int N, int K) {
     if (!pl.ok) return pl;
     pl.MB = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     const int G = N / 128, tiles = K / 16;
-    pl.TW = (pl.MB == 4 && tiles >= 2048) ? 2 : 1;
+    pl.TW = 1;  // two tiles per wave (TW = 2) halve the fragment reads per MFMA but spill with the tile-group loop (hipcc, 256 VGPRs)
     pl.tile_groups = (tiles + QM3_WAVES * pl.TW - 1) / (QM3_WAVES * pl.TW);
     const int cand[4] = {10, 8, 5, 4};
     pl.LM = 4;
     for (int lm : cand) {
         if (qmm3_lds_bytes(pl.MB, lm) > 100 * 1024) continue;
+        if (pl.MB == 2 && lm == 10) continue;  // 256 VGPRs + scratch; 8 groups per slice stay in registers
         const int slices = (G + lm - 1) / lm;
         pl.LM = lm;
         if ((long)slices * pl.tile_groups >= 192 || lm == 4) break;
@@ -226,6 +270,9 @@ inline Qmm3Plan qmm3_plan(int M, int N, int K) {
     pl.slices = (G + pl.LM - 1) / pl.LM;
     pl.lds = qmm3_lds_bytes(pl.MB, pl.LM);
     pl.partial_bytes = (size_t)pl.slices * M * K * 4;
+    // resident workgroups: 160 KiB of LDS per CU, at most 2 of these 512-thread workgroups per CU are useful
+    const int per_cu = (int)std::min<size_t>(2, std::max<size_t>(1, (size_t)(160 * 1024) / (pl.lds + 1024)));
+    pl.grid_x = std::min(pl.tile_groups, std::max(1, (256 * per_cu + pl.slices - 1) / pl.slices));
     return pl;
 }
 

@@ -104,7 +104,7 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro) {
     const Qmm3Plan pl = qmm3_plan(args.M, args.N, args.K);
     if (!pl.ok) return -1;
     if (pro == PRO_RMSNORM && (!args.ss || !args.norm_w)) return -1;
-    const dim3 grid(pl.tile_groups, pl.slices), block(QM3_WAVES * 64);
+    const dim3 grid(pl.grid_x, pl.slices), block(QM3_WAVES * 64);
 #define QM3_CASE(MBv, TWv, LMv)                                                                                     \
     if (pl.MB == MBv && pl.TW == TWv && pl.LM == LMv) {                                                             \
         auto kern = pro == PRO_RMSNORM ? qmm3_kernel<MBv, TWv, LMv, PRO_RMSNORM> : qmm3_kernel<MBv, TWv, LMv, PRO_NONE>; \
