@@ -5,6 +5,8 @@ MODEL_SHORTCUTS = {
     "qwen3-1.7b": "Qwen/Qwen3-1.7B-MLX-4bit",
     "qwen3-4b": "Qwen/Qwen3-4B-MLX-4bit",
     "qwen3-8b": "Qwen/Qwen3-8B-MLX-4bit",
+    "qwen3-30b-a3b": "Qwen/Qwen3-30B-A3B-MLX-4bit",
+    "qwen3-moe-30b-a3b": "Qwen/Qwen3-30B-A3B-MLX-4bit",
 }
 
 

@@ -56,7 +56,9 @@ def scaled_dot_product_attention_grouped(
     elif mask is not None:
         full = torch.broadcast_to(mask, (*lead, heads, q_len, ctx))
         scores = scores + full.reshape(*lead, kv_heads, rep, q_len, ctx)
-    return torch.matmul(softmax(scores, axis=-1), v).reshape(shape)
+    probs = softmax(scores, axis=-1)
+    # an fp32 mask on 16-bit inputs promotes the scores (as MLX's type promotion does); the values follow them
+    return torch.matmul(probs, v.to(probs.dtype)).reshape(shape)
 
 
 def _validate_page_metadata(context_values, block_rows, *, page_size, max_pages, num_physical_pages, L) -> None:

@@ -5,6 +5,12 @@ from typing import Callable
 import torch
 
 
+def _default_device(device=None) -> str:
+    """The extension is GPU-only; without a GPU (CPU test tier, schedule-only runs) tensors stay on the host."""
+    return device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+
+
+
 def _release_kv_cache(kv_cache) -> None:
     if kv_cache is None:
         return
@@ -18,9 +24,9 @@ def _log_softmax_last(logits: torch.Tensor) -> torch.Tensor:
 
 
 def simple_generate(model, tokenizer, prompt: str, sampler: Callable[[torch.Tensor], torch.Tensor] | None,
-                    device: str = "cuda", max_new_tokens: int | None = None) -> str:
+                    device: str | None = None, max_new_tokens: int | None = None) -> str:
     """Week-1 loop: the whole context is re-run for every token (no KV cache)."""
-    tokens = torch.tensor(tokenizer.encode(prompt, add_special_tokens=False), dtype=torch.int32, device=device)
+    tokens = torch.tensor(tokenizer.encode(prompt, add_special_tokens=False), dtype=torch.int32, device=_default_device(device))
     detok = tokenizer.detokenizer
     detok.reset()
     produced = 0
@@ -37,12 +43,12 @@ def simple_generate(model, tokenizer, prompt: str, sampler: Callable[[torch.Tens
     return detok.text
 
 
-def simple_generate_with_kv_cache(model, tokenizer, prompt: str, device: str = "cuda",
+def simple_generate_with_kv_cache(model, tokenizer, prompt: str, device: str | None = None,
                                   max_new_tokens: int | None = None) -> str:
     """Week-2/3 loop: one prefill call, then one token per call, one host sync per token."""
     kv_cache = model.create_kv_cache()
     try:
-        tokens = torch.tensor(tokenizer.encode(prompt, add_special_tokens=False), dtype=torch.int32, device=device)
+        tokens = torch.tensor(tokenizer.encode(prompt, add_special_tokens=False), dtype=torch.int32, device=_default_device(device))
         detok = tokenizer.detokenizer
         detok.reset()
         offset = 0
@@ -64,7 +70,7 @@ def simple_generate_with_kv_cache(model, tokenizer, prompt: str, device: str = "
 
 
 def speculative_generate(draft_model, model, draft_tokenizer, tokenizer, prompt: str, proposal_length: int = 4,
-                         device: str = "cuda") -> str:
+                         device: str | None = None) -> str:
     """Greedy speculative decoding (reference: src/tiny_llm_ref/generate.py:84-322, tests_refsol/test_week_3_day_7.py).
 
     The draft model proposes up to ``proposal_length`` tokens; the target scores the pending token plus the proposals in ONE
@@ -103,7 +109,7 @@ def speculative_generate(draft_model, model, draft_tokenizer, tokenizer, prompt:
 
     def greedy(net, ids, offset, cache, keep=1):
         """argmax of the last `keep` positions of net(ids) appended at `offset`."""
-        y = torch.tensor(ids, dtype=torch.int32, device=device)
+        y = torch.tensor(ids, dtype=torch.int32, device=_default_device(device))
         logits = net(y[None], offset, cache, logits_to_keep=keep)[:, -keep:, :].to(torch.float32)
         return [int(t) for t in torch.argmax(logits, dim=-1).reshape(-1).tolist()]
 

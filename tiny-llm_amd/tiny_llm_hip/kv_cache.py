@@ -15,7 +15,14 @@ if TYPE_CHECKING:  # pragma: no cover
 
 def materialize_tensors(*tensors: torch.Tensor) -> None:
     """Counterpart of ``mx.eval(...)`` on cache storage.  PyTorch launches eagerly, so there is no lazy graph
-    to cut; the hook exists so schedulers keep the reference's call structure (and tests can observe it)."""
+    to cut; the hook exists so schedulers keep the reference's call structure (and tests can observe it).
+    When the `mlx.core` import facade (tiny-llm_amd/compat) is loaded, the call goes through ITS ``eval`` -- harness code
+    written against the reference instruments ``mx.eval`` (tests_refsol/test_week_3_day_3.py:289-306)."""
+    import sys
+
+    facade = sys.modules.get("mlx.core")
+    if facade is not None and hasattr(facade, "eval"):
+        facade.eval(*tensors)
     return None
 
 
