@@ -30,7 +30,7 @@ int main(int argc, char **argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / iters;
         printf("  %-8s M=%d (MB%d TW%d LM%d, %d x %d workgroups, lds %zu): %7.1f us  weights %6.1f GB/s  %6.1f TFLOP/s\n", sh.name, M, pl.MB, pl.TW, pl.LM,
-               pl.tile_groups, pl.slices, pl.lds, us, wwords * 4 / us / 1e3, 2.0 * M * K * N / us / 1e6);
+               pl.grid_x, pl.slices, pl.lds, us, wwords * 4 / us / 1e3, 2.0 * M * K * N / us / 1e6);
         CK(hipFree(w)); CK(hipFree(sb)); CK(hipFree(a)); CK(hipFree(partial));
     }
     return 0;
