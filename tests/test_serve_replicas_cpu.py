@@ -95,3 +95,15 @@ def test_two_replicas_over_gloo_match_one_replica_serving_everything(tmp_path):
     assert a["requests"] == b["requests"] == 96 and a["generated_tokens"] == b["generated_tokens"]
     assert [r["requests"] for r in b["per_replica"]] == [48, 48]
     assert 0.4 < b["wall_s"] / a["wall_s"] < 0.75
+
+
+def test_config1_week1_cpu_runner_smoke():
+    """BASELINE config 1 (Qwen3-0.6B Week-1 greedy decode on the host CPU): the runner builds the dense Week-1 model of the
+    host mirror on CPU tensors and generates greedily without a KV cache (shrunk to 2 layers / 4k vocabulary here)."""
+    from benches.bench_config1 import main
+
+    out = main(["--layers", "2", "--vocab", "4096", "--prompt-len", "8", "--new-tokens", "4"])
+    assert out["generated_tokens"] == 4 and out["prompt_tokens"] == 8 and out["layers"] == 2
+    assert all(0 <= t < 4096 for t in out["first_ids"]) and out["decode_tok_s"] > 0
+    again = main(["--layers", "2", "--vocab", "4096", "--prompt-len", "8", "--new-tokens", "4"])
+    assert again["first_ids"] == out["first_ids"], "seeded weights and prompt: the greedy ids must reproduce"
