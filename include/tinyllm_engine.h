@@ -206,13 +206,15 @@ typedef struct tl_linear_info {
     int kernel;
     int launches;
     int rows_per_pass; /* activation rows per launch (the GEMV splits M when the staged rows exceed LDS) */
-    int p[5];
+    int p[5]; /* GEMV: MR, KS, CW, LM, workgroups.  Skinny matmul: MB (16-row blocks), TW (tiles per wave; 0 = the persistent
+                 grid, one workgroup per CU), LM (groups per slice), slices, workgroups */
 } tl_linear_info;
 
 /* out = epilogue(prologue(a) @ W^T) over M (1..64) bf16 rows, exactly as one projection of a decode step:
  *   prologue 0 none | 1 RMSNorm(a, norm_w, eps) rounded to bf16;  epilogue 0 store | 1 residual + bf16(acc) |
  *   2 SwiGLU over interleaved (gate_i, up_i) rows -> out [M, rows/2].
- *   kernel 0 = the engine's routing by M and matrix size, 1 = force the fused GEMV (M <= 8), 2 = force the skinny matmul.
+ *   kernel 0 = the engine's routing by M and matrix size, 1 = force the fused GEMV (M <= 8), 2 = force the skinny matmul
+ *   (grid chosen by shape as the engine does), 3 / 4 = the skinny matmul on its one-shot / persistent grid.
  * The engine uses the pairs (1,0) qkv / lm_head, (0,1) wo / w_down, (1,2) gate|up, (0,0). */
 size_t tl_decode_linear_workspace_bytes(int M, int rows, int cols);
 int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,

@@ -156,17 +156,32 @@ def test_fused_gemv_at_qwen3_4b_shapes(ext, projection, M):
         _check(p, got, M, variant, what)
 
 
-@pytest.mark.parametrize("M", [5, 9, 16, 33, 64])
+# The skinny matmul has two grids (csrc/qmm3.h): kernel 3 = one workgroup per (tile group, slice), kernel 4 = persistent (one
+# workgroup per CU, 8-group slices); the planner's choice by shape (qmm3_prefers_persistent, from the r02 lab) for the real
+# matrices, by 16-row blocks MB = 1 (<= 16 rows), 2 (<= 32), 4 (<= 64):
+PERSISTENT_FROM_MB = {"qkv": None, "wo": None, "gate_up": 1, "down": 2, "lm_head": 2}
+
+
+@pytest.mark.parametrize("M", [5, 9, 16, 17, 32, 33, 64])
 @pytest.mark.parametrize("projection", list(PROJECTIONS), indirect=True)
 def test_skinny_matmul_at_qwen3_4b_shapes(ext, projection, M):
-    """qmm3_kernel + qmm3_reduce_kernel (batched decode, 5..64 rows): fp32 slice partials summed in slice order, the
-    engine's epilogues applied by the reduction; includes the 64-row lm_head whose partials are the largest workspace."""
+    """qmm3_kernel / qmm3p_kernel + qmm3_reduce_kernel (batched decode, 5..64 rows): fp32 slice partials summed in slice order,
+    the engine's epilogues applied by the reduction; includes the 64-row lm_head whose partials are the largest workspace.
+    Both grids are held against the oracle for every projection and row count; the grid the planner picks is asserted."""
     p = projection
-    for variant in _variants(p):
-        got, info = p.run(ext, M, variant, kernel=2)
-        what = f"qmm3 {p.name} M={M} variant={variant} {info}"
-        assert info["kernel"] == 2, what
-        _check(p, got, M, variant, what)
+    MB = 1 if M <= 16 else (2 if M <= 32 else 4)
+    for grid in (3, 4):
+        for variant in _variants(p):
+            got, info = p.run(ext, M, variant, kernel=grid)
+            what = f"qmm3 grid {grid} {p.name} M={M} variant={variant} {info}"
+            assert info["kernel"] == 2 and info["p"][0] == MB, what
+            assert (info["p"][1] == 0) == (grid == 4), f"{what}: p[1] = tiles per wave, 0 on the persistent grid"
+            if grid == 4:
+                assert info["p"][2] in (4, 8) and info["p"][4] <= 256, f"{what}: at most one workgroup per CU"
+            _check(p, got, M, variant, what)
+    _, info = p.run(ext, M, (p.pro, p.epi), kernel=2)
+    want_persistent = PERSISTENT_FROM_MB[p.name] is not None and MB >= PERSISTENT_FROM_MB[p.name] and not (p.name == "lm_head" and MB == 1)
+    assert info["kernel"] == 2 and (info["p"][1] == 0) == want_persistent, f"planner's grid for {p.name} at M={M}: {info}"
     if M > 8:  # the engine's own routing sends more than 8 rows here as well
         _, info = p.run(ext, M, (p.pro, p.epi), kernel=0)
         assert info["kernel"] == 2, f"routing at M={M}: {info}"

@@ -82,6 +82,7 @@ struct tl_engine {
     bool attn_wide_vector_ids = false;  // TL_ATTN_VECTOR_IDS=1: page ids by vector loads even where scalar loads apply
     tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
     int force_linear = 0;               // kernel-level entry points: 1 = fused GEMV, 2 = skinny matmul
+    int qmm3_mode = -1;                 // skinny matmul grid: -1 by shape (qmm3_plan), 0 one-shot, 1 persistent
     size_t attn_ws_bytes = 0;
     int rows_cap = 0;
     int ring_cap = 4096;
@@ -271,7 +272,7 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
     // qmm3_min_rows .. 64 rows (batched decode): K-sliced skinny MFMA matmul over the tiled weights, then the slice
     // reduction with the epilogue.  RMSNorm runs as its own launch (a slice does not see the whole row).
     const auto tiled = e->tiled.find(w.weight_dev);
-    const Qmm3Plan p3 = qmm3_plan(M, w.cols, w.rows);
+    const Qmm3Plan p3 = qmm3_plan(M, w.cols, w.rows, e->qmm3_mode);
     if (e->use_qmm3 && M <= 64 && tiled != e->tiled.end() && p3.ok) {
         const bool fused_norm = pro == PRO_RMSNORM && ss_in != nullptr && e->fuse_norm;
         if (pro == PRO_RMSNORM && !fused_norm) {
@@ -291,9 +292,9 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
         q.norm_w = (const uint16_t *)norm_w;
         q.ss = ss_in;
         q.eps = c.rms_norm_eps;
-        if (launch_qmm3_bf16(q, e->stream, fused_norm ? PRO_RMSNORM : PRO_NONE) != 0)
+        if (launch_qmm3_bf16(q, e->stream, fused_norm ? PRO_RMSNORM : PRO_NONE, e->qmm3_mode) != 0)
             return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul launch failed");
-        if (pc) prof_after(e, pc, kind, p3.grid_x * p3.slices);
+        if (pc) prof_after(e, pc, kind, p3.persistent ? p3.grid_x : p3.grid_x * p3.slices);
         float *ss_dst = (ss_out && e->fuse_norm && qmm3_reduce_can_emit_ss(epi, w.rows)) ? ss_out : nullptr;
         int reduce_wg = 0;
         if (launch_qmm3_reduce_bf16(q.partial, p3.slices, M, w.rows, epi, residual, out, q.prof, e->stream, ss_dst, &reduce_wg) != 0)
@@ -306,7 +307,8 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
             li.kernel = 2;
             li.launches += 2 + (pro == PRO_RMSNORM && !fused_norm ? 1 : 0);
             li.rows_per_pass = M;
-            li.p[0] = p3.MB, li.p[1] = p3.TW, li.p[2] = p3.LM, li.p[3] = p3.slices, li.p[4] = p3.tile_groups;
+            li.p[0] = p3.MB, li.p[1] = p3.persistent ? 0 : p3.TW, li.p[2] = p3.LM, li.p[3] = p3.slices;
+            li.p[4] = p3.persistent ? p3.grid_x : p3.grid_x * p3.slices;
         }
         return TL_OK;
     }
@@ -1415,9 +1417,12 @@ extern "C" void tl_tiled_w4_destroy(tl_tiled_w4 *t) {
 extern "C" size_t tl_decode_linear_workspace_bytes(int M, int rows, int cols) {
     if (M <= 0 || rows <= 0 || cols <= 0) return 0;
     size_t need = align_up((size_t)M * cols * 2, 256);  // RMSNorm output ahead of the skinny matmul
-    const Qmm3Plan p3 = qmm3_plan(std::min(M, 64), cols, rows);
-    if (p3.ok) need += p3.partial_bytes;
-    return need;
+    size_t partial = 0;
+    for (int mode = 0; mode < 2; ++mode) {  // either grid of the skinny matmul (kernel 3 / 4 pin one)
+        const Qmm3Plan p3 = qmm3_plan(std::min(M, 64), cols, rows, mode);
+        if (p3.ok) partial = std::max(partial, p3.partial_bytes);
+    }
+    return need + partial;
 }
 
 extern "C" int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
@@ -1430,7 +1435,8 @@ extern "C" int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *o
                "decode_linear: epilogue is 0 (store), 1 (residual add) or 2 (SwiGLU over interleaved rows)");
     TL_REQUIRE(prologue != PRO_RMSNORM || norm_w_dev, "decode_linear: the RMSNorm prologue needs its weight");
     TL_REQUIRE(epilogue != EPI_RESIDUAL || residual_dev, "decode_linear: the residual epilogue needs the residual rows");
-    TL_REQUIRE(kernel >= 0 && kernel <= 2, "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV) or 2 (skinny matmul)");
+    TL_REQUIRE(kernel >= 0 && kernel <= 4,
+               "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV), 2 (skinny matmul), 3 / 4 (its one-shot / persistent grid)");
     TL_REQUIRE(epilogue != EPI_SWIGLU || w->w.rows % 2 == 0, "decode_linear: SwiGLU needs an even number of weight rows");
     // the engine's own fused variants: RMSNorm+store (qkv, lm_head), residual (wo, w_down), RMSNorm+SwiGLU (gate|up), plain
     TL_REQUIRE((prologue == PRO_NONE && epilogue != EPI_SWIGLU) || (prologue == PRO_RMSNORM && epilogue != EPI_RESIDUAL),
@@ -1445,7 +1451,8 @@ extern "C" int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *o
     const size_t xn_bytes = align_up((size_t)M * w->w.cols * 2, 256);
     e.splitk_ws = (char *)workspace_dev + xn_bytes;
     e.splitk_ws_bytes = workspace_bytes - xn_bytes;
-    e.force_linear = kernel;
+    e.force_linear = kernel >= 2 ? 2 : kernel;
+    e.qmm3_mode = kernel == 3 ? 0 : (kernel == 4 ? 1 : -1);
     tl_linear_info li{};
     e.linfo = &li;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e.qmm3_min_rows = std::max(1, atoi(q));

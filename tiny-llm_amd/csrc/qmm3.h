@@ -28,7 +28,8 @@
 namespace tl {
 
 #ifndef QMM3_ABL
-#define QMM3_ABL 0  // tools/lab/qmm3_lab only: 1 no MFMA, 2 no activation staging, 4 no partial stores, 8 no group-sum arithmetic
+#define QMM3_ABL 0  // tools/lab/qmm3_lab only: 1 no MFMA, 2 no activation staging, 4 no partial stores, 8 no group-sum arithmetic,
+                    // 64 per-wave phase stamps of the persistent kernel into args.prof
 #endif
 constexpr int QM3_WAVES = 8;
 // The staged rows are NOT padded: a 128-element group is exactly one 64-bank row, and the 16-byte chunks inside it are
@@ -53,6 +54,79 @@ struct Qmm3Args {
 
 __host__ __device__ inline size_t qmm3_lds_bytes(int MB, int LM) {
     return (size_t)MB * 16 * (LM * 128 + QM3_PAD) * 2 + (size_t)LM * MB * 16 * 4;
+}
+
+// Activation slice [MB*16 rows][LM groups] -> LDS (XOR-swizzled 16-byte chunks, see QM3_PAD) + per-(group,row) sums, by all
+// QM3_WAVES*64 threads of the workgroup.  chunk = 8 consecutive elements; a row of the slice has LM*16 chunks; 16 consecutive
+// lanes cover one group of one row.  The loads of SB chunks per thread are issued together (one dependent round trip per
+// chunk cost ~1 us each).  PRO_RMSNORM: the rows are normalised on the way in (bf16(x * inv * w), the reference's rounding point).
+template <int MB, int LM, int PRO, int SBMAX = 5>
+__device__ __forceinline__ void qmm3_stage_slice(const Qmm3Args &p, int g0, int gn, uint16_t *xs, float *xsum, int tid) {
+    constexpr int T = QM3_WAVES * 64;
+    constexpr int ROWS = MB * 16;
+    constexpr int XS = LM * 128 + QM3_PAD;
+    const int N = p.N;
+    constexpr int CPR = LM * 16;
+    constexpr int CHUNKS = ROWS * CPR;
+    constexpr int ITER = (CHUNKS + T - 1) / T;
+    constexpr int SB = ITER < SBMAX ? ITER : SBMAX;
+    for (int it0 = 0; it0 < ITER; it0 += SB) {
+        u32x4 v[SB], gw[SB];
+        f32x4 s0[SB], s1[SB];
+        bool ok[SB];
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            const int ch = min(tid + (it0 + j) * T, CHUNKS - 1);
+            const int row = ch / CPR;
+            const int cc = ch - row * CPR;
+            ok[j] = tid + (it0 + j) * T < CHUNKS && row < p.M && (cc >> 4) < gn && !(QMM3_ABL & 2);
+            v[j] = *reinterpret_cast<const u32x4 *>(p.a + (ok[j] ? ((size_t)row * N + (size_t)g0 * 128 + (size_t)cc * 8) : 0));
+            if constexpr (PRO == PRO_RMSNORM) {
+                const size_t rrow = ok[j] ? (size_t)row : 0;
+                s0[j] = *reinterpret_cast<const f32x4 *>(p.ss + rrow * QM3_SS);
+                s1[j] = *reinterpret_cast<const f32x4 *>(p.ss + rrow * QM3_SS + 4);
+                gw[j] = *reinterpret_cast<const u32x4 *>(p.norm_w + (ok[j] ? ((size_t)g0 * 128 + (size_t)cc * 8) : 0));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            const int chu = tid + (it0 + j) * T;
+            if (chu >= CHUNKS) break;  // CHUNKS is a multiple of 64: whole waves drop out, a 16-lane group stays in one row/group
+            const int row = chu / CPR;
+            const int cc = chu - row * CPR;
+            const int g = cc >> 4;
+            u32x4 x = ok[j] ? v[j] : u32x4{0u, 0u, 0u, 0u};
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = BF16::to_float((uint16_t)(x[e] & 0xffffu));
+                f[2 * e + 1] = BF16::to_float((uint16_t)(x[e] >> 16));
+            }
+            if constexpr (PRO == PRO_RMSNORM) {
+                // the row's sum of squares from its producers' partials (fixed summation tree), the weights of this chunk
+                const float tot = ((s0[j][0] + s0[j][1]) + (s0[j][2] + s0[j][3])) + ((s1[j][0] + s1[j][1]) + (s1[j][2] + s1[j][3]));
+                const float inv = rsqrtf(tot / (float)N + p.eps);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f[2 * e] = bf16_round(f[2 * e] * inv * BF16::to_float((uint16_t)(gw[j][e] & 0xffffu)));
+                    f[2 * e + 1] = bf16_round(f[2 * e + 1] * inv * BF16::to_float((uint16_t)(gw[j][e] >> 16)));
+                    x[e] = ok[j] ? BF16::pack2(f[2 * e], f[2 * e + 1]) : 0u;
+                }
+            }
+            {
+                const int rr = row & 15;
+                const int sw = rr ^ ((rr >= 4 && rr < 12) ? 4 : 0);
+                *reinterpret_cast<u32x4 *>(xs + (size_t)row * XS + (size_t)((cc & ~15) | ((cc & 15) ^ sw)) * 8) = x;
+            }
+            if constexpr (QMM3_ABL & 8) {
+                if ((cc & 15) == 0) xsum[g * ROWS + row] = f[0];
+                continue;
+            }
+            float sum = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+            sum = group16_sum(sum);
+            if ((cc & 15) == 0) xsum[g * ROWS + row] = sum;
+        }
+    }
 }
 
 template <int MB, int TW, int LM, int PRO = PRO_NONE>
@@ -92,71 +166,7 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- 2. activation slice -> LDS, per-(group,row) sums ------------------------------------------------------------
-    // chunk = 8 consecutive elements; a row of the slice has LM*16 chunks; 16 consecutive lanes cover one group of one row.
-    // The loads of SB chunks per thread are issued together (one dependent round trip per chunk cost ~1 us each).
-    {
-        constexpr int CPR = LM * 16;
-        constexpr int CHUNKS = ROWS * CPR;
-        constexpr int ITER = (CHUNKS + T - 1) / T;
-        constexpr int SB = ITER < 5 ? ITER : 5;
-        for (int it0 = 0; it0 < ITER; it0 += SB) {
-            u32x4 v[SB], gw[SB];
-            f32x4 s0[SB], s1[SB];
-            bool ok[SB];
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                const int ch = min(tid + (it0 + j) * T, CHUNKS - 1);
-                const int row = ch / CPR;
-                const int cc = ch - row * CPR;
-                ok[j] = tid + (it0 + j) * T < CHUNKS && row < p.M && (cc >> 4) < gn && !(QMM3_ABL & 2);
-                v[j] = *reinterpret_cast<const u32x4 *>(p.a + (ok[j] ? ((size_t)row * N + (size_t)g0 * 128 + (size_t)cc * 8) : 0));
-                if constexpr (PRO == PRO_RMSNORM) {
-                    const size_t rrow = ok[j] ? (size_t)row : 0;
-                    s0[j] = *reinterpret_cast<const f32x4 *>(p.ss + rrow * QM3_SS);
-                    s1[j] = *reinterpret_cast<const f32x4 *>(p.ss + rrow * QM3_SS + 4);
-                    gw[j] = *reinterpret_cast<const u32x4 *>(p.norm_w + (ok[j] ? ((size_t)g0 * 128 + (size_t)cc * 8) : 0));
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                const int chu = tid + (it0 + j) * T;
-                if (chu >= CHUNKS) break;  // CHUNKS is a multiple of 64: whole waves drop out, a 16-lane group stays in one row/group
-                const int row = chu / CPR;
-                const int cc = chu - row * CPR;
-                const int g = cc >> 4;
-                u32x4 x = ok[j] ? v[j] : u32x4{0u, 0u, 0u, 0u};
-                float f[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    f[2 * e] = BF16::to_float((uint16_t)(x[e] & 0xffffu));
-                    f[2 * e + 1] = BF16::to_float((uint16_t)(x[e] >> 16));
-                }
-                if constexpr (PRO == PRO_RMSNORM) {
-                    // the row's sum of squares from its producers' partials (fixed summation tree), the weights of this chunk
-                    const float tot = ((s0[j][0] + s0[j][1]) + (s0[j][2] + s0[j][3])) + ((s1[j][0] + s1[j][1]) + (s1[j][2] + s1[j][3]));
-                    const float inv = rsqrtf(tot / (float)N + p.eps);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        f[2 * e] = bf16_round(f[2 * e] * inv * BF16::to_float((uint16_t)(gw[j][e] & 0xffffu)));
-                        f[2 * e + 1] = bf16_round(f[2 * e + 1] * inv * BF16::to_float((uint16_t)(gw[j][e] >> 16)));
-                        x[e] = ok[j] ? BF16::pack2(f[2 * e], f[2 * e + 1]) : 0u;
-                    }
-                }
-                {
-                    const int rr = row & 15;
-                    const int sw = rr ^ ((rr >= 4 && rr < 12) ? 4 : 0);
-                    *reinterpret_cast<u32x4 *>(xs + (size_t)row * XS + (size_t)((cc & ~15) | ((cc & 15) ^ sw)) * 8) = x;
-                }
-                if constexpr (QMM3_ABL & 8) {
-                    if ((cc & 15) == 0) xsum[g * ROWS + row] = f[0];
-                    continue;
-                }
-                float sum = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-                sum = group16_sum(sum);
-                if ((cc & 15) == 0) xsum[g * ROWS + row] = sum;
-            }
-        }
-    }
+    qmm3_stage_slice<MB, LM, PRO>(p, g0, gn, xs, xsum, tid);
     __syncthreads();
 
     // ---- 3. MFMA over the slice --------------------------------------------------------------------------------------
@@ -228,40 +238,296 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
     prof_end(p.prof, prof_t0);
 }
 
+// Persistent variant: ONE workgroup per CU.  A workgroup stages its activation slice once and its 8 waves then walk the 16-row
+// weight tiles of the workgroup's tile range (tile = first + wave + 8 j) -- the weight stream never stops for a staging pass or a
+// workgroup hand-over (the one-shot grid above spends 2.4 rounds of load -> stage -> compute -> store per CU on gate|up at 64
+// rows).  The weights move in UNITS of 4 quantisation groups of one tile (4 KiB per wave): two register sets, one in flight
+// while the other runs through the MFMAs.  A slice is NU units wide: with NU = 2 a tile's accumulators live across its two
+// units, so the slice is 8 groups (128 KiB of LDS at 64 rows) while the register budget stays that of 4 -- 3 slices instead of
+// 5 on the 2,560-column projections, i.e. 40 % fewer fp32 partials to write here and to read in the slice reduction (at 64
+// rows 5 slices of partials weigh as much as the weights themselves).  A short last slice (<= 4 groups left) runs the NU = 1
+// body and gets proportionally fewer workgroups.  Same arithmetic, same partial layout, same slice reduction as qmm3_kernel.
+#ifndef QMM3P_SB
+#define QMM3P_SB 8  // staging chunks in flight per thread
+#endif
+template <int MB, int NU, int PRO>
+__device__ __forceinline__ void qmm3p_body(const Qmm3Args &p, char *smem, const int slice, const int g0, const int gn, const int wg,
+                                           const int tiles_per_wg) {
+    constexpr int LM = 4 * NU;
+    constexpr int ROWS = MB * 16;
+    constexpr int XS = LM * 128 + QM3_PAD;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int r = lane & 15, c = lane >> 4;
+    const int K = p.K, G = p.N >> 7;
+    const int tiles = K >> 4;
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);
+    float *xsum = reinterpret_cast<float *>(smem + (size_t)ROWS * XS * 2);  // [LM][ROWS]
+    const int first = wg * tiles_per_wg + wave;
+    const int last = min(tiles, (wg + 1) * tiles_per_wg);
+    const int n_tiles = first < last ? (last - first + QM3_WAVES - 1) / QM3_WAVES : 0;  // wave-uniform
+#if QMM3_ABL & 64  // lab: per-wave phase stamps (start, loads issued, staged, after each unit ...) into p.prof[(wg*8+wave)*16 + k]
+    unsigned long long stamps[16];
+    int n_stamps = 0;
+#define QM3_STAMP() do { if (n_stamps < 16) stamps[n_stamps++] = wall_clock64(); } while (0)
+#else
+#define QM3_STAMP() do { } while (0)
+#endif
+    QM3_STAMP();
+
+    u32x4 wqa[4], wqb[4];
+    uint32_t sqa[4], sqb[4];
+    // uniform (SGPR) block base + per-lane 32-bit offset + group offset: one address register per stream instead of one per load
+    const uint32_t lane_w = (uint32_t)lane * 16u, lane_s = (uint32_t)r * 4u;
+    const uint32_t st_off = ((uint32_t)(4 * c) * (uint32_t)K + (uint32_t)r) * 4u;  // partial-store offset of this lane inside a row block
+    const __amdgpu_buffer_rsrc_t prs =  // this slice's [M][K] partial plane: stores at or beyond M*K*4 bytes are dropped by the range check
+        __builtin_amdgcn_make_buffer_rsrc(p.partial + (size_t)slice * p.M * K, 0, (int)((uint32_t)p.M * (uint32_t)K * 4u), 0x00020000);
+    auto fetch = [&](u32x4(&wq)[4], uint32_t(&sq)[4], int tile, int unit) {
+        const int tc = __builtin_amdgcn_readfirstlane(min(tile, tiles - 1));
+        const char *wbase = reinterpret_cast<const char *>(p.wt) + ((size_t)tc * G + g0) * 1024;
+        const char *sbase = reinterpret_cast<const char *>(p.sbt) + ((size_t)tc * G + g0) * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t gi = (uint32_t)min(unit * 4 + i, gn - 1);  // past the slice's last group: re-read it (scaled by zero later)
+            sq[i] = *reinterpret_cast<const uint32_t *>(sbase + (lane_s + gi * 64u));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t gi = (uint32_t)min(unit * 4 + i, gn - 1);
+            wq[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(wbase + (lane_w + gi * 1024u)));
+        }
+    };
+    // ---- 1. the first two units of this wave in flight before the staging ------------------------------------------
+    fetch(wqa, sqa, first, 0);
+    if constexpr (NU == 2) fetch(wqb, sqb, first, 1);
+    else fetch(wqb, sqb, first + QM3_WAVES, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    QM3_STAMP();
+
+    // ---- 2. activation slice -> LDS, once per workgroup ----------------------------------------------------------------
+    qmm3_stage_slice<MB, LM, PRO, QMM3P_SB>(p, g0, gn, xs, xsum, tid);
+    QM3_STAMP();
+    __syncthreads();
+    QM3_STAMP();
+
+    const int swr = r ^ ((r >= 4 && r < 12) ? 4 : 0);
+    int xbase = r * XS;  // element offset of this lane's row; laundered per unit so the (tile-invariant) fragment reads stay in the loop
+    int xoff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xoff[t] = ((4 * c + t) ^ swr) * 8;
+    uint32_t nib_mask = 0x000f000fu;
+    uint32_t magic = 0x43004300u;
+    asm volatile("" : "+s"(nib_mask));
+    asm volatile("" : "+v"(magic));
+
+    // ---- 3. one unit: 16 k-steps of MFMA over 4 groups of the slice; the tile's partial sums go out after its last unit ----
+    // The k-steps run as an explicit pipeline (a scheduling fence per step pins it): fragment reads two steps ahead of the MFMAs
+    // that use them (ring of three), the quantisation-group scaling of group i applied one step into group i+1 (two sets of raw
+    // accumulators), so neither the LDS latency nor the MFMA latency sits on the issue path.
+    f32x4 acc[MB];
+    auto run_unit = [&](const u32x4(&wq)[4], const uint32_t(&sq)[4], int tile, auto unit_tag) {
+        constexpr int UNIT = decltype(unit_tag)::value;
+        asm volatile("" : "+v"(xbase));
+        const uint16_t *xrow = xs + xbase + UNIT * 512;
+        const float *xsl = xsum + ((xbase - r * XS) + 4 * c) + UNIT * 4 * ROWS;  // same laundering for the group sums
+        constexpr int STEPS = 16;
+        f32x4 d[2][MB], xg[MB];
+        u32x4 ax[3][MB];
+        if constexpr (UNIT == 0) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        auto read_step = [&](int st, u32x4(&dst)[MB]) {
+            const int i = st >> 2, t = st & 3;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                dst[mb] = *reinterpret_cast<const u32x4 *>(xrow + xoff[t] + (size_t)mb * 16 * XS + i * 128);
+        };
+        auto apply_group = [&](int i) {
+            const uint32_t sw = UNIT * 4 + i < gn ? sq[i] : 0u;  // groups past the end of the row contribute nothing
+            const float sc = __uint_as_float(sw << 16);
+            const float be = __uint_as_float(sw & 0xffff0000u) - 128.0f * sc;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mb][j] += sc * d[i & 1][mb][j] + be * xg[mb][j];
+        };
+        read_step(0, ax[0]);
+        read_step(1, ax[1]);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int i = st >> 2, t = st & 3;
+            if (st + 2 < STEPS) read_step(st + 2, ax[(st + 2) % 3]);
+            if (t == 0) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) d[i & 1][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (t == 2) {  // after the previous group's scaling (t == 1) has consumed its sums
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) xg[mb] = *reinterpret_cast<const f32x4 *>(xsl + i * ROWS + mb * 16);
+            }
+            const u32x4 bq = unpack_w4_bf16(wq[i][t], nib_mask, magic);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                d[i & 1][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ax[st % 3][mb]),
+                                                                       __builtin_bit_cast(bf16x8_t, bq), d[i & 1][mb], 0, 0, 0);
+            if (t == 1 && i > 0) apply_group(i - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        apply_group(3);
+        if constexpr (UNIT == NU - 1) {
+            // lane (weight row r, c) holds activation rows 16 mb + 4c + j; rows >= M fall outside the slice's buffer and are dropped
+            const uint32_t base = ((uint32_t)__builtin_amdgcn_readfirstlane(tile) << 6) + st_off;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!(QMM3_ABL & 4) || acc[mb][j] == 123.f)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mb][j]), prs, base + (uint32_t)(mb * 16 + j) * (uint32_t)K * 4u, 0, 0);
+        }
+    };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, NU - 1>;
+    if constexpr (NU == 2) {
+        for (int u = 0; u < n_tiles; ++u) {
+            const int tile = first + u * QM3_WAVES;
+            run_unit(wqa, sqa, tile, U0{});
+            if (u + 1 < n_tiles) fetch(wqa, sqa, tile + QM3_WAVES, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            QM3_STAMP();
+            run_unit(wqb, sqb, tile, U1{});
+            if (u + 1 < n_tiles) fetch(wqb, sqb, tile + QM3_WAVES, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            QM3_STAMP();
+        }
+    } else {
+        for (int u = 0; u < n_tiles; u += 2) {
+            const int tile = first + u * QM3_WAVES;
+            run_unit(wqa, sqa, tile, U0{});
+            if (u + 2 < n_tiles) fetch(wqa, sqa, tile + 2 * QM3_WAVES, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + 1 < n_tiles) {
+                run_unit(wqb, sqb, tile + QM3_WAVES, U0{});
+                if (u + 3 < n_tiles) fetch(wqb, sqb, tile + 3 * QM3_WAVES, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#if QMM3_ABL & 64
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    QM3_STAMP();
+    if (lane == 0 && p.prof) {
+        unsigned long long *o = p.prof + ((size_t)blockIdx.x * QM3_WAVES + wave) * 16;
+        for (int k = 0; k < 16; ++k) o[k] = k < n_stamps ? stamps[k] : 0ull;
+    }
+#endif
+}
+
+struct Qmm3pGrid {
+    int full_slices, wgs_full, tpw_full;  // slices of 4*NU groups: workgroups and tiles per workgroup of each
+    int last_groups, wgs_last, tpw_last;  // the short last slice (0 groups = none)
+};
+template <int MB, int NU, int PRO = PRO_NONE>
+__global__ __launch_bounds__(QM3_WAVES * 64) void qmm3p_kernel(const Qmm3Args p, const Qmm3pGrid gr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#if QMM3_ABL & 64
+    const prof_t prof_t0 = 0;
+#else
+    const prof_t prof_t0 = prof_begin(p.prof);
+#endif
+    const int bid = blockIdx.x;
+    const int nfull = gr.full_slices * gr.wgs_full;
+    if (bid < nfull) {
+        const int slice = bid / gr.wgs_full;
+        qmm3p_body<MB, NU, PRO>(p, smem, slice, slice * 4 * NU, 4 * NU, bid - slice * gr.wgs_full, gr.tpw_full);
+    } else if (NU == 2 && gr.last_groups <= 4) {
+        qmm3p_body<MB, 1, PRO>(p, smem, gr.full_slices, gr.full_slices * 4 * NU, gr.last_groups, bid - nfull, gr.tpw_last);
+    } else {
+        qmm3p_body<MB, NU, PRO>(p, smem, gr.full_slices, gr.full_slices * 4 * NU, gr.last_groups, bid - nfull, gr.tpw_last);
+    }
+#if !(QMM3_ABL & 64)
+    prof_end(p.prof, prof_t0);
+#endif
+}
+
 struct Qmm3Plan {
     int MB, TW, LM, slices, tile_groups;
-    int grid_x;  // = tile_groups: one workgroup per (tile group, slice).  A persistent variant (each workgroup staging its slice
-                 // once and walking several tile groups) was built and measured in r02: the tile loop cost more in the MFMA
-                 // phase (32.9 us against 31.5 us for gate|up at 64 rows) than the staging it saved.
+    int grid_x;        // one-shot: tile groups (one workgroup per (tile group, slice)); persistent: workgroups per slice
+    int persistent;    // 0: qmm3_kernel, 1: qmm3p_kernel (one workgroup per CU walking tiles_per_wg tiles)
+    int tiles_per_wg;  // persistent grids only
+    int NU;            // qmm3p_kernel only: units (4 groups) per slice
+    Qmm3pGrid pgrid;   // qmm3p_kernel only
     size_t lds, partial_bytes;
     bool ok;
 };
-// LM is the largest of {10, 8, 5, 4} whose slice fits the LDS and that still yields about one workgroup per CU.
-inline Qmm3Plan qmm3_plan(int M, int N, int K) {
+int qmm3_num_cus();       // qmm3.hip: CUs of the current device (256 when no device is visible)
+int qmm3_default_mode();  // qmm3.hip: TL_QMM3_PERSISTENT = 0 / 1 pins the grid, unset (-1) = by shape (below)
+int qmm3_forced_lm();     // qmm3.hip: TL_QMM3P_LM (lab: pin the persistent grid's slice width; 0 = planner's choice)
+
+// mode 0: the one-shot grid, LM the largest of {10, 8, 5, 4} whose slice fits the LDS and that still yields about one
+// workgroup per CU.  mode 1: the persistent grid.  mode -1: by shape, from the r02 lab (profiles/r02_labs/qmm3_lab_r02*.log,
+// matmul + slice reduction): the persistent grid wins where a CU has several tiles to walk -- gate|up (1,216 tiles) at any
+// row count, lm_head (9,496) from 17 rows, w_down (76 groups: 10 slices instead of 16-19) from 17 rows -- and loses on the
+// small projections (qkv, wo: 3-4 tiles per workgroup, the staged slice is most of the kernel) and on lm_head at <= 16 rows
+// (two 10-group slices fit the one-shot grid there).
+inline bool qmm3_prefers_persistent(int MB, int G, int tiles) {
+    if (MB >= 2) return tiles >= 1024 || G >= 64;
+    return tiles >= 1024 && tiles < 4096;
+}
+inline Qmm3Plan qmm3_plan(int M, int N, int K, int mode = -1) {
     Qmm3Plan pl{};
     pl.ok = M >= 1 && M <= 64 && N > 0 && N % 128 == 0 && K > 0 && K % 16 == 0;
     if (!pl.ok) return pl;
     pl.MB = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     const int G = N / 128, tiles = K / 16;
-    pl.TW = (pl.MB == 4 && tiles >= 2048) ? 2 : 1;
-    pl.tile_groups = (tiles + QM3_WAVES * pl.TW - 1) / (QM3_WAVES * pl.TW);
-    const int cand[4] = {10, 8, 5, 4};
-    pl.LM = 4;
-    for (int lm : cand) {
-        if (qmm3_lds_bytes(pl.MB, lm) > 100 * 1024) continue;
-        const int slices = (G + lm - 1) / lm;
-        pl.LM = lm;
-        if ((long)slices * pl.tile_groups >= 192 || lm == 4) break;
+    if (mode < 0) mode = qmm3_default_mode();
+    if (mode < 0) mode = qmm3_prefers_persistent(pl.MB, G, tiles) ? 1 : 0;
+    if (mode == 1) {
+        // slices of 8 groups (two units) where the LDS holds them, workgroups shared out in proportion to the groups of a slice
+        const int ncu = qmm3_num_cus();
+        int nu = qmm3_lds_bytes(pl.MB, 8) <= 150 * 1024 && G > 4 ? 2 : 1;
+        if (qmm3_forced_lm() == 4) nu = 1;
+        pl.NU = nu;
+        pl.LM = 4 * nu;
+        Qmm3pGrid &gr = pl.pgrid;
+        gr.full_slices = G / pl.LM;
+        gr.last_groups = G - gr.full_slices * pl.LM;
+        pl.slices = gr.full_slices + (gr.last_groups ? 1 : 0);
+        auto share = [&](int groups, int &wgs, int &tpw) {
+            wgs = std::min(std::max(1, (int)((long)ncu * groups / G)), tiles);
+            tpw = (tiles + wgs - 1) / wgs;
+            wgs = (tiles + tpw - 1) / tpw;
+        };
+        gr.wgs_full = gr.tpw_full = gr.wgs_last = gr.tpw_last = 0;
+        if (gr.full_slices) share(pl.LM, gr.wgs_full, gr.tpw_full);
+        if (gr.last_groups) share(gr.last_groups, gr.wgs_last, gr.tpw_last);
+        pl.grid_x = gr.full_slices * gr.wgs_full + gr.wgs_last;
+        pl.tiles_per_wg = gr.full_slices ? gr.tpw_full : gr.tpw_last;
+        pl.persistent = 1;
+        pl.TW = 1;
+        pl.tile_groups = (tiles + QM3_WAVES - 1) / QM3_WAVES;
+    } else {
+        pl.TW = (pl.MB == 4 && tiles >= 2048) ? 2 : 1;
+        pl.tile_groups = (tiles + QM3_WAVES * pl.TW - 1) / (QM3_WAVES * pl.TW);
+        const int cand[4] = {10, 8, 5, 4};
+        pl.LM = 4;
+        for (int lm : cand) {
+            if (qmm3_lds_bytes(pl.MB, lm) > 100 * 1024) continue;
+            const int slices = (G + lm - 1) / lm;
+            pl.LM = lm;
+            if ((long)slices * pl.tile_groups >= 192 || lm == 4) break;
+        }
+        pl.slices = (G + pl.LM - 1) / pl.LM;
+        pl.grid_x = pl.tile_groups;
     }
-    pl.slices = (G + pl.LM - 1) / pl.LM;
     pl.lds = qmm3_lds_bytes(pl.MB, pl.LM);
     pl.partial_bytes = (size_t)pl.slices * M * K * 4;
-    pl.grid_x = pl.tile_groups;
     return pl;
 }
 
 // qmm3.hip
-int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro = PRO_NONE);
+int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro = PRO_NONE, int mode = -1);
 // out = epilogue(sum over slices); epi = EPI_STORE / EPI_RESIDUAL (residual [M,K]) / EPI_SWIGLU (out [M,K/2]).
 // ss_out (optional, EPI_STORE / EPI_RESIDUAL with K <= QM3_SS * 1024): [M][QM3_SS] partial sums of squares of the bf16 output rows
 // for the next projection's fused RMSNorm; returns the number of workgroups launched through *n_wg.

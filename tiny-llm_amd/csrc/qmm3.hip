@@ -100,11 +100,50 @@ int launch_qmm3_reduce_bf16(const float *partial, int slices, int M, int K, int 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro) {
-    const Qmm3Plan pl = qmm3_plan(args.M, args.N, args.K);
+int qmm3_num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return 256;
+        return cus;
+    }();
+    return n;
+}
+int qmm3_default_mode() {
+    static const int m = [] {
+        const char *v = getenv("TL_QMM3_PERSISTENT");
+        return v ? (atoi(v) != 0 ? 1 : 0) : -1;
+    }();
+    return m;
+}
+
+int qmm3_forced_lm() {
+    static const int m = [] {
+        const char *v = getenv("TL_QMM3P_LM");
+        return v ? atoi(v) : 0;
+    }();
+    return m;
+}
+
+int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
+    const Qmm3Plan pl = qmm3_plan(args.M, args.N, args.K, mode);
     if (!pl.ok) return -1;
     if (pro == PRO_RMSNORM && (!args.ss || !args.norm_w)) return -1;
     const dim3 grid(pl.grid_x, pl.slices), block(QM3_WAVES * 64);
+    if (pl.persistent) {
+        const dim3 pgrid(pl.grid_x);
+#define QM3P_CASE(MBv, NUv)                                                                                          \
+    if (pl.MB == MBv && pl.NU == NUv) {                                                                              \
+        auto kern = pro == PRO_RMSNORM ? qmm3p_kernel<MBv, NUv, PRO_RMSNORM> : qmm3p_kernel<MBv, NUv, PRO_NONE>;     \
+        if (pl.lds > 64 * 1024)                                                                                      \
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);  \
+        hipLaunchKernelGGL(kern, pgrid, block, pl.lds, st, args, pl.pgrid);                                          \
+        return hipGetLastError() == hipSuccess ? 0 : -1;                                                             \
+    }
+        QM3P_CASE(1, 1) QM3P_CASE(1, 2) QM3P_CASE(2, 1) QM3P_CASE(2, 2) QM3P_CASE(4, 1) QM3P_CASE(4, 2)
+#undef QM3P_CASE
+        return -2;
+    }
 #define QM3_CASE(MBv, TWv, LMv)                                                                                     \
     if (pl.MB == MBv && pl.TW == TWv && pl.LM == LMv) {                                                             \
         auto kern = pro == PRO_RMSNORM ? qmm3_kernel<MBv, TWv, LMv, PRO_RMSNORM> : qmm3_kernel<MBv, TWv, LMv, PRO_NONE>; \

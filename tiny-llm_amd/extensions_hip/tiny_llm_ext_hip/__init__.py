@@ -548,6 +548,8 @@ __all__ = [
 # ---- kernel-level entry points of the decode path (include/tinyllm_engine.h, last section) -------------------------
 PRO_NONE, PRO_RMSNORM = 0, 1
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2
+# values of tl_linear_info.kernel (what RAN); the `kernel` argument of decode_linear selects: 0 engine routing, 1 GEMV,
+# 2 skinny matmul (grid by shape), 3 / 4 skinny matmul on its one-shot / persistent grid
 LINEAR_KERNELS = {1: "qmv3 (fused MFMA GEMV)", 2: "qmm3 (skinny MFMA matmul + slice reduction)",
                   3: "qmv (packed-dot GEMV fallback)", 4: "prefill GEMM path"}
 
