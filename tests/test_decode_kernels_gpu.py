@@ -303,8 +303,28 @@ def test_decode_attention_contexts_up_to_4k(ext, ctx, mode, monkeypatch):
         assert info["scalar_page_ids"] in (1, 2, 4), f"{what}: page 128 windows take their page ids through s_load"
     if mode == "default":
         assert info["tokens_per_split"] == 64 or info["n_splits"] == 64, what
+        assert info["launches"] == (1 if info["n_splits"] == 1 else 2), what
     _check_attention(case, got, kpa, vpa, [False], what)
     log_parity({"what": "decode_attention", "ctx": ctx, "mode": mode, **info})
+
+
+@pytest.mark.parametrize("ctx", [70, 300, 511])
+def test_decode_attention_in_kernel_merge_matches_merge_launch(ext, ctx, monkeypatch):
+    """The optional split merge inside the attention kernel (TL_ATTN_FUSED_MERGE=1: last-arriving workgroup, splits in index
+    order; off by default, measured neutral) against the merge launch: same partials, same order -- the bf16 outputs must be
+    IDENTICAL, call after call (the arrival counters return to zero)."""
+    rng = np.random.default_rng(77 + ctx)
+    case = _attention_case(rng, [ctx, 5, ctx - 3])
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("TL_ATTN_FUSED_MERGE", fused)
+        for rep in range(3):
+            got, kpa, vpa, info = _run_attention(ext, case, ctx)
+            assert info["launches"] == (1 if fused == "1" or info["n_splits"] == 1 else 2), info
+            outs[(fused, rep)] = got
+    ref = outs[("0", 0)]
+    for key, val in outs.items():
+        assert np.array_equal(val, ref), f"ctx={ctx}: run {key} differs from the merge-launch result in {int((val != ref).sum())} values"
 
 
 @pytest.mark.parametrize("nw", [4, 8, 16])

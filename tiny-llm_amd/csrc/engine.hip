@@ -64,6 +64,12 @@ struct tl_engine {
     uint16_t *x = nullptr, *h = nullptr, *xn = nullptr, *qkv = nullptr, *q_t = nullptr, *attn_t = nullptr,
              *attn = nullptr, *gu = nullptr, *act = nullptr, *tmp = nullptr, *logits = nullptr;
     float *attn_ws = nullptr;
+    int last_attn_launches = 0;
+    unsigned int *attn_counters = nullptr;  // [max_batch][Hkv][4] arrival counters of the in-kernel split merge (zero at rest)
+    // TL_ATTN_FUSED_MERGE=1: 2 .. 8 splits merged by the last workgroup to arrive instead of a merge launch.  Off by default:
+    // measured neutral (r02: 913 vs 909 tok/s single stream, 1.97 vs 1.90 ms at 4 sequences) -- the arrival costs three
+    // dependent memory-side round trips (coherent stores acknowledged, counter, coherent loads), about what the launch costs.
+    bool attn_fused_merge = false;
     float *ss_x = nullptr, *ss_h = nullptr;  // [max_batch][QM3_SS] partial sums of squares of the rows of x / h (qmm3.h)
     bool fuse_norm = true;                   // TL_QMM3_FUSED_NORM=0: RMSNorm ahead of a skinny matmul always as its own launch
     int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
@@ -462,6 +468,10 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
         if ((1 << sh) == c.page_size) a.page_shift = sh;
     a.rope_cur = e->rope_cur;
     a.prof = pc ? pc->buf : nullptr;
+    // 2 .. 8 splits of the looped kernel: merged by the last workgroup to arrive; more splits (long contexts) keep the
+    // column-parallel merge launch -- one workgroup folding hundreds of partial rows would be a serial tail
+    const bool fused_merge = e->attn_fused_merge && e->attn_counters != nullptr && sp.nw == 0 && n_splits > 1 && n_splits <= 8 && chunks <= 4;
+    a.merge_counters = fused_merge ? e->attn_counters : nullptr;
     TL_REQUIRE((size_t)batch * c.num_heads * n_splits * (D + 2) * sizeof(float) <= e->attn_ws_bytes || n_splits == 1,
                "engine: attention workspace too small for this split plan");
     const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
@@ -483,7 +493,8 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
         }
     }
     if (pc) prof_after(e, pc, 5, (int)(grid.x * grid.y * grid.z));
-    if (n_splits > 1) {
+    e->last_attn_launches = 1 + ((n_splits > 1 && !fused_merge) ? 1 : 0);
+    if (n_splits > 1 && !fused_merge) {
         const dim3 mg(batch * c.num_heads), mb(128);
         prof_t *pb = pc ? pc->buf : nullptr;
         int merge_wg = batch * c.num_heads;
@@ -724,6 +735,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
                                                                                          c.max_pages_per_seq, c.num_heads,
                                                                                          c.num_kv_heads, 0));
     const size_t o_ws = carve(e->attn_ws_bytes);
+    const size_t o_cnt = carve((size_t)c.max_batch * c.num_kv_heads * 4 * sizeof(unsigned int));
     e->arena_bytes = off;
 
     auto cleanup_fail = [&](const std::string &msg) {
@@ -774,6 +786,10 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->act = (uint16_t *)(A + o_act);
     e->logits = (uint16_t *)(A + o_log);
     e->attn_ws = (float *)(A + o_ws);
+    e->attn_counters = (unsigned int *)(A + o_cnt);
+    if (hipMemsetAsync(e->attn_counters, 0, (size_t)c.max_batch * c.num_kv_heads * 4 * sizeof(unsigned int), e->stream) != hipSuccess)
+        return cleanup_fail("engine_create: memset(attention counters) failed");
+    if (const char *q = getenv("TL_ATTN_FUSED_MERGE")) e->attn_fused_merge = atoi(q) != 0;
     e->verify_ids = (int32_t *)(A + o_vid);
     e->ss_x = (float *)(A + o_ssx);
     e->ss_h = (float *)(A + o_ssh);
@@ -1482,6 +1498,7 @@ __global__ __launch_bounds__(64) void rope_rows_kernel(const int32_t *__restrict
 extern "C" size_t tl_decode_attention_fused_workspace_bytes(int batch, int num_heads, int head_dim) {
     if (batch <= 0 || num_heads <= 0 || head_dim <= 0) return 0;
     return align_up((size_t)batch * (head_dim / 2) * sizeof(float2), 256) +
+           align_up((size_t)batch * num_heads * 4 * sizeof(unsigned int), 256) +  // arrival counters (<= Hq KV heads x 4 chunks)
            (size_t)batch * num_heads * 256 * (head_dim + 2) * sizeof(float);
 }
 
@@ -1513,8 +1530,12 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
     e.context_lens = const_cast<int32_t *>(context_lens_dev);
     e.rope_cur = (float2 *)workspace_dev;
     const size_t rc_bytes = align_up((size_t)batch * (head_dim / 2) * sizeof(float2), 256);
-    e.attn_ws = (float *)((char *)workspace_dev + rc_bytes);
-    e.attn_ws_bytes = workspace_bytes - rc_bytes;
+    const size_t cnt_bytes = align_up((size_t)batch * num_heads * 4 * sizeof(unsigned int), 256);
+    e.attn_counters = (unsigned int *)((char *)workspace_dev + rc_bytes);
+    TL_REQUIRE(hipMemsetAsync(e.attn_counters, 0, cnt_bytes, e.stream) == hipSuccess, "decode_attention_fused: memset failed");
+    e.attn_ws = (float *)((char *)workspace_dev + rc_bytes + cnt_bytes);
+    e.attn_ws_bytes = workspace_bytes - rc_bytes - cnt_bytes;
+    if (const char *q = getenv("TL_ATTN_FUSED_MERGE")) e.attn_fused_merge = atoi(q) != 0;
     if (const char *q = getenv("TL_ATTN_RQ")) e.attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e.attn_rq1_ctx = atoi(q);
     if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e.attn_max_splits = std::min(256, std::max(1, atoi(q)));
@@ -1535,7 +1556,7 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
         info->wide_waves = sp.nw;
         info->wide_rows_in_flight = sp.u;
         info->scalar_page_ids = sp.npw;
-        info->launches = 1 + (sp.n_splits > 1 ? 1 : 0);
+        info->launches = e.last_attn_launches;
     }
     return rc;
 }

@@ -155,6 +155,9 @@ struct AttnDecodeArgs {
     int split_shift;  // log2(n_splits): the split count is a power of two
     int rep;          // query heads per KV head
     int page_shift;   // log2(page_size), or -1 when the page size is not a power of two (then: integer division)
+    // attn_decode_fused_kernel, 2 .. 8 splits: one arrival counter per (sequence, KV head, head chunk), zero between launches.
+    // The workgroup that arrives last merges the splits itself (no merge launch); nullptr = partials only.
+    unsigned int *merge_counters;
     prof_t *prof;
 };
 
@@ -432,10 +435,18 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             p.out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : vs / gl);
         } else {
             float *w = p.ws + (orow * p.n_splits + split) * STRIDE;
-            w[d] = vs;
-            if (d == 0) {
-                w[D] = gm;
-                w[D + 1] = gl;
+            if (p.merge_counters != nullptr) {  // read by another workgroup of THIS launch: device-coherent stores (below)
+                __hip_atomic_store(w + d, vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (d == 0) {
+                    __hip_atomic_store(w + D, gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(w + D + 1, gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                w[d] = vs;
+                if (d == 0) {
+                    w[D] = gm;
+                    w[D + 1] = gl;
+                }
             }
         }
     }
@@ -446,6 +457,57 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         const long off = (((long)wpage * Hkv + kvh) * p.page_size + wslot) * D + t * VD;
         store_row<VD>(p.key_pages + off, k_new);
         store_raw<VD>(p.value_pages + off, vraw_new);
+    }
+    // ---- 2 .. 8 splits: the last workgroup to arrive merges them (what attn_merge_kernel did in a launch of its own: one
+    // launch boundary and ~1.3 us of kernel per layer of a decode step).  The splits may run on other XCDs, behind other L2s.
+    // A device-scope release/acquire fence pair would make the partials visible, but it writes back and invalidates whole L2s
+    // per workgroup (measured: 105 -> 1,117 us of attention per step).  Instead only the partials themselves are coherent:
+    // relaxed device-scope atomic stores / loads (sc1: written through to, and read from, the memory side), and the arrival
+    // counter is bumped after the workgroup's stores have been acknowledged (vmcnt(0) + barrier).  The splits are folded in
+    // index order, whoever arrives last: the result does not depend on the timing.  The counter returns to zero.
+    if (p.merge_counters != nullptr && p.n_splits > 1) {
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int *cnt = p.merge_counters + ((long)b * Hkv + kvh) * p.n_row_chunks + chunk;
+            const unsigned int prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = prev == (unsigned int)(p.n_splits - 1);
+            if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_last) {
+            for (int item = threadIdx.x; item < RQ * D; item += 256) {
+                const int r = item / D;
+                const int d = item - r * D;
+                const int hq = chunk * RQ + r;
+                if (hq >= rep) continue;
+                const long orow = (long)b * Hq + kvh * rep + hq;
+                const float *base = p.ws + orow * p.n_splits * STRIDE;
+                float ms[8], ls[8], vs[8];
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) {
+                    const float *rowp = base + (long)min(s2, p.n_splits - 1) * STRIDE;
+                    ms[s2] = __hip_atomic_load(rowp + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ls[s2] = __hip_atomic_load(rowp + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vs[s2] = __hip_atomic_load(rowp + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                float gm = -1e30f;
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2)
+                    if (s2 < p.n_splits) gm = fmaxf(gm, ms[s2]);
+                float gl = 0.f, accm = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) {
+                    if (s2 < p.n_splits) {
+                        const float f = exp2f(ms[s2] - gm);
+                        gl += ls[s2] * f;
+                        accm += vs[s2] * f;
+                    }
+                }
+                p.out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : accm / gl);
+            }
+        }
     }
     prof_end(p.prof, prof_t0);
 }

@@ -132,7 +132,6 @@ __device__ __forceinline__ void qmm3_stage_slice(const Qmm3Args &p, int g0, int 
 template <int MB, int TW, int LM, int PRO = PRO_NONE>
 __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int T = QM3_WAVES * 64;
     constexpr int ROWS = MB * 16;
     constexpr int XS = LM * 128 + QM3_PAD;  // staged row stride (elements)
     const prof_t prof_t0 = prof_begin(p.prof);
