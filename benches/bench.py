@@ -84,6 +84,9 @@ def parse_args(argv=None) -> argparse.Namespace:
     ap.add_argument("--prefill-budget", type=int, default=None,
                     help="prompt tokens a serving turn may spend on admission before its decode step (default: one "
                          "--prefill-step chunk, the reference's schedule; config 4 uses 2048 so that 64 slots fill)")
+    ap.add_argument("--staging-slots", type=int, default=1,
+                    help="--batch-decode: prompts prefilled together per turn (1 = one at a time as the reference; > 1 packs them "
+                         "into one multi-token pass of at most --prefill-budget rows)")
     ap.add_argument("--page-size", type=int, default=128)
     ap.add_argument("--json-output", type=Path)
     args = ap.parse_args(argv)
@@ -165,10 +168,11 @@ def main(argv=None) -> None:
     if args.solution == "engine":
         from tiny_llm_hip.engine import DecodeEngine
 
-        slots = args.batch_size + 1 if args.batch_decode else 1
+        slots = args.batch_size + max(1, args.staging_slots) if args.batch_decode else 1
         pages_per_seq = (longest + args.page_size - 1) // args.page_size + 1
         engine = DecodeEngine(mlx_model, page_size=args.page_size, num_pages=pages_per_seq * slots + 2, max_batch=slots,
-                              max_pages_per_seq=pages_per_seq, max_prefill_rows=max(args.prefill_step, 8))
+                              max_pages_per_seq=pages_per_seq,
+                              max_prefill_rows=max(args.prefill_step, (args.prefill_budget or 0) if args.staging_slots > 1 else 0, 8))
 
         kv_page_bytes = 2 * cfg["num_hidden_layers"] * cfg["num_key_value_heads"] * args.page_size * cfg["head_dim"] * 2
 
@@ -179,7 +183,8 @@ def main(argv=None) -> None:
 
                 metrics = serve_requests(engine, reqs, batch_size=args.batch_size, prefill_step=args.prefill_step,
                                          prefill_budget=args.prefill_budget, page_size=args.page_size,
-                                         kv_bytes_per_page=kv_page_bytes, capacity_pages=pages_per_seq * slots + 2)
+                                         kv_bytes_per_page=kv_page_bytes, capacity_pages=pages_per_seq * slots + 2,
+                                         staging_slots=args.staging_slots)
                 return metrics.generated_tokens, metrics.decode_tokens, metrics.prefill_time, metrics.decode_time
             gen = dec = 0
             pt = dt = 0.0

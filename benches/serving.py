@@ -78,11 +78,18 @@ def median(values) -> float:
 
 def serve_requests(engine, requests, *, batch_size: int, prefill_step: int, prefill_budget: int | None = None,
                    page_size: int = 128, kv_bytes_per_page: int = 0, capacity_pages: int = 0,
-                   clock=time.perf_counter) -> ServingMetrics:
+                   clock=time.perf_counter, staging_slots: int = 1) -> ServingMetrics:
     """Serve ``requests`` (objects with prompt_token_ids, max_new_tokens) through ``engine`` with ``batch_size`` decode slots
-    and one staging slot (index batch_size).  Timers wrap a synchronised engine, like the reference's mx.eval inside them."""
+    and ``staging_slots`` staging slots (indices batch_size ..).  Timers wrap a synchronised engine, like the reference's
+    mx.eval inside them.  One staging slot = the reference's policy (one request prefilled at a time, batch.py:48-76);
+    several = the admitted prompts' chunks go through ONE packed multi-token pass per turn (engine.prefill_packed), at most
+    ``prefill_budget`` rows together."""
     if prefill_budget is None:
         prefill_budget = prefill_step
+    if staging_slots > 1:
+        return _serve_requests_packed(engine, requests, batch_size=batch_size, prefill_step=prefill_step,
+                                      prefill_budget=prefill_budget, page_size=page_size, kv_bytes_per_page=kv_bytes_per_page,
+                                      capacity_pages=capacity_pages, clock=clock, staging_slots=staging_slots)
     m = ServingMetrics()
     staging = batch_size
     slots: list[dict | None] = [None] * batch_size
@@ -181,6 +188,10 @@ def serve_requests(engine, requests, *, batch_size: int, prefill_step: int, pref
                 engine.release(slot)
             except RuntimeError:
                 pass
+    return _finish_metrics(engine, m, gaps_ms)
+
+
+def _finish_metrics(engine, m: "ServingMetrics", gaps_ms: list) -> "ServingMetrics":
     stats = engine.stats() if hasattr(engine, "stats") else {}
     m.reused_page_allocations = int(stats.get("reused_page_allocations", 0))
     m.decode_step_count = len(m.decode_step_ms)
@@ -192,6 +203,117 @@ def serve_requests(engine, requests, *, batch_size: int, prefill_step: int, pref
     m.decode_gap_p95_ms = nearest_rank(gaps_ms, 0.95)
     m.decode_gap_max_ms = max(gaps_ms, default=0.0)
     return m
+
+
+def _serve_requests_packed(engine, requests, *, batch_size, prefill_step, prefill_budget, page_size, kv_bytes_per_page,
+                           capacity_pages, clock, staging_slots) -> "ServingMetrics":
+    """The serving loop with several staging slots: every turn admits requests into the free staging slots, sends the next
+    chunk of every staged prompt through ONE packed prefill pass (at most ``prefill_budget`` rows together, ``prefill_step``
+    per prompt, 16 prompts), moves the prompts that finished into free decode slots (admission order), then runs one decode
+    step over the occupied prefix.  Same counters as the one-at-a-time loop."""
+    m = ServingMetrics()
+    staging_slots = min(staging_slots, 16)
+    slots: list[dict | None] = [None] * batch_size
+    staged: list[dict] = []  # admission order; each holds its staging slot index
+    free_staging = list(range(batch_size, batch_size + staging_slots))
+    next_idx = 0
+    live: set[int] = set()
+    gaps_ms: list[float] = []
+    last_completion: float | None = None
+
+    def snapshot():
+        states = [s for s in slots if s is not None] + staged
+        m.peak_active_requests = max(m.peak_active_requests, len(states))
+        pages = sum((s["ctx"] + page_size - 1) // page_size for s in states)
+        waste = sum((-s["ctx"]) % page_size for s in states if s["ctx"] > 0)
+        m.peak_live_pages = max(m.peak_live_pages, pages)
+        m.peak_capacity_pages = max(m.peak_capacity_pages, capacity_pages)
+        m.peak_kv_bytes = max(m.peak_kv_bytes, capacity_pages * kv_bytes_per_page)
+        if waste > m.peak_tail_waste_slots:
+            m.peak_tail_waste_slots = waste
+            m.peak_tail_waste_live_slots = pages * page_size
+            m.peak_tail_waste_bytes = waste * (kv_bytes_per_page // page_size if page_size else 0)
+            m.peak_tail_waste_fraction = waste / (pages * page_size) if pages else 0.0
+
+    try:
+        while next_idx < len(requests) or staged or any(s is not None for s in slots):
+            m.turns += 1
+            while free_staging and next_idx < len(requests):
+                st = free_staging.pop(0)
+                engine.begin(st)
+                live.add(st)
+                staged.append({"req": requests[next_idx], "offset": 0, "count": 0, "ctx": 0, "staging": st})
+                next_idx += 1
+            budget = prefill_budget
+            chunks = []
+            for p in staged:
+                tokens = p["req"].prompt_token_ids
+                rem = len(tokens) - p["offset"]
+                if rem <= 0 or budget <= 0:
+                    continue
+                n = min(prefill_step, rem, budget)
+                chunks.append((p, tokens[p["offset"]:p["offset"] + n], p["offset"] + n >= len(tokens)))
+                budget -= n
+            if chunks:
+                t0 = clock()
+                engine.prefill_packed([(p["staging"], chunk, last) for p, chunk, last in chunks])
+                engine.synchronize()
+                m.prefill_time += clock() - t0
+                m.prefill_chunks += len(chunks)
+                for p, chunk, last in chunks:
+                    p["offset"] += len(chunk)
+                    p["ctx"] += len(chunk)
+                    if last:
+                        p["count"] = 1
+                        m.generated_tokens += 1
+                snapshot()
+            for p in list(staged):  # admission order: the first prompt that finished takes the first free slot
+                if p["offset"] < len(p["req"].prompt_token_ids):
+                    continue
+                if p["count"] >= p["req"].max_new_tokens:  # a one-token request never enters the batch
+                    engine.release(p["staging"])
+                elif (free := next((i for i, s in enumerate(slots) if s is None), None)) is not None:
+                    engine.move(p["staging"], free)
+                    live.add(free)
+                    slots[free] = p
+                else:
+                    continue  # prefilled and waiting for a slot
+                live.discard(p["staging"])
+                free_staging.append(p["staging"])
+                staged.remove(p)
+            active = [i for i, s in enumerate(slots) if s is not None]
+            if not active:
+                last_completion = None
+                continue
+            rows = min(next((b for b in ROW_BUCKETS if b >= active[-1] + 1), batch_size), batch_size)
+            t0 = clock()
+            engine.decode(1, batch=rows)
+            engine.synchronize()
+            now = clock()
+            m.decode_time += now - t0
+            m.decode_step_ms.append((now - t0) * 1e3)
+            if last_completion is not None:
+                gaps_ms.append((now - last_completion) * 1e3)
+            last_completion = now
+            for i in active:
+                s = slots[i]
+                s["count"] += 1
+                s["ctx"] += 1
+                m.generated_tokens += 1
+                m.decode_tokens += 1
+            snapshot()
+            for i in active:
+                if slots[i]["count"] >= slots[i]["req"].max_new_tokens:
+                    engine.release(i)
+                    live.discard(i)
+                    slots[i] = None
+    finally:
+        for slot in list(live):
+            try:
+                engine.release(slot)
+            except RuntimeError:
+                pass
+    return _finish_metrics(engine, m, gaps_ms)
 
 
 def report_lines(num_seqs: int, prompt_tokens: int, total_time: float, m: ServingMetrics) -> list[str]:
@@ -252,6 +374,16 @@ class ScheduleOnlyEngine:
             raise RuntimeError("slot holds no sequence")
         self.slots[slot] += len(tokens)
         self.now += len(tokens) * self.prefill_ms_per_token * 1e-3
+
+    def prefill_packed(self, chunks):
+        """One pass over several slots' chunks: rows cost the same, the fixed per-pass overhead is paid once."""
+        if len({c[0] for c in chunks}) != len(chunks):
+            raise RuntimeError("a slot appears twice in a packed prefill")
+        for slot, tokens, _last in chunks:
+            if self.slots[slot] is None:
+                raise RuntimeError("slot holds no sequence")
+            self.slots[slot] += len(tokens)
+        self.now += sum(len(c[1]) for c in chunks) * self.prefill_ms_per_token * 1e-3
 
     def move(self, src, dst):
         if self.slots[src] is None or self.slots[dst] is not None:

@@ -125,6 +125,15 @@ int tl_engine_move(tl_engine *e, int src, int dst);
  * the slot's pending input token for the next decode step.  n <= max_prefill_rows. */
 int tl_engine_prefill(tl_engine *e, int slot, const int32_t *tokens, int n, int want_logits);
 
+/* The same for up to 16 slots in ONE pass (continuous batching: several admitted prompts prefilled together -- reference
+ * batch.py:48-76 prefills one request per turn; here the projections run once over the concatenated rows, at the row count
+ * the MFMA GEMM is efficient at, while RoPE / KV append / paged attention stay per sequence).  tokens = the chunks back to
+ * back (sum of lens <= max_prefill_rows), lens[i] tokens for slots[i] at positions [context_i, context_i + lens[i]);
+ * want_logits[i] != 0: that chunk ends its prompt -> last-row logits + greedy token become the slot's pending token.
+ * All-or-nothing: slot states, page counts and row totals are checked before anything is reserved. */
+int tl_engine_prefill_packed(tl_engine *e, int n_seqs, const int *slots, const int32_t *tokens, const int *lens,
+                             const int *want_logits);
+
 /* Prefix sharing (reference KvPrefixGenerator fork/restore, agent/branching.py:42-208): make the
  * free slot `dst` a second sequence with the same tokens as the live slot `src`.  Full KV pages are shared (reference
  * counted, never rewritten), a partially filled tail page is copied; the pending input token is copied too.  Afterwards

@@ -584,3 +584,63 @@ def test_fork_shares_prefix_pages_and_branches_decode_independently(ckpt, err):
         assert st["pages_in_use"] == 0 and st["pages_free"] == 32
     finally:
         eng.close()
+
+
+def test_packed_prefill_of_several_slots(ckpt, err):
+    """tl_engine_prefill_packed: several slots' chunks through ONE multi-token pass (projections over the concatenated rows,
+    RoPE / KV append / paged FlashAttention per sequence).  Every prompt's last-row logits are held against the oracle and
+    the float64 truth exactly like a solo prefill's; prompts split over two packed calls with different partners (a cached
+    context plus a fresh prompt in the same pass) and a following batched decode step must agree with the same requests
+    served alone; all-or-nothing argument checks."""
+    from tiny_llm_hip.engine import DecodeEngine
+
+    w, model = ckpt
+    prompts = [prompt_ids(n, seed=700 + n) for n in (100, 37, 200, 9)]
+    oracle_rows = [O.OracleQwen3(TINY_CFG, w).forward(p)[0, -1] for p in prompts]
+    truth_rows = [O.TruthQwen3(TINY_CFG, w).forward(p)[0, -1] for p in prompts]
+    eng = DecodeEngine(model, page_size=16, num_pages=128, max_batch=4, max_prefill_rows=512)
+    try:
+        # 1. four whole prompts in one pass
+        for s in range(4):
+            eng.begin(s)
+        eng.prefill_packed([(s, prompts[s], True) for s in range(4)])
+        got = eng.logits(4).float().cpu().numpy()
+        for s in range(4):
+            check_against_truth(got[s][None], oracle_rows[s][None], truth_rows[s][None], what=f"packed prefill, prompt {s} ({len(prompts[s])} tokens)")
+        assert [eng.context_len(s) for s in range(4)] == [len(p) for p in prompts]
+        first = eng.read_pending(4)
+        for s in range(4):
+            assert_near_greedy(got[s], first[s], err["hip_vs_oracle"], f"packed prefill first token of prompt {s}")
+        eng.decode(1, batch=4)
+        batch_rows = eng.logits(4).float().cpu().numpy()
+        for s in range(4):
+            eng.release(s)
+        # 2. the same requests alone (sequential prefill, same first token fed)
+        for s in range(4):
+            eng.begin(0)
+            eng.prefill(0, prompts[s], chunk=512)
+            eng.set_token(0, first[s])
+            eng.decode(1, batch=1)
+            solo = eng.logits(1)[0].float().cpu().numpy()
+            eng.release(0)
+            assert float(np.abs(solo - batch_rows[s]).max()) <= err["hip_vs_hip"], f"decode step after a packed prefill, prompt {s}"
+        # 3. prompts split over two passes with different partners
+        for s in range(3):
+            eng.begin(s)
+        eng.prefill_packed([(0, prompts[0][:60], False), (1, prompts[1], True)])
+        eng.prefill_packed([(2, prompts[2], True), (0, prompts[0][60:], True)])  # slot 0 continues behind a fresh prompt
+        got2 = eng.logits(2).float().cpu().numpy()  # rows in chunk order: prompt 2, prompt 0
+        check_against_truth(got2[0][None], oracle_rows[2][None], truth_rows[2][None], what="packed prefill, second pass, fresh prompt")
+        check_against_truth(got2[1][None], oracle_rows[0][None], truth_rows[0][None], what="packed prefill, prompt continued in a second pass")
+        # 4. argument checks leave everything as it was
+        ctx_before = [eng.context_len(s) for s in range(3)]
+        free_before = eng.stats()["pages_free"]
+        for bad in ([(0, [1, 2], True), (0, [3], True)], [(3, [1], True)], [(0, list(range(1, 400)), True), (1, list(range(1, 200)), True)]):
+            with pytest.raises(RuntimeError):
+                eng.prefill_packed(bad)
+        assert [eng.context_len(s) for s in range(3)] == ctx_before and eng.stats()["pages_free"] == free_before
+        for s in range(3):
+            eng.release(s)
+        assert eng.stats()["pages_in_use"] == 0
+    finally:
+        eng.close()

@@ -107,3 +107,44 @@ def test_config1_week1_cpu_runner_smoke():
     assert all(0 <= t < 4096 for t in out["first_ids"]) and out["decode_tok_s"] > 0
     again = main(["--layers", "2", "--vocab", "4096", "--prompt-len", "8", "--new-tokens", "4"])
     assert again["first_ids"] == out["first_ids"], "seeded weights and prompt: the greedy ids must reproduce"
+
+
+def test_packed_admission_schedule_only():
+    """serve_requests with several staging slots (benches/serving.py _serve_requests_packed): every request gets exactly its
+    tokens, a packed pass never exceeds the budget, 16 chunks or one chunk per slot, finished prompts enter the batch in
+    admission order, all slots come back; with ONE staging slot the engine never sees a packed call (reference policy)."""
+    from random import Random
+
+    from benches.serving import ScheduleOnlyEngine, serve_requests
+
+    class Req:
+        def __init__(self, n, m):
+            self.prompt_token_ids = list(range(1, n + 1))
+            self.max_new_tokens = m
+
+    rng = Random(5)
+    reqs = [Req(rng.randint(1, 700), rng.randint(1, 40)) for _ in range(60)]
+
+    class Spy(ScheduleOnlyEngine):
+        def __init__(self, slots):
+            super().__init__(slots)
+            self.passes = []
+
+        def prefill_packed(self, chunks):
+            self.passes.append([(slot, len(toks), last) for slot, toks, last in chunks])
+            super().prefill_packed(chunks)
+
+    for staging, budget, step in ((4, 512, 512), (16, 2048, 128), (3, 100, 64)):
+        eng = Spy(8 + staging)
+        m = serve_requests(eng, reqs, batch_size=8, prefill_step=step, prefill_budget=budget, clock=eng.clock, staging_slots=staging)
+        assert m.generated_tokens == sum(r.max_new_tokens for r in reqs)
+        assert all(x is None for x in eng.slots), "every slot released"
+        assert m.peak_active_requests <= 8 + staging
+        assert eng.passes and max(len(p) for p in eng.passes) > 1, "prompts are really packed"
+        for p in eng.passes:
+            assert sum(n for _, n, _ in p) <= budget and len(p) <= 16 and all(n <= step for _, n, _ in p)
+            assert all(slot >= 8 for slot, _, _ in p), "prefill happens in the staging slots only"
+        assert sum(n for p in eng.passes for _, n, _ in p) == sum(len(r.prompt_token_ids) for r in reqs)
+    eng = Spy(9)
+    m = serve_requests(eng, reqs, batch_size=8, prefill_step=128, prefill_budget=2048, clock=eng.clock)
+    assert not eng.passes and m.generated_tokens == sum(r.max_new_tokens for r in reqs)

@@ -132,6 +132,7 @@ _SIGNATURES.update({
     "tl_engine_fork": (_c_int, [_c_void_p, _c_int, _c_int]),
     "tl_engine_read_pending": (_c_int, [_c_void_p, _c_int, _P(ctypes.c_int32)]),
     "tl_engine_prefill": (_c_int, [_c_void_p, _c_int, _P(ctypes.c_int32), _c_int, _c_int]),
+    "tl_engine_prefill_packed": (_c_int, [_c_void_p, _c_int, _P(ctypes.c_int), _P(ctypes.c_int32), _P(ctypes.c_int), _P(ctypes.c_int)]),
     "tl_engine_verify": (_c_int, [_c_void_p, _c_int, _P(ctypes.c_int32), _c_int, _P(ctypes.c_int32)]),
     "tl_engine_set_token": (_c_int, [_c_void_p, _c_int, ctypes.c_int32]),
     "tl_engine_decode": (_c_int, [_c_void_p, _c_int, _c_int, _c_int]),

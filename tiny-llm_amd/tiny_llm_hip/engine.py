@@ -164,6 +164,20 @@ class DecodeEngine:
             last = start + chunk >= len(tokens)
             _ext.check(_lib.tl_engine_prefill(self._h, slot, arr, len(part), int(last and want_logits)))
 
+    def prefill_packed(self, chunks: Sequence[tuple[int, Sequence[int], bool]]) -> None:
+        """One pass of the multi-token path over several slots' chunks: ``chunks`` = (slot, token ids, ends_prompt) for up to 16
+        slots, together at most ``max_prefill_rows`` tokens (tl_engine_prefill_packed).  A chunk that ends its prompt produces
+        the slot's first generated token, like the last chunk of ``prefill``."""
+        if not 1 <= len(chunks) <= 16:
+            raise ValueError("prefill_packed takes between 1 and 16 chunks")
+        flat = [int(t) for _, toks, _ in chunks for t in toks]
+        n = len(chunks)
+        slots = (ctypes.c_int * n)(*[int(c[0]) for c in chunks])
+        lens = (ctypes.c_int * n)(*[len(c[1]) for c in chunks])
+        want = (ctypes.c_int * n)(*[int(bool(c[2])) for c in chunks])
+        arr = (ctypes.c_int32 * len(flat))(*flat)
+        _ext.check(_lib.tl_engine_prefill_packed(self._h, n, slots, arr, lens, want))
+
     def verify(self, slot: int, tokens: Sequence[int]) -> list[int]:
         """Speculative verification: append 1..8 tokens to the slot and return, for each of them, the greedy token that
         follows it (reference speculative_generate's target call with logits_to_keep = all rows).  Synchronises."""
