@@ -96,12 +96,23 @@ __device__ __forceinline__ u32x4 dequant_word(uint32_t w, float s, float beta) {
 #ifndef QMM_OCC
 #define QMM_OCC 3  // waves per SIMD the register allocation aims for (136 registers fit 3; 4 costs 5 spilled VGPRs)
 #endif
-template <typename TT, int MT>
-__global__ __launch_bounds__(256, QMM_OCC) void qmm_mfma_kernel(const uint16_t *__restrict__ scales,
+#ifndef QMM_OCC8
+#define QMM_OCC8 4  // the same for the 8-wave (256-column) tile: two workgroups per CU
+#endif
+// NW = waves per workgroup: the tile is (32*MT) x (32*NW).  Every byte the kernel moves comes through the CU's memory pipe
+// (~25-28 GB/s per CU when all 256 stream at once: r02 lab), and the activation tile re-read by every column tile is most of
+// it: bytes per flop = 1/TN + 0.25/TM (bf16 activations, 4-bit weights) -- 128 x 128: 734 TFLOP/s at 28 GB/s per CU, close to
+// what the kernel measures.  128 x 256 halves the activation traffic; measured it gains 10 % on gate|up and loses elsewhere
+// (mfma_nw below).
+template <typename TT, int MT, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_mfma_kernel(const uint16_t *__restrict__ scales,
                                                        const uint16_t *__restrict__ biases,
                                                        const uint16_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                        uint16_t *__restrict__ out, int M, int N, int K,
                                                        int partition_size, size_t partition_stride) {
+    constexpr int NT = 64 * NW;
+    constexpr int AQ = 32 * MT * 8 / NT;  // 16-byte activation chunks per thread and 64-wide reduction step
+    static_assert(AQ >= 1 && AQ * NT == 32 * MT * 8, "the activation tile must divide evenly over the threads");
     constexpr int BM = 32 * MT;
     __shared__ __attribute__((aligned(16))) uint16_t atile[2][BM * 64];
     const int tid = threadIdx.x;
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256, QMM_OCC) void qmm_mfma_kernel(const uint16_t *
     const int lane = tid & 63;
     const int l32 = lane & 31;
     const int h = lane >> 5;
-    const int bn0 = blockIdx.x * 128;
+    const int bn0 = blockIdx.x * (32 * NW);
     const int bm0 = blockIdx.y * BM;
     const int red0 = blockIdx.z * partition_size;
     const int j0 = red0 >> 6;
@@ -129,11 +140,11 @@ __global__ __launch_bounds__(256, QMM_OCC) void qmm_mfma_kernel(const uint16_t *
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-    u32x4 areg[MT];
+    u32x4 areg[AQ];
     auto load_a = [&](int j) {
 #pragma unroll
-        for (int q = 0; q < MT; ++q) {
-            const int c = tid + q * 256;
+        for (int q = 0; q < AQ; ++q) {
+            const int c = tid + q * NT;
             const int r = c >> 3;
             const int ch = c & 7;
             const int gr = bm0 + r;
@@ -146,8 +157,8 @@ __global__ __launch_bounds__(256, QMM_OCC) void qmm_mfma_kernel(const uint16_t *
     };
     auto store_a = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < MT; ++q) {
-            const int c = tid + q * 256;
+        for (int q = 0; q < AQ; ++q) {
+            const int c = tid + q * NT;
             const int r = c >> 3;
             const int ch = c & 7;
             const int sw = ch ^ ((r >> 1) & 7);
@@ -216,16 +227,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const uint16_t *__re
 }
 
 static int mfma_mt(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
+// 8 waves (a 128 x 256 tile) for the widest projection at full chunks only -- r02 lab at 2,048 rows: gate|up 710 -> 781
+// TFLOP/s, but qkv 767 -> 660 and the split-K projections (o, down) 531 / 596 -> 470 / 517, and everything slower at 512 rows
+// (profiles/r02_labs/gemm_lab_r02_waves_per_workgroup.log): halving the activation re-reads is not the whole story, the
+// 8-wave barrier per 64-wide reduction step costs about as much.  TL_QMM_NW = 4 / 8 pins it (lab).
+static int mfma_nw(int M, int K) {
+    static const int forced = getenv("TL_QMM_NW") ? atoi(getenv("TL_QMM_NW")) : 0;
+    if (forced == 4 || forced == 8) return (forced == 8 && M > 64) ? 8 : 4;
+    return (M >= 1024 && K >= 8192) ? 8 : 4;
+}
 
 // Split-K policy.  Reference (quantized_matmul.cpp:138-151) targets 320
 // threadgroups of 32x32 on an M4 Pro; here a tile is (32*MT)x128 and the
 // target is two workgroups per CU on 256 CUs.
 static int split_k_policy(int M, int N, int K) {
     const int mt = mfma_mt(M);
-    const int tiles = ceil_div(M, 32 * mt) * ceil_div(K, 128);
+    const int tiles = ceil_div(M, 32 * mt) * ceil_div(K, 32 * mfma_nw(M, K));
     // three workgroups fit a CU (136 registers per lane): split until about 768 are in flight.  320 tiles (a 2048-row chunk
     // against the 2560-row o / down projections) measured 471 / 482 TFLOP/s unsplit against 750 for the wide projections.
-    const int target = getenv("TL_QMM_SPLIT_TARGET") ? atoi(getenv("TL_QMM_SPLIT_TARGET")) : 768;
+    // (two of the 8-wave workgroups fit: 512)
+    const int target = getenv("TL_QMM_SPLIT_TARGET") ? atoi(getenv("TL_QMM_SPLIT_TARGET")) : (mfma_nw(M, K) == 8 ? 512 : 768);
     constexpr int max_split = 16;
     // at least two quantisation groups per slice: a one-group slice is a K loop of 4 MFMA steps behind a full prologue and a
     // reduction pass (the reference's own fallback case -- 128 x 2560 over N = 256 -- must stay unsplit and bit-identical,
@@ -282,8 +303,9 @@ static int run_qmm(const void *scales, const void *biases, const void *a, const 
     }
     if (use_simdgroup) {
         const int mt = mfma_mt(M);
+        const int nw = mfma_nw(M, K);
         const int split = use_split_k ? split_k_policy(M, N, K) : 1;
-        const dim3 grid(ceil_div(K, 128), ceil_div(M, 32 * mt), split), block(256);
+        const dim3 grid(ceil_div(K, 32 * nw), ceil_div(M, 32 * mt), split), block(64 * nw);
         uint16_t *dst = O;
         if (split > 1) {
             const size_t need = (size_t)split * M * K * 2;
@@ -293,10 +315,14 @@ static int run_qmm(const void *scales, const void *biases, const void *a, const 
         }
         const int psize = N / split;
         const size_t pstride = (size_t)M * K;
-        switch (mt) {
-            case 1: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 1>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
-            case 2: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 2>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
-            default: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 4>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
+        if (nw == 8) {
+            hipLaunchKernelGGL((qmm_mfma_kernel<TT, 4, 8>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride);
+        } else {
+            switch (mt) {
+                case 1: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 1>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
+                case 2: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 2>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
+                default: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 4>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
+            }
         }
         if (split > 1) {
             const size_t elements = (size_t)M * K;
