@@ -168,6 +168,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
 
     u32x4 wcur = u32x4{0u, 0u, 0u, 0u}, wnext = wcur;
     float sc = 0.f, be = 0.f;
+    // Scale / bias of the NEXT 64-wide step are requested together with its weights and consumed behind this step's MFMAs.
+    // Read where they are used, right after the prefetch requests, they made every other step wait out its own prefetch
+    // (loads return in issue order): r02 lab, 2,048 rows: qkv 753 -> 838, gate|up 762 -> 838 TFLOP/s.  Also tried there and
+    // dropped: activation tiles two steps ahead (two register sets: slower), an explicit sub-step pipeline of fragment reads
+    // and dequantisation (no gain), two 32-column blocks per wave (128 x 256 tile on four waves: no gain at two waves per SIMD).  (32-bit holders: as
+    // 16-bit values the compiler packs the pair into one register right behind the loads -- the same wait again.)
+    uint32_t sc_next = 0, be_next = 0;
+    if (wok) {
+        sc = TT::to_float(ssrc[j0 >> 1]);
+        be = TT::to_float(bsrc[j0 >> 1]);
+    }
     load_a(j0);
     if (wok) wcur = *reinterpret_cast<const u32x4 *>(wsrc + j0 * 8 + h * 4);
     int buf = 0;
@@ -176,11 +187,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
         __syncthreads();
         if (j + 1 < j1) {
             if (!(QMM_ABL & 4)) load_a(j + 1);
-            if (wok) wnext = *reinterpret_cast<const u32x4 *>(wsrc + (j + 1) * 8 + h * 4);
-        }
-        if (((j & 1) == 0 || j == j0) && wok) {
-            sc = TT::to_float(ssrc[j >> 1]);
-            be = TT::to_float(bsrc[j >> 1]);
+            if (wok) {
+                wnext = *reinterpret_cast<const u32x4 *>(wsrc + (j + 1) * 8 + h * 4);
+                sc_next = ssrc[(j + 1) >> 1];
+                be_next = bsrc[(j + 1) >> 1];
+            }
         }
         u32x4 bf[4];
 #pragma unroll
@@ -200,7 +211,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
             }
         }
         buf ^= 1;
+        __builtin_amdgcn_sched_barrier(0);
         wcur = wnext;
+        sc = TT::to_float((uint16_t)sc_next);
+        be = TT::to_float((uint16_t)be_next);
     }
 
     if (!wok) return;
