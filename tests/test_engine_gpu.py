@@ -644,3 +644,22 @@ def test_packed_prefill_of_several_slots(ckpt, err):
         assert eng.stats()["pages_in_use"] == 0
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("n_prompt,rows", [(300, 512), (77, 80), (40, 64), (600, 256)])
+def test_prefill_gemm_fused_epilogue_is_bit_identical(ckpt, monkeypatch, n_prompt, rows, wide):
+    """Residual add / SwiGLU folded into the prefill GEMM's store (unsplit reduction) or into its split-K reduction
+    (csrc/qmm.hip qmm_bf16_epilogue) against the separate elementwise launches (TL_GEMM_FUSED_EPILOGUE=0): the epilogue is
+    applied to the same bf16-rounded matmul result with the same expressions, so every logit must be IDENTICAL -- over chunk
+    lengths that exercise row tiles of 32 / 64 / 128 and both the split and the unsplit reduction."""
+    if wide:
+        cfg, model = WIDE_CFG, to_mlx_shaped(WIDE_CFG, O.make_qwen3_weights(WIDE_CFG, seed=5, sigma=0.03))
+    else:
+        cfg, model = TINY_CFG, ckpt[1]
+    prompt = [int(t) for t in np.random.default_rng(n_prompt).integers(1, cfg["vocab_size"], size=n_prompt)]
+    monkeypatch.setenv("TL_GEMM_FUSED_EPILOGUE", "0")
+    separate = _prefill_logits(model, prompt, rows)
+    monkeypatch.setenv("TL_GEMM_FUSED_EPILOGUE", "1")
+    fused = _prefill_logits(model, prompt, rows)
+    assert np.array_equal(separate, fused), f"{int((separate != fused).sum())} logits differ, max {np.abs(separate - fused).max()}"

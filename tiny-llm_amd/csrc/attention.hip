@@ -425,17 +425,21 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     for (int i = 0; i < FA_CPT; ++i) kv_ok[i] = v_ok[i] = false;
     // page_shift = log2(page_size), or -1 (integer division, ~30 VALU ops each, 16 of them per stage and thread)
     auto logical_page = [&](int tok) { return page_shift >= 0 ? (tok >> page_shift) : tok / page_size; };
-    auto page_of_token = [&](int tok) {
+    // The id is NOT touched here (no "in ? id : -1"): any use of the loaded word right behind the load makes the compiler wait
+    // for it on the spot -- and, loads returning in issue order, for the K/V rows of the next stage requested just before it,
+    // i.e. the stage prefetch stopped overlapping the MFMAs (r02: found in the ISA as vmcnt(0) behind load_pids).  Whether the
+    // token has a page at all is kept as a flag computed from the token index alone and applied where the id is used.
+    bool pid_in[FA_CPT], pidv_in[FA_CPT];
+    auto page_of_token = [&](int tok, bool &in) {
         const int lp = logical_page(tok);
-        const bool in = tok < ctx && lp < max_pages;
-        const int id = block_table[(long)b * max_pages + (in ? lp : 0)];  // unconditional load from a clamped address
-        return in ? id : -1;
+        in = tok < ctx && lp < max_pages;
+        return block_table[(long)b * max_pages + (in ? lp : 0)];  // unconditional load from a clamped address
     };
     auto load_pids = [&](int stage) {
 #pragma unroll
         for (int i = 0; i < FA_CPT; ++i) {
-            pid_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) >> 4));
-            pidv_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) & (FA_BK - 1)));
+            pid_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) >> 4), pid_in[i]);
+            pidv_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) & (FA_BK - 1)), pidv_in[i]);
         }
     };
     auto stage_load = [&](int stage) {
@@ -447,7 +451,8 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
             const int tok = stage * FA_BK + tok_in;
             const int lp = logical_page(tok);
             const int slot = tok - lp * page_size;
-            const int page_id = pid_reg[i];
+            const int page_id = pid_in[i] ? pid_reg[i] : -1;
+            const int page_idv = pidv_in[i] ? pidv_reg[i] : -1;
             // unconditional loads from a clamped address (a divergent branch around a load makes hipcc wait for it at the
             // join, i.e. before the MFMAs it should overlap); rows of unused pages are zeroed when they are stored to LDS
             const long off = (((long)max(page_id, 0) * num_kv_heads + kvh) * page_size + slot) * D + ch * 8;
@@ -457,9 +462,9 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
             const int tokv = stage * FA_BK + (c & (FA_BK - 1));
             const int lpv = logical_page(tokv);
             const int slotv = tokv - lpv * page_size;
-            const long offv = (((long)max(pidv_reg[i], 0) * num_kv_heads + kvh) * page_size + slotv) * D + (c / FA_BK) * 8;
+            const long offv = (((long)max(page_idv, 0) * num_kv_heads + kvh) * page_size + slotv) * D + (c / FA_BK) * 8;
             vreg[i] = *reinterpret_cast<const u32x4 *>(value_pages + offv);
-            v_ok[i] = pidv_reg[i] >= 0;
+            v_ok[i] = page_idv >= 0;
         }
     };
 

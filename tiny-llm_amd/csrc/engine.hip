@@ -89,6 +89,7 @@ struct tl_engine {
     tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
     int force_linear = 0;               // kernel-level entry points: 1 = fused GEMV, 2 = skinny matmul
     int qmm3_mode = -1;                 // skinny matmul grid: -1 by shape (qmm3_plan), 0 one-shot, 1 persistent
+    bool gemm_fused_epilogue = true;    // TL_GEMM_FUSED_EPILOGUE=0: residual / SwiGLU of the prefill GEMM as separate launches
     size_t attn_ws_bytes = 0;
     int rows_cap = 0;
     int ring_cap = 4096;
@@ -242,6 +243,14 @@ static int engine_qmm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
 // the dequantised weights to bf16 first), then SwiGLU / residual as separate launches.
 static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int epi,
                        const uint16_t *residual) {
+    if (epi != EPI_STORE && M > 8 && e->gemm_fused_epilogue) {  // residual / SwiGLU inside the GEMM store or its split-K reduction
+        const size_t need = tl_quantized_matmul_workspace_bytes(M, w.cols, w.rows, TL_BF16, 1, 1);
+        TL_TRY(ensure_splitk(e, need));
+        TL_TRY(qmm_bf16_epilogue(w.scales_dev, w.biases_dev, a, w.weight_dev, out, M, w.cols, w.rows, epi, residual, e->splitk_ws,
+                                 e->splitk_ws_bytes, e->stream));
+        TL_CHECK_LAUNCH("engine matmul");
+        return TL_OK;
+    }
     uint16_t *plain = epi == EPI_STORE ? out : (epi == EPI_SWIGLU ? e->gu : e->tmp);
     TL_TRY(engine_qmm(e, w, a, plain, M));
     if (epi == EPI_SWIGLU) {
@@ -794,6 +803,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->ss_x = (float *)(A + o_ssx);
     e->ss_h = (float *)(A + o_ssh);
     if (const char *q = getenv("TL_QMM3_FUSED_NORM")) e->fuse_norm = atoi(q) != 0;
+    if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
     if (const char *q = getenv("TL_QMM3_SMALL_ELEMS")) e->qmm3_small_elems = (size_t)atoll(q);

@@ -104,12 +104,16 @@ __device__ __forceinline__ u32x4 dequant_word(uint32_t w, float s, float beta) {
 // it: bytes per flop = 1/TN + 0.25/TM (bf16 activations, 4-bit weights) -- 128 x 128: 734 TFLOP/s at 28 GB/s per CU, close to
 // what the kernel measures.  128 x 256 halves the activation traffic; measured it gains 10 % on gate|up and loses elsewhere
 // (mfma_nw below).
-template <typename TT, int MT, int NW = 4>
+// EPI (engine prefill only; the operator uses EPI_STORE): applied by the kernel when the reduction is not split, by the split-K
+// reduction otherwise -- on the SAME bf16-rounded matmul result and with the same expressions as the separate residual /
+// SwiGLU launches they replace (residual_add_kernel, swiglu_interleaved_kernel), so the results are bit-identical.
+template <typename TT, int MT, int NW = 4, int EPI = EPI_STORE>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_mfma_kernel(const uint16_t *__restrict__ scales,
                                                        const uint16_t *__restrict__ biases,
                                                        const uint16_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                        uint16_t *__restrict__ out, int M, int N, int K,
-                                                       int partition_size, size_t partition_stride) {
+                                                       int partition_size, size_t partition_stride,
+                                                       const uint16_t *__restrict__ residual = nullptr) {
     constexpr int NT = 64 * NW;
     constexpr int AQ = 32 * MT * 8 / NT;  // 16-byte activation chunks per thread and 64-wide reduction step
     static_assert(AQ >= 1 && AQ * NT == 32 * MT * 8, "the activation tile must divide evenly over the threads");
@@ -217,6 +221,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
         be = TT::to_float((uint16_t)be_next);
     }
 
+    if constexpr (EPI == EPI_SWIGLU) {
+        // weight rows interleaved (even = gate_i, odd = up_i): the partner column sits in the neighbouring lane
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float mine = TT::to_float(TT::from_float(acc[mt][r]));
+                const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0xb1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+                if (wok && (l32 & 1) == 0 && m < M) out[(size_t)m * (K / 2) + (wrow >> 1)] = TT::from_float((mine / (1.0f + expf(-mine))) * other);
+            }
+        }
+        return;
+    }
     if (!wok) return;
     uint16_t *dst = out + (size_t)blockIdx.z * partition_stride;
 #pragma unroll
@@ -224,7 +242,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = bm0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m < M) dst[(size_t)m * K + wrow] = TT::from_float(acc[mt][r]);
+            if (m < M) {
+                if constexpr (EPI == EPI_RESIDUAL)
+                    dst[(size_t)m * K + wrow] = TT::from_float(TT::to_float(residual[(size_t)m * K + wrow]) + TT::to_float(TT::from_float(acc[mt][r])));
+                else
+                    dst[(size_t)m * K + wrow] = TT::from_float(acc[mt][r]);
+            }
         }
     }
 }
@@ -238,6 +261,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const uint16_t *__re
     float sum = 0.f;
     for (int p = 0; p < split_k; ++p) sum += TT::to_float(partials[(size_t)p * elements + i]);
     out[i] = TT::from_float(sum);
+}
+// the same with the engine's epilogue on the rounded sum: one thread = two adjacent elements (a gate / up pair under SwiGLU)
+template <typename TT, int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const uint16_t *__restrict__ partials, uint16_t *__restrict__ out,
+                                                                size_t elements, int split_k, const uint16_t *__restrict__ residual) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= elements) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int p = 0; p < split_k; ++p) {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(partials + (size_t)p * elements + i);
+        s0 += TT::to_float((uint16_t)(v & 0xffffu));
+        s1 += TT::to_float((uint16_t)(v >> 16));
+    }
+    const float r0 = TT::to_float(TT::from_float(s0)), r1 = TT::to_float(TT::from_float(s1));
+    if constexpr (EPI == EPI_SWIGLU) {
+        out[i >> 1] = TT::from_float((r0 / (1.0f + expf(-r0))) * r1);
+    } else {
+        const uint32_t rv = *reinterpret_cast<const uint32_t *>(residual + i);
+        const uint16_t o0 = TT::from_float(TT::to_float((uint16_t)(rv & 0xffffu)) + r0);
+        const uint16_t o1 = TT::from_float(TT::to_float((uint16_t)(rv >> 16)) + r1);
+        *reinterpret_cast<uint32_t *>(out + i) = (uint32_t)o0 | ((uint32_t)o1 << 16);
+    }
 }
 
 static int mfma_mt(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
@@ -347,6 +392,50 @@ static int run_qmm(const void *scales, const void *biases, const void *a, const 
     }
     hipLaunchKernelGGL((qmm_vanilla_kernel<TT>), dim3(ceil_div(K, 64), ceil_div(M, 4)), dim3(256), 0, st, S, Bi, A, b, O,
                        M, N, K);
+    return TL_OK;
+}
+
+// The engine's prefill projection: the W4 MFMA GEMM of the operator (same kernels, same tile / split-K policy, therefore the same
+// bits) with the residual add or the SwiGLU of the interleaved gate|up rows folded into the kernel's store (unsplit) or into the
+// split-K reduction -- the separate elementwise launch and a round trip of the [M, K] intermediate through HBM are gone.
+int qmm_bf16_epilogue(const void *scales, const void *biases, const uint16_t *A, const uint32_t *b, uint16_t *O, int M, int N, int K,
+                      int epi, const uint16_t *residual, void *workspace, size_t workspace_bytes, hipStream_t st) {
+    if (M <= 8 || epi == EPI_STORE) return fail(TL_ERR_INVALID, "qmm_bf16_epilogue: for more than 8 rows and a real epilogue");
+    if (epi == EPI_RESIDUAL && !residual) return fail(TL_ERR_INVALID, "qmm_bf16_epilogue: residual rows missing");
+    if (epi == EPI_SWIGLU && (K % 2) != 0) return fail(TL_ERR_INVALID, "qmm_bf16_epilogue: SwiGLU needs an even number of weight rows");
+    auto S = (const uint16_t *)scales;
+    auto Bi = (const uint16_t *)biases;
+    const int mt = mfma_mt(M);
+    const int nw = mfma_nw(M, K);
+    const int split = split_k_policy(M, N, K);
+    const dim3 grid(ceil_div(K, 32 * nw), ceil_div(M, 32 * mt), split), block(64 * nw);
+    const int psize = N / split;
+    const size_t pstride = (size_t)M * K;
+    if (split > 1) {
+        const size_t need = (size_t)split * M * K * 2;
+        if (!workspace || workspace_bytes < need) return fail(TL_ERR_INVALID, "qmm_bf16_epilogue: split-K workspace is missing or too small");
+        uint16_t *dst = (uint16_t *)workspace;
+        if (nw == 8) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4, 8>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr);
+        else if (mt == 1) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 1>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr);
+        else if (mt == 2) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 2>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr);
+        else hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr);
+        const size_t elements = (size_t)M * K;
+        const dim3 rg(ceil_div(elements / 2, 256));
+        if (epi == EPI_SWIGLU) hipLaunchKernelGGL((splitk_reduce_epi_kernel<BF16, EPI_SWIGLU>), rg, dim3(256), 0, st, dst, O, elements, split, residual);
+        else hipLaunchKernelGGL((splitk_reduce_epi_kernel<BF16, EPI_RESIDUAL>), rg, dim3(256), 0, st, dst, O, elements, split, residual);
+        return TL_OK;
+    }
+#define QMM_EPI_LAUNCH(EPIv)                                                                                                     \
+    if (nw == 8) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4, 8, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual); \
+    else if (mt == 1) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 1, 4, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual); \
+    else if (mt == 2) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 2, 4, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual); \
+    else hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4, 4, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual);
+    if (epi == EPI_SWIGLU) {
+        QMM_EPI_LAUNCH(EPI_SWIGLU)
+    } else {
+        QMM_EPI_LAUNCH(EPI_RESIDUAL)
+    }
+#undef QMM_EPI_LAUNCH
     return TL_OK;
 }
 

@@ -400,4 +400,7 @@ inline QmvPlan qmv_plan(int M, int N, int K) {
 // Returns 0, or -1 when the activation tile does not fit in LDS, -2 for an unknown plan.
 int launch_qmv_fused_bf16(const QmvArgs &args, int pro, int epi, hipStream_t st);
 
+// qmm.hip: the prefill W4 GEMM with the engine's epilogue folded in (rows > 8; epi = EPI_RESIDUAL / EPI_SWIGLU)
+int qmm_bf16_epilogue(const void *scales, const void *biases, const uint16_t *a, const uint32_t *b, uint16_t *out, int M, int N, int K,
+                      int epi, const uint16_t *residual, void *workspace, size_t workspace_bytes, hipStream_t st);
 }  // namespace tl
