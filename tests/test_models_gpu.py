@@ -203,3 +203,22 @@ def test_week3_model_with_moe_layers():
     # two experts' outputs are rounded to bf16, weighted by bf16 probabilities and summed in bf16 (moe.py:60-89): more
     # rounding points than the dense MLP the oracle models
     check_against_truth(many[0], oracle, truth, what="MoE 4 identical experts / top-2 == dense, TINY", factor=2.5)
+
+
+@pytest.mark.gpu
+def test_profile_week2_kernel_group_replay_runs_on_a_tiny_model():
+    """benches/profile_week2_kernels.py: every default checkpoint / phase builds its model and replays its kernel groups
+    (projections, attention, pointwise, KV growth on decode) on the HIP operators; shares sum to one."""
+    from benches import profile_week2_kernels as P
+    from tiny_llm_hip.synthetic import synthetic_qwen3
+
+    cfg = dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=128,
+               intermediate_size=512, vocab_size=1024, rope_theta=1000000, rms_norm_eps=1e-6, max_position_embeddings=4096,
+               tie_word_embeddings=True)
+    model = synthetic_qwen3(cfg, seed=1, sigma=0.05, device="cuda")
+    for spec in P.DEFAULT_CASES:
+        case = P.parse_case(spec)
+        out = P.profile_case(model, case, warmup=1, iterations=2, seed=0)
+        names = [c["name"] for c in out["categories"]]
+        assert names == list(P.GROUPS[:4 if case.phase == "decode" else 3])
+        assert abs(sum(c["share"] for c in out["categories"]) - 1.0) < 1e-9 and out["attributed_us"] > 0

@@ -8,6 +8,8 @@ import sys
 from pathlib import Path
 from random import Random
 
+import pytest
+
 ROOT = Path(__file__).resolve().parent.parent
 
 
@@ -148,3 +150,33 @@ def test_packed_admission_schedule_only():
     eng = Spy(9)
     m = serve_requests(eng, reqs, batch_size=8, prefill_step=128, prefill_budget=2048, clock=eng.clock)
     assert not eng.passes and m.generated_tokens == sum(r.max_new_tokens for r in reqs)
+
+
+def test_profile_week2_kernels_harness_logic(monkeypatch):
+    """benches/profile_week2_kernels.py (reference: benches/profile_week2_kernels.py:88-156): the case syntax, the rotated
+    group order and the median -- against a fake clock, no GPU."""
+    import argparse
+
+    from benches import profile_week2_kernels as P
+
+    assert P.parse_case("split-k:prefill:32") == P.ProfileCase("split-k", "prefill", 32)
+    for bad in ("split-k:prefill", "a:warmup:3", "a:decode:0", "a:decode:x"):
+        with pytest.raises(argparse.ArgumentTypeError):
+            P.parse_case(bad)
+    assert [c.checkpoint for c in P.parse_args([]).case] == [c.split(":")[0] for c in P.DEFAULT_CASES]
+    calls, now = [], [0.0]
+    cost = {"a": 1.0, "b": 2.0, "c": 4.0}
+
+    def builder(name):
+        def build():
+            calls.append(name)
+            return [name]
+        return build
+
+    def evaluate(outputs):
+        now[0] += cost[outputs[0]]
+
+    monkeypatch.setattr(P, "perf_counter", lambda: now[0])
+    got = P.benchmark_groups([(n, builder(n)) for n in "abc"], warmup=2, iterations=3, evaluate=evaluate)
+    assert got == {"a": 1e6, "b": 2e6, "c": 4e6}
+    assert "".join(calls) == "abc" "bca" "cab" "abc" "bca", "order rotated by one every round, warm-up rounds included"
