@@ -416,9 +416,9 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     // page ids travel one stage ahead of the K/V rows they address: a stage's loads are then ONE global round trip behind
     // the MFMAs of the previous stage instead of two dependent ones (block table, then rows)
     // K chunk c = tid + 256 i  ->  (token c / 16, 16-byte chunk c % 16): coalesced rows, b128 stores into the swizzled K tile.
-    // V chunk c            ->  (token c % FA_BK, chunk c / FA_BK): the 64 lanes of a wave hold 64 consecutive TOKENS of one
-    // chunk, so the 2-byte stores into the transposed tile vt[dim][token] hit consecutive addresses (the K mapping would
-    // put 16 lanes on two LDS banks).  The price is a strided global read of V (rows 256 B apart), absorbed by the L1.
+    // V (below)            ->  a token pair and two chunks per thread: consecutive lanes hold consecutive token pairs of one
+    // chunk, so the stores into the transposed tile vt[dim][token] hit consecutive words (the K mapping would put 16 lanes
+    // on two LDS banks).  The price is a strided global read of V (rows 256 B apart), absorbed by the L1.
     int pid_reg[FA_CPT], pidv_reg[FA_CPT];
     bool kv_ok[FA_CPT], v_ok[FA_CPT];
 #pragma unroll
@@ -435,12 +435,15 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
         in = tok < ctx && lp < max_pages;
         return block_table[(long)b * max_pages + (in ? lp : 0)];  // unconditional load from a clamped address
     };
+    // V: thread -> token PAIR (2p, 2p + 1), p = tid & 31, and chunks chv = (tid >> 5) + 8 i (i < 2): the pair's values of one
+    // dim land in ONE 32-bit word of the transposed tile vt[dim][token], so a stage costs 16 ds_write_b32 per thread instead of
+    // 32 ds_write_b16 (the LDS store path is per instruction, not per byte).  vreg[2 i + t], pidv_reg[t] for token 2p + t.
+    const int vp = tid & 31, vch0 = tid >> 5;
     auto load_pids = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < FA_CPT; ++i) {
-            pid_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) >> 4), pid_in[i]);
-            pidv_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) & (FA_BK - 1)), pidv_in[i]);
-        }
+        for (int i = 0; i < FA_CPT; ++i) pid_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) >> 4), pid_in[i]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) pidv_reg[t] = page_of_token(stage * FA_BK + 2 * vp + t, pidv_in[t]);
     };
     auto stage_load = [&](int stage) {
 #pragma unroll
@@ -452,19 +455,25 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
             const int lp = logical_page(tok);
             const int slot = tok - lp * page_size;
             const int page_id = pid_in[i] ? pid_reg[i] : -1;
-            const int page_idv = pidv_in[i] ? pidv_reg[i] : -1;
             // unconditional loads from a clamped address (a divergent branch around a load makes hipcc wait for it at the
             // join, i.e. before the MFMAs it should overlap); rows of unused pages are zeroed when they are stored to LDS
             const long off = (((long)max(page_id, 0) * num_kv_heads + kvh) * page_size + slot) * D + ch * 8;
             kreg[i] = *reinterpret_cast<const u32x4 *>(key_pages + off);
             kv_ok[i] = page_id >= 0;
             if (ch == 0) tile_page[stage & 1][tok_in] = page_id;  // read one iteration later, after two barriers
-            const int tokv = stage * FA_BK + (c & (FA_BK - 1));
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int tokv = stage * FA_BK + 2 * vp + t;
             const int lpv = logical_page(tokv);
             const int slotv = tokv - lpv * page_size;
-            const long offv = (((long)max(page_idv, 0) * num_kv_heads + kvh) * page_size + slotv) * D + (c / FA_BK) * 8;
-            vreg[i] = *reinterpret_cast<const u32x4 *>(value_pages + offv);
-            v_ok[i] = page_idv >= 0;
+            const int page_idv = pidv_in[t] ? pidv_reg[t] : -1;
+            const long rowv = (((long)max(page_idv, 0) * num_kv_heads + kvh) * page_size + slotv) * D;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                vreg[2 * i + t] = *reinterpret_cast<const u32x4 *>(value_pages + rowv + (vch0 + 8 * i) * 8);
+                v_ok[2 * i + t] = page_idv >= 0;
+            }
         }
     };
 
@@ -475,13 +484,18 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
             const int tok_in = c >> 4;
             const int ch = c & 15;
             if (!kv_ok[i]) kreg[i] = u32x4{0u, 0u, 0u, 0u};
-            if (!v_ok[i]) vreg[i] = u32x4{0u, 0u, 0u, 0u};
             *reinterpret_cast<u32x4 *>(&ks[tok_in * D + ((ch ^ (tok_in & 15)) * 8)]) = kreg[i];
-            const int tokv = c & (FA_BK - 1), chv = c / FA_BK;
+        }
+        uint32_t *vt32 = reinterpret_cast<uint32_t *>(vt);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                vt[(chv * 8 + 2 * e) * FA_LDV + tokv] = (uint16_t)(vreg[i][e] & 0xffffu);
-                vt[(chv * 8 + 2 * e + 1) * FA_LDV + tokv] = (uint16_t)(vreg[i][e] >> 16);
+        for (int i = 0; i < 2; ++i) {
+            const u32x4 v0 = v_ok[2 * i] ? vreg[2 * i] : u32x4{0u, 0u, 0u, 0u};
+            const u32x4 v1 = v_ok[2 * i + 1] ? vreg[2 * i + 1] : u32x4{0u, 0u, 0u, 0u};
+            const int chv = vch0 + 8 * i;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {  // word e of a chunk = dims 2e (low half) and 2e + 1 (high half) of its token
+                vt32[((chv * 8 + 2 * e) * FA_LDV) / 2 + vp] = (v0[e] & 0xffffu) | (v1[e] << 16);
+                vt32[((chv * 8 + 2 * e + 1) * FA_LDV) / 2 + vp] = (v0[e] >> 16) | (v1[e] & 0xffff0000u);
             }
         }
     };
