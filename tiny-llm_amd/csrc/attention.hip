@@ -334,6 +334,11 @@ constexpr int FA_SUB = FA_BK / 32;
 constexpr int FA_CPT = FA_BK / 16;    // 16-byte K (and V) chunks per thread and stage
 constexpr int FA_LDV = FA_BK + 4;    // row length of the transposed V tile
 
+// ONEPAGE: the page size is a power of two >= FA_BK, so a 64-token stage lies inside ONE page.  Its page id is then a single
+// wave-uniform word and every K/V address of the stage is (uniform base of the page's rows) + (a per-thread offset fixed for
+// the whole kernel): the per-chunk page lookups (8 vector loads per thread and stage) and the 64-bit address chains behind them
+// (~20 VALU instructions per chunk, as much as the softmax of the stage) disappear.
+template <bool ONEPAGE>
 __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ key_pages, const uint16_t *__restrict__ value_pages,
     const int32_t *__restrict__ block_table, const int32_t *__restrict__ context_lens, uint16_t *__restrict__ out,
@@ -439,13 +444,43 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     // dim land in ONE 32-bit word of the transposed tile vt[dim][token], so a stage costs 16 ds_write_b32 per thread instead of
     // 32 ds_write_b16 (the LDS store path is per instruction, not per byte).  vreg[2 i + t], pidv_reg[t] for token 2p + t.
     const int vp = tid & 31, vch0 = tid >> 5;
+    int page_next = -1;  // ONEPAGE: the (uniform) page id of the stage whose rows are requested next
     auto load_pids = [&](int stage) {
+        if constexpr (ONEPAGE) {
+            const int lp = (stage * FA_BK) >> page_shift;
+            const int id = block_table[(long)b * max_pages + min(lp, max_pages - 1)];  // same address in every lane
+            page_next = id;                                                              // made uniform where it is used
+            pid_in[0] = lp < max_pages;
+        } else {
 #pragma unroll
-        for (int i = 0; i < FA_CPT; ++i) pid_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) >> 4), pid_in[i]);
+            for (int i = 0; i < FA_CPT; ++i) pid_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) >> 4), pid_in[i]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) pidv_reg[t] = page_of_token(stage * FA_BK + 2 * vp + t, pidv_in[t]);
+            for (int t = 0; t < 2; ++t) pidv_reg[t] = page_of_token(stage * FA_BK + 2 * vp + t, pidv_in[t]);
+        }
     };
     auto stage_load = [&](int stage) {
+        if constexpr (ONEPAGE) {
+            const int page = pid_in[0] ? __builtin_amdgcn_readfirstlane(page_next) : -1;
+            const int slot0 = (stage * FA_BK) & (page_size - 1);
+            const long base = (((long)max(page, 0) * num_kv_heads + kvh) * page_size + slot0) * D;  // uniform
+            const uint16_t *kbase = key_pages + base;
+            const uint16_t *vbase = value_pages + base;
+#pragma unroll
+            for (int i = 0; i < FA_CPT; ++i) {
+                const int c = tid + i * 256;  // token c / 16, chunk c % 16: the stage's 64 K rows are contiguous
+                kreg[i] = *reinterpret_cast<const u32x4 *>(kbase + (size_t)c * 8);
+                kv_ok[i] = page >= 0 && stage * FA_BK + (c >> 4) < ctx;  // rows past the context are zeroed in LDS as before
+                if ((c & 15) == 0) tile_page[stage & 1][c >> 4] = kv_ok[i] ? page : -1;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    vreg[2 * i + t] = *reinterpret_cast<const u32x4 *>(vbase + (size_t)(2 * vp + t) * D + (vch0 + 8 * i) * 8);
+                    v_ok[2 * i + t] = page >= 0 && stage * FA_BK + 2 * vp + t < ctx;
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < FA_CPT; ++i) {
             const int c = tid + i * 256;
@@ -779,10 +814,16 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
         int page_shift = -1;
         for (int sh = 0; sh < 30; ++sh)
             if ((1 << sh) == page_size) page_shift = sh;
-        hipLaunchKernelGGL(paged_fa_bf16_d128_kernel, grid, dim3(256), 0, st, (const uint16_t *)q,
-                           (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,
-                           (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, page_shift, max_pages, num_heads,
-                           num_kv_heads, scale, is_causal);
+        if (page_shift >= 6)  // a 64-token stage never straddles pages
+            hipLaunchKernelGGL(paged_fa_bf16_d128_kernel<true>, grid, dim3(256), 0, st, (const uint16_t *)q,
+                               (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,
+                               (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, page_shift, max_pages, num_heads,
+                               num_kv_heads, scale, is_causal);
+        else
+            hipLaunchKernelGGL(paged_fa_bf16_d128_kernel<false>, grid, dim3(256), 0, st, (const uint16_t *)q,
+                               (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,
+                               (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, page_shift, max_pages, num_heads,
+                               num_kv_heads, scale, is_causal);
         TL_CHECK_LAUNCH("paged_attention(prefill)");
         if (fa_splits > 1) {
             hipLaunchKernelGGL((paged_merge_kernel<BF16>), dim3(N * L), dim3(128), 0, st, (const float *)workspace,
