@@ -403,16 +403,20 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     return SplitPlan{s, std::max(64, std::min(per_split, bucket / s)), rq};
 }
 
-template <int VD, bool SP>
+template <int VD, bool SP, bool IP = false>
 static void launch_attn_decode_sp(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq) {
     const size_t lds = (size_t)16 * rq * (16 * VD + 2) * sizeof(float);
-    if (rq == 1) hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, 1, SP>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP>), grid, dim3(256), lds, st, a);
+    if (rq == 1) hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, 1, SP, IP>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP>), grid, dim3(256), lds, st, a);
 }
 template <int VD>
 static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq) {
     const bool single_page = a.tokens_per_split <= a.page_size && a.page_size % a.tokens_per_split == 0;
+    // every 64-token stage of a window inside one page: windows are multiples of 64 tokens, pages a power of two >= 64
+    static const bool stage_pages_off = getenv("TL_ATTN_STAGE_PAGES") && atoi(getenv("TL_ATTN_STAGE_PAGES")) == 0;
+    const bool stage_page = !single_page && !stage_pages_off && a.page_shift >= 6 && a.tokens_per_split % 64 == 0;
     if (single_page) launch_attn_decode_sp<VD, true>(a, grid, st, rq);
+    else if (stage_page) launch_attn_decode_sp<VD, false, true>(a, grid, st, rq);
     else launch_attn_decode_sp<VD, false>(a, grid, st, rq);
 }
 

@@ -208,7 +208,11 @@ __device__ __forceinline__ void store_raw(uint16_t *dst, const RawRow<VD> &r) {
 // VALU chain of a step at the price of re-reading the K/V window from L2 once per extra workgroup
 // SP = the workgroup's token window lies inside ONE page (tokens_per_split divides page_size): the page id is then a
 // scalar load that returns long before the vector round trip, and the K/V rows no longer wait for it
-template <int VD, int U, int RQ, bool SP>
+// IP = the window spans several pages, but every 16 U-token stage of the walk lies inside one (page size a power of two >= 16 U,
+// windows start on stage boundaries): the stage's page id is one scalar word fetched a stage ahead, and a row address is
+// (uniform row base of the stage) + (a lane offset fixed for the kernel) -- no per-row page lookups (2 U vector loads per lane and
+// stage) and no per-row 64-bit address chains.  The long-context plan (512-token windows over 128-token pages) runs this way.
+template <int VD, int U, int RQ, bool SP, bool IP = false>
 __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecodeArgs p) {
     constexpr int D = 16 * VD;
     constexpr int STRIDE = D + 2;
@@ -242,7 +246,12 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     sload_i32(brow, first_page);
     if constexpr (SP) sload_i32(brow + min(page_of(t_begin), p.max_pages - 1), pid_s);
     int pid[U], pid_next[U];
-    if constexpr (!SP) {
+    int pg_nxt = 0, pg_new = 0;  // IP: page id of the next stage / of the one after it (scalar)
+    if constexpr (IP) {
+        sload_i32(brow + min(page_of(t_begin), p.max_pages - 1), pid_s);
+        sload_i32(brow + min(page_of(t_begin + 16 * U), p.max_pages - 1), pg_nxt);
+    }
+    if constexpr (!SP && !IP) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int tok = t_begin + u * 16 + g;
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     float cs[VD], sn[VD];
     rope_from_table<VD>(p.rope_cur + (long)b * (D / 2), t, cs, sn);
     __builtin_amdgcn_sched_barrier(0);
-    sload_wait(ctx, first_page, pid_s);
+    sload_wait(ctx, first_page, pid_s, pg_nxt);
     const bool live = first_page >= 0;  // a sequence always owns its first page; idle slots have an all -1 row and produce zeros
     if constexpr (SP) {
 #pragma unroll
@@ -290,7 +299,22 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             load_raw<VD>(p.value_pages + off, vv[u]);
         }
     };
-    issue_kv(t_begin, pid, kr, vr, ok);
+    const int lane_row = g * D + t * VD;  // IP: element offset of this lane's 16 bytes inside a stage's first 16 rows
+    auto issue_kv_stage = [&](int base, int pg, RawRow<VD> (&kk)[U], RawRow<VD> (&vv)[U], bool (&valid)[U]) {
+        const int lp = page_of(base);  // uniform
+        const bool page_ok = lp < p.max_pages && pg >= 0;
+        const long rowbase = (((long)max(pg, 0) * Hkv + kvh) * p.page_size + (base - lp * p.page_size)) * D;  // uniform
+        const uint16_t *kb = p.key_pages + rowbase, *vb = p.value_pages + rowbase;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tok = base + u * 16 + g;
+            valid[u] = tok < ctx && tok < t_begin + C && page_ok;
+            load_raw<VD>(kb + lane_row + u * 16 * D, kk[u]);
+            load_raw<VD>(vb + lane_row + u * 16 * D, vv[u]);
+        }
+    };
+    if constexpr (IP) issue_kv_stage(t_begin, pid_s, kr, vr, ok);
+    else issue_kv(t_begin, pid, kr, vr, ok);
 
     // ---- prologue math while the K/V rows are in flight ---------------------------------------------------------------
     auto norm_rope = [&](const RawRow<VD> &x, const RawRow<VD> &w, float (&out)[VD]) {
@@ -333,7 +357,12 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     for (int it = 0; it < n_it; ++it) {
         bool ok_next[U];
         const bool more = it + 1 < n_it;
-        if (more) {  // uniform
+        if constexpr (IP) {
+            if (more) {  // uniform
+                issue_kv_stage(t_begin + (it + 1) * 16 * U, pg_nxt, kr_next, vr_next, ok_next);
+                sload_i32(brow + min(page_of(t_begin + (it + 2) * 16 * U), p.max_pages - 1), pg_new);  // waited for at the end of this stage
+            }
+        } else if (more) {  // uniform
             issue_kv(t_begin + (it + 1) * 16 * U, pid_next, kr_next, vr_next, ok_next);
             if constexpr (!SP) {
 #pragma unroll
@@ -379,6 +408,10 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
                 kr[u] = kr_next[u];
                 vr[u] = vr_next[u];
                 ok[u] = ok_next[u];
+            }
+            if constexpr (IP) {
+                sload_wait(pg_new);
+                pg_nxt = pg_new;
             }
         }
     }
