@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
             const float score = group16_sum(part);
             if (tok < rq_vis[r]) {
                 const float nm = fmaxf(m[r], score);
-                const float of = exp2f(m[r] - nm);
-                const float sf = exp2f(score - nm);
+                const float of = exp2_hw(m[r] - nm);
+                const float sf = exp2_hw(score - nm);
                 l[r] = l[r] * of + sf;
 #pragma unroll
                 for (int i = 0; i < VD; ++i) acc[r][i] = acc[r][i] * of + sf * vf[i];
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float *src = psm + ((long)j * PD_RQ + r) * stride;
-            const float f = exp2f(src[D] - gm);
+            const float f = exp2_hw(src[D] - gm);
             gl += src[D + 1] * f;
             vs += src[d] * f;
         }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(128) void paged_merge_kernel(const float *__restric
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
         float gl = 0.f, vs = 0.f;
         for (int s = 0; s < n_splits; ++s) {
-            const float f = exp2f(base[s * stride + D] - gm);
+            const float f = exp2_hw(base[s * stride + D] - gm);
             gl += base[s * stride + D + 1] * f;
             vs += base[s * stride + d] * f;
         }
@@ -602,18 +602,18 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
         const float new_max = fmaxf(run_max, tmax);
         float prev_scale, tsum = 0.f;
         if (interior) {  // every score is finite: exp2f(-inf) of the first tile's running maximum is the wanted 0
-            prev_scale = exp2f(run_max - new_max);
+            prev_scale = exp2_hw(run_max - new_max);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sacc[r] = exp2f(sacc[r] - new_max);
+                sacc[r] = exp2_hw(sacc[r] - new_max);
                 tsum += sacc[r];
             }
         } else {
             const bool finite_row = q_valid && new_max != -INFINITY;
-            prev_scale = (run_max == -INFINITY || !finite_row) ? 0.f : exp2f(run_max - new_max);
+            prev_scale = (run_max == -INFINITY || !finite_row) ? 0.f : exp2_hw(run_max - new_max);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = (sacc[r] == -INFINITY || !finite_row) ? 0.f : exp2f(sacc[r] - new_max);
+                const float p = (sacc[r] == -INFINITY || !finite_row) ? 0.f : exp2_hw(sacc[r] - new_max);
                 sacc[r] = p;
                 tsum += p;
             }

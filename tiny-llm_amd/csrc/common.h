@@ -77,6 +77,9 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// Softmax exponentials: the bare v_exp_f32.  exp2f() wraps it in denormal-range handling (compare, scale, select, ldexp: four
+// more VALU instructions per call); a weight below 2^-126 is zero at every precision the attention result is kept in.
+__device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }
 // reduce over aligned groups of 16 lanes
 __device__ __forceinline__ float group16_sum(float v) {
 #pragma unroll

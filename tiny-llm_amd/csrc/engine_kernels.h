@@ -389,14 +389,14 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             float nm = m[r];
 #pragma unroll
             for (int u = 0; u < U; ++u) nm = fmaxf(nm, sc[r][u]);
-            const float of = exp2f(m[r] - nm);
+            const float of = exp2_hw(m[r] - nm);
             m[r] = nm;
             l[r] *= of;
 #pragma unroll
             for (int i = 0; i < VD; ++i) acc[r][i] *= of;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float pw = (ok[u] && live) ? exp2f(sc[r][u] - nm) : 0.f;
+                const float pw = (ok[u] && live) ? exp2_hw(sc[r][u] - nm) : 0.f;
                 l[r] += pw;
 #pragma unroll
                 for (int i = 0; i < VD; ++i) acc[r][i] += pw * BF16::to_float(vr[u].v[i]);
@@ -425,8 +425,8 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             const float score = group16_allsum(part);
             if (live && g == 0) {
                 const float nm = fmaxf(m[r], score);
-                const float of = exp2f(m[r] - nm);
-                const float sf = exp2f(score - nm);
+                const float of = exp2_hw(m[r] - nm);
+                const float sf = exp2_hw(score - nm);
                 l[r] = l[r] * of + sf;
 #pragma unroll
                 for (int i = 0; i < VD; ++i) acc[r][i] = acc[r][i] * of + sf * v_new[i];
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float *src = psm + ((long)j * RQ + r) * STRIDE;
-            const float f = exp2f(src[D] - gm);
+            const float f = exp2_hw(src[D] - gm);
             gl += src[D + 1] * f;
             vs += src[d] * f;
         }
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
 #pragma unroll
                 for (int s2 = 0; s2 < 8; ++s2) {
                     if (s2 < p.n_splits) {
-                        const float f = exp2f(ms[s2] - gm);
+                        const float f = exp2_hw(ms[s2] - gm);
                         gl += ls[s2] * f;
                         accm += vs[s2] * f;
                     }
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_wide_kernel(const AttnDec
     float l = 0.f;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const float pw = (ok[u] && live) ? exp2f(sc[u] - m) : 0.f;
+        const float pw = (ok[u] && live) ? exp2_hw(sc[u] - m) : 0.f;
         l += pw;
 #pragma unroll
         for (int i = 0; i < VD; ++i) acc[i] += pw * BF16::to_float(vr[u].v[i]);
@@ -713,8 +713,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_wide_kernel(const AttnDec
         const float score = group16_allsum(part);
         if (live && g == 0) {
             const float nm = fmaxf(m, score);
-            const float of = exp2f(m - nm);
-            const float sf = exp2f(score - nm);
+            const float of = exp2_hw(m - nm);
+            const float sf = exp2_hw(score - nm);
             l = l * of + sf;
 #pragma unroll
             for (int i = 0; i < VD; ++i) acc[i] = acc[i] * of + sf * v_new[i];
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_wide_kernel(const AttnDec
         const float om = __shfl_xor(m, o, 64);
         const float ol = __shfl_xor(l, o, 64);
         const float nm = fmaxf(m, om);
-        const float f1 = exp2f(m - nm), f2 = exp2f(om - nm);
+        const float f1 = exp2_hw(m - nm), f2 = exp2_hw(om - nm);
         l = l * f1 + ol * f2;
 #pragma unroll
         for (int i = 0; i < VD; ++i) acc[i] = acc[i] * f1 + __shfl_xor(acc[i], o, 64) * f2;
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_wide_kernel(const AttnDec
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const float *src = psm + (long)j * STRIDE;
-            const float f = exp2f(src[D] - gm);
+            const float f = exp2_hw(src[D] - gm);
             gl += src[D + 1] * f;
             vs += src[d] * f;
         }
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict
     float gl = 0.f, acc = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) {
-        const float f = exp2f(ms[s2] - gm);
+        const float f = exp2_hw(ms[s2] - gm);
         gl += ls[s2] * f;
         acc += vs[s2] * f;
     }
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256) void attn_merge_cols_kernel(const float *__res
         for (int j = 0; j < 8; ++j) {
             if (s0 + 8 * j < n_splits) {  // uniform per split group; no load inside
                 const float nm = fmaxf(m, ms[j]);
-                const float f0 = exp2f(m - nm), f1 = exp2f(ms[j] - nm);
+                const float f0 = exp2_hw(m - nm), f1 = exp2_hw(ms[j] - nm);
                 l = l * f0 + ls[j] * f1;
                 acc = acc * f0 + vs[j] * f1;
                 m = nm;
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void attn_merge_cols_kernel(const float *__res
         float gl = 0.f, ga = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float f = exp2f(s_m[j][c] - gm);
+            const float f = exp2_hw(s_m[j][c] - gm);
             gl += s_l[j][c] * f;
             ga += s_a[j][c] * f;
         }
