@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     // 32 ds_write_b16 (the LDS store path is per instruction, not per byte).  vreg[2 i + t], pidv_reg[t] for token 2p + t.
     const int vp = tid & 31, vch0 = tid >> 5;
     int page_next = -1;  // ONEPAGE: the (uniform) page id of the stage whose rows are requested next
+    bool stage_full = false;  // ONEPAGE: every row of the stage in the registers is a live token (no zeroing at the store)
     auto load_pids = [&](int stage) {
         if constexpr (ONEPAGE) {
             const int lp = (stage * FA_BK) >> page_shift;
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
             const long base = (((long)max(page, 0) * num_kv_heads + kvh) * page_size + slot0) * D;  // uniform
             const uint16_t *kbase = key_pages + base;
             const uint16_t *vbase = value_pages + base;
+            stage_full = page >= 0 && (stage + 1) * FA_BK <= ctx;  // uniform: nothing to zero when the store comes
 #pragma unroll
             for (int i = 0; i < FA_CPT; ++i) {
                 const int c = tid + i * 256;  // token c / 16, chunk c % 16: the stage's 64 K rows are contiguous
@@ -518,14 +520,15 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
             const int c = tid + i * 256;
             const int tok_in = c >> 4;
             const int ch = c & 15;
-            if (!kv_ok[i]) kreg[i] = u32x4{0u, 0u, 0u, 0u};
+            if (!(ONEPAGE && stage_full) && !kv_ok[i]) kreg[i] = u32x4{0u, 0u, 0u, 0u};
             *reinterpret_cast<u32x4 *>(&ks[tok_in * D + ((ch ^ (tok_in & 15)) * 8)]) = kreg[i];
         }
         uint32_t *vt32 = reinterpret_cast<uint32_t *>(vt);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const u32x4 v0 = v_ok[2 * i] ? vreg[2 * i] : u32x4{0u, 0u, 0u, 0u};
-            const u32x4 v1 = v_ok[2 * i + 1] ? vreg[2 * i + 1] : u32x4{0u, 0u, 0u, 0u};
+            const bool keep = ONEPAGE && stage_full;
+            const u32x4 v0 = (keep || v_ok[2 * i]) ? vreg[2 * i] : u32x4{0u, 0u, 0u, 0u};
+            const u32x4 v1 = (keep || v_ok[2 * i + 1]) ? vreg[2 * i + 1] : u32x4{0u, 0u, 0u, 0u};
             const int chv = vch0 + 8 * i;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {  // word e of a chunk = dims 2e (low half) and 2e + 1 (high half) of its token
@@ -579,12 +582,10 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
         float tmax = -INFINITY;
         const bool interior = page_shift >= 5 && tile * 32 + 31 < ctx && tile_page[stage & 1][tb] >= 0 &&
                               (!is_causal || tile * 32 + 31 <= qb * 32 + (ctx - L));
-        if (interior) {
+        if (interior) {  // raw scores here; the scale goes into the exponent's FMA below (16 multiplies fewer per tile)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sacc[r] *= scale_log2;
-                tmax = fmaxf(tmax, sacc[r]);
-            }
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[r]);
+            tmax *= scale_log2;  // scale > 0: max and scaling commute
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
             prev_scale = exp2_hw(run_max - new_max);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sacc[r] = exp2_hw(sacc[r] - new_max);
+                sacc[r] = exp2_hw(fmaf(sacc[r], scale_log2, -new_max));
                 tsum += sacc[r];
             }
         } else {
