@@ -176,7 +176,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
     // Read where they are used, right after the prefetch requests, they made every other step wait out its own prefetch
     // (loads return in issue order): r02 lab, 2,048 rows: qkv 753 -> 838, gate|up 762 -> 838 TFLOP/s.  Also tried there and
     // dropped: activation tiles two steps ahead (two register sets: slower), an explicit sub-step pipeline of fragment reads
-    // and dequantisation (no gain), two 32-column blocks per wave (128 x 256 tile on four waves: no gain at two waves per SIMD).  (32-bit holders: as
+    // and dequantisation (no gain), two 32-column blocks per wave (128 x 256 tile on four waves: no gain at two waves per SIMD),
+    // eight row tiles per wave (256 x 128: the counters say 11 VALU instructions per MFMA, and a dequantised fragment then
+    // feeds 8 MFMAs -- but at two waves per SIMD the layer got 5 % slower).  (32-bit holders: as
     // 16-bit values the compiler packs the pair into one register right behind the loads -- the same wait again.)
     uint32_t sc_next = 0, be_next = 0;
     if (wok) {
