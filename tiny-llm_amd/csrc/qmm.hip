@@ -155,12 +155,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
             const int c = tid + q * NT;
             const int r = c >> 3;
             const int ch = c & 7;
-            const int gr = bm0 + r;
-            if (gr < M) {
-                areg[q] = *reinterpret_cast<const u32x4 *>(a + (size_t)gr * N + j * 64 + ch * 8);
-            } else {
-                areg[q] = u32x4{0u, 0u, 0u, 0u};
-            }
+            // rows past M re-read the last row instead of being zeroed under a branch (their outputs are never stored): the
+            // branch cost an exec-mask dance and four zero moves per chunk in every reduction step
+            const int gr = min(bm0 + r, M - 1);
+            areg[q] = *reinterpret_cast<const u32x4 *>(a + (size_t)gr * N + j * 64 + ch * 8);
         }
     };
     auto store_a = [&](int buf) {
@@ -197,11 +195,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
         __syncthreads();
         if (j + 1 < j1) {
             if (!(QMM_ABL & 4)) load_a(j + 1);
-            if (wok) {
-                wnext = *reinterpret_cast<const u32x4 *>(wsrc + (j + 1) * 8 + h * 4);
-                sc_next = ssrc[(j + 1) >> 1];
-                be_next = bsrc[(j + 1) >> 1];
-            }
+            // (columns past K read weight row 0 -- wsrc / ssrc / bsrc are clamped -- and are never stored)
+            wnext = *reinterpret_cast<const u32x4 *>(wsrc + (j + 1) * 8 + h * 4);
+            sc_next = ssrc[(j + 1) >> 1];
+            be_next = bsrc[(j + 1) >> 1];
         }
         u32x4 bf[4];
 #pragma unroll
