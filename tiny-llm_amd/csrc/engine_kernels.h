@@ -381,9 +381,31 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
                 float part = 0.f;
 #pragma unroll
                 for (int i = 0; i < VD; ++i) part += qv[r][i] * kf[i];
-                sc[r][u] = (ok[u] && live) ? group16_allsum(part) : -1e30f;
+                sc[r][u] = part;
             }
         }
+        // the RQ*U partial dot products go through the four DPP rotations TOGETHER, step by step: reduced one value at a time,
+        // each add waits for the one before it (a DPP operand needs two wait states behind the VALU write: the compiler filled
+        // them with 128 s_nop per stage)
+#pragma unroll
+        for (int r = 0; r < RQ; ++r)
+#pragma unroll
+            for (int u = 0; u < U; ++u) sc[r][u] += row_ror<8>(sc[r][u]);
+#pragma unroll
+        for (int r = 0; r < RQ; ++r)
+#pragma unroll
+            for (int u = 0; u < U; ++u) sc[r][u] += row_ror<4>(sc[r][u]);
+#pragma unroll
+        for (int r = 0; r < RQ; ++r)
+#pragma unroll
+            for (int u = 0; u < U; ++u) sc[r][u] += row_ror<2>(sc[r][u]);
+#pragma unroll
+        for (int r = 0; r < RQ; ++r)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                sc[r][u] += row_ror<1>(sc[r][u]);
+                sc[r][u] = (ok[u] && live) ? sc[r][u] : -1e30f;
+            }
 #pragma unroll
         for (int r = 0; r < RQ; ++r) {
             float nm = m[r];
