@@ -354,16 +354,19 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     }
 
     // ---- walk the window: request the next batch, then reduce the current one ------------------------------------------
-    for (int it = 0; it < n_it; ++it) {
-        bool ok_next[U];
+    // Two register sets for the K/V rows, used alternately (the loop is unrolled by two through this lambda): handing the
+    // prefetched rows over by copying them cost 96 v_mov per stage.
+    bool ok_next[U];
+    auto walk_stage = [&](int it, RawRow<VD>(&kc)[U], RawRow<VD>(&vc)[U], bool(&okc)[U], RawRow<VD>(&kn)[U], RawRow<VD>(&vn)[U],
+                          bool(&okn)[U]) {
         const bool more = it + 1 < n_it;
         if constexpr (IP) {
             if (more) {  // uniform
-                issue_kv_stage(t_begin + (it + 1) * 16 * U, pg_nxt, kr_next, vr_next, ok_next);
+                issue_kv_stage(t_begin + (it + 1) * 16 * U, pg_nxt, kn, vn, okn);
                 sload_i32(brow + min(page_of(t_begin + (it + 2) * 16 * U), p.max_pages - 1), pg_new);  // waited for at the end of this stage
             }
         } else if (more) {  // uniform
-            issue_kv(t_begin + (it + 1) * 16 * U, pid_next, kr_next, vr_next, ok_next);
+            issue_kv(t_begin + (it + 1) * 16 * U, pid_next, kn, vn, okn);
             if constexpr (!SP) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         for (int u = 0; u < U; ++u) {
             float kf[VD];
 #pragma unroll
-            for (int i = 0; i < VD; ++i) kf[i] = BF16::to_float(kr[u].v[i]);
+            for (int i = 0; i < VD; ++i) kf[i] = BF16::to_float(kc[u].v[i]);
 #pragma unroll
             for (int r = 0; r < RQ; ++r) {
                 float part = 0.f;
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 sc[r][u] += row_ror<1>(sc[r][u]);
-                sc[r][u] = (ok[u] && live) ? sc[r][u] : -1e30f;
+                sc[r][u] = (okc[u] && live) ? sc[r][u] : -1e30f;
             }
 #pragma unroll
         for (int r = 0; r < RQ; ++r) {
@@ -418,24 +421,22 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             for (int i = 0; i < VD; ++i) acc[r][i] *= of;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float pw = (ok[u] && live) ? exp2_hw(sc[r][u] - nm) : 0.f;
+                const float pw = (okc[u] && live) ? exp2_hw(sc[r][u] - nm) : 0.f;
                 l[r] += pw;
 #pragma unroll
-                for (int i = 0; i < VD; ++i) acc[r][i] += pw * BF16::to_float(vr[u].v[i]);
+                for (int i = 0; i < VD; ++i) acc[r][i] += pw * BF16::to_float(vc[u].v[i]);
             }
         }
         if (more) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                kr[u] = kr_next[u];
-                vr[u] = vr_next[u];
-                ok[u] = ok_next[u];
-            }
             if constexpr (IP) {
                 sload_wait(pg_new);
                 pg_nxt = pg_new;
             }
         }
+    };
+    for (int it = 0; it < n_it; it += 2) {
+        walk_stage(it, kr, vr, ok, kr_next, vr_next, ok_next);
+        if (it + 1 < n_it) walk_stage(it + 1, kr_next, vr_next, ok_next, kr, vr, ok);
     }
     // the token being decoded (position ctx), straight from registers
     if (split == 0) {
