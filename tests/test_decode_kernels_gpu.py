@@ -189,16 +189,17 @@ def test_skinny_matmul_at_qwen3_4b_shapes(ext, projection, M):
 
 @pytest.mark.parametrize("projection", list(PROJECTIONS), indirect=True)
 def test_engine_routing_between_gemv_and_skinny_matmul(ext, projection):
-    """1..4 rows: fused GEMV everywhere.  5..8 rows: GEMV for projections of up to 20 Mi weights (qkv, wo), skinny matmul for
-    the larger ones (gate|up, w_down, lm_head) (csrc/engine.hip engine_linear); both agree with the oracle at 8 rows."""
+    """1..4 rows: fused GEMV everywhere.  5 rows and more: the skinny matmul for every projection (csrc/engine.hip
+    engine_linear); it agrees with the oracle at 5 and 8 rows."""
     p = projection
     variant = (p.pro, p.epi)
     for M in (1, 3, 4):
         _, info = p.run(ext, M, variant, kernel=0)
         assert info["kernel"] == 1, f"{p.name} M={M}: {info}"
-    got, info = p.run(ext, 8, variant, kernel=0)
-    assert info["kernel"] == (2 if p.K * p.N > (20 << 20) else 1), f"{p.name} M=8: {info}"
-    _check(p, got, 8, variant, f"routing {p.name} M=8")
+    for M in (5, 8):
+        got, info = p.run(ext, M, variant, kernel=0)
+        assert info["kernel"] == 2, f"{p.name} M={M}: {info}"
+        _check(p, got, M, variant, f"routing {p.name} M={M}")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -353,10 +354,11 @@ def test_decode_attention_long_contexts(ext, ctxs, mode, monkeypatch):
     """BASELINE configs 3 and 5 (8k and 32k cached tokens, page 128), 1 and 4 sequences (ragged, one idle slot written as
     -1): the default plan (one workgroup per GQA group walking 64-token stages, split + merge), the one-head wide kernel
     forced onto long contexts, 256 context splits (attn_merge_many_kernel), and the one-head split kernel."""
-    for name in ("TL_ATTN_WIDE_MAX", "TL_ATTN_NW", "TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_RQ1_CTX"):
+    for name in ("TL_ATTN_WIDE_MAX", "TL_ATTN_NW", "TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_RQ1_CTX", "TL_ATTN_RQ1_BATCH"):
         monkeypatch.delenv(name, raising=False)
     if mode == "one_head_wide":
         monkeypatch.setenv("TL_ATTN_RQ1_CTX", "65536")
+        monkeypatch.setenv("TL_ATTN_RQ1_BATCH", "4")
         monkeypatch.setenv("TL_ATTN_MAX_SPLITS", "256")
         monkeypatch.setenv("TL_ATTN_WIDE_MAX", "512")
     elif mode == "splits256":

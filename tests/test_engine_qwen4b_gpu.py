@@ -88,8 +88,7 @@ def test_single_stream_decode_matches_truth_as_closely_as_the_bf16_oracle(model_
 
 @pytest.mark.parametrize("n_seq", [4, 8, 12])
 def test_batched_decode_rows_match_truth(model_and_weights, n_seq):
-    """4 rows: the fused GEMV with MR = 4.  8 rows: GEMV for the small projections, skinny matmul for w_down / lm_head.
-    12 rows: skinny matmul everywhere.  First, middle and last sequence of the batch against their own truth."""
+    """4 rows: the fused GEMV with MR = 4.  8 and 12 rows: the skinny matmul (MB = 1) for every projection.  First, middle and last sequence of the batch against their own truth."""
     from tiny_llm_hip.engine import DecodeEngine
 
     model, weights = model_and_weights

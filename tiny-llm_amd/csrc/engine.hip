@@ -74,10 +74,10 @@ struct tl_engine {
     bool fuse_norm = true;                   // TL_QMM3_FUSED_NORM=0: RMSNorm ahead of a skinny matmul always as its own launch
     int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
-    size_t qmm3_small_elems = (size_t)20 << 20;  // TL_QMM3_SMALL_ELEMS: see engine_linear
     bool use_qmm3 = true;   // TL_NO_QMM3=1 at create: rows > 8 go through the prefill GEMM path instead
     int attn_rq = 0;             // query heads per decode-attention workgroup; 0 = by context (TL_ATTN_RQ at create: 1 or 4)
     int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup (TL_ATTN_RQ1_CTX)
+    int attn_rq1_batch = 2;      // ... and up to this many sequences (TL_ATTN_RQ1_BATCH); at 4 the re-read windows cost 261 vs 180 us
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
     int attn_max_splits = 64;    // most context splits per sequence (TL_ATTN_MAX_SPLITS, a power of two <= 256)
     // largest window of the wide one-head kernel (TL_ATTN_WIDE_MAX: 0 = off, 64 .. 512).  Off by default: measured on the
@@ -264,8 +264,9 @@ static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
     return TL_OK;
 }
 
-// One projection of the decode step over `M` activation rows.  Few rows: the fused MFMA GEMV (weights streamed once,
-// RMSNorm / residual / SwiGLU inside).  5 .. 64 rows: the skinny matmul (qmm3.h).  More rows, or TL_NO_QMM3: the
+// One projection of the decode step over `M` activation rows.  Up to 4 rows: the fused MFMA GEMV (weights streamed once,
+// RMSNorm / residual / SwiGLU inside).  5 .. 64 rows: the skinny matmul (qmm3.h) for every projection -- at 8 rows the GEMV
+// re-stages all rows in every workgroup (qkv 10.3 us against 4.8 + reduction; profiles/r02_labs/batched_rows_routing.log).  More rows, or TL_NO_QMM3: the
 // reference's own op sequence -- RMSNorm kernel, W4 MFMA GEMM (quantize.py:54-65 routes rows > 8 to the matmul path),
 // then SwiGLU / residual kernels.
 // ss_in: partial sums of squares of the rows of `a` when its producer emitted them (fused RMSNorm of the skinny matmul),
@@ -276,11 +277,6 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
     if (ss_emitted) *ss_emitted = false;
     if (e->force_linear == 1) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
     if (e->force_linear != 2 && (M < e->qmm3_min_rows || (M <= 8 && !e->use_qmm3)))
-        return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
-    // 5 .. 8 rows: the fused GEMV still wins on the small projections (one launch instead of norm + matmul + reduction)
-    // as long as all rows fit its LDS in one pass; the big ones (down: 9728 columns, lm_head) go to the skinny matmul
-    if (e->force_linear != 2 && M <= 8 && e->tiled.count(w.weight_dev) != 0 && qmv3_plan(M, w.cols, w.rows).ok &&
-        (size_t)w.rows * w.cols <= e->qmm3_small_elems)
         return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
     const tl_engine_config &c = e->cfg;
     const uint16_t *in = a;
@@ -357,7 +353,7 @@ struct SplitPlan {
 static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
     const int rep = e->cfg.num_heads / e->cfg.num_kv_heads;
     int rq = e->attn_rq;
-    if (rq <= 0) rq = (max_ctx <= e->attn_rq1_ctx && batch <= 4) ? 1 : AD_RQ;
+    if (rq <= 0) rq = (max_ctx <= e->attn_rq1_ctx && batch <= e->attn_rq1_batch) ? 1 : AD_RQ;
     if (rq != 1) rq = AD_RQ;
     int bucket = 64;
     while (bucket < max_ctx) bucket *= 2;
@@ -810,9 +806,9 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
-    if (const char *q = getenv("TL_QMM3_SMALL_ELEMS")) e->qmm3_small_elems = (size_t)atoll(q);
     if (const char *q = getenv("TL_ATTN_RQ")) e->attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e->attn_rq1_ctx = atoi(q);
+    if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e->attn_rq1_batch = atoi(q);
     if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q));
     if (const char *q = getenv("TL_ATTN_WIDE_MAX")) e->attn_wide_max = std::min(512, std::max(0, atoi(q)));
@@ -1623,7 +1619,6 @@ extern "C" int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *o
     tl_linear_info li{};
     e.linfo = &li;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e.qmm3_min_rows = std::max(1, atoi(q));
-    if (const char *q = getenv("TL_QMM3_SMALL_ELEMS")) e.qmm3_small_elems = (size_t)atoll(q);
     const int rc = engine_linear(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, prologue, epilogue, norm_w_dev,
                                  (const uint16_t *)residual_dev, nullptr, 0);
     e.splitk_ws = nullptr;  // borrowed
@@ -1689,6 +1684,7 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
     if (const char *q = getenv("TL_ATTN_FUSED_MERGE")) e.attn_fused_merge = atoi(q) != 0;
     if (const char *q = getenv("TL_ATTN_RQ")) e.attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e.attn_rq1_ctx = atoi(q);
+    if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e.attn_rq1_batch = atoi(q);
     if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e.attn_max_splits = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e.attn_min_tokens = std::max(64, atoi(q));
     if (const char *q = getenv("TL_ATTN_WIDE_MAX")) e.attn_wide_max = std::min(512, std::max(0, atoi(q)));
