@@ -68,3 +68,15 @@ def write_checkpoint(path: Path, cfg: dict, w: dict, *, group_size: int = 128, b
         "chat_template": "{% for m in messages %}{{ m['role'] }} {{ m['content'] }} {% endfor %}{% if add_generation_prompt %}assistant{% endif %}"}))
     (path / "generation_config.json").write_text(json.dumps({"eos_token_id": [0]}))
     return path
+
+
+def write_hf_cache_snapshot(hf_home: Path, repo_id: str, cfg: dict, w: dict, **kwargs) -> Path:
+    """The same checkpoint laid out as a snapshot of `repo_id` in a Hugging Face cache rooted at `hf_home`
+    (hub/models--ORG--NAME/{refs/main, snapshots/<revision>/...}): what `huggingface_hub.snapshot_download(repo_id,
+    local_files_only=True)` resolves, i.e. how the reference finds "Qwen/Qwen3-0.6B-MLX-4bit" (tests_refsol/utils.py:118-125,
+    benches/bench.py:601-609)."""
+    revision = "0" * 40
+    repo = Path(hf_home) / "hub" / ("models--" + repo_id.replace("/", "--"))
+    (repo / "refs").mkdir(parents=True, exist_ok=True)
+    (repo / "refs" / "main").write_text(revision)
+    return write_checkpoint(repo / "snapshots" / revision, cfg, w, **kwargs)

@@ -13,6 +13,7 @@ Used by tests/test_refsol_facade_cpu.py:  pytest -p refsol_oracle_plugin <refere
 """
 
 import ctypes
+import os
 import sys
 from pathlib import Path
 
@@ -85,6 +86,17 @@ class FakeLib:
         _store(out, y, dt)
         return 0
 
+    def tl_gather_quantized_matvec(self, scales, biases, a, b, expert_ids, out, M, N, K, num_experts, group_size, bits, dt,
+                                   stream):
+        E, name = num_experts, _NAME[dt]
+        s = _load(scales, E * K * (N // 128), dt).reshape(E, K, N // 128)
+        z = _load(biases, E * K * (N // 128), dt).reshape(E, K, N // 128)
+        x = _load(a, M * N, dt).reshape(M, N)
+        w = _raw(b, E * K * (N // 8), ctypes.c_uint32).reshape(E, K, N // 8)
+        ids = np.clip(_raw(expert_ids, M, ctypes.c_int32), 0, E - 1)  # out-of-range ids are clamped (include/tinyllm_hip.h:104-110)
+        _store(out, self.O.gather_quantized_matvec(s, z, x, w, ids, name), dt)
+        return 0
+
     def tl_quantized_embedding(self, indices, indices_unsigned, scales, biases, weight, out, tokens, dim, vocab, group_size, bits,
                                dt, stream):
         idx = _raw(indices, tokens, ctypes.c_int32)
@@ -150,3 +162,8 @@ def pytest_configure(config):
     ext._workspace = lambda nbytes, device: None
     ext._lib = FakeLib(ext._lib)
     ext.load_library = lambda path: None
+    if os.environ.get("REFSOL_REFERENCE_BENCHES") == "1":
+        # the reference's OWN benches/ package (a namespace package) must win over this repository's benches/ (a regular
+        # package): the oracle is already imported, so the repository root can leave the module search path
+        sys.modules.pop("benches", None)
+        sys.path[:] = [p for p in sys.path if Path(p or ".").resolve() != ROOT]

@@ -169,6 +169,32 @@ def _array_protocol(self, dtype=None, *args, **kwargs):
     return _torch_array(t, dtype) if dtype is not None else _torch_array(t)
 
 
+_torch_size = _torch.Tensor.size
+
+
+class _Size(int):
+    """`a.size` is the element COUNT in MLX (an int property: benches/bench.py:297 `offset += context.size`) and a METHOD in
+    torch (`t.size()`, `t.size(0)`).  One object serves both: an int that, when called, answers as torch's method does."""
+
+    def __new__(cls, tensor):
+        self = super().__new__(cls, tensor.numel())
+        self._tensor = tensor
+        return self
+
+    def __call__(self, *args, **kwargs):
+        return _torch_size(self._tensor, *args, **kwargs)
+
+
+class _SizeProperty(property):
+    __name__ = "size"  # torch.overrides enumerates Tensor attributes by __name__
+
+    def __call__(self, tensor, *args, **kwargs):
+        # tensor subclasses with __torch_function__ are handed `torch.Tensor.size` (looked up by name) to call
+        with _torch._C.DisableTorchFunctionSubclass():
+            return _torch_size(tensor, *args, **kwargs)
+
+
+_torch.Tensor.size = _SizeProperty(_Size)
 _torch.Tensor.astype = _astype
 _torch.Tensor.at = property(lambda self: _At(self))
 _torch.Tensor.transpose = _transpose
@@ -180,7 +206,7 @@ def _dev():
     return _state.device
 
 
-def array(value, dtype=None):
+def _make_array(value, dtype=None):
     if isinstance(value, _torch.Tensor):
         out = value.to(_dev())
         return out.to(dtype) if dtype is not None else out
@@ -196,6 +222,23 @@ def array(value, dtype=None):
         elif probe.dtype.kind == "b":
             dtype = bool_
     return _torch.tensor(value, dtype=dtype, device=_dev())
+
+
+class _ArrayType(type):
+    """`mx.array` is a TYPE in MLX: harness code writes `isinstance(mask, mx.array)` and `mx.array | str | None`."""
+
+    def __instancecheck__(cls, obj):
+        return isinstance(obj, _torch.Tensor)
+
+    def __subclasscheck__(cls, sub):
+        return issubclass(sub, _torch.Tensor)
+
+
+class array(metaclass=_ArrayType):  # noqa: N801  (MLX's name)
+    """`mx.array(value, dtype=None)` -> a torch.Tensor on the default device (arrays ARE tensors in this facade)."""
+
+    def __new__(cls, value, dtype=None):
+        return _make_array(value, dtype)
 
 
 def zeros(shape, dtype=float32, stream=None):

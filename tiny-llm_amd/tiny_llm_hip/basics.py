@@ -13,7 +13,11 @@ def softmax(x: torch.Tensor, axis: int) -> torch.Tensor:
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
-    """``x @ w.T (+ bias)`` with w stored [out, in] (reference basics.py:10-18)."""
+    """``x @ w.T (+ bias)`` with w stored [out, in] (reference basics.py:10-18).  Mixed float operands are promoted
+    as ``mx.matmul`` promotes them (f16 activations on f32 weights -> f32: tests_refsol/test_week_1_day_3.py:171-199)."""
+    if x.dtype != w.dtype:
+        common = torch.promote_types(x.dtype, w.dtype)
+        x, w = x.to(common), w.to(common)
     y = torch.matmul(x, w.transpose(-1, -2))
     return y if bias is None else y + bias
 

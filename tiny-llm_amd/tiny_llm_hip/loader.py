@@ -198,6 +198,16 @@ class TokenizerWrapper:
     def eos_token_id(self):
         return self._tok.eos_token_id
 
+    @property
+    def vocab_size(self) -> int:
+        return int(self._tok.vocab_size)
+
+    def __getattr__(self, name):
+        # like mlx_lm's wrapper, anything else is answered by the wrapped Hugging Face tokenizer
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._tok, name)
+
     def encode(self, text: str, add_special_tokens: bool = False) -> list[int]:
         return list(self._tok.encode(text, add_special_tokens=add_special_tokens))
 

@@ -31,11 +31,11 @@ def quantize(w: torch.Tensor, group_size: int = 128, bits: int = 4):
     per 32-bit word with element 8j+i in bits [4i, 4i+4) (reference quantize.py:113-115)."""
     if bits != 4:
         raise ValueError("only 4-bit quantisation is supported")
-    K, N = w.shape
+    *lead, N = w.shape  # leading dimensions (rows; an expert stack [E, K, N]) are quantised independently
     if N % group_size:
         raise ValueError("last dimension must be divisible by group_size")
     dtype = w.dtype
-    g = w.to(torch.float32).reshape(K, N // group_size, group_size)
+    g = w.to(torch.float32).reshape(*lead, N // group_size, group_size)
     hi = g.amax(dim=-1)
     lo = g.amin(dim=-1)
     scale = torch.clamp((hi - lo) / 15.0, min=1e-7)
@@ -51,7 +51,7 @@ def quantize(w: torch.Tensor, group_size: int = 128, bits: int = 4):
     s32 = scale.to(torch.float32)
     safe = torch.where(s32 == 0, torch.ones_like(s32), s32)
     codes = torch.clamp(torch.round((g - bias.to(torch.float32)[..., None]) / safe[..., None]), 0, 15)
-    codes = codes.to(torch.int64).reshape(K, N // 8, 8)
+    codes = codes.to(torch.int64).reshape(*lead, N // 8, 8)
     shifts = torch.arange(0, 32, 4, dtype=torch.int64, device=w.device)
     words = (codes << shifts).sum(dim=-1)  # < 2^32
     words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
