@@ -109,3 +109,51 @@ def test_untied_head_and_missing_directory(tmp_path):
     np.testing.assert_array_equal(model.lm_head.weight.numpy().view(np.uint32), np.asarray(w["lm_head"][0], np.uint32))
     with pytest.raises(FileNotFoundError, match="neither a checkpoint directory"):
         loader.resolve_model_dir(str(tmp_path / "nope"))
+
+
+def test_load_reads_a_qwen3_moe_checkpoint(tmp_path):
+    """Sparse layers come back as `mlp.gate` + `mlp.switch_mlp.{gate,up,down}_proj` with a leading expert axis (the tree
+    reference qwen3_week3.py:258-272 builds its Moe blocks from); dense layers (mlp_only_layers) keep the dense MLP."""
+    from checkpoint_fixture import MOE_CFG_OVERRIDES, make_moe_weights
+
+    loader = _loader()
+    cfg = dict(TINY_CFG, **MOE_CFG_OVERRIDES)
+    w = make_moe_weights(cfg, seed=5)
+    ckpt = write_checkpoint(tmp_path / "moe", cfg, w, shards=2)
+    assert json.loads((ckpt / "config.json").read_text())["model_type"] == "qwen3_moe"
+    model, _ = loader.load(str(ckpt), device="cpu")
+    a = model.args
+    assert (a.num_experts, a.num_experts_per_tok, a.moe_intermediate_size, a.norm_topk_prob) == (4, 2, 256, True)
+    assert hasattr(model.model.layers[0].mlp, "gate_proj") and not hasattr(model.model.layers[0].mlp, "switch_mlp")
+    for layer, lw in zip(model.model.layers[1:], w["layers"][1:]):
+        assert not hasattr(layer.mlp, "gate_proj")
+        for got, want in ((layer.mlp.gate, lw["moe"]["router"]), (layer.mlp.switch_mlp.gate_proj, lw["moe"]["gate_proj"]),
+                          (layer.mlp.switch_mlp.up_proj, lw["moe"]["up_proj"]), (layer.mlp.switch_mlp.down_proj, lw["moe"]["down_proj"])):
+            np.testing.assert_array_equal(got.weight.numpy().view(np.uint32), np.asarray(want[0], dtype=np.uint32))
+            np.testing.assert_array_equal(got.scales.float().numpy(), np.asarray(want[1], dtype=np.float32))
+            np.testing.assert_array_equal(got.biases.float().numpy(), np.asarray(want[2], dtype=np.float32))
+        assert tuple(layer.mlp.switch_mlp.down_proj.weight.shape) == (4, 256, 256 // 8)
+
+    # a config that announces experts but not their width is refused by name
+    broken = json.loads((ckpt / "config.json").read_text())
+    del broken["moe_intermediate_size"]
+    (ckpt / "config.json").write_text(json.dumps(broken))
+    with pytest.raises(ValueError, match="moe_intermediate_size"):
+        loader.load_weights(ckpt, device="cpu")
+
+
+def test_week3_model_runs_a_loaded_moe_checkpoint(built_libs):
+    """Loader -> Qwen3ModelWeek3 with Moe blocks -> logits, against the facade's mlx_lm MoE model on the same tensors
+    (tests/moe_checkpoint_case.py; the numpy oracle answers the C ABI in this container, the grouped-expert HIP kernel and
+    the MoE block are held against the same oracle on the GPU: tests/test_ops_gpu.py, tests/test_models_gpu.py)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=str(root / "tests"))
+    proc = subprocess.run([sys.executable, "-m", "pytest", str(root / "tests" / "moe_checkpoint_case.py"), "-p", "no:cacheprovider",
+                           "-p", "refsol_oracle_plugin", "-q", "--tb=short"], cwd=root, env=env, capture_output=True, text=True,
+                          timeout=600)
+    assert proc.returncode == 0 and "1 passed" in proc.stdout, proc.stdout[-3000:]

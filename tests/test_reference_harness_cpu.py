@@ -1,0 +1,134 @@
+"""CPU tier: the reference's OWN scripts -- benches/bench.py in every mode, the operator / attention / kernel-group
+microbenches, the fresh-process progression drivers, main.py and batch-main.py -- run UNMODIFIED, end to end, through the
+import facade (BASELINE north_star: "the benches/ harness stay intact").  tests/run_reference_script.py puts the numpy
+oracle behind libtinyllm_hip.so's C ABI (no GPU in this container) and the facade where `src/` stands in a reference
+checkout; the checkpoints are the synthetic stand-ins of tests/checkpoint_fixture.py under the repository names the scripts
+look up.  Checked here: exit status, the report lines / tables each script prints and the JSON bench.py writes -- i.e. that
+argument handling, model dispatch, caches, scheduler, counters and reports work on the product's host mirror.  The timings
+printed are oracle timings and mean nothing.  Skipped where /root/reference is absent (GPU box).
+"""
+
+import json
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+REFERENCE = Path("/root/reference")
+pytestmark = pytest.mark.skipif(not (REFERENCE / "benches").is_dir(), reason="/root/reference is not present (GPU box)")
+
+SMALL = ["--num-seqs", "4", "--min-input-len", "5", "--max-input-len", "40", "--min-output-len", "3", "--max-output-len", "6"]
+SERVE = ["--num-seqs", "4", "--batch-size", "2", "--min-input-len", "10", "--max-input-len", "40", "--min-output-len", "2",
+         "--max-output-len", "4", "--warmup", "0", "--repeats", "2", "--offline"]
+
+
+@pytest.fixture(scope="module")
+def hf_home(built_libs, tmp_path_factory):
+    from checkpoint_fixture import write_stand_in_checkpoints
+
+    home = tmp_path_factory.mktemp("hf")
+    write_stand_in_checkpoints(home, eos_friendly=True)
+    return home
+
+
+def run_script(hf_home: Path, script: str, *args: str, timeout: int = 600) -> str:
+    env = dict(os.environ, HF_HOME=str(hf_home), HF_HUB_OFFLINE="1", PYTHONDONTWRITEBYTECODE="1",
+               OMP_NUM_THREADS="2", MKL_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")  # several scripts run side by side
+    env.pop("PYTHONPATH", None)
+    proc = subprocess.run([sys.executable, str(ROOT / "tests" / "run_reference_script.py"), script, *args], env=env,
+                          capture_output=True, text=True, timeout=timeout)
+    assert proc.returncode == 0, f"{script} {' '.join(args)}\n{proc.stdout[-1500:]}\n{proc.stderr[-2500:]}"
+    return proc.stdout
+
+
+def run_all(hf_home: Path, jobs: list, timeout: int = 600) -> list:
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+        return list(pool.map(lambda job: run_script(hf_home, *job, timeout=timeout), jobs))
+
+
+def test_reference_bench_py_runs_in_every_mode(hf_home, tmp_path):
+    base = ["benches/bench.py", "--model", "qwen3-0.6b", *SMALL, "--warmup", "1"]
+    w2_json, w3_json = tmp_path / "week2.json", tmp_path / "week3.json"
+    jobs = [
+        [*base, "--solution", "ref", "--loader", "week2", "--json-output", str(w2_json)],
+        [*base, "--solution", "ref", "--loader", "week3", "--batch-decode", "--batch-size", "3", "--prefill-step", "16",
+         "--json-output", str(w3_json)],
+        [*base, "--solution", "ref", "--loader", "week3", "--disable-paged-attention", "--batch-decode", "--batch-size", "3",
+         "--prefill-step", "16"],
+        [*base, "--solution", "ref", "--loader", "week2", "--batch-decode", "--batch-size", "3", "--prefill-step", "16"],
+        [*base, "--solution", "ref", "--loader", "week1", "--device", "cpu"],
+        [*base, "--solution", "mlx", "--device", "cpu", "--prefill-logits", "last"],
+        *[[*base, "--solution", "ref", "--loader", "week2", "--week2-checkpoint", c, "--prefill-logits", "last"]
+          for c in ("kv-cache", "decode-attention", "split-k")],  # all eight by hand: profiles/r02_labs/reference_harness_through_facade.txt
+    ]
+    outs = run_all(hf_home, jobs)
+    for out in outs:
+        assert "Decode throughput:" in out and "Requests: 4," in out
+    paged, dense_gather, dense = outs[1], outs[2], outs[3]
+    for line in ("Peak active requests: 3", "Peak live KV pages:", "Peak KV capacity pages:", "Peak tail waste slots:",
+                 "Decode step latency ms (median/p95/max):", "Page-pool growths:", "Paged KV bytes copied during pool growth:"):
+        assert line in paged, line
+    assert "Dense KV bytes copied into batch tensors: 0" in paged
+    assert "Dense KV bytes copied into batch tensors: 0" not in dense_gather  # the gather checkpoint stages dense K/V
+    assert "Peak live KV pages: 0" in dense and "Dense KV bytes copied during growth: 0" not in dense
+    week2, week3 = json.loads(w2_json.read_text()), json.loads(w3_json.read_text())
+    assert week2["configuration"]["loader"] == "week2" and len(week2["request_trace"]) == 4
+    assert week2["metrics"]["decode_tokens_per_second"] > 0
+    for key in ("peak_active_requests", "peak_live_pages", "peak_capacity_pages", "peak_tail_waste_slots", "storage_growths",
+                "reused_page_allocations", "decode_step_p95_ms", "paged_growth_copy_bytes"):
+        assert key in week3["metrics"], key
+    # every solution sees the same seeded trace (reference build_requests)
+    assert week2["request_trace"] == week3["request_trace"]
+
+
+def test_reference_operator_and_progression_drivers_run(hf_home):
+    m = ["--model", "qwen3-0.6b"]
+    jobs = [
+        ["benches/bench_week2_operators.py", *m, "--solution", "tiny_llm_ref", "--warmup", "1", "--iterations", "6",
+         "--include-split-k"],  # no --json-output: its metadata block shells out to macOS tools (xcodebuild)
+        ["benches/bench_week3_attention.py", "--contexts", "128", "256", "--page-size", "64", "--warmup", "1", "--iterations", "2",
+         "--repeats", "2"],
+        ["benches/bench_long_context_attention.py", "--contexts", "128", "--warmup", "1", "--iterations", "2", "--repeats", "1"],
+        ["benches/profile_week2_kernels.py", *m, "--warmup", "1", "--iterations", "2"],
+        ["benches/bench_chunked_prefill.py", *m, "--solution", "ref", "--prefill-steps", "8", "32", *SERVE],
+        ["benches/bench_serving_progression.py", *m, "--solution", "ref", "--prefill-step", "16", *SERVE],
+        ["benches/bench_course_progression.py", *m, "--solution", "ref", "--input-len", "12", "--output-len", "4", "--warmup", "0",
+         "--repeats", "2", "--offline"],
+    ]
+    ops, attn3, long_ctx, profile, chunked, serving, course = run_all(hf_home, jobs)
+    for line in ("decode-projections/lm head: vanilla=", "prefill-projections/prefill q matmul: simd=", "split-k=",
+                 "model-kernels/RMSNorm: readable=", "attention/decode attention: readable="):
+        assert line in ops, line
+    assert "| Context | Dense + gather us | Direct paged us | MLX fused us |" in attn3 and "| 256 |" in attn3
+    assert "attention_only_decode_ceiling_tok_s" in long_ctx
+    assert "split-k" in profile and "projections" in profile and "normalization, position, and activation" in profile
+    assert "| Prefill step | Output tok/s |" in chunked and "| 32 |" in chunked
+    for row in ("Dense KV reconstruction", "Paged KV + dense gather", "Direct paged attention", "Paged allocator: peak_live_pages="):
+        assert row in serving, row
+    for row in ("| Week 1 readable |", "| Week 2 decode |", "| Week 3 paged FlashAttention |", "| MLX |"):
+        assert row in course, row
+
+
+def test_reference_main_and_batch_main_run(hf_home):
+    m = ["main.py", "--model", "qwen3-8b", "--prompt", "w1 w2 w3", "--solution", "ref"]
+    jobs = [
+        [*m, "--loader", "week1", "--device", "cpu"],
+        [*m, "--loader", "week2"],
+        [*m, "--loader", "week3"],
+        [*m, "--loader", "week3", "--disable-paged-attention"],
+        [*m, "--loader", "week2", "--draft-model", "qwen3-8b"],
+        [*m, "--loader", "week3", "--draft-model", "qwen3-8b"],
+        ["main.py", "--model", "qwen3-8b", "--prompt", "w1 w2 w3", "--solution", "mlx", "--device", "cpu"],
+        ["batch-main.py", "--model", "qwen3-8b", "--solution", "ref", "--loader", "week3", "--batch-size", "4", "--prefill-step",
+         "64", "--max-seq-len", "176"],
+    ]
+    *mains, batch = run_all(hf_home, jobs, timeout=300)  # a generation loop that never meets <eos> fails here, it cannot hang
+    texts = [out.strip().splitlines()[-1] for out in mains]
+    assert all(t.startswith("w") for t in texts), texts
+    # Week 2, Week 3 (paged and dense-gather) and both speculative runs decode the same greedy text on the same weights
+    assert len(set(texts[1:6])) == 1, texts
+    assert "--- 15 ---" in batch and "--- 16 ---" not in batch and "Q: What is the capital of France?" in batch

@@ -41,24 +41,7 @@ TEST_FILES = ["test_week_1_day_1.py", "test_week_1_day_2.py", "test_week_1_day_3
 BENCH_TEST_FILES = ["test_bench_course_progression.py", "test_bench_week2_operators.py", "test_bench_week3.py",
                     "test_profile_week2_kernels.py"]
 
-# synthetic stand-ins for the three checkpoints the reference's tests look for: (repo id, config overrides, seed)
-STAND_INS = [
-    ("Qwen/Qwen3-0.6B-MLX-4bit", dict(), 11),
-    ("Qwen/Qwen3-1.7B-MLX-4bit", dict(hidden_size=384, num_attention_heads=3, num_key_value_heads=1, intermediate_size=640,
-                                      num_hidden_layers=3, tie_word_embeddings=False), 12),
-    ("Qwen/Qwen3-4B-MLX-4bit", dict(hidden_size=512, num_attention_heads=8, num_key_value_heads=2, intermediate_size=768), 13),
-]
-
-
-def write_stand_in_checkpoints(hf_home: Path) -> None:
-    from checkpoint_fixture import write_hf_cache_snapshot
-    from helpers import TINY_CFG
-    from oracle import tiny_oracle as O
-
-    words = [f"w{i}" for i in range(200)]
-    for repo_id, overrides, seed in STAND_INS:
-        cfg = dict(TINY_CFG, **overrides)
-        write_hf_cache_snapshot(hf_home, repo_id, cfg, O.make_qwen3_weights(cfg, seed=seed, sigma=0.05), vocab_words=words)
+from checkpoint_fixture import write_stand_in_checkpoints  # noqa: E402  (synthetic stand-ins under the repository names)
 
 
 def facade_env(hf_home: Path) -> dict:

@@ -154,6 +154,9 @@ class Model(nn.Module):
                          rms_norm_eps=a.rms_norm_eps, vocab_size=a.vocab_size, num_key_value_heads=a.num_key_value_heads,
                          max_position_embeddings=getattr(a, "max_position_embeddings", 40960), rope_theta=a.rope_theta,
                          head_dim=a.head_dim, tie_word_embeddings=a.tie_word_embeddings)
+        for key, value in vars(a).items():  # fields beyond the dense Qwen3 arguments (num_experts, norm_topk_prob, ...)
+            if not hasattr(args, key):
+                setattr(args, key, value)
         model = cls(args)
 
         def q(layer):
@@ -166,8 +169,19 @@ class Model(nn.Module):
                 setattr(block.self_attn, name, q(getattr(src.self_attn, name)))
             block.self_attn.q_norm.weight = src.self_attn.q_norm.weight
             block.self_attn.k_norm.weight = src.self_attn.k_norm.weight
-            for name in ("gate_proj", "up_proj", "down_proj"):
-                setattr(block.mlp, name, q(getattr(src.mlp, name)))
+            if hasattr(src.mlp, "switch_mlp"):  # Qwen3-MoE layer (mlx_lm.models.qwen3_moe): router + grouped experts
+                from .qwen3_moe import Qwen3MoeSparseMoeBlock
+                from .switch_layers import QuantizedSwitchLinear
+
+                moe = Qwen3MoeSparseMoeBlock(a)
+                moe.gate = q(src.mlp.gate)
+                for name in ("gate_proj", "up_proj", "down_proj"):
+                    e = getattr(src.mlp.switch_mlp, name)
+                    setattr(moe.switch_mlp, name, QuantizedSwitchLinear(e.weight, e.scales, e.biases, e.group_size, e.bits))
+                block.mlp = moe
+            else:
+                for name in ("gate_proj", "up_proj", "down_proj"):
+                    setattr(block.mlp, name, q(getattr(src.mlp, name)))
             block.input_layernorm.weight = src.input_layernorm.weight
             block.post_attention_layernorm.weight = src.post_attention_layernorm.weight
         model.model.norm.weight = tree.model.norm.weight

@@ -10,6 +10,10 @@ tokenizer files) and returns the same two objects the reference gets from ``mlx_
 * a tokenizer wrapper with the surface the generation loops use (``encode``, ``eos_token_id``, ``get_vocab``,
   ``detokenizer`` with ``reset / add_token / last_segment / text / finalize``, ``apply_chat_template``).
 
+Qwen3-MoE checkpoints (``num_experts`` in config.json) load too: sparse layers carry ``mlp.gate`` (router) and
+``mlp.switch_mlp.{gate,up,down}_proj`` with a leading expert axis, the tree Qwen3ModelWeek3 builds its Moe blocks from
+(reference qwen3_week3.py:258-272).
+
 Only what the hot path supports is accepted: affine 4-bit weights in groups of 128 (SURVEY.md §8, quantize.py:103-121);
 anything else raises ``ValueError`` naming the offending field.  No network access: names are resolved in the local
 Hugging Face cache only.
@@ -121,15 +125,48 @@ def load_weights(model_dir: str | Path, device: str = "cuda") -> SimpleNamespace
             raise ValueError(f"{name}: expected shape ({n},), found {tuple(w.shape)}")
         return SimpleNamespace(weight=w.to(device))
 
+    def experts(prefix: str, count: int, out_dim: int, in_dim: int) -> SimpleNamespace:
+        """One stacked expert projection of a Qwen3-MoE layer (mlx_lm SwitchLinear): weight [E, out, in/8] u32,
+        scales / biases [E, out, in/128] (what grouped_expert_linear consumes, reference moe.py:7-36)."""
+        w, s, b = (src.get(f"{prefix}.{part}") for part in ("weight", "scales", "biases"))
+        if w.dtype not in (torch.uint32, torch.int32) or s.dtype not in (torch.bfloat16, torch.float16) or b.dtype != s.dtype:
+            raise ValueError(f"{prefix}: expected packed uint32 words with 16-bit float scales / biases, found "
+                             f"{w.dtype}/{s.dtype}/{b.dtype}")
+        if tuple(w.shape) != (count, out_dim, in_dim * bits // 32) or tuple(s.shape) != (count, out_dim, in_dim // group_size) \
+                or tuple(b.shape) != tuple(s.shape):
+            raise ValueError(f"{prefix}: shapes {tuple(w.shape)}, {tuple(s.shape)}, {tuple(b.shape)} do not describe {count} "
+                             f"[{out_dim}, {in_dim}] expert matrices in {bits}-bit groups of {group_size}")
+        return SimpleNamespace(weight=w.view(torch.int32).to(device), scales=s.to(device), biases=b.to(device),
+                               group_size=group_size, bits=bits)
+
     hs, inter = config["hidden_size"], config["intermediate_size"]
     hq, hkv, hd = config["num_attention_heads"], config["num_key_value_heads"], config["head_dim"]
     dims = {"q_proj": (hq * hd, hs), "k_proj": (hkv * hd, hs), "v_proj": (hkv * hd, hs), "o_proj": (hs, hq * hd),
             "gate_proj": (inter, hs), "up_proj": (inter, hs), "down_proj": (hs, inter)}
+    n_experts = int(config.get("num_experts", 0) or 0)
+    if n_experts > 0:
+        # Qwen3-MoE (`model_type: qwen3_moe`, e.g. Qwen3-30B-A3B): the fields Qwen3ModelWeek3 reads (reference
+        # qwen3_week3.py:208-215,258-272) must be present; the router and the experts are W4 like every other matrix
+        for key in ("num_experts_per_tok", "moe_intermediate_size"):
+            if key not in config:
+                raise ValueError(f"config.json has num_experts={n_experts} but lacks {key!r}")
+        config.setdefault("norm_topk_prob", False)
+        config.setdefault("decoder_sparse_step", 1)
+        config.setdefault("mlp_only_layers", [])
     layers = []
     for i in range(config["num_hidden_layers"]):
         base = f"model.layers.{i}"
         blocks = {}
+        sparse = (n_experts > 0 and i not in config["mlp_only_layers"] and (i + 1) % config["decoder_sparse_step"] == 0)
         for block, names in _LINEARS.items():
+            if block == "mlp" and sparse:
+                moe_inter = config["moe_intermediate_size"]
+                blocks[block] = SimpleNamespace(
+                    gate=linear(f"{base}.mlp.gate", n_experts, hs),
+                    switch_mlp=SimpleNamespace(gate_proj=experts(f"{base}.mlp.switch_mlp.gate_proj", n_experts, moe_inter, hs),
+                                               up_proj=experts(f"{base}.mlp.switch_mlp.up_proj", n_experts, moe_inter, hs),
+                                               down_proj=experts(f"{base}.mlp.switch_mlp.down_proj", n_experts, hs, moe_inter)))
+                continue
             blocks[block] = SimpleNamespace(**{n: linear(f"{base}.{block}.{n}", *dims[n]) for n in names})
         blocks["self_attn"].q_norm = norm(f"{base}.self_attn.q_norm.weight", hd)
         blocks["self_attn"].k_norm = norm(f"{base}.self_attn.k_norm.weight", hd)
