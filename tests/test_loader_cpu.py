@@ -142,10 +142,10 @@ def test_load_reads_a_qwen3_moe_checkpoint(tmp_path):
         loader.load_weights(ckpt, device="cpu")
 
 
-def test_week3_model_runs_a_loaded_moe_checkpoint(built_libs):
-    """Loader -> Qwen3ModelWeek3 with Moe blocks -> logits, against the facade's mlx_lm MoE model on the same tensors
-    (tests/moe_checkpoint_case.py; the numpy oracle answers the C ABI in this container, the grouped-expert HIP kernel and
-    the MoE block are held against the same oracle on the GPU: tests/test_ops_gpu.py, tests/test_models_gpu.py)."""
+def test_course_models_on_loaded_checkpoints_against_the_facade_mlx_lm_model(built_libs):
+    """Loader -> Week 1 / Week 2 / Week 3 (dense and Qwen3-MoE) models -> logits, against the facade's mlx_lm model on the
+    same tensors, in the pattern of the reference's checkpoint-dependent tests (tests/facade_model_cases.py).  The numpy
+    oracle answers the C ABI in this container; the same cases run on the HIP kernels from tests/test_compat_facade_gpu.py."""
     import os
     import subprocess
     import sys
@@ -153,7 +153,7 @@ def test_week3_model_runs_a_loaded_moe_checkpoint(built_libs):
 
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=str(root / "tests"))
-    proc = subprocess.run([sys.executable, "-m", "pytest", str(root / "tests" / "moe_checkpoint_case.py"), "-p", "no:cacheprovider",
+    proc = subprocess.run([sys.executable, "-m", "pytest", str(root / "tests" / "facade_model_cases.py"), "-p", "no:cacheprovider",
                            "-p", "refsol_oracle_plugin", "-q", "--tb=short"], cwd=root, env=env, capture_output=True, text=True,
                           timeout=600)
-    assert proc.returncode == 0 and "1 passed" in proc.stdout, proc.stdout[-3000:]
+    assert proc.returncode == 0 and "4 passed" in proc.stdout, proc.stdout[-3000:]
