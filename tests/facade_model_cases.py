@@ -10,7 +10,7 @@ against the facade's `mlx_lm` model (fp32 torch restatement, shares no code with
 * the Week-3 model on a loaded Qwen3-MoE checkpoint (router + stacked experts; reference qwen3_week3.py:258-272).
 
 This file is not collected by `pytest tests/` (name).  It runs
-  * on the MI355X from tests/test_compat_facade_gpu.py (the HIP kernels answer), and
+  * on the MI355X from tests/test_zz_facade_models_gpu.py (the HIP kernels answer), and
   * in the build container through `pytest tests/facade_model_cases.py -p refsol_oracle_plugin` (the numpy oracle answers the
     C ABI), started by tests/test_loader_cpu.py -- so every line below is executed before it reaches the GPU box.
 """

@@ -149,28 +149,3 @@ def test_week3_model_matches_week2_model_on_an_mx_built_checkpoint():
                 c.release()
         assert float(mx.max(mx.abs(outs[0] - outs[1])).item()) <= 2 * 2 ** -7 * max(1.0, float(mx.max(mx.abs(outs[0])).item()))
 
-
-# ---- checkpoint directory -> loader -> course model on the HIP kernels, against the facade's mlx_lm model -----------------------
-# (the reference's checkpoint-dependent tests, which it skips without a downloaded model; tests/facade_model_cases.py holds the
-# cases and runs them in the build container too, with the numpy oracle behind the C ABI)
-def test_week1_model_on_a_loaded_checkpoint(tmp_path):
-    import facade_model_cases as cases
-
-    with _mx().stream(_mx().gpu):
-        cases.case_week1_model(tmp_path)
-
-
-@pytest.mark.parametrize("checkpoint", ["kv-cache", "quantized-matvec", "decode-attention", "split-k"])
-def test_week2_incremental_decode_on_a_loaded_checkpoint(tmp_path, checkpoint):
-    import facade_model_cases as cases
-
-    with _mx().stream(_mx().gpu):
-        cases.case_week2_incremental_decode(tmp_path, checkpoint)
-
-
-@pytest.mark.parametrize("moe", [False, True], ids=["dense", "qwen3-moe"])
-def test_week3_staggered_batching_on_a_loaded_checkpoint(tmp_path, moe):
-    import facade_model_cases as cases
-
-    with _mx().stream(_mx().gpu):
-        cases.case_week3_staggered_batching(tmp_path, moe=moe)

@@ -145,7 +145,7 @@ def test_load_reads_a_qwen3_moe_checkpoint(tmp_path):
 def test_course_models_on_loaded_checkpoints_against_the_facade_mlx_lm_model(built_libs):
     """Loader -> Week 1 / Week 2 / Week 3 (dense and Qwen3-MoE) models -> logits, against the facade's mlx_lm model on the
     same tensors, in the pattern of the reference's checkpoint-dependent tests (tests/facade_model_cases.py).  The numpy
-    oracle answers the C ABI in this container; the same cases run on the HIP kernels from tests/test_compat_facade_gpu.py."""
+    oracle answers the C ABI in this container; the same cases run on the HIP kernels from tests/test_zz_facade_models_gpu.py."""
     import os
     import subprocess
     import sys
