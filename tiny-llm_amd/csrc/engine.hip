@@ -161,7 +161,7 @@ static int check_w4(const tl_w4 &w, int rows, int cols, const char *name) {
 // GEMV with fused prologue/epilogue over M <= 8 rows; splits the rows when the activation tile exceeds LDS.
 static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
                       const void *norm_w, const uint16_t *residual, ProfCtx *pc = nullptr, int kind = 0) {
-    int step = M;
+    int step = std::min(M, 8);  // both GEMV kernels hold at most 8 activation rows (MR <= 8): more rows go in passes of 8
     const bool has_tiled = e->tiled.count(w.weight_dev) != 0;
     auto fits = [&](int rows) {
         return (has_tiled && qmv3_plan(rows, w.cols, w.rows).ok) || qmv_plan(rows, w.cols, w.rows).lds <= 150 * 1024;
@@ -1220,6 +1220,11 @@ static int prefill_packed_impl(tl_engine *e, int n_seqs, const int *slots, const
         total += lens[i];
     }
     TL_REQUIRE(total <= c.max_prefill_rows, "engine_prefill_packed: the chunks together exceed max_prefill_rows");
+    {
+        int wanted = 0;
+        for (int i = 0; i < n_seqs; ++i) wanted += want_logits[i] ? 1 : 0;
+        TL_REQUIRE(wanted <= std::max(c.max_batch, 8), "engine_prefill_packed: more prompts end in this pass than the logits buffer has rows (max(max_batch, 8))");
+    }
     TL_REQUIRE(extra_pages <= e->free_pages.size(), "engine: KV page pool exhausted");  // checked before anything is mutated
     for (int i = 0; i < total; ++i) TL_REQUIRE(tokens[i] >= 0 && tokens[i] < c.vocab_size, "engine_prefill_packed: token id out of range");
 
