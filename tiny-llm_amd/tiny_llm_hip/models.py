@@ -1,4 +1,5 @@
-"""Model dispatch (reference: src/tiny_llm_ref/models.py:8-18)."""
+"""Model dispatch (reference: src/tiny_llm_ref/models.py:8-18).  With TINY_LLM_FUSED_ENGINE=1 the Week-2 / Week-3 entry (no
+``--week2-checkpoint``) is the fused decode engine behind the same call surface (engine_model.py)."""
 
 from model_names import shortcut_name_to_full_name
 
@@ -14,4 +15,9 @@ def dispatch_model(model_name: str, mlx_model, week: int, **kwargs):
     cls = _BY_WEEK.get(week)
     if cls is None or not full.startswith("Qwen/Qwen3"):
         raise ValueError(f"{full} for week {week} not supported")
+    if week in (2, 3) and not kwargs.get("checkpoint"):
+        from .engine_model import Qwen3ModelFused, fused_engine_requested
+
+        if fused_engine_requested():  # TINY_LLM_FUSED_ENGINE=1: the same call surface on the fused decode engine
+            return Qwen3ModelFused(mlx_model, **kwargs)
     return cls(mlx_model, **kwargs)
