@@ -23,7 +23,8 @@ def test_packed_prefill_with_more_than_eight_ending_prompts(n_prompts):
 
     w = O.make_qwen3_weights(TINY_CFG, seed=3, sigma=0.05)
     model = to_mlx_shaped(TINY_CFG, w)
-    prompts = [prompt_ids(3 + 2 * i, seed=900 + i) for i in range(n_prompts)]
+    # every prompt longer than 8 tokens: packed rows always take the GEMM path, and so does the oracle for more than 8 rows
+    prompts = [prompt_ids(9 + 2 * i, seed=900 + i) for i in range(n_prompts)]
     oracle_rows = [O.OracleQwen3(TINY_CFG, w).forward(p)[0, -1] for p in prompts]
     truth_rows = [O.TruthQwen3(TINY_CFG, w).forward(p)[0, -1] for p in prompts]
     eng = DecodeEngine(model, page_size=16, num_pages=96, max_batch=n_prompts, max_prefill_rows=512)
@@ -32,9 +33,12 @@ def test_packed_prefill_with_more_than_eight_ending_prompts(n_prompts):
             eng.begin(s)
         eng.prefill_packed([(s, prompts[s], True) for s in range(n_prompts)])
         got = eng.logits(n_prompts).float().cpu().numpy()
+        # all rows in one statement (HIP error <= 1.5 x the oracle's own error over the same rows), and no single row far out:
+        # a row the lm_head pass skipped would be garbage, tens of logit units away
+        check_against_truth(got, np.stack(oracle_rows), np.stack(truth_rows), what=f"packed prefill of {n_prompts} ending prompts")
+        worst_oracle = float(np.abs(np.stack(oracle_rows) - np.stack(truth_rows)).max())
         for s in range(n_prompts):
-            check_against_truth(got[s][None], oracle_rows[s][None], truth_rows[s][None],
-                                what=f"packed prefill of {n_prompts} prompts, row {s} ({len(prompts[s])} tokens)")
+            assert float(np.abs(got[s] - truth_rows[s]).max()) <= 3.0 * worst_oracle + 0.05, f"row {s}"
         first = eng.read_pending(n_prompts)
         for s in range(n_prompts):  # the pending token of every slot is the greedy id of ITS row
             assert int(first[s]) == int(np.argmax(got[s])), f"slot {s}"
