@@ -167,3 +167,16 @@ def pytest_configure(config):
         # package): the oracle is already imported, so the repository root can leave the module search path
         sys.modules.pop("benches", None)
         sys.path[:] = [p for p in sys.path if Path(p or ".").resolve() != ROOT]
+
+
+try:  # the reference's benches/test_attention.py and test_quantized_matmul.py take pytest-benchmark's `benchmark` fixture;
+    import pytest_benchmark  # noqa: F401  the plugin is not installed in this image: a one-call stand-in keeps their ASSERTIONS
+except ImportError:
+    import pytest
+
+    @pytest.fixture
+    def benchmark():
+        def run_once(function, *args, **kwargs):
+            return function(*args, **kwargs)
+
+        return run_once

@@ -37,9 +37,10 @@ TEST_FILES = ["test_week_1_day_1.py", "test_week_1_day_2.py", "test_week_1_day_3
               "test_week_3_day_5.py", "test_week_3_day_6.py", "test_week_3_day_7.py", "test_model_names.py"]
 # the reference's tests of its bench harness (benches/bench.py, bench_week2_operators.py, bench_chunked_prefill.py,
 # bench_serving_progression.py, bench_course_progression.py, profile_week2_kernels.py), run on the reference's own harness
-# files; benches/test_attention.py and test_quantized_matmul.py need the pytest-benchmark plugin, which is not installed
+# files; benches/test_attention.py and test_quantized_matmul.py take pytest-benchmark's `benchmark` fixture (not installed:
+# tests/refsol_oracle_plugin.py supplies a one-call stand-in, their assertions against the mx.* built-ins stay)
 BENCH_TEST_FILES = ["test_bench_course_progression.py", "test_bench_week2_operators.py", "test_bench_week3.py",
-                    "test_profile_week2_kernels.py"]
+                    "test_profile_week2_kernels.py", "test_attention.py", "test_quantized_matmul.py"]
 
 from checkpoint_fixture import write_stand_in_checkpoints  # noqa: E402  (synthetic stand-ins under the repository names)
 
@@ -62,8 +63,8 @@ def test_reference_tests_pass_unmodified_through_the_facade(built_libs, tmp_path
     tail = proc.stdout[-3000:]
     summary = re.search(r"(\d+) passed(?:, (\d+) skipped)?", proc.stdout)
     assert proc.returncode == 0, tail
-    # 363 passed / 2 skipped at the time of writing; the two skips are the reference's own unconditional ones
+    # 378 passed / 2 skipped at the time of writing; the two skips are the reference's own unconditional ones
     # (tests_refsol/test_week_1_day_6.py:4, test_week_1_day_7.py:4: "No unit tests ...: use main.py instead")
-    assert summary and int(summary.group(1)) >= 360, tail
+    assert summary and int(summary.group(1)) >= 375, tail
     assert int(summary.group(2) or 0) <= 2, tail
     assert "failed" not in proc.stdout.splitlines()[-1] and "error" not in proc.stdout.splitlines()[-1], tail
