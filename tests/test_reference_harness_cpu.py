@@ -129,6 +129,6 @@ def test_reference_main_and_batch_main_run(hf_home):
     *mains, batch = run_all(hf_home, jobs, timeout=300)  # a generation loop that never meets <eos> fails here, it cannot hang
     texts = [out.strip().splitlines()[-1] for out in mains]
     assert all(t.startswith("w") for t in texts), texts
-    # Week 2, Week 3 (paged and dense-gather) and both speculative runs decode the same greedy text on the same weights
-    assert len(set(texts[1:6])) == 1, texts
+    # (no equality across loaders is asserted: the reference takes the argmax of bf16 log-probabilities, logits - logsumexp rounded
+    # to 8 bits, so on a random model near-ties between the top candidates fall differently for every summation order)
     assert "--- 15 ---" in batch and "--- 16 ---" not in batch and "Q: What is the capital of France?" in batch

@@ -285,11 +285,38 @@ def _axis(kwargs):
     return kwargs.get("axis", None)
 
 
-exp, log, sin, cos, abs, sqrt, rsqrt, sigmoid, tanh, square = (  # noqa: A001
-    _torch.exp, _torch.log, _torch.sin, _torch.cos, _torch.abs, _torch.sqrt, _torch.rsqrt, _torch.sigmoid, _torch.tanh,
-    _torch.square)
-erf = _torch.erf
-matmul, outer, where, maximum, minimum = _torch.matmul, _torch.outer, _torch.where, _torch.maximum, _torch.minimum
+def _unary(fn):
+    """MLX's element-wise functions also take Python scalars (`mx.rsqrt(self.head_dim)`, reference qwen3_week1.py:35) and
+    return a 0-d float32 array for them."""
+
+    def apply(a, stream=None):
+        if not isinstance(a, _torch.Tensor):
+            a = _torch.tensor(float(a), dtype=float32, device=_dev())
+        return fn(a)
+
+    apply.__name__ = fn.__name__
+    return apply
+
+
+exp, log, sin, cos, abs, sqrt, rsqrt, sigmoid, tanh, square, erf = (  # noqa: A001
+    _unary(f) for f in (_torch.exp, _torch.log, _torch.sin, _torch.cos, _torch.abs, _torch.sqrt, _torch.rsqrt, _torch.sigmoid,
+                        _torch.tanh, _torch.square, _torch.erf))
+matmul, outer, maximum, minimum = _torch.matmul, _torch.outer, _torch.maximum, _torch.minimum
+
+
+def where(condition, x, y, stream=None):
+    """MLX selects on any non-zero condition (`mx.where(mx.tril(mx.ones(...)), 0, -inf)`, reference attention.py:26) and
+    promotes x / y like an arithmetic op."""
+    if not isinstance(condition, _torch.Tensor):
+        condition = _torch.tensor(condition, device=_dev())
+    if condition.dtype != _torch.bool:
+        condition = condition != 0
+    if isinstance(x, _torch.Tensor) and isinstance(y, _torch.Tensor) and x.dtype != y.dtype:
+        common = _torch.promote_types(x.dtype, y.dtype)
+        x, y = x.to(common), y.to(common)
+    return _torch.where(condition, x, y)
+
+
 multiply, add, subtract, divide = _torch.mul, _torch.add, _torch.sub, _torch.div
 
 

@@ -4,12 +4,12 @@ import torch
 
 
 def softmax(x: torch.Tensor, axis: int) -> torch.Tensor:
-    """Numerically-stable softmax; rows that are entirely -inf come out as zeros instead of NaN."""
-    peak = torch.amax(x, dim=axis, keepdim=True)
-    peak = torch.where(torch.isfinite(peak), peak, torch.zeros_like(peak))
-    e = torch.exp(x - peak)
-    total = e.sum(dim=axis, keepdim=True)
-    return e / torch.where(total == 0, torch.ones_like(total), total)
+    """The library softmax, as in the reference (basics.py:5-7: ``mx.softmax(x, axis=axis)``) -- 16-bit inputs are reduced in
+    float32 and rounded once -- except that a row that is entirely -inf (an idle row of a batch whose mask hides every key)
+    comes out as zeros instead of NaN."""
+    out = torch.softmax(x, dim=axis)
+    dead = torch.isneginf(x).all(dim=axis, keepdim=True)
+    return torch.where(dead, torch.zeros_like(out), out)
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:

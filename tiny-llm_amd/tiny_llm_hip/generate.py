@@ -19,8 +19,11 @@ def _release_kv_cache(kv_cache) -> None:
 
 
 def _log_softmax_last(logits: torch.Tensor) -> torch.Tensor:
-    wide = logits[:, -1, :].to(torch.float32)
-    return wide - torch.logsumexp(wide, dim=-1, keepdim=True)
+    """Log-probabilities of the last position IN THE LOGITS' OWN DTYPE, as the reference forms them
+    (generate.py:24-27,56-58: ``logits - mx.logsumexp(logits, keepdims=True)`` on the bf16 model output): a wider type here would
+    break ties of the rounded values differently from the reference's argmax."""
+    last = logits[:, -1, :]
+    return last - torch.logsumexp(last, dim=-1, keepdim=True)
 
 
 def simple_generate(model, tokenizer, prompt: str, sampler: Callable[[torch.Tensor], torch.Tensor] | None,
