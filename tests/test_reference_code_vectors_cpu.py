@@ -1,0 +1,100 @@
+"""CPU tier: tests/golden/reference_code_vectors.npz -- logits produced by the REFERENCE'S OWN PYTHON SOURCES (Week-1 model and
+the Week-2 readable `kv-cache` checkpoint, /root/reference/src/tiny_llm_ref imported as it is; the arithmetic underneath is the
+torch facade of mlx, see tests/golden/make_reference_code_vectors.py) -- against
+
+  * the product's host mirror on host tensors: BIT-identical (the same statement tests/test_reference_differential_cpu.py
+    makes live, here against the committed file, i.e. also where /root/reference does not exist);
+  * the numpy oracle and the float64 truth: the reference's own bf16 pipeline and the oracle's restatement of it sit equally far
+    from the truth (that distance is the E every tolerance of this repository is built from);
+  * a fresh run of the generator, where /root/reference is present: the committed file is current.
+"""
+
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import TINY_CFG, to_mlx_shaped
+from oracle import tiny_oracle as O
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLDEN = ROOT / "tests" / "golden" / "reference_code_vectors.npz"
+CASES = {  # the generator's table (tests/golden/make_reference_code_vectors.py)
+    "tiny_p5": (dict(), 3), "tiny_p37": (dict(), 3), "tiny_p150": (dict(), 3),
+    "untied_gqa3_p23": (dict(hidden_size=384, num_attention_heads=3, num_key_value_heads=1, intermediate_size=640, num_hidden_layers=3,
+                             tie_word_embeddings=False), 12),
+}
+
+
+def from_bits(a) -> np.ndarray:
+    return (np.asarray(a, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_host_mirror_reproduces_the_reference_code_bit_for_bit(golden, name):
+    from tiny_llm_hip import Qwen3ModelWeek1, Qwen3ModelWeek2
+
+    overrides, wseed = CASES[name]
+    cfg = dict(TINY_CFG, **overrides)
+    model = to_mlx_shaped(cfg, O.make_qwen3_weights(cfg, seed=wseed, sigma=0.05), device="cpu")
+    prompt, ids = golden[f"{name}/prompt"].tolist(), golden[f"{name}/ids"].tolist()
+    week2 = Qwen3ModelWeek2(model, checkpoint="kv-cache")
+    cache = week2.create_kv_cache()
+    logits = week2(torch.tensor([prompt], dtype=torch.int32), 0, cache)
+    assert logits.dtype == torch.bfloat16
+    np.testing.assert_array_equal(logits[0, -8:].float().numpy(), from_bits(golden[f"{name}/week2_kv_cache_prefill_logits_last8"]))
+    rows, offset = [logits[0, -1]], len(prompt)
+    for tok in ids[:-1]:
+        rows.append(week2(torch.tensor([[tok]], dtype=torch.int32), offset, cache, logits_to_keep=1)[0, -1])
+        offset += 1
+    for layer_cache in cache:
+        layer_cache.release()
+    got = torch.stack(rows).float().numpy()
+    np.testing.assert_array_equal(got, from_bits(golden[f"{name}/week2_kv_cache_step_logits"]))
+    assert [int(np.argmax(r)) for r in got] == ids
+    if f"{name}/week1_logits_last8" in golden:
+        week1 = Qwen3ModelWeek1(model)(torch.tensor([prompt], dtype=torch.int32))[0, -8:].float().numpy()
+        np.testing.assert_array_equal(week1, from_bits(golden[f"{name}/week1_logits_last8"]))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_is_as_close_to_the_truth_as_the_reference_code(golden, name):
+    overrides, wseed = CASES[name]
+    cfg = dict(TINY_CFG, **overrides)
+    w = O.make_qwen3_weights(cfg, seed=wseed, sigma=0.05)
+    prompt, ids = golden[f"{name}/prompt"].tolist(), golden[f"{name}/ids"].tolist()
+    reference_rows = from_bits(golden[f"{name}/week2_kv_cache_step_logits"]).astype(np.float64)
+    oracle, truth = O.OracleQwen3(cfg, w), O.TruthQwen3(cfg, w)
+    o_rows, t_rows = [oracle.forward(prompt)[0, -1]], [truth.forward(prompt)[0, -1]]
+    for tok in ids[:-1]:
+        o_rows.append(oracle.forward([tok])[0, -1])
+        t_rows.append(truth.forward([tok])[0, -1])
+    o_rows, t_rows = np.stack(o_rows).astype(np.float64), np.stack(t_rows)
+    e_reference = float(np.abs(reference_rows - t_rows).max())
+    e_oracle = float(np.abs(o_rows - t_rows).max())
+    print(f"{name}: max |reference code - truth| = {e_reference:.4f}, max |oracle - truth| = {e_oracle:.4f}, "
+          f"max |oracle - reference code| = {float(np.abs(o_rows - reference_rows).max()):.4f}")
+    ulp = 2.0 ** -7 * float(np.abs(t_rows).max())
+    assert e_oracle <= 1.5 * e_reference + ulp and e_reference <= 1.5 * e_oracle + ulp
+    assert float(np.abs(o_rows - reference_rows).max()) <= e_oracle + e_reference
+
+
+@pytest.mark.skipif(not Path("/root/reference/src/tiny_llm_ref").is_dir(), reason="/root/reference is not present (GPU box)")
+def test_committed_vectors_are_what_the_reference_code_produces_now(tmp_path):
+    script = (ROOT / "tests" / "golden" / "make_reference_code_vectors.py").read_text().replace(
+        'HERE / "reference_code_vectors.npz"', f'Path({str(tmp_path / "fresh.npz")!r})')
+    (tmp_path / "make.py").write_text(script.replace("HERE = Path(__file__).resolve().parent", f"HERE = Path({str(GOLDEN.parent)!r})"))
+    proc = subprocess.run([sys.executable, str(tmp_path / "make.py")], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    fresh, committed = np.load(tmp_path / "fresh.npz"), np.load(GOLDEN)
+    assert sorted(fresh.files) == sorted(committed.files)
+    for key in committed.files:
+        np.testing.assert_array_equal(fresh[key], committed[key], err_msg=key)
