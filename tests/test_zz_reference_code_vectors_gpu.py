@@ -17,6 +17,7 @@ from oracle import tiny_oracle as O
 from test_reference_code_vectors_cpu import CASES, from_bits
 
 pytestmark = pytest.mark.gpu
+DEVICE = "cuda" if torch.cuda.is_available() else "cpu"  # "cpu" only in the build container's dry run (oracle behind the C ABI)
 GOLDEN = Path(__file__).resolve().parent / "golden" / "reference_code_vectors.npz"
 
 
@@ -37,13 +38,13 @@ def test_week2_kernel_model_against_the_reference_code(name):
     cfg = dict(TINY_CFG, **overrides)
     w = O.make_qwen3_weights(cfg, seed=wseed, sigma=0.05)
     prompt, ids = golden[f"{name}/prompt"].tolist(), golden[f"{name}/ids"].tolist()
-    model = Qwen3ModelWeek2(to_mlx_shaped(cfg, w))  # the completed Week-2 model: every HIP kernel
+    model = Qwen3ModelWeek2(to_mlx_shaped(cfg, w, device=DEVICE))  # the completed Week-2 model: every HIP kernel
     cache = model.create_kv_cache()
     try:
-        logits = model(torch.tensor([prompt], dtype=torch.int32, device="cuda"), 0, cache, logits_to_keep=1)
+        logits = model(torch.tensor([prompt], dtype=torch.int32, device=DEVICE), 0, cache, logits_to_keep=1)
         rows, offset = [logits[0, -1].float().cpu().numpy()], len(prompt)
         for tok in ids[:-1]:
-            step = model(torch.tensor([[tok]], dtype=torch.int32, device="cuda"), offset, cache, logits_to_keep=1)
+            step = model(torch.tensor([[tok]], dtype=torch.int32, device=DEVICE), offset, cache, logits_to_keep=1)
             rows.append(step[0, -1].float().cpu().numpy())
             offset += 1
     finally:
