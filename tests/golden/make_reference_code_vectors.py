@@ -41,6 +41,9 @@ CASES = {  # name -> (config overrides, weight seed, prompt length, prompt seed,
 }
 
 
+BATCH_PROMPT_LENS, BATCH_STEPS = (7, 33, 12, 60), 4
+
+
 def bits(t):
     assert t.dtype == mx.bfloat16
     return t.contiguous().view(torch.int16).numpy().view(np.uint16)
@@ -71,6 +74,34 @@ def main() -> None:
             out[f"{name}/week2_kv_cache_step_logits"] = bits(mx.stack(rows))  # [1 + steps, vocab]: prefill's last row, then each step
             if n <= 40:
                 out[f"{name}/week1_logits_last8"] = bits(R.Qwen3ModelWeek1(model)(mx.array([prompt], dtype=mx.int32))[0, -8:])
+        # continuous batching on the readable path: four requests prefilled one by one, then decoded TOGETHER on a
+        # BatchingKvCache (reference kv_cache.py BatchingKvCache; the shape of tests_refsol/test_week_3_day_1.py:128-195)
+        cfg = dict(TINY_CFG)
+        model = to_mlx_shaped(cfg, O.make_qwen3_weights(cfg, seed=3, sigma=0.05), device="cpu")
+        week2 = R.Qwen3ModelWeek2(model, checkpoint="kv-cache")
+        lens = BATCH_PROMPT_LENS
+        prompts = [[int(t) for t in np.random.default_rng(300 + n).integers(1, cfg["vocab_size"], size=n)] for n in lens]
+        batch = [R.BatchingKvCache(max_active_requests=len(lens), max_seq_len=128) for _ in range(week2.num_hidden_layers)]
+        first_rows, tokens = [], []
+        for rid, prompt in enumerate(prompts):
+            own = week2.create_kv_cache()
+            logits = week2(mx.array([prompt], dtype=mx.int32), 0, own, logits_to_keep=1)
+            first_rows.append(logits[0, -1])
+            tokens.append(int(logits[0, -1].argmax()))
+            for layer_batch, layer_own in zip(batch, own):
+                layer_batch.add_request(layer_own, rid)
+        step_rows, step_ids, offsets = [], [list(tokens)], list(lens)
+        for _ in range(BATCH_STEPS):
+            logits = week2(mx.array(tokens, dtype=mx.int32).reshape(-1, 1), mx.array(offsets, dtype=mx.int32), batch, logits_to_keep=1)
+            step_rows.append(logits[:, -1])
+            tokens = [int(logits[i, -1].argmax()) for i in range(len(lens))]
+            step_ids.append(list(tokens))
+            offsets = [o + 1 for o in offsets]
+        for i, prompt in enumerate(prompts):
+            out[f"batch4/prompt{i}"] = np.asarray(prompt, dtype=np.int32)
+        out["batch4/ids"] = np.asarray(step_ids, dtype=np.int32)  # [1 + steps, 4]: the token fed at each step, then the last greedy ids
+        out["batch4/prefill_last_logits"] = bits(mx.stack(first_rows))  # [4, vocab]
+        out["batch4/step_logits"] = bits(mx.stack(step_rows))  # [steps, 4, vocab]
     np.savez_compressed(HERE / "reference_code_vectors.npz", **out)
     print({k: v.shape for k, v in out.items()})
 

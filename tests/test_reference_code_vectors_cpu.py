@@ -87,6 +87,53 @@ def test_oracle_is_as_close_to_the_truth_as_the_reference_code(golden, name):
     assert float(np.abs(o_rows - reference_rows).max()) <= e_oracle + e_reference
 
 
+def batch_case(golden):
+    prompts = [golden[f"batch4/prompt{i}"].tolist() for i in range(4)]
+    return prompts, golden["batch4/ids"], from_bits(golden["batch4/prefill_last_logits"]), from_bits(golden["batch4/step_logits"])
+
+
+def test_host_mirror_reproduces_the_reference_code_in_a_batch(golden):
+    """Four requests prefilled one by one, then decoded together on a BatchingKvCache (readable path): bit for bit."""
+    from tiny_llm_hip import BatchingKvCache, Qwen3ModelWeek2
+
+    prompts, ids, first, steps = batch_case(golden)
+    model = Qwen3ModelWeek2(to_mlx_shaped(TINY_CFG, O.make_qwen3_weights(TINY_CFG, seed=3, sigma=0.05), device="cpu"), checkpoint="kv-cache")
+    batch = [BatchingKvCache(max_active_requests=4, max_seq_len=128) for _ in range(model.num_hidden_layers)]
+    for rid, prompt in enumerate(prompts):
+        own = model.create_kv_cache()
+        logits = model(torch.tensor([prompt], dtype=torch.int32), 0, own, logits_to_keep=1)
+        np.testing.assert_array_equal(logits[0, -1].float().numpy(), first[rid])
+        for layer_batch, layer_own in zip(batch, own):
+            layer_batch.add_request(layer_own, rid)
+    offsets = [len(p) for p in prompts]
+    for step in range(steps.shape[0]):
+        logits = model(torch.tensor(ids[step], dtype=torch.int32).reshape(-1, 1), torch.tensor(offsets, dtype=torch.int32), batch, logits_to_keep=1)
+        np.testing.assert_array_equal(logits[:, -1].float().numpy(), steps[step])
+        assert logits[:, -1].argmax(-1).tolist() == ids[step + 1].tolist()
+        offsets = [o + 1 for o in offsets]
+
+
+def batch_truth_and_oracle(prompts, ids):
+    """Teacher-forced on the reference's ids: per request the float64 truth and the bf16 oracle, [steps, 4, vocab] each."""
+    w = O.make_qwen3_weights(TINY_CFG, seed=3, sigma=0.05)
+    t_rows, o_rows = [], []
+    for r, prompt in enumerate(prompts):
+        truth, oracle = O.TruthQwen3(TINY_CFG, w), O.OracleQwen3(TINY_CFG, w)
+        truth.forward(prompt), oracle.forward(prompt)
+        t_rows.append([truth.forward([int(ids[s, r])])[0, -1] for s in range(ids.shape[0] - 1)])
+        o_rows.append([oracle.forward([int(ids[s, r])])[0, -1] for s in range(ids.shape[0] - 1)])
+    return np.asarray(t_rows).transpose(1, 0, 2), np.asarray(o_rows, dtype=np.float64).transpose(1, 0, 2)
+
+
+def test_oracle_is_as_close_to_the_truth_as_the_reference_code_in_a_batch(golden):
+    prompts, ids, _, steps = batch_case(golden)
+    truth, oracle = batch_truth_and_oracle(prompts, ids)
+    e_reference, e_oracle = float(np.abs(steps - truth).max()), float(np.abs(oracle - truth).max())
+    print(f"batch of 4: max |reference code - truth| = {e_reference:.4f}, max |oracle - truth| = {e_oracle:.4f}")
+    ulp = 2.0 ** -7 * float(np.abs(truth).max())
+    assert e_oracle <= 1.5 * e_reference + ulp and e_reference <= 1.5 * e_oracle + ulp
+
+
 @pytest.mark.skipif(not Path("/root/reference/src/tiny_llm_ref").is_dir(), reason="/root/reference is not present (GPU box)")
 def test_committed_vectors_are_what_the_reference_code_produces_now(tmp_path):
     script = (ROOT / "tests" / "golden" / "make_reference_code_vectors.py").read_text().replace(

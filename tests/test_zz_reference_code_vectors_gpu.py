@@ -14,7 +14,7 @@ import torch
 
 from helpers import TINY_CFG, check_against_truth, to_mlx_shaped
 from oracle import tiny_oracle as O
-from test_reference_code_vectors_cpu import CASES, from_bits
+from test_reference_code_vectors_cpu import CASES, batch_case, batch_truth_and_oracle, from_bits
 
 # First device run pending (the round's GPU budget was spent before these were written): recorded as xpassed / xfailed instead
 # of turning the suite red on a run nobody could rehearse.  Remove the xfail mark after the first device run.
@@ -79,3 +79,33 @@ def test_fused_engine_against_the_reference_code(name):
         eng.close()
     check_against_truth(np.stack(rows), from_bits(golden[f"{name}/week2_kv_cache_step_logits"]), truth_rows(cfg, w, prompt, ids),
                         what=f"fused engine vs the reference's own readable path, {name}")
+
+
+def test_fused_engine_batched_decode_against_the_reference_code():
+    """Four sequences decoded together (the batched GEMV / skinny-matmul and batched attention path), teacher-forced on the ids
+    of the reference's own readable model decoding the same four requests on its BatchingKvCache."""
+    from tiny_llm_hip.engine import DecodeEngine
+
+    golden = np.load(GOLDEN)
+    prompts, ids, first, steps = batch_case(golden)
+    truth, _ = batch_truth_and_oracle(prompts, ids)
+    w = O.make_qwen3_weights(TINY_CFG, seed=3, sigma=0.05)
+    eng = DecodeEngine(to_mlx_shaped(TINY_CFG, w), page_size=16, num_pages=64, max_batch=4, max_prefill_rows=128)
+    try:
+        for slot, prompt in enumerate(prompts):
+            eng.begin(slot)
+            eng.prefill(slot, prompt, chunk=128)
+        rows = []
+        for step in range(steps.shape[0]):
+            for slot in range(4):
+                eng.set_token(slot, int(ids[step, slot]))
+            eng.decode(1, batch=4)
+            rows.append(eng.logits(4).float().cpu().numpy())
+        for slot in range(4):
+            eng.release(slot)
+        assert eng.stats()["pages_in_use"] == 0
+    finally:
+        eng.close()
+    got = np.stack(rows)  # [steps, 4, vocab]
+    check_against_truth(got.reshape(-1, got.shape[-1]), steps.reshape(-1, steps.shape[-1]), truth.reshape(-1, truth.shape[-1]),
+                        what="fused engine, 4 sequences per step, vs the reference's own readable path")
