@@ -162,6 +162,20 @@ def pytest_configure(config):
     ext._workspace = lambda nbytes, device: None
     ext._lib = FakeLib(ext._lib)
     ext.load_library = lambda path: None
+    if os.environ.get("REFSOL_REFERENCE_SOURCES") == "1":
+        # CONTROL RUN: the reference's OWN tiny_llm_ref sources (not the product's host mirror) on the same stand-ins -- the torch
+        # facade for mlx, this oracle-backed binding for its Metal extension.  If the reference's solution passes the reference's
+        # tests on these stand-ins, the stand-ins are faithful at the tests' tolerances (tests/test_refsol_facade_cpu.py).
+        import types
+
+        pkg = types.ModuleType("extensions_ref")
+        pkg.__path__ = []
+        pkg.tiny_llm_ext_ref = ext
+        sys.modules["extensions_ref"] = pkg
+        sys.modules["extensions_ref.tiny_llm_ext_ref"] = ext
+        for name in [k for k in sys.modules if k == "tiny_llm_ref" or k.startswith("tiny_llm_ref.")]:
+            del sys.modules[name]
+        sys.path.insert(0, os.path.join(os.environ.get("TINYLLM_REFERENCE_ROOT", "/root/reference"), "src"))
     if os.environ.get("REFSOL_REFERENCE_BENCHES") == "1":
         # the reference's OWN benches/ package (a namespace package) must win over this repository's benches/ (a regular
         # package): the oracle is already imported, so the repository root can leave the module search path

@@ -301,7 +301,18 @@ def _unary(fn):
 exp, log, sin, cos, abs, sqrt, rsqrt, sigmoid, tanh, square, erf = (  # noqa: A001
     _unary(f) for f in (_torch.exp, _torch.log, _torch.sin, _torch.cos, _torch.abs, _torch.sqrt, _torch.rsqrt, _torch.sigmoid,
                         _torch.tanh, _torch.square, _torch.erf))
-matmul, outer, maximum, minimum = _torch.matmul, _torch.outer, _torch.maximum, _torch.minimum
+outer, maximum, minimum = _torch.outer, _torch.maximum, _torch.minimum
+
+
+def matmul(a, b, stream=None):
+    """MLX promotes mixed operands (a float16 activation on float32 weights gives float32: reference basics.py:18 on the Week-1
+    tests' inputs); torch.matmul refuses them."""
+    if a.dtype != b.dtype:
+        common = _torch.promote_types(a.dtype, b.dtype)
+        a, b = a.to(common), b.to(common)
+    return _torch.matmul(a, b)
+
+
 
 
 def where(condition, x, y, stream=None):
