@@ -25,8 +25,13 @@ def main() -> None:
     refsol_oracle_plugin.pytest_configure(None)
     for extra in (REFERENCE / "src", REFERENCE):  # the reference's own `pythonpath = ["src", "."]` (pyproject.toml:63-65)
         sys.path.insert(0, str(extra))
-    # ... except that `tiny_llm_ref` / `extensions_ref` / `mlx*` must resolve to the facade, not to the reference's sources
-    sys.path.insert(0, str(ROOT / "tiny-llm_amd" / "compat"))
+    # ... except that `tiny_llm_ref` / `extensions_ref` / `mlx*` must resolve to the facade, not to the reference's sources --
+    # unless this is the CONTROL run (REFSOL_REFERENCE_SOURCES=1: the reference's own tiny_llm_ref on the same stand-ins; the
+    # plugin has already aliased the extension), where only `mlx*` comes from the facade
+    if os.environ.get("REFSOL_REFERENCE_SOURCES") == "1":
+        sys.path.insert(sys.path.index(str(REFERENCE / "src")) + 1, str(ROOT / "tiny-llm_amd" / "compat"))
+    else:
+        sys.path.insert(0, str(ROOT / "tiny-llm_amd" / "compat"))
     # child interpreters (the drivers' fresh worker processes) get the same module search path and the same stand-in
     child_path = [ROOT / "tests" / "facade_site", ROOT / "tests", ROOT / "tiny-llm_amd" / "compat", ROOT / "tiny-llm_amd",
                   ROOT / "tiny-llm_amd" / "extensions_hip", REFERENCE]

@@ -35,10 +35,13 @@ def hf_home(built_libs, tmp_path_factory):
     return home
 
 
-def run_script(hf_home: Path, script: str, *args: str, timeout: int = 600) -> str:
+def run_script(hf_home: Path, script: str, *args: str, timeout: int = 600, reference_sources: bool = False) -> str:
     env = dict(os.environ, HF_HOME=str(hf_home), HF_HUB_OFFLINE="1", PYTHONDONTWRITEBYTECODE="1",
                OMP_NUM_THREADS="2", MKL_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")  # several scripts run side by side
     env.pop("PYTHONPATH", None)
+    env.pop("REFSOL_REFERENCE_SOURCES", None)
+    if reference_sources:  # CONTROL: the reference's own tiny_llm_ref sources under its harness, same stand-ins
+        env["REFSOL_REFERENCE_SOURCES"] = "1"
     proc = subprocess.run([sys.executable, str(ROOT / "tests" / "run_reference_script.py"), script, *args], env=env,
                           capture_output=True, text=True, timeout=timeout)
     assert proc.returncode == 0, f"{script} {' '.join(args)}\n{proc.stdout[-1500:]}\n{proc.stderr[-2500:]}"
@@ -132,3 +135,27 @@ def test_reference_main_and_batch_main_run(hf_home):
     # (no equality across loaders is asserted: the reference takes the argmax of bf16 log-probabilities, logits - logsumexp rounded
     # to 8 bits, so on a random model near-ties between the top candidates fall differently for every summation order)
     assert "--- 15 ---" in batch and "--- 16 ---" not in batch and "Q: What is the capital of France?" in batch
+
+
+TIMED = ("time", "second", "_ms")
+
+
+@pytest.mark.parametrize("mode", [("week3",), ("week3", "--disable-paged-attention"), ("week2",)], ids=["paged", "paged-dense-gather", "dense"])
+def test_serving_counters_equal_those_of_the_reference_sources(hf_home, tmp_path, mode):
+    """The reference's serving benchmark (benches/bench.py --batch-decode) run twice on the same seeded trace and stand-ins: with the
+    product's host mirror behind `tiny_llm_ref`, and with the reference's OWN sources.  Every counter that is not a wall-clock
+    quantity -- generated / decode tokens, peak active requests, live and capacity pages, tail-waste slots / bytes / fraction, KV
+    bytes, step and gap counts, reused allocations, pool growths, copied pages and bytes -- must be IDENTICAL, and so must the trace."""
+    args = ["benches/bench.py", "--model", "qwen3-0.6b", "--num-seqs", "6", "--min-input-len", "5", "--max-input-len", "70", "--min-output-len", "3",
+            "--max-output-len", "9", "--warmup", "1", "--solution", "ref", "--loader", mode[0], *mode[1:], "--batch-decode", "--batch-size", "3",
+            "--prefill-step", "16"]
+    own_json, ref_json = tmp_path / "product.json", tmp_path / "reference.json"
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        a = pool.submit(run_script, hf_home, *args, "--json-output", str(own_json))
+        b = pool.submit(run_script, hf_home, *args, "--json-output", str(ref_json), reference_sources=True)
+        a.result(), b.result()
+    own, ref = json.loads(own_json.read_text()), json.loads(ref_json.read_text())
+    assert own["request_trace"] == ref["request_trace"] and own["configuration"] == ref["configuration"]
+    counters = [k for k in ref["metrics"] if not any(t in k for t in TIMED)]
+    assert len(counters) >= 18, counters
+    assert {k: own["metrics"][k] for k in counters} == {k: ref["metrics"][k] for k in counters}
