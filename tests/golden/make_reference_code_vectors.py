@@ -8,6 +8,8 @@ reference's.  Only paths that need no Metal extension are used: `Qwen3ModelWeek1
 `Qwen3ModelWeek2(checkpoint="kv-cache")` (the course's readable pre-kernel path with its KV cache: reference main.py:48-60 allows
 exactly this checkpoint on `--device cpu`).  Greedy decode, the ids are stored with the logits so that consumers can
 teacher-force.  The checkpoints come from oracle.make_qwen3_weights (numpy, seeded): consumers rebuild them bit-identically.
+Generated with ONE torch thread (the summation order of the CPU matmul, and with it the last bit of a bf16 logit, depends on the
+thread count); consumers that want bit equality pin one thread too.
 
     python tests/golden/make_reference_code_vectors.py        (build container only: needs /root/reference)
 """
@@ -50,6 +52,7 @@ def bits(t):
 
 
 def main() -> None:
+    torch.set_num_threads(1)  # the fp32 summation order of torch's CPU matmul depends on the thread count: one thread = one order
     out = {}
     with mx.stream(mx.cpu):
         for name, (overrides, wseed, n, pseed, steps) in CASES.items():
