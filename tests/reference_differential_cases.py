@@ -446,3 +446,68 @@ def test_moe_block_and_sampler(monkeypatch):
                 same((ref > 0).tolist(), (own > 0).tolist(), f"sampler support temp={temp} top_p={top_p} top_k={top_k}")
                 close(ref, own / own.sum(), f"sampler distribution temp={temp} top_p={top_p} top_k={top_k}", 1e-6)
             same(R.make_sampler(0, None, None)(row).tolist(), P.make_sampler(0, None, None)(row).tolist(), "greedy sampler")
+
+
+# ---- error behaviour --------------------------------------------------------------------------------------------------------
+def outcome(fn):
+    try:
+        fn()
+    except Exception as exc:  # noqa: BLE001  (the point is to compare whatever is raised)
+        return type(exc).__name__, str(exc)
+    return "no error", ""
+
+
+def test_precondition_failures_read_alike():
+    """Every rejected call must be rejected by both code bases with the same exception type and the same message."""
+    with mx.stream(mx.cpu):
+        mx.random.seed(12)
+        P_, Hkv, page, D, Hq = 6, 2, 4, 8, 4
+        kp = mx.random.normal((P_, Hkv, page, D)).astype(mx.bfloat16)
+        vp = mx.random.normal((P_, Hkv, page, D)).astype(mx.bfloat16)
+        q = mx.random.normal((2, Hq, 1, D)).astype(mx.bfloat16)
+        table = mx.array([[0, 1, -1], [2, 3, 4]], dtype=mx.int32)
+        ctx = mx.array([5, 9], dtype=mx.int32)
+        good = dict(query=q, key_pages=kp, value_pages=vp, block_table=table, context_lens=ctx, page_size=page, scale=0.3, mask=None)
+
+        def call(module, **changes):
+            args = dict(good, **changes)
+            return lambda: module.paged_attention(args["query"], args["key_pages"], args["value_pages"], args["block_table"], args["context_lens"],
+                                                  args["page_size"], scale=args["scale"], mask=args["mask"])
+
+        bad = [
+            dict(mask=mx.zeros((2, Hq, 1, 9))), dict(mask="full"), dict(query=q[0]), dict(key_pages=kp[0]), dict(value_pages=vp[:, :1]),
+            dict(block_table=table[0]), dict(context_lens=ctx[None]), dict(block_table=table.astype(mx.float32)), dict(page_size=0),
+            dict(page_size=page + 1), dict(query=mx.random.normal((2, 3, 1, D)).astype(mx.bfloat16)),
+            dict(query=mx.random.normal((2, Hq, 1, D + 8)).astype(mx.bfloat16)), dict(context_lens=mx.array([5], dtype=mx.int32)),
+            dict(query=q.astype(mx.float32)), dict(query=q.astype(mx.float16), key_pages=kp.astype(mx.float16), value_pages=vp.astype(mx.float16)),
+            dict(context_lens=mx.array([-1, 9], dtype=mx.int32)), dict(context_lens=mx.array([5, 13], dtype=mx.int32)),
+            dict(block_table=mx.array([[0, 1, -1], [2, 1, 4]], dtype=mx.int32)), dict(block_table=mx.array([[0, 7, -1], [2, 3, 4]], dtype=mx.int32)),
+            dict(block_table=mx.array([[0, -1, 1], [2, 3, 4]], dtype=mx.int32)), dict(block_table=mx.zeros((2, 0), dtype=mx.int32)),
+        ]
+        same(outcome(call(R)), outcome(call(P)), "the valid call")
+        assert outcome(call(R))[0] == "no error"
+        for changes in bad:
+            ref, own = outcome(call(R, **changes)), outcome(call(P, **changes))
+            assert ref[0] != "no error", f"the reference accepts {sorted(changes)}"
+            same(ref, own, f"paged_attention with {sorted(changes)}")
+        # caches and the pool
+        for make_r, make_p, what in (
+            (lambda: R.TinyKvFullCache().rewind(1), lambda: P.TinyKvFullCache().rewind(1), "rewind past the start of a dense cache"),
+            (lambda: R.TinyKvPagedPool(page_size=0), lambda: P.TinyKvPagedPool(page_size=0), "a pool with page size 0"),
+            (lambda: R.BatchingKvCache(max_active_requests=1, max_seq_len=8).remove_request(0),
+             lambda: P.BatchingKvCache(max_active_requests=1, max_seq_len=8).remove_request(0), "removing a request that was never added"),
+            (lambda: R.BatchingKvCache(max_active_requests=1, max_seq_len=8).add_request(R.TinyKvFullCache(), 3),
+             lambda: P.BatchingKvCache(max_active_requests=1, max_seq_len=8).add_request(P.TinyKvFullCache(), 3), "adding a request beyond the batch"),
+            (lambda: R.quantized_matmul(mx.zeros((2, 1), mx.bfloat16), mx.zeros((2, 1), mx.bfloat16), 64, 4, mx.zeros((1, 128), mx.bfloat16),
+                                        mx.zeros((2, 16), mx.uint32), True),
+             lambda: P.quantized_matmul(mx.zeros((2, 1), mx.bfloat16), mx.zeros((2, 1), mx.bfloat16), 64, 4, mx.zeros((1, 128), mx.bfloat16),
+                                        mx.zeros((2, 16), mx.uint32), True), "a group size the kernel does not support"),
+            (lambda: R.dispatch_model("llama-3", None, week=2), lambda: P.dispatch_model("llama-3", None, week=2), "an unknown model family"),
+            (lambda: R.make_sampler(0.5, None, None)(mx.zeros((1, 4)) + float("nan")), lambda: P.make_sampler(0.5, None, None)(mx.zeros((1, 4)) + float("nan")),
+             "NaN log-probabilities"),
+        ):
+            ref, own = outcome(make_r), outcome(make_p)
+            if ref[0] == "no error":
+                assert own[0] == "no error", f"{what}: the reference accepts it, the product raises {own}"
+            else:
+                assert own[0] == ref[0], f"{what}: {ref} vs {own}"
