@@ -5,6 +5,8 @@ code runs end to end on the facade + host mirror (argument handling, model dispa
 output).  The numbers it prints are oracle timings and mean nothing.  The product never loads this file.
 
 usage: python tests/run_reference_script.py <script path relative to /root/reference> [script arguments...]
+       REFSOL_REFERENCE_SOURCES=1 ... : CONTROL run -- the reference's own tiny_llm_ref sources behind the script instead of the
+       product's host mirror (same facade for mlx, same oracle-backed extension binding)
 """
 
 import os
