@@ -511,3 +511,33 @@ def test_precondition_failures_read_alike():
                 assert own[0] == "no error", f"{what}: the reference accepts it, the product raises {own}"
             else:
                 assert own[0] == ref[0], f"{what}: {ref} vs {own}"
+
+
+# ---- the bench harness's pure-Python parts ---------------------------------------------------------------------------------
+def test_bench_trace_generator_and_percentiles():
+    """This repository's benches/bench.py and benches/serving.py against the reference's benches/bench.py: the seeded request trace
+    (reference build_requests, 201-225) and the report's order statistics (sample_median 575-576, nearest_rank_percentile 579-585)."""
+    import importlib.util
+    from random import Random
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        module = importlib.util.module_from_spec(spec)
+        sys.modules[name] = module
+        spec.loader.exec_module(module)
+        return module
+
+    ref = load("reference_benches_bench", REFERENCE / "benches" / "bench.py")
+    own = load("product_benches_bench", ROOT / "benches" / "bench.py")
+    serving = load("product_benches_serving", ROOT / "benches" / "serving.py")
+    for seed, vocab, eos in ((0, 151936, 151645), (7, 1024, 0), (3, 300, 299)):
+        kwargs = dict(num_seqs=9, vocab_size=vocab, eos_token_id=eos, min_input_len=3, max_input_len=40, min_output_len=1, max_output_len=9)
+        a, b = ref.build_requests(rng=Random(seed), **kwargs), own.build_requests(rng=Random(seed), **kwargs)
+        same([(r.prompt_token_ids, r.max_new_tokens) for r in a], [(r.prompt_token_ids, r.max_new_tokens) for r in b], f"trace, seed {seed}")
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 5, 20, 101):
+        samples = [float(x) for x in rng.random(n)]
+        same(ref.sample_median(samples), serving.median(samples), f"median of {n}")
+        for q in (0.5, 0.9, 0.95, 0.99, 1.0):
+            same(ref.nearest_rank_percentile(samples, q), serving.nearest_rank(samples, q), f"p{q} of {n}")
+    same(ref.safe_div(3.0, 0.0), own.safe_div(3.0, 0.0), "safe_div by zero")
