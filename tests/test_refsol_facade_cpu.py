@@ -54,12 +54,24 @@ FACADE_PATHS = " ".join(str(p) for p in (ROOT / "tiny-llm_amd" / "compat", ROOT 
                                          ROOT / "tiny-llm_amd" / "extensions_hip"))
 
 
-@pytest.mark.skipif(not (REFERENCE / "tests_refsol").is_dir(), reason="/root/reference is not present (GPU box)")
-def test_reference_tests_pass_unmodified_through_the_facade(built_libs, tmp_path):
-    write_stand_in_checkpoints(tmp_path / "hf")
+def _run_reference_tests(hf_home: Path, reference_sources: bool) -> subprocess.CompletedProcess:
     cmd = [sys.executable, "-m", "pytest", *[f"tests_refsol/{f}" for f in TEST_FILES], *[f"benches/{f}" for f in BENCH_TEST_FILES],
            "-p", "no:cacheprovider", "-p", "refsol_oracle_plugin", "-o", f"pythonpath={FACADE_PATHS}", "-q", "--tb=line", "-rs"]
-    proc = subprocess.run(cmd, cwd=REFERENCE, env=facade_env(tmp_path / "hf"), capture_output=True, text=True, timeout=1500)
+    env = facade_env(hf_home)
+    if reference_sources:
+        env["REFSOL_REFERENCE_SOURCES"] = "1"
+    return subprocess.run(cmd, cwd=REFERENCE, env=env, capture_output=True, text=True, timeout=1500)
+
+
+@pytest.fixture(scope="module")
+def both_runs(built_libs, tmp_path_factory):
+    """The product run and the control run on the same stand-in checkpoints."""
+    home = tmp_path_factory.mktemp("hf")
+    write_stand_in_checkpoints(home)
+    return _run_reference_tests(home, False), _run_reference_tests(home, True)  # one after the other: each saturates the cores
+
+
+def _check(proc: subprocess.CompletedProcess) -> None:
     tail = proc.stdout[-3000:]
     summary = re.search(r"(\d+) passed(?:, (\d+) skipped)?", proc.stdout)
     assert proc.returncode == 0, tail
@@ -71,18 +83,15 @@ def test_reference_tests_pass_unmodified_through_the_facade(built_libs, tmp_path
 
 
 @pytest.mark.skipif(not (REFERENCE / "tests_refsol").is_dir(), reason="/root/reference is not present (GPU box)")
-def test_control_the_reference_solution_passes_its_own_tests_on_the_same_stand_ins(built_libs, tmp_path):
+def test_reference_tests_pass_unmodified_through_the_facade(both_runs):
+    _check(both_runs[0])
+
+
+@pytest.mark.skipif(not (REFERENCE / "tests_refsol").is_dir(), reason="/root/reference is not present (GPU box)")
+def test_control_the_reference_solution_passes_its_own_tests_on_the_same_stand_ins(both_runs):
     """CONTROL for the test above: the same files, the same stand-ins (torch facade for mlx, oracle-backed binding for the Metal
     extension, synthetic checkpoints) -- but with the REFERENCE'S OWN `tiny_llm_ref` sources under test instead of the product's
     host mirror (REFSOL_REFERENCE_SOURCES=1 puts /root/reference/src first and hands the reference this repository's extension
     binding).  The reference's solution passing its own tests here is what shows that the stand-ins are faithful at the tests'
     tolerances, i.e. that a pass of the product on them means something."""
-    write_stand_in_checkpoints(tmp_path / "hf")
-    cmd = [sys.executable, "-m", "pytest", *[f"tests_refsol/{f}" for f in TEST_FILES], *[f"benches/{f}" for f in BENCH_TEST_FILES],
-           "-p", "no:cacheprovider", "-p", "refsol_oracle_plugin", "-o", f"pythonpath={FACADE_PATHS}", "-q", "--tb=line", "-rs"]
-    env = dict(facade_env(tmp_path / "hf"), REFSOL_REFERENCE_SOURCES="1")
-    proc = subprocess.run(cmd, cwd=REFERENCE, env=env, capture_output=True, text=True, timeout=1500)
-    tail = proc.stdout[-3000:]
-    summary = re.search(r"(\d+) passed(?:, (\d+) skipped)?", proc.stdout)
-    assert proc.returncode == 0, tail
-    assert summary and int(summary.group(1)) >= 375 and int(summary.group(2) or 0) <= 2, tail
+    _check(both_runs[1])
