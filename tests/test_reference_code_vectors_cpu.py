@@ -158,6 +158,45 @@ def test_oracle_is_as_close_to_the_truth_as_the_reference_code_in_a_batch(golden
     assert e_oracle <= 1.5 * e_reference + ulp and e_reference <= 1.5 * e_oracle + ulp
 
 
+# ---- the reference's STACK: its Python sources on its own kernel code (tests/golden/make_reference_stack_vectors.py) ----------------
+STACK = ROOT / "tests" / "golden" / "reference_stack_vectors.npz"
+STACK_CASES = ("week3_paged_p20", "week2_kernels_p12")
+STACK_CHUNK = 8
+
+
+def stack_rows(model_forward, prompt, ids):
+    """Feeds the prompt in chunks of STACK_CHUNK tokens, then the given ids one by one; the last-position logits of every call."""
+    rows = []
+    for start in range(0, len(prompt), STACK_CHUNK):
+        rows.append(model_forward(prompt[start:start + STACK_CHUNK]))
+    for tok in ids[:-1]:
+        rows.append(model_forward([int(tok)]))
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("name", STACK_CASES)
+def test_oracle_tracks_the_reference_stack(name):
+    """Logits of the reference's own Python on the reference's own kernels (oracle/_ref) against the numpy oracle driven the same way:
+    the oracle restates those kernels (bit-identical per kernel, tests/test_oracle_vs_reference_kernels_cpu.py), so through a whole
+    model the two may drift apart only by single roundings -- at most two bf16 steps of the largest logit -- and sit equally far from
+    the float64 truth."""
+    stack = np.load(STACK)
+    prompt, ids = stack[f"{name}/prompt"].tolist(), stack[f"{name}/ids"].tolist()
+    reference_rows = from_bits(stack[f"{name}/logits"]).astype(np.float64)
+    w = O.make_qwen3_weights(TINY_CFG, seed=3, sigma=0.05)
+    oracle, truth = O.OracleQwen3(TINY_CFG, w), O.TruthQwen3(TINY_CFG, w)
+    o_rows = stack_rows(lambda toks: oracle.forward(toks)[0, -1], prompt, ids).astype(np.float64)
+    t_rows = stack_rows(lambda toks: truth.forward(toks)[0, -1], prompt, ids)
+    step = 2.0 ** -7 * float(np.abs(t_rows).max())
+    e_reference, e_oracle = float(np.abs(reference_rows - t_rows).max()), float(np.abs(o_rows - t_rows).max())
+    apart = float(np.abs(o_rows - reference_rows).max())
+    print(f"{name}: max |reference stack - truth| = {e_reference:.4f}, max |oracle - truth| = {e_oracle:.4f}, max |oracle - reference stack| = "
+          f"{apart:.4f} ({float(np.mean(o_rows == reference_rows)) * 100:.1f}% of the logits bit-identical)")
+    assert apart <= 2 * step, (apart, step)
+    assert e_oracle <= 1.5 * e_reference + step and e_reference <= 1.5 * e_oracle + step
+    assert [int(np.argmax(r)) for r in reference_rows[len(reference_rows) - len(ids):]] == ids
+
+
 @pytest.mark.skipif(not Path("/root/reference/src/tiny_llm_ref").is_dir(), reason="/root/reference is not present (GPU box)")
 def test_committed_vectors_are_what_the_reference_code_produces_now(tmp_path):
     script = (ROOT / "tests" / "golden" / "make_reference_code_vectors.py").read_text().replace(
