@@ -379,12 +379,11 @@ def test_generation_loops(stand_in):
     model, tokenizer = stand_in
     with mx.stream(mx.cpu):
         prompt = "w1 w2 w3 w4"
-        for sampler_args in (None, (0.8, 0.9, 20)):
-            mx.random.seed(5)
-            ref = captured(R.simple_generate, R.Qwen3ModelWeek1(model), tokenizer, prompt, sampler_args and R.make_sampler(*sampler_args))
-            mx.random.seed(5)
-            own = captured(P.simple_generate, P.Qwen3ModelWeek1(model), tokenizer, prompt, sampler_args and P.make_sampler(*sampler_args))
-            same_run(ref, own, f"simple_generate (Week 1, sampler {sampler_args})")
+        # greedy (sampler None); with a sampler the two draw from different random streams -- what their samplers hand to the random
+        # primitive is compared in test_moe_block_and_sampler
+        ref = captured(R.simple_generate, R.Qwen3ModelWeek1(model), tokenizer, prompt, None)
+        own = captured(P.simple_generate, P.Qwen3ModelWeek1(model), tokenizer, prompt, None)
+        same_run(ref, own, "simple_generate (Week 1)")
         for week, kwargs in ((2, dict(checkpoint="kv-cache")), (2, dict()), (3, dict())):
             rm = (R.Qwen3ModelWeek2 if week == 2 else R.Qwen3ModelWeek3)(model, **kwargs)
             pm = (P.Qwen3ModelWeek2 if week == 2 else P.Qwen3ModelWeek3)(model, **kwargs)
