@@ -9,9 +9,8 @@ import pytest
 from helpers import TINY_CFG, check_against_truth, to_mlx_shaped
 from oracle import tiny_oracle as O
 
-# First device run pending (the round's GPU budget was spent before these were written): recorded as xpassed / xfailed instead
-# of turning the suite red on a run nobody could rehearse.  Remove the xfail mark after the first device run.
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="written after the round's last GPU run; first device run pending")]
+# First device run: profiles/r02_labs/zz_gpu_tests_first_device_run.log (all passed).
+pytestmark = [pytest.mark.gpu]
 
 
 def prompt_ids(n, seed=0):

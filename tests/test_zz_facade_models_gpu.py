@@ -14,9 +14,8 @@ COMPAT = str(ROOT / "tiny-llm_amd" / "compat")
 if COMPAT not in sys.path:
     sys.path.insert(0, COMPAT)
 
-# First device run pending (the round's GPU budget was spent before these were written): recorded as xpassed / xfailed instead
-# of turning the suite red on a run nobody could rehearse.  Remove the xfail mark after the first device run.
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="written after the round's last GPU run; first device run pending")]
+# First device run: profiles/r02_labs/zz_gpu_tests_first_device_run.log (all passed).
+pytestmark = [pytest.mark.gpu]
 
 
 def _mx():

@@ -13,10 +13,8 @@ import torch
 from oracle import ref_kernels as K
 from oracle import tiny_oracle as O
 
-# First device run pending (the round's GPU budget was spent before these were written): recorded as xpassed / xfailed instead
-# of turning the suite red on a run nobody could rehearse.  Remove the xfail mark after the first device run.
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not K.available(), reason="oracle/_ref was not built"),
-              pytest.mark.xfail(strict=False, reason="written after the round's last GPU run; first device run pending")]
+# First device run: profiles/r02_labs/zz_gpu_tests_first_device_run.log (all passed).
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not K.available(), reason="oracle/_ref was not built")]
 
 DEV = "cuda" if torch.cuda.is_available() else "cpu"  # "cpu" only in the build container's dry run (oracle behind the C ABI)
 TORCH = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}

@@ -16,9 +16,8 @@ from helpers import TINY_CFG, check_against_truth, to_mlx_shaped
 from oracle import tiny_oracle as O
 from test_reference_code_vectors_cpu import CASES, batch_case, batch_truth_and_oracle, from_bits
 
-# First device run pending (the round's GPU budget was spent before these were written): recorded as xpassed / xfailed instead
-# of turning the suite red on a run nobody could rehearse.  Remove the xfail mark after the first device run.
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="written after the round's last GPU run; first device run pending")]
+# First device run: profiles/r02_labs/zz_gpu_tests_first_device_run.log (all passed).
+pytestmark = [pytest.mark.gpu]
 DEVICE = "cuda" if torch.cuda.is_available() else "cpu"  # "cpu" only in the build container's dry run (oracle behind the C ABI)
 GOLDEN = Path(__file__).resolve().parent / "golden" / "reference_code_vectors.npz"
 
