@@ -1,0 +1,81 @@
+"""GPU tier (collected last): TL_ATTN_QKV_PARTIALS=1 -- at 5..64 decode rows the qkv projection's slice-reduction launch is
+dropped and the decode-attention kernel adds the skinny matmul's fp32 slice partials itself (csrc/engine_kernels.h, QP; csrc/engine.hip
+engine_linear `keep`).  The kernel adds the slices in the reduction kernel's order and rounds once like it, so the two routes must
+agree BIT FOR BIT: same greedy tokens, same final logits, over several decode steps (the appended K/V rows feed later steps).
+The default route is the one held against the oracle and the float64 truth elsewhere (tests/test_engine_gpu.py,
+tests/test_engine_qwen4b_gpu.py); this file only has to show the opt-in route computes the same thing, and that it really
+drops a launch per layer."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import QWEN4B_CFG, TINY_CFG, to_mlx_shaped
+from oracle import tiny_oracle as O
+
+# Written with the round's last GPU seconds: the five TINY cases ran on the device and passed
+# (profiles/r02_labs/qkv_partials_tiny_first_device_run.log: one slice per projection at that width), the Qwen3-4B-shaped cases
+# (4 slices, launch count) have not run yet -- recorded as xpassed / xfailed instead of turning the suite red on a run nobody could
+# rehearse.  Remove the mark after their first device run.
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="written after the round's last GPU run; first device run pending")]
+
+
+def run(model, cfg, n_seq, steps, page_size, partials, profile=False):
+    from tiny_llm_hip.engine import DecodeEngine
+
+    rng = np.random.default_rng(500 + n_seq)
+    prompts = [[int(t) for t in rng.integers(1, cfg["vocab_size"], size=3 + (7 * i) % 19)] for i in range(n_seq)]
+    old = os.environ.pop("TL_ATTN_QKV_PARTIALS", None)
+    if partials:
+        os.environ["TL_ATTN_QKV_PARTIALS"] = "1"  # read when the engine is created
+    try:
+        eng = DecodeEngine(model, page_size=page_size, num_pages=n_seq * 3 + 2, max_batch=n_seq, max_prefill_rows=32)
+    finally:
+        os.environ.pop("TL_ATTN_QKV_PARTIALS", None)
+        if old is not None:
+            os.environ["TL_ATTN_QKV_PARTIALS"] = old
+    try:
+        for i, p in enumerate(prompts):
+            eng.begin(i)
+            eng.prefill(i, p, chunk=32)
+        first = eng.read_pending(n_seq)
+        eng.decode(steps, batch=n_seq)
+        logits = eng.logits(n_seq).clone()
+        tokens = [eng.read_tokens(i, steps + 1) for i in range(n_seq)]
+        prof = eng.profile_step(n_seq) if profile else None
+        for i in range(n_seq):
+            eng.release(i)
+        assert eng.stats()["pages_in_use"] == 0
+    finally:
+        eng.close()
+    return first, tokens, logits, prof
+
+
+@pytest.mark.parametrize("n_seq", [5, 8, 16, 33, 64])
+def test_tiny_model_same_bits_with_and_without_the_reduction_launch(n_seq):
+    """TINY_CFG: head_dim 128, 4 query heads on 2 KV heads -- a GQA group of TWO in a kernel that holds four query rows per
+    workgroup (the clamped rows), 16-token pages so the window walk takes the per-row page ids."""
+    w = O.make_qwen3_weights(TINY_CFG, seed=3, sigma=0.05)
+    model = to_mlx_shaped(TINY_CFG, w)
+    a = run(model, TINY_CFG, n_seq, steps=6, page_size=16, partials=False)
+    b = run(model, TINY_CFG, n_seq, steps=6, page_size=16, partials=True)
+    assert a[0] == b[0] and a[1] == b[1], "greedy tokens differ"
+    assert torch.equal(a[2].view(torch.int16), b[2].view(torch.int16)), "final logits differ in their bits"
+
+
+@pytest.mark.parametrize("n_seq", [5, 12, 40])
+def test_qwen3_4b_shapes_same_bits_and_one_launch_fewer_per_layer(n_seq):
+    """Qwen3-4B's layer shapes (32 query heads on 8 KV heads, 2,560 wide: the qkv projection is cut into 4 slices), 3 layers,
+    128-token pages (one scalar page id per stage)."""
+    from tiny_llm_hip.synthetic import synthetic_qwen3
+
+    cfg = dict(QWEN4B_CFG, num_hidden_layers=3)
+    model = synthetic_qwen3(cfg, seed=4, sigma=0.02, device="cuda")
+    a = run(model, cfg, n_seq, steps=4, page_size=128, partials=False, profile=True)
+    b = run(model, cfg, n_seq, steps=4, page_size=128, partials=True, profile=True)
+    assert a[0] == b[0] and a[1] == b[1], "greedy tokens differ"
+    assert torch.equal(a[2].view(torch.int16), b[2].view(torch.int16)), "final logits differ in their bits"
+    launches = [sum(v["launches"] for v in r[3]["kinds"].values()) for r in (a, b)]
+    assert launches[1] == launches[0] - cfg["num_hidden_layers"], f"launches per step {launches}: expected one fewer per layer"

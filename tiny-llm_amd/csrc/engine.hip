@@ -71,6 +71,9 @@ struct tl_engine {
     // dependent memory-side round trips (coherent stores acknowledged, counter, coherent loads), about what the launch costs.
     bool attn_fused_merge = false;
     float *ss_x = nullptr, *ss_h = nullptr;  // [max_batch][QM3_SS] partial sums of squares of the rows of x / h (qmm3.h)
+    // TL_ATTN_QKV_PARTIALS=1: at 5 .. 64 decode rows the qkv projection's slice reduction is not launched; the decode-attention
+    // kernel adds the fp32 slice partials itself (engine_kernels.h, QP).  Off until measured on the device.
+    bool attn_qkv_partials = false;
     bool fuse_norm = true;                   // TL_QMM3_FUSED_NORM=0: RMSNorm ahead of a skinny matmul always as its own launch
     int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
@@ -271,10 +274,18 @@ static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
 // then SwiGLU / residual kernels.
 // ss_in: partial sums of squares of the rows of `a` when its producer emitted them (fused RMSNorm of the skinny matmul),
 // else nullptr.  ss_out / *ss_emitted: where the slice reduction should leave the partials of `out`, and whether it did.
+// keep (EPI_STORE only): the caller's consumer adds the slices itself -- the reduction launch is skipped and *keep says where the
+// fp32 planes are; `out` is then NOT written.  Left empty (partial == nullptr) when another kernel took the projection.
+struct KeptPartials {
+    const float *partial = nullptr;
+    int slices = 0;
+    long plane = 0;  // elements between slices (= rows * output columns)
+};
 static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
                          const void *norm_w, const uint16_t *residual, ProfCtx *pc, int kind, const float *ss_in = nullptr,
-                         float *ss_out = nullptr, bool *ss_emitted = nullptr) {
+                         float *ss_out = nullptr, bool *ss_emitted = nullptr, KeptPartials *keep = nullptr) {
     if (ss_emitted) *ss_emitted = false;
+    if (keep) *keep = KeptPartials{};
     if (e->force_linear == 1) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
     if (e->force_linear != 2 && (M < e->qmm3_min_rows || (M <= 8 && !e->use_qmm3)))
         return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
@@ -307,16 +318,23 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
             return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul launch failed");
         if (pc) prof_after(e, pc, kind, p3.persistent ? p3.grid_x : p3.grid_x * p3.slices);
         float *ss_dst = (ss_out && e->fuse_norm && qmm3_reduce_can_emit_ss(epi, w.rows)) ? ss_out : nullptr;
-        int reduce_wg = 0;
-        if (launch_qmm3_reduce_bf16(q.partial, p3.slices, M, w.rows, epi, residual, out, q.prof, e->stream, ss_dst, &reduce_wg) != 0)
-            return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul reduction launch failed");
-        if (pc) prof_after(e, pc, kind, reduce_wg);
+        const bool kept = keep != nullptr && epi == EPI_STORE && ss_dst == nullptr;
+        if (kept) {
+            keep->partial = q.partial;
+            keep->slices = p3.slices;
+            keep->plane = (long)M * w.rows;
+        } else {
+            int reduce_wg = 0;
+            if (launch_qmm3_reduce_bf16(q.partial, p3.slices, M, w.rows, epi, residual, out, q.prof, e->stream, ss_dst, &reduce_wg) != 0)
+                return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul reduction launch failed");
+            if (pc) prof_after(e, pc, kind, reduce_wg);
+        }
         if (ss_emitted) *ss_emitted = ss_dst != nullptr;
         TL_CHECK_LAUNCH("engine skinny matmul");
         if (e->linfo) {
             tl_linear_info &li = *e->linfo;
             li.kernel = 2;
-            li.launches += 2 + (pro == PRO_RMSNORM && !fused_norm ? 1 : 0);
+            li.launches += (kept ? 1 : 2) + (pro == PRO_RMSNORM && !fused_norm ? 1 : 0);
             li.rows_per_pass = M;
             li.p[0] = p3.MB, li.p[1] = p3.persistent ? 0 : p3.TW, li.p[2] = p3.LM, li.p[3] = p3.slices;
             li.p[4] = p3.persistent ? p3.grid_x : p3.grid_x * p3.slices;
@@ -399,9 +417,18 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     return SplitPlan{s, std::max(64, std::min(per_split, bucket / s)), rq};
 }
 
+// head_dim 128 with a whole GQA group per workgroup is the only shape that takes qkv slice partials (batched decode of 5+ rows)
+static bool attn_takes_qkv_partials(int head_dim, int rq) { return head_dim == 128 && rq == AD_RQ; }
 template <int VD, bool SP, bool IP = false>
 static void launch_attn_decode_sp(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq) {
     const size_t lds = (size_t)16 * rq * (16 * VD + 2) * sizeof(float);
+    if constexpr (VD == 8) {
+        if (a.qkv_partial != nullptr && rq == AD_RQ) {
+            const size_t staged = (size_t)(2 + AD_RQ) * 16 * VD * sizeof(uint16_t);
+            hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP, true>), grid, dim3(256), lds + staged, st, a);
+            return;
+        }
+    }
     if (rq == 1) hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, 1, SP, IP>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP>), grid, dim3(256), lds, st, a);
 }
@@ -443,7 +470,8 @@ static bool launch_attn_wide(const AttnDecodeArgs &a, dim3 grid, hipStream_t st,
 // q/k-norm + RoPE + KV append + decode attention of one layer over slots [0, batch) (+ the merge launch when the context
 // is split).  qkv [batch, (Hq + 2 Hkv) D] -> out [batch, Hq D]; partials in e->attn_ws.
 static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_norm, const void *k_norm, uint16_t *key_pages,
-                            uint16_t *value_pages, uint16_t *out, int batch, const SplitPlan &sp, ProfCtx *pc) {
+                            uint16_t *value_pages, uint16_t *out, int batch, const SplitPlan &sp, ProfCtx *pc,
+                            const KeptPartials *qkv_parts = nullptr) {
     const tl_engine_config &c = e->cfg;
     const int D = c.head_dim;
     const int n_splits = sp.n_splits;
@@ -481,6 +509,12 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
     // column-parallel merge launch -- one workgroup folding hundreds of partial rows would be a serial tail
     const bool fused_merge = e->attn_fused_merge && e->attn_counters != nullptr && sp.nw == 0 && n_splits > 1 && n_splits <= 8 && chunks <= 4;
     a.merge_counters = fused_merge ? e->attn_counters : nullptr;
+    if (qkv_parts && qkv_parts->partial) {
+        TL_REQUIRE(sp.nw == 0 && attn_takes_qkv_partials(D, sp.rq), "engine: this decode-attention plan does not read qkv slice partials");
+        a.qkv_partial = qkv_parts->partial;
+        a.qkv_slices = qkv_parts->slices;
+        a.qkv_plane = qkv_parts->plane;
+    }
     TL_REQUIRE((size_t)batch * c.num_heads * n_splits * (D + 2) * sizeof(float) <= e->attn_ws_bytes || n_splits == 1,
                "engine: attention workspace too small for this split plan");
     const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
@@ -531,9 +565,11 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     bool x_ss = true;
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
+        KeptPartials qkv_parts;
+        const bool keep_qkv = e->attn_qkv_partials && sp.nw == 0 && attn_takes_qkv_partials(c.head_dim, sp.rq);
         TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0,
-                             x_ss ? e->ss_x : nullptr));
-        TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc));
+                             x_ss ? e->ss_x : nullptr, nullptr, nullptr, keep_qkv ? &qkv_parts : nullptr));
+        TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, &qkv_parts));
         bool h_ss = false;
         TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, &h_ss));
         TL_TRY(engine_linear(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2,
@@ -803,6 +839,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->ss_x = (float *)(A + o_ssx);
     e->ss_h = (float *)(A + o_ssh);
     if (const char *q = getenv("TL_QMM3_FUSED_NORM")) e->fuse_norm = atoi(q) != 0;
+    if (const char *q = getenv("TL_ATTN_QKV_PARTIALS")) e->attn_qkv_partials = atoi(q) != 0;
     if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));

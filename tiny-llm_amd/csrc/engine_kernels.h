@@ -158,6 +158,12 @@ struct AttnDecodeArgs {
     // attn_decode_fused_kernel, 2 .. 8 splits: one arrival counter per (sequence, KV head, head chunk), zero between launches.
     // The workgroup that arrives last merges the splits itself (no merge launch); nullptr = partials only.
     unsigned int *merge_counters;
+    // attn_decode_fused_kernel<.., QP = true> (TL_ATTN_QKV_PARTIALS=1): the qkv projection ran as the K-sliced skinny matmul and
+    // its slice reduction was NOT launched -- the rows arrive as qkv_slices fp32 planes [slice][batch][(Hq + 2 Hkv) D]
+    // (plane stride qkv_plane elements), added here in slice order and rounded once, exactly as qmm3_reduce_kernel does.
+    const float *qkv_partial;
+    int qkv_slices;
+    long qkv_plane;
     prof_t *prof;
 };
 
@@ -212,11 +218,15 @@ __device__ __forceinline__ void store_raw(uint16_t *dst, const RawRow<VD> &r) {
 // windows start on stage boundaries): the stage's page id is one scalar word fetched a stage ahead, and a row address is
 // (uniform row base of the stage) + (a lane offset fixed for the kernel) -- no per-row page lookups (2 U vector loads per lane and
 // stage) and no per-row 64-bit address chains.  The long-context plan (512-token windows over 128-token pages) runs this way.
-template <int VD, int U, int RQ, bool SP, bool IP = false>
+// QP = the new token's q / k / v rows are read as fp32 slice partials of the skinny matmul (AttnDecodeArgs::qkv_partial) instead
+// of bf16 rows: the (2 + RQ) D values a workgroup needs are 4-column chunks shared out over its threads (one global round
+// trip, all slices of a chunk in flight together), summed in slice order, rounded to bf16 and handed to every 16-lane group
+// through LDS -- the qkv projection's slice-reduction launch (a dependent phase of ~3.3 us per layer) is gone.
+template <int VD, int U, int RQ, bool SP, bool IP = false, bool QP = false>
 __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecodeArgs p) {
     constexpr int D = 16 * VD;
     constexpr int STRIDE = D + 2;
-    extern __shared__ __attribute__((aligned(16))) float psm[];  // [16][RQ][STRIDE]
+    extern __shared__ __attribute__((aligned(16))) float psm[];  // [16][RQ][STRIDE] (+ QP: [(2 + RQ)][D] bf16 staged rows)
     const prof_t prof_t0 = prof_begin(p.prof);
     // wave-uniform indices stay on the scalar unit (readfirstlane: hipcc otherwise parks blockIdx in VGPRs after the
     // profiling branch and emulates every division below on the VALU, in front of the first load)
@@ -260,14 +270,38 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         }
     }
     RawRow<VD> kraw_new, vraw_new, qraw[RQ], qw, kw;
-    load_raw<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
-    load_raw<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
     load_raw<VD>(p.q_norm_w + t * VD, qw);
     load_raw<VD>(p.k_norm_w + t * VD, kw);
+    // QP: staged rows 0 = k, 1 = v, 2 + r = query head r of this workgroup; chunk c of the workgroup = 4 columns of one row
+    constexpr int QP_ROWS = 2 + RQ;
+    constexpr int QP_CHUNKS = QP_ROWS * D / 4;
+    constexpr int QP_PER = (QP_CHUNKS + 255) / 256;  // chunks per thread
+    constexpr int QP_INFLIGHT = 4;                   // slices of a chunk in flight together
+    f32x4 qp_x[QP ? QP_PER : 1][QP ? QP_INFLIGHT : 1];
+    auto qp_col = [&](int ch) {  // first column (inside a [batch, (Hq + 2 Hkv) D] plane row) of chunk ch
+        const int prow = ch / (D / 4);
+        const int c4 = ch - prow * (D / 4);
+        const int head = prow == 0 ? Hq + kvh : (prow == 1 ? Hq + Hkv + kvh : kvh * rep + min(chunk * RQ + (prow - 2), rep - 1));
+        return (long)head * D + c4 * 4;
+    };
+    if constexpr (QP) {
+        const float *prow_base = p.qkv_partial + (long)b * (Hq + 2 * Hkv) * D;
 #pragma unroll
-    for (int r = 0; r < RQ; ++r) {
-        const int hq = min(chunk * RQ + r, rep - 1);
-        load_raw<VD>(row + (long)(kvh * rep + hq) * D + t * VD, qraw[r]);
+        for (int j = 0; j < QP_PER; ++j) {
+            const int ch = min((int)threadIdx.x + j * 256, QP_CHUNKS - 1);
+            const float *src = prow_base + qp_col(ch);
+#pragma unroll
+            for (int s = 0; s < QP_INFLIGHT; ++s)
+                qp_x[j][s] = *reinterpret_cast<const f32x4 *>(src + (long)min(s, p.qkv_slices - 1) * p.qkv_plane);
+        }
+    } else {
+        load_raw<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
+        load_raw<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
+#pragma unroll
+        for (int r = 0; r < RQ; ++r) {
+            const int hq = min(chunk * RQ + r, rep - 1);
+            load_raw<VD>(row + (long)(kvh * rep + hq) * D + t * VD, qraw[r]);
+        }
     }
 
     float cs[VD], sn[VD];
@@ -315,6 +349,41 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     };
     if constexpr (IP) issue_kv_stage(t_begin, pid_s, kr, vr, ok);
     else issue_kv(t_begin, pid, kr, vr, ok);
+
+    if constexpr (QP) {
+        // slice partials -> bf16 rows in LDS -> every 16-lane group's registers (the K/V rows requested above stay in flight:
+        // the barrier waits for LDS traffic only)
+        uint16_t *qs = reinterpret_cast<uint16_t *>(psm + 16 * RQ * STRIDE);
+        const float *prow_base = p.qkv_partial + (long)b * (Hq + 2 * Hkv) * D;
+#pragma unroll
+        for (int j = 0; j < QP_PER; ++j) {
+            const int chu = (int)threadIdx.x + j * 256;
+            const int ch = min(chu, QP_CHUNKS - 1);
+            f32x4 acc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < QP_INFLIGHT; ++s)
+                if (s < p.qkv_slices) {  // uniform
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) acc4[e2] += qp_x[j][s][e2];
+                }
+            for (int s = QP_INFLIGHT; s < p.qkv_slices; ++s) {  // more than QP_INFLIGHT slices (not planned for qkv shapes): dependent loads
+                const f32x4 x4 = *reinterpret_cast<const f32x4 *>(prow_base + qp_col(ch) + (long)s * p.qkv_plane);
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) acc4[e2] += x4[e2];
+            }
+            if (chu < QP_CHUNKS) {
+                uint2 packed;
+                packed.x = BF16::pack2(acc4[0], acc4[1]);  // round-to-nearest-even, as BF16::from_float in qmm3_reduce_kernel
+                packed.y = BF16::pack2(acc4[2], acc4[3]);
+                *reinterpret_cast<uint2 *>(qs + ch * 4) = packed;
+            }
+        }
+        __syncthreads();
+        load_raw<VD>(qs + 0 * D + t * VD, kraw_new);
+        load_raw<VD>(qs + 1 * D + t * VD, vraw_new);
+#pragma unroll
+        for (int r = 0; r < RQ; ++r) load_raw<VD>(qs + (2 + r) * D + t * VD, qraw[r]);
+    }
 
     // ---- prologue math while the K/V rows are in flight ---------------------------------------------------------------
     auto norm_rope = [&](const RawRow<VD> &x, const RawRow<VD> &w, float (&out)[VD]) {
