@@ -41,6 +41,10 @@ def parse_args(argv=None) -> argparse.Namespace:
     ap.add_argument("--iterations", type=int, default=30)
     ap.add_argument("--repeats", type=int, default=6)
     ap.add_argument("--json-output", type=Path)
+    ap.add_argument("--mfma-rows", action="store_true",
+                    help="lab column (not in the reference's table): the same decode through the MFMA FlashAttention kernel of the "
+                         "public operator -- every head's single query row padded to 16 rows, non-causal -- i.e. what the prefill "
+                         "kernel's K/V pipeline sustains when the arithmetic is negligible; the yardstick for an MFMA decode kernel")
     args = ap.parse_args(argv)
     if args.warmup < 0 or args.iterations <= 0 or args.repeats <= 0:
         ap.error("--warmup must be non-negative; --iterations and --repeats must be positive")
@@ -158,8 +162,25 @@ def main(argv=None) -> dict:
         _, info = fused(0)
         med = {}
         samples = {}
-        for name, call in (("dense_gather", gather), ("direct_paged", direct), ("engine_fused", fused)):
+        variants = [("dense_gather", gather), ("direct_paged", direct), ("engine_fused", fused)]
+        if args.mfma_rows:
+            q16 = torch.zeros((QUERY_HEADS, 16, HEAD_DIM), dtype=torch.bfloat16, device="cuda")
+            q16[:, 0] = qn[:, 0]
+
+            def mfma_rows(i):
+                kp, vp, table = pools[i % copies]
+                return ext.paged_attention(q16, kp, vp, table, ctx, HEAD_DIM ** -0.5, False, num_kv_heads=KV_HEADS,
+                                           num_heads=QUERY_HEADS, max_context_hint=context)
+
+            got16 = mfma_rows(0)[:, 0].reshape(1, QUERY_HEADS, 1, HEAD_DIM)
+            if not torch.allclose(got16.float(), expected.float(), rtol=2e-2, atol=2e-2):
+                raise AssertionError("the 16-row MFMA call does not match dense attention on its real row")
+            variants.append(("mfma_rows", mfma_rows))
+        for name, call in variants:
             med[name], samples[name] = timed(call, args.warmup, args.iterations, args.repeats)
+        if args.mfma_rows:
+            print(f"|   lab: MFMA FlashAttention kernel, 16-row queries: {med['mfma_rows']:.2f} us = "
+                  f"{kv_bytes / med['mfma_rows'] / 1e3:.0f} GB/s of K/V |", flush=True)
         gbps = kv_bytes / med["engine_fused"] / 1e3
         print(f"| {context} | {med['dense_gather']:.2f} | {med['direct_paged']:.2f} | {med['engine_fused']:.2f} | "
               f"{gbps:.0f} ({gbps / HBM_PEAK_GBPS:.3f}) | {err:.5f} |", flush=True)

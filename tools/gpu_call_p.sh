@@ -1,0 +1,23 @@
+#!/bin/bash
+# First call of round 3 (everything here was written at the end of round 2 without device time):
+#   1. the eight cases of tests/test_zz_attn_qkv_partials_gpu.py (qkv slice partials read by the attention kernel) -- the three
+#      Qwen3-4B-shaped ones have never run;
+#   2. the step time with and without TL_ATTN_QKV_PARTIALS=1 at 5 .. 64 sequences (expected: 36 launches and ~0.12 ms fewer);
+#   3. decode attention through the MFMA FlashAttention kernel (16-row queries) next to the engine's kernel, 1k .. 32k tokens:
+#      what an MFMA decode-attention kernel could sustain (Next, item 3).
+# A warm box charges ~12-15 s per gpurun call on top of the command's own time: short calls are cheap.
+OUT=gpurun_out/call_p
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 300 python -m pytest tests/test_zz_attn_qkv_partials_gpu.py -q -p no:cacheprovider -rxXfE 2>&1 | tail -14 | tee $OUT/qkv_partials_tests.log
+rm -f $OUT/ab.jsonl
+run() { B=$1; shift; timeout 300 python tools/decode_ab.py --batch $B --prompt-len 256 --steps 64 --profile-steps 2 "$@" >> $OUT/ab.jsonl 2>> $OUT/ab.err; }
+for B in 5 8 16 32 64; do run $B - TL_ATTN_QKV_PARTIALS=1; done
+python - <<'PY'
+import json
+for l in open("gpurun_out/call_p/ab.jsonl"):
+    r=json.loads(l); u=r.get("us_per_step",{})
+    print(r["batch"],r["variant"],"ms",r["ms_per_step"],"launches",r.get("launches"),"kernel_us",r.get("kernel_us_per_step"),"attn",u.get("attention"),"qkv",u.get("gemv_qkv"))
+PY
+tail -3 $OUT/ab.err
+timeout 300 python benches/bench_week3_attention.py --contexts 1024 8192 32768 --mfma-rows --json-output $OUT/attention_mfma_rows.json 2>&1 | tee $OUT/attention_mfma_rows.txt | tail -12
