@@ -74,6 +74,10 @@ struct tl_engine {
     // TL_ATTN_QKV_PARTIALS=1: at 5 .. 64 decode rows the qkv projection's slice reduction is not launched; the decode-attention
     // kernel adds the fp32 slice partials itself (engine_kernels.h, QP).  Off until measured on the device.
     bool attn_qkv_partials = false;
+    // TL_WO_MERGES_ATTN=1: single-row decode with the context split 2 / 4 / 8 ways -- the merge launch behind the attention kernel
+    // is dropped and the wo GEMV forms the merged row from the split partials while it stages it (qmv3.h, PRO_ATTN_MERGE).  Off
+    // until measured on the device.
+    bool wo_merges_attn = false;
     bool fuse_norm = true;                   // TL_QMM3_FUSED_NORM=0: RMSNorm ahead of a skinny matmul always as its own launch
     int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
@@ -467,11 +471,45 @@ static bool launch_attn_wide(const AttnDecodeArgs &a, dim3 grid, hipStream_t st,
     return false;
 }
 
+// Can the wo GEMV of ONE decode row take the attention split partials instead of the merged row (qmv3.hip,
+// launch_qmv3_attn_merge_bf16: the instantiated plans)?
+static bool wo_merge_applicable(const tl_engine *e, const tl_w4 &wo, int batch, const SplitPlan &sp, bool fused_merge) {
+    if (!e->wo_merges_attn || batch != 1 || sp.nw != 0 || fused_merge || e->force_linear != 0) return false;
+    if (sp.n_splits != 2 && sp.n_splits != 4 && sp.n_splits != 8) return false;
+    if (e->cfg.head_dim != 128 || wo.cols != e->cfg.num_heads * 128 || e->tiled.count(wo.weight_dev) == 0) return false;
+    if (1 >= e->qmm3_min_rows && e->use_qmm3) return false;  // a single row would not take the GEMV
+    const Qmv3Plan pl = qmv3_plan(1, wo.cols, wo.rows);
+    const bool shape = (pl.KS == 2 && pl.CW == 4) || (pl.KS == 4 && pl.CW == 4) || (pl.KS == 8 && pl.CW == 8);
+    return pl.ok && pl.MR == 1 && shape && wo.cols / 8 <= 2 * pl.CW * 64;
+}
+// h = x + merge(attention partials) @ wo^T for one row.
+static int engine_wo_merge(tl_engine *e, const tl_w4 &wo, const uint16_t *residual, uint16_t *out, int n_splits, ProfCtx *pc) {
+    const auto tiled = e->tiled.find(wo.weight_dev);
+    Qmv3Args a3{};
+    a3.wt = tiled->second.wt;
+    a3.sbt = tiled->second.sbt;
+    a3.a = nullptr;
+    a3.out = out;
+    a3.residual = residual;
+    a3.eps = e->cfg.rms_norm_eps;
+    a3.M = 1;
+    a3.N = wo.cols;
+    a3.K = wo.rows;
+    a3.prof = pc ? pc->buf : nullptr;
+    a3.merge_ws = e->attn_ws;
+    if (launch_qmv3_attn_merge_bf16(a3, n_splits, e->stream) != 0)
+        return fail(TL_ERR_UNSUPPORTED, "engine: no wo GEMV that merges the attention partials for this shape");
+    if (pc) prof_after(e, pc, 1, qmv3_plan(1, wo.cols, wo.rows).blocks);
+    TL_CHECK_LAUNCH("engine wo gemv with merge");
+    return TL_OK;
+}
+
 // q/k-norm + RoPE + KV append + decode attention of one layer over slots [0, batch) (+ the merge launch when the context
 // is split).  qkv [batch, (Hq + 2 Hkv) D] -> out [batch, Hq D]; partials in e->attn_ws.
 static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_norm, const void *k_norm, uint16_t *key_pages,
                             uint16_t *value_pages, uint16_t *out, int batch, const SplitPlan &sp, ProfCtx *pc,
-                            const KeptPartials *qkv_parts = nullptr) {
+                            const KeptPartials *qkv_parts = nullptr, const tl_w4 *merging_wo = nullptr, bool *merge_left = nullptr) {
+    if (merge_left) *merge_left = false;
     const tl_engine_config &c = e->cfg;
     const int D = c.head_dim;
     const int n_splits = sp.n_splits;
@@ -536,8 +574,11 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
         }
     }
     if (pc) prof_after(e, pc, 5, (int)(grid.x * grid.y * grid.z));
-    e->last_attn_launches = 1 + ((n_splits > 1 && !fused_merge) ? 1 : 0);
-    if (n_splits > 1 && !fused_merge) {
+    // the consumer (the wo GEMV of a single row) merges the partials itself: no merge launch, `out` is not written
+    const bool leave_merge = merging_wo != nullptr && merge_left != nullptr && wo_merge_applicable(e, *merging_wo, batch, sp, fused_merge);
+    if (leave_merge) *merge_left = true;
+    e->last_attn_launches = 1 + ((n_splits > 1 && !fused_merge && !leave_merge) ? 1 : 0);
+    if (n_splits > 1 && !fused_merge && !leave_merge) {
         const dim3 mg(batch * c.num_heads), mb(128);
         prof_t *pb = pc ? pc->buf : nullptr;
         int merge_wg = batch * c.num_heads;
@@ -569,9 +610,12 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
         const bool keep_qkv = e->attn_qkv_partials && sp.nw == 0 && attn_takes_qkv_partials(c.head_dim, sp.rq);
         TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0,
                              x_ss ? e->ss_x : nullptr, nullptr, nullptr, keep_qkv ? &qkv_parts : nullptr));
-        TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, &qkv_parts));
+        bool merge_left = false;
+        TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, &qkv_parts,
+                                &w.wo, &merge_left));
         bool h_ss = false;
-        TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, &h_ss));
+        if (merge_left) TL_TRY(engine_wo_merge(e, w.wo, e->x, e->h, sp.n_splits, pc));
+        else TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, &h_ss));
         TL_TRY(engine_linear(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2,
                              h_ss ? e->ss_h : nullptr));
         TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, &x_ss));
@@ -840,6 +884,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->ss_h = (float *)(A + o_ssh);
     if (const char *q = getenv("TL_QMM3_FUSED_NORM")) e->fuse_norm = atoi(q) != 0;
     if (const char *q = getenv("TL_ATTN_QKV_PARTIALS")) e->attn_qkv_partials = atoi(q) != 0;
+    if (const char *q = getenv("TL_WO_MERGES_ATTN")) e->wo_merges_attn = atoi(q) != 0;
     if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));

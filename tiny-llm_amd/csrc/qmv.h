@@ -32,7 +32,7 @@
 
 namespace tl {
 
-enum { PRO_NONE = 0, PRO_RMSNORM = 1 };
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN_MERGE = 2 };  // PRO_ATTN_MERGE: qmv3.h only (Qmv3Args::merge_ws)
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2 };
 
 struct QmvArgs {

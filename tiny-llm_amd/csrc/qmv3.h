@@ -44,6 +44,11 @@ struct Qmv3Args {
     float eps;
     int M, N, K;
     prof_t *prof;
+    // PRO_ATTN_MERGE (the wo projection of a single decode row, TL_WO_MERGES_ATTN=1): `a` is not read; the activation row is
+    // the merge of the decode-attention kernel's split partials merge_ws [head][NS][128 + 2] (value sums, running max, running
+    // sum; head dimension 128, N = heads * 128), formed while the row is staged -- attn_merge_kernel's arithmetic, term for
+    // term, so the staged bf16 row has the bits that kernel would have written; its launch is dropped.
+    const float *merge_ws;
 #ifdef QMV3_LAB
     int ablate;  // lab only: 1 = skip MFMA math, 2 = skip the staging arithmetic / LDS stores, 4 = skip the activation loads
 #endif
@@ -84,8 +89,9 @@ __device__ __forceinline__ u32x4 unpack_w4_bf16(uint32_t w, uint32_t mask_s, uin
 
 // LM = groups per compute wave (the fixed-length body): the per-wave dependent chain (unpack + MFMA per group) is what
 // bounds the small projections, so LM is the smallest listed value that covers ceil(G / KS)
-template <int MR, int KS, int CW, int PRO, int EPI, int LM>
+template <int MR, int KS, int CW, int PRO, int EPI, int LM, int NS = 0>
 __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
+    static_assert(PRO != PRO_ATTN_MERGE || (MR == 1 && (NS == 2 || NS == 4 || NS == 8)), "PRO_ATTN_MERGE: one row, 2 / 4 / 8 splits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = CW * 64;
     constexpr int WR = CW / KS;
@@ -119,6 +125,23 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
     constexpr int CCU = MR <= 2 ? 3 : 2;
     const bool reg_path = cpr <= CCU * T;  // all activation chunks fit in registers: one global round trip
     u32x4 xv[CCU][MR], nwv[CCU];
+    // PRO_ATTN_MERGE: chunk cc = 8 columns of head cc / 16; per split its 8 value sums and the head's (max, sum) pair
+    constexpr int MS = PRO == PRO_ATTN_MERGE ? NS : 1;
+    constexpr int MCCU = PRO == PRO_ATTN_MERGE ? 2 : 1;  // chunk sets a merging thread owns: the launcher admits N / 8 <= 2 T only
+    f32x2 mval[MCCU][MS][4], mml[MCCU][MS];
+    if constexpr (PRO == PRO_ATTN_MERGE) {
+#pragma unroll
+        for (int k = 0; k < MCCU; ++k) {  // no branch around these loads: every thread reads from a clamped address
+            const int cc = min(tid + k * T, cpr - 1);
+            const float *hb = p.merge_ws + (size_t)(cc >> 4) * NS * 130;
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) mml[k][s2] = *reinterpret_cast<const f32x2 *>(hb + s2 * 130 + 128);
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mval[k][s2][e] = *reinterpret_cast<const f32x2 *>(hb + s2 * 130 + (cc & 15) * 8 + 2 * e);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < CCU; ++k) {
         const int cc = tid + k * T;
@@ -126,6 +149,10 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
         const size_t coff = (size_t)(okc ? cc : 0) * 8;
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
+            if constexpr (PRO == PRO_ATTN_MERGE) {
+                xv[k][m] = u32x4{0u, 0u, 0u, 0u};  // filled from the partials below, once they have arrived
+                continue;
+            }
             const bool ok = okc && m < p.M;
             if (Q3_ABL(4)) {
                 xv[k][m] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
@@ -192,6 +219,33 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
         sum = group16_sum(sum);
         if ((cc & 15) == 0) xsum[(cc >> 4) * 16 + m] = sum;
     };
+    if constexpr (PRO == PRO_ATTN_MERGE) {
+        // attn_merge_kernel (engine_kernels.h), per output column: gm = max_s m_s; f_s = 2^(m_s - gm); l = sum_s l_s f_s;
+        // acc = sum_s v_s f_s (both in split order); out = bf16(l == 0 ? 0 : acc / l)
+#pragma unroll
+        for (int k = 0; k < MCCU; ++k) {
+            float gm = -1e30f;
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) gm = fmaxf(gm, mml[k][s2][0]);
+            float gl = 0.f, f2[NS];
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                f2[s2] = exp2_hw(mml[k][s2][0] - gm);
+                gl += mml[k][s2][1] * f2[s2];
+            }
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float acc1 = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) acc1 += mval[k][s2][e >> 1][e & 1] * f2[s2];
+                o[e] = gl == 0.f ? 0.f : acc1 / gl;
+            }
+            const bool okc = reg_path && tid + k * T < cpr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[k][0][e] = okc ? BF16::pack2(o[2 * e], o[2 * e + 1]) : 0u;
+        }
+    }
     float inv[MR];
 #pragma unroll
     for (int m = 0; m < MR; ++m) inv[m] = 1.0f;
@@ -378,6 +432,7 @@ inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0, int force_cw = 
 
 // qmv3.hip
 int launch_qmv3_bf16(const Qmv3Args &args, int pro, int epi, hipStream_t st, int force_ks = 0, int force_cw = 0);  // -1: not applicable
+int launch_qmv3_attn_merge_bf16(const Qmv3Args &args, int n_splits, hipStream_t st);  // -1: not applicable, nothing launched
 // standard checkpoint layout -> tiled layout (device to device, stream ordered)
 int repack_w4_tiled(const uint32_t *w, const uint16_t *scales, const uint16_t *biases, uint32_t *wt, uint32_t *sbt, int K,
                     int N, hipStream_t st);

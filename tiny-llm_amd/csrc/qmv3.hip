@@ -73,6 +73,37 @@ static int launch_variant3(const Qmv3Args &args, hipStream_t st, int force_ks, i
     return -2;
 }
 
+// PRO_ATTN_MERGE + EPI_RESIDUAL, one row: the wo projection reading the decode-attention split partials (Qmv3Args::merge_ws).
+// Instantiated for the plans a single row takes (4 waves with 2- or 4-way, 8 waves with 8-way reduction splits) and 2 / 4 / 8
+// attention splits; every chunk of the row must sit in two register sets (N / 8 <= 2 * threads).  -1: not applicable (the caller keeps
+// the merge launch).
+template <int NS>
+static int launch_merge_variant3(const Qmv3Args &args, hipStream_t st, const Qmv3Plan &pl) {
+    const dim3 grid(pl.blocks), block(pl.CW * 64);
+#define Q3_MCASE(KSv, CWv, LMv)                                                                                      \
+    if (pl.KS == KSv && pl.CW == CWv && pl.LM == LMv) {                                                              \
+        auto kern = qmv3_kernel<1, KSv, CWv, PRO_ATTN_MERGE, EPI_RESIDUAL, LMv, NS>;                                  \
+        if (pl.lds > 64 * 1024)                                                                                      \
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);  \
+        hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                                     \
+        return 0;                                                                                                    \
+    }
+#define Q3_MLM(KSv, CWv) Q3_MCASE(KSv, CWv, 4) Q3_MCASE(KSv, CWv, 5) Q3_MCASE(KSv, CWv, 8) Q3_MCASE(KSv, CWv, 10)
+    Q3_MLM(2, 4) Q3_MLM(4, 4) Q3_MLM(8, 8)
+#undef Q3_MLM
+#undef Q3_MCASE
+    return -1;
+}
+int launch_qmv3_attn_merge_bf16(const Qmv3Args &args, int n_splits, hipStream_t st) {
+    if (args.M != 1 || !args.merge_ws || !args.residual || args.N % 128 != 0) return -1;
+    const Qmv3Plan pl = qmv3_plan(1, args.N, args.K);
+    if (!pl.ok || pl.MR != 1 || args.N / 8 > 2 * pl.CW * 64) return -1;  // two chunk sets per thread (qmv3.h, MCCU)
+    if (n_splits == 2) return launch_merge_variant3<2>(args, st, pl);
+    if (n_splits == 4) return launch_merge_variant3<4>(args, st, pl);
+    if (n_splits == 8) return launch_merge_variant3<8>(args, st, pl);
+    return -1;
+}
+
 int launch_qmv3_bf16(const Qmv3Args &args, int pro, int epi, hipStream_t st, int force_ks, int force_cw) {
     if (pro == PRO_NONE && epi == EPI_STORE) return launch_variant3<PRO_NONE, EPI_STORE>(args, st, force_ks, force_cw);
     if (pro == PRO_RMSNORM && epi == EPI_STORE) return launch_variant3<PRO_RMSNORM, EPI_STORE>(args, st, force_ks, force_cw);
