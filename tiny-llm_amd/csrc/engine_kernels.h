@@ -158,13 +158,14 @@ struct AttnDecodeArgs {
     // attn_decode_fused_kernel, 2 .. 8 splits: one arrival counter per (sequence, KV head, head chunk), zero between launches.
     // The workgroup that arrives last merges the splits itself (no merge launch); nullptr = partials only.
     unsigned int *merge_counters;
+    prof_t *prof;
+    // (new members go below `prof`: the offsets of everything above are what the tuned kernels were compiled against)
     // attn_decode_fused_kernel<.., QP = true> (TL_ATTN_QKV_PARTIALS=1): the qkv projection ran as the K-sliced skinny matmul and
     // its slice reduction was NOT launched -- the rows arrive as qkv_slices fp32 planes [slice][batch][(Hq + 2 Hkv) D]
     // (plane stride qkv_plane elements), added here in slice order and rounded once, exactly as qmm3_reduce_kernel does.
     const float *qkv_partial;
     int qkv_slices;
     long qkv_plane;
-    prof_t *prof;
 };
 
 // Scalar (wave-uniform) 32-bit load through the scalar cache, and the wait that makes its result usable.  The address must
@@ -270,6 +271,10 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         }
     }
     RawRow<VD> kraw_new, vraw_new, qraw[RQ], qw, kw;
+    if constexpr (!QP) {
+        load_raw<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
+        load_raw<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
+    }
     load_raw<VD>(p.q_norm_w + t * VD, qw);
     load_raw<VD>(p.k_norm_w + t * VD, kw);
     // QP: staged rows 0 = k, 1 = v, 2 + r = query head r of this workgroup; chunk c of the workgroup = 4 columns of one row
@@ -295,8 +300,6 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
                 qp_x[j][s] = *reinterpret_cast<const f32x4 *>(src + (long)min(s, p.qkv_slices - 1) * p.qkv_plane);
         }
     } else {
-        load_raw<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
-        load_raw<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
 #pragma unroll
         for (int r = 0; r < RQ; ++r) {
             const int hq = min(chunk * RQ + r, rep - 1);

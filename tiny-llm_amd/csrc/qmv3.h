@@ -44,14 +44,14 @@ struct Qmv3Args {
     float eps;
     int M, N, K;
     prof_t *prof;
+#ifdef QMV3_LAB
+    int ablate;  // lab only: 1 = skip MFMA math, 2 = skip the staging arithmetic / LDS stores, 4 = skip the activation loads
+#endif
     // PRO_ATTN_MERGE (the wo projection of a single decode row, TL_WO_MERGES_ATTN=1): `a` is not read; the activation row is
     // the merge of the decode-attention kernel's split partials merge_ws [head][NS][128 + 2] (value sums, running max, running
     // sum; head dimension 128, N = heads * 128), formed while the row is staged -- attn_merge_kernel's arithmetic, term for
     // term, so the staged bf16 row has the bits that kernel would have written; its launch is dropped.
     const float *merge_ws;
-#ifdef QMV3_LAB
-    int ablate;  // lab only: 1 = skip MFMA math, 2 = skip the staging arithmetic / LDS stores, 4 = skip the activation loads
-#endif
 };
 
 #ifdef QMV3_LAB
