@@ -15,11 +15,13 @@ import torch
 from helpers import QWEN4B_CFG, TINY_CFG, to_mlx_shaped
 from oracle import tiny_oracle as O
 
-# Written with the round's last GPU seconds: the five TINY cases ran on the device and passed
-# (profiles/r02_labs/qkv_partials_tiny_first_device_run.log: one slice per projection at that width), the Qwen3-4B-shaped cases
-# (4 slices, launch count) have not run yet -- recorded as xpassed / xfailed instead of turning the suite red on a run nobody could
-# rehearse.  Remove the mark after their first device run.
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="written after the round's last GPU run; first device run pending")]
+# The five TINY cases ran on the device with the round's last GPU seconds and passed
+# (profiles/r02_labs/qkv_partials_tiny_first_device_run.log: one slice per projection at that width).  The Qwen3-4B-shaped cases
+# (4 slices, launch count) have never run: a kernel nobody has rehearsed can do worse than fail (a memory fault ends the whole
+# pytest process), so they run only when TL_UNREHEARSED_GPU_TESTS=1 (tools/gpu_call_p.sh sets it) -- remove the gate after that run.
+pytestmark = [pytest.mark.gpu]
+unrehearsed = pytest.mark.skipif(os.environ.get("TL_UNREHEARSED_GPU_TESTS") != "1",
+                                 reason="never run on the device yet: TL_UNREHEARSED_GPU_TESTS=1 (tools/gpu_call_p.sh) runs it")
 
 
 def run(model, cfg, n_seq, steps, page_size, partials, profile=False):
@@ -65,6 +67,7 @@ def test_tiny_model_same_bits_with_and_without_the_reduction_launch(n_seq):
     assert torch.equal(a[2].view(torch.int16), b[2].view(torch.int16)), "final logits differ in their bits"
 
 
+@unrehearsed
 @pytest.mark.parametrize("n_seq", [5, 12, 40])
 def test_qwen3_4b_shapes_same_bits_and_one_launch_fewer_per_layer(n_seq):
     """Qwen3-4B's layer shapes (32 query heads on 8 KV heads, 2,560 wide: the qkv projection is cut into 4 slices), 3 layers,

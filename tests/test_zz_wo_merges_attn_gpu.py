@@ -13,9 +13,11 @@ import torch
 
 from helpers import QWEN4B_CFG
 
-# Written after the round's GPU budget was spent: the first device run is recorded as xpassed / xfailed instead of turning the
-# suite red on a run nobody could rehearse.  Remove the mark after the first device run.
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="written after the round's last GPU run; first device run pending")]
+# Written after the round's GPU budget was spent, never run: a kernel nobody has rehearsed can do worse than fail (a memory fault
+# ends the whole pytest process), so this file runs only when TL_UNREHEARSED_GPU_TESTS=1 (tools/gpu_call_p.sh sets it) -- remove the
+# gate after that run.
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("TL_UNREHEARSED_GPU_TESTS") != "1",
+                                                  reason="never run on the device yet: TL_UNREHEARSED_GPU_TESTS=1 (tools/gpu_call_p.sh) runs it")]
 
 CFG = dict(QWEN4B_CFG, num_hidden_layers=3)
 

@@ -10,6 +10,7 @@
 OUT=gpurun_out/call_p
 mkdir -p $OUT
 export TMPDIR=/tmp
+export TL_UNREHEARSED_GPU_TESTS=1  # the gated tests of the two opt-in routes (a crash here must not take a full pytest run with it)
 timeout 300 python -m pytest tests/test_zz_attn_qkv_partials_gpu.py tests/test_zz_wo_merges_attn_gpu.py -q -p no:cacheprovider -rxXfE 2>&1 | tail -20 | tee $OUT/opt_in_route_tests.log
 rm -f $OUT/ab.jsonl
 run() { B=$1; shift; timeout 300 python tools/decode_ab.py --batch $B --prompt-len 256 --steps 64 --profile-steps 2 "$@" >> $OUT/ab.jsonl 2>> $OUT/ab.err; }
