@@ -67,29 +67,96 @@ def timed_steps(run, sync, steps: int, dist=None, device=None):
     return local, local
 
 
-def rocprof_gemv_rate(stats_csv: Path, gemv_bytes_per_step: float) -> dict | None:
+def rocprof_gemv_rate(stats_csv: Path, kinds: dict, num_layers: int) -> dict | None:
     """GEMV-stream rate recomputed from a COMMITTED `rocprofv3 --kernel-trace --stats` summary of this same command
-    (profiles/<round>/bench_kernel_stats.csv): sum of the qmv3 rows' total durations / decode steps in the trace (= calls of
-    step_end_kernel).  rocprofv3 brackets each dispatch (wave launch ramp + end-of-kernel write-back), so its durations are
-    ~1 us per launch longer than the in-kernel stamps; both fractions are reported side by side."""
+    (profiles/<round>_rocprofv3/bench_config<N>_kernel_stats.csv).  NOT measured in this run: the block is labelled so, carries
+    the file's modification time, and is only as fresh as that file.  Decode steps in the trace = calls of the gate|up GEMV
+    (the only kernel with the SwiGLU epilogue, one per layer and step) / layers -- prefill launches a step_end_kernel and an
+    lm_head GEMV of its own, so neither of those counts steps.  rocprofv3 brackets each dispatch (wave launch ramp +
+    end-of-kernel write-back): its durations are ~1 us per launch longer than the in-kernel stamps.
+    Kernel names carry the template arguments <MR, KS, CW, PRO, EPI, LM>: EPI 2 = SwiGLU (gate|up), EPI 1 = residual (KS 8:
+    w_down, else wo), PRO 1 + EPI 0 = RMSNorm prologue + plain store (qkv and lm_head share that instantiation)."""
     import csv
+    import re
 
     try:
         rows = list(csv.DictReader(open(stats_csv)))
     except OSError:
         return None
-    steps = sum(int(r["Calls"]) for r in rows if "step_end_kernel" in r["Name"])
-    gemv = [r for r in rows if "tl::qmv3_kernel" in r["Name"]]
-    if not steps or not gemv:
+    gemv = []
+    for r in rows:
+        m = re.search(r"tl::qmv3_kernel<(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)", r["Name"])
+        if not m:
+            continue
+        mr, ks, cw, pro, epi, lm = (int(x) for x in m.groups())
+        which = "gate_up" if epi == 2 else ("down" if epi == 1 and ks >= 8 else ("o" if epi == 1 else "qkv+lm_head"))
+        gemv.append((which, r))
+    gu_calls = sum(int(r["Calls"]) for w, r in gemv if w == "gate_up")
+    if not gu_calls or gu_calls % num_layers:
         return None
-    # prefill's last-row lm_head and the warm-up steps are qmv3 launches too: count launches per step from the trace itself
-    total_ns = sum(float(r["TotalDurationNs"]) for r in gemv)
-    launches = sum(int(r["Calls"]) for r in gemv)
+    steps = gu_calls // num_layers
+    b = {k: kinds[f"gemv_{k}"]["bytes"] for k in ("qkv", "o", "gate_up", "down", "lm_head")}
+    per_step_bytes = {"gate_up": b["gate_up"], "down": b["down"], "o": b["o"], "qkv+lm_head": b["qkv"] + b["lm_head"]}
+    total_ns = sum(float(r["TotalDurationNs"]) for _, r in gemv)
+    launches = sum(int(r["Calls"]) for _, r in gemv)
     us_per_step = total_ns / 1e3 / steps
-    ach = gemv_bytes_per_step / us_per_step / 1e3
-    return {"file": str(stats_csv.relative_to(ROOT)), "steps_in_trace": steps, "gemv_launches_per_step": round(launches / steps, 2),
+    g_bytes = sum(b.values())
+    ach = g_bytes / us_per_step / 1e3
+    per = {}
+    for which in per_step_bytes:
+        ns = sum(float(r["TotalDurationNs"]) for w, r in gemv if w == which)
+        calls = sum(int(r["Calls"]) for w, r in gemv if w == which)
+        if ns > 0:
+            gbps = per_step_bytes[which] * steps / ns
+            per[which] = {"avg_launch_us": round(ns / 1e3 / calls, 3), "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+    return {"measured_in_this_run": False, "source": "committed rocprofv3 --kernel-trace --stats summary of this command",
+            "file": str(stats_csv.relative_to(ROOT)), "file_mtime": time.strftime("%Y-%m-%d %H:%M", time.gmtime(stats_csv.stat().st_mtime)),
+            "steps_in_trace": steps, "gemv_launches_per_step": round(launches / steps, 2),
             "gemv_us_per_step": round(us_per_step, 1), "avg_launch_us": round(total_ns / 1e3 / launches, 3),
-            "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4)}
+            "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4), "per_projection": per}
+
+
+def latest_rocprof_stats(config: int) -> Path | None:
+    """The newest committed profiles/r<NN>_rocprofv3/bench_config<N>_kernel_stats.csv."""
+    found = sorted((ROOT / "profiles").glob(f"r*_rocprofv3/bench_config{config}_kernel_stats.csv"))
+    return found[-1] if found else None
+
+
+def self_launch(argv: list[str], n: int) -> None:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one per GPU,
+    rendezvous on 127.0.0.1) and hand their exit status on.  Rank 0's JSON line goes to this process's stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+class SleepEngine:
+    """--engine sleep: a stand-in with the call surface main() uses and a fixed cost per step, so that the launch / rendezvous /
+    timing / reporting path of this file can be exercised without a GPU (tests/test_bench_dist_cpu.py).  Its line says
+    "data": "none (--engine sleep ...)" and is never a measurement."""
+
+    def __init__(self, step_s: float = 0.002):
+        self.step_s = step_s
+        self.steps = 0
+
+    def begin(self, slot): pass
+    def prefill(self, slot, prompt, chunk=None): time.sleep(self.step_s)
+    def decode(self, k, batch=1, use_graph=True):
+        time.sleep(self.step_s * k)
+        self.steps += k
+    def synchronize(self): pass
+    def step_bytes(self, batch): return 0
+    def read_tokens(self, slot, n): return [0] * n
+    def stats(self): return {"graph_captures": 0, "graph_replays": 0, "decode_steps": self.steps, "kv_bytes": 0}
+    def release(self, slot): pass
 
 
 def aggregate_value(n_gpus: int, steps: int, elapsed_max_s: float) -> float:
@@ -205,7 +272,14 @@ def main() -> None:
     ap.add_argument("--profile-steps", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (for rocprofv3 kernel traces)")
+    ap.add_argument("--rocprof-stats", default=None,
+                    help="rocprofv3 --kernel-trace --stats CSV of this command to recompute the GEMV rate from (default: the newest "
+                         "committed profiles/r*_rocprofv3/bench_config<N>_kernel_stats.csv; 'none' to leave the block out)")
+    ap.add_argument("--engine", default="hip", choices=("hip", "sleep"),
+                    help="sleep = launch-path plumbing test without a GPU (gloo); never a measurement")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(sys.argv[1:], args.gpus)  # does not return
     workload = {2: ("Qwen3-4B int4 single-prompt KV-cache decode (BASELINE.json configs[1])", 128, 128, 256),
                 3: ("Qwen3-4B int4 chunked-prefill 8k + paged-KV decode (BASELINE.json configs[2])", 8192, 2048, 64),
                 5: ("Qwen3-4B 32k long-context paged FlashAttention prefill + split-K decode (BASELINE.json configs[4])",
@@ -226,32 +300,44 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    if not torch.cuda.is_available():
+    dry = args.engine == "sleep"
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    if not dry:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from tiny_llm_hip.engine import DecodeEngine
-    from tiny_llm_hip.synthetic import QWEN3_CONFIGS, synthetic_qwen3
+    from tiny_llm_hip.synthetic import QWEN3_CONFIGS
 
     cfg = dict(QWEN3_CONFIGS[args.model])
-    device = f"cuda:{local_rank}"
-    mlx_model = synthetic_qwen3(cfg, seed=args.seed, sigma=0.02, device=device)
+    device = "cpu" if dry else f"cuda:{local_rank}"
     total_ctx = args.prompt_len + args.warmup + args.steps + args.profile_steps + 64
     page = 128
-    engine = DecodeEngine(mlx_model, page_size=page, num_pages=(total_ctx + page - 1) // page + 2, max_batch=1,
-                          max_prefill_rows=max(args.prefill_step, 8))
+    if dry:
+        mlx_model, engine = None, SleepEngine()
+        args.profile_steps, args.no_cpu_baseline = 0, True
+    else:
+        from tiny_llm_hip.engine import DecodeEngine
+        from tiny_llm_hip.synthetic import synthetic_qwen3
+
+        mlx_model = synthetic_qwen3(cfg, seed=args.seed, sigma=0.02, device=device)
+        engine = DecodeEngine(mlx_model, page_size=page, num_pages=(total_ctx + page - 1) // page + 2, max_batch=1,
+                              max_prefill_rows=max(args.prefill_step, 8))
     prompt = build_prompt(random.Random(args.seed * 1000 + rank), args.prompt_len, cfg["vocab_size"])
     use_graph = not args.no_graph
 
     def sync():
         engine.synchronize()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     engine.begin(0)
     t_p0 = time.perf_counter()
@@ -316,8 +402,8 @@ def main() -> None:
         })
         if kv_bytes > g_bytes:  # long contexts: the K/V stream, not the weights, is the dominant traffic
             roofline["dominant"] = "decode attention (K/V pages): see attention_kv; achieved/frac stay the GEMV stream's"
-        stats_csv = ROOT / "profiles" / "r02_rocprofv3" / f"bench_config{args.config}_kernel_stats.csv"
-        rp = rocprof_gemv_rate(stats_csv, g_bytes)
+        stats_csv = None if args.rocprof_stats == "none" else (Path(args.rocprof_stats).resolve() if args.rocprof_stats else latest_rocprof_stats(args.config))
+        rp = rocprof_gemv_rate(stats_csv, kinds, cfg["num_hidden_layers"]) if stats_csv else None
         if rp:
             rp["stamp_minus_rocprof_us_per_launch"] = round(rp["avg_launch_us"] - g_us / g_launch, 3)
             roofline["rocprof"] = rp
@@ -325,6 +411,8 @@ def main() -> None:
         if traffic_file.exists():
             try:
                 roofline["traffic"] = json.loads(traffic_file.read_text()).get("qmv_hbm_bytes_per_launch")
+                roofline["traffic_note"] = ("HBM bytes per GEMV launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; NOT measured in "
+                                            "this run: replayed from the committed profiles/traffic.json")
             except Exception:
                 roofline["traffic"] = None
     roofline["step_achieved"] = round(step_gbps, 1)
@@ -348,7 +436,8 @@ def main() -> None:
         "vs_baseline": None,
         "dtype": "bf16",
         "dtype_note": "int4 (W4A16, group 128) weights x bf16 activations on bf16 MFMA, fp32 accumulate",
-        "data": "synthetic (random-init Qwen3-4B-shaped W4 weights, synthetic token ids)",
+        "data": "none (--engine sleep: launch-path plumbing test, NOT a measurement)" if dry else
+                "synthetic (random-init Qwen3-4B-shaped W4 weights, synthetic token ids)",
         "config": {"workload": workload[0],
                    "prompt_tokens": args.prompt_len, "decode_steps": args.steps, "batch_per_gpu": 1,
                    "parallelism": f"request-parallel x{args.gpus} (no collective on the data path)",

@@ -102,11 +102,31 @@ def parse_args(argv=None) -> argparse.Namespace:
     ap.add_argument("--page-size", type=int, default=128)
     ap.add_argument("--warmup-requests", type=int, default=None, help="requests of an untimed warm-up pass (default: batch size)")
     ap.add_argument("--json-output", type=Path)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="replicas; started without a launcher (WORLD_SIZE unset) and N > 1, this script starts its own N ranks "
+                         "under torch.distributed.run on 127.0.0.1")
     return ap.parse_args(argv)
+
+
+def self_launch(argv: list[str], n: int) -> None:
+    """One rank per GPU under torch.distributed.run; rank 0's report goes to this process's stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main(argv=None) -> dict | None:
     args = parse_args(argv)
+    if args.gpus and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(list(sys.argv[1:] if argv is None else argv), args.gpus)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

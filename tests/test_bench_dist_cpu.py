@@ -67,3 +67,22 @@ def test_single_rank_needs_no_process_group():
     elapsed, local = bench.timed_steps(lambda k: time.sleep(0.001 * k), lambda: None, 10)
     assert elapsed == local and elapsed >= 0.01
     assert bench.aggregate_value(1, 10, elapsed) == pytest.approx(10 / elapsed)
+
+
+def test_bench_py_starts_its_own_ranks_when_no_launcher_did():
+    """The driver's command shape is `python3 bench.py --gpus N ...` (BENCH_rNN.json "cmd").  With N > 1 and WORLD_SIZE unset the
+    script starts N ranks of itself under torch.distributed.run on 127.0.0.1; rank 0 prints the one JSON line.  Exercised here at
+    world size 2 over gloo with --engine sleep (the launch / rendezvous / barrier / MAX-over-ranks / report path without a GPU)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--engine", "sleep"],
+                          env=env, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["value"] == pytest.approx(2 * 6 / (out["ms_per_step"] * 6 / 1e3), rel=1e-3)  # whole-job aggregate over both ranks
+    assert out["data"].startswith("none") and out["config"]["parallelism"].startswith("request-parallel x2")

@@ -149,3 +149,56 @@ def test_week3_model_matches_week2_model_on_an_mx_built_checkpoint():
                 c.release()
         assert float(mx.max(mx.abs(outs[0] - outs[1])).item()) <= 2 * 2 ** -7 * max(1.0, float(mx.max(mx.abs(outs[0])).item()))
 
+
+
+def _course_fake_model(mx):
+    """The fake model of tests_refsol/test_week_3_day_3.py:29-105, restated: two layers, hidden 128, vocabulary 128, four query
+    heads over two KV heads of 32, intermediate 256, tied head; N(0, 1) bf16 weights through mx.quantize (group 128, 4 bit),
+    unit norm weights; seed 0."""
+    from types import SimpleNamespace as NS
+
+    mx.random.seed(0)
+
+    def ql(rows, cols):
+        packed, scales, biases = mx.quantize(mx.random.normal(shape=(rows, cols), dtype=mx.bfloat16), group_size=128, bits=4)
+        return NS(weight=packed, scales=scales, biases=biases, group_size=128, bits=4)
+
+    ones = lambda n: NS(weight=mx.ones((n,), dtype=mx.bfloat16))
+    args = NS(num_hidden_layers=2, hidden_size=128, vocab_size=128, num_attention_heads=4, num_key_value_heads=2, head_dim=32,
+              intermediate_size=256, rms_norm_eps=1e-5, max_position_embeddings=128, rope_theta=10000, tie_word_embeddings=True)
+    embed = ql(128, 128)
+    layers = [NS(self_attn=NS(q_proj=ql(128, 128), k_proj=ql(64, 128), v_proj=ql(64, 128), o_proj=ql(128, 128), q_norm=ones(32),
+                              k_norm=ones(32)),
+                 mlp=NS(gate_proj=ql(256, 128), up_proj=ql(256, 128), down_proj=ql(128, 256)), input_layernorm=ones(128),
+                 post_attention_layernorm=ones(128)) for _ in range(2)]
+    return NS(args=args, model=NS(embed_tokens=embed, layers=layers, norm=ones(128)))
+
+
+@pytest.mark.parametrize("paged", [False, True])
+def test_the_reference_1e_3_check_of_week3_against_week2_at_its_own_tolerance(paged):
+    """north_star: "logits match ... within 1e-3".  The reference asserts 1e-3 in ONE place -- tests_refsol/test_week_3_day_3.py:
+    386-402, Qwen3ModelWeek3(page_size=4, enable_paged_attention=False) against Qwen3ModelWeek2 on its fake model, six tokens fed
+    one at a time, log-softmax of the logits, rtol = atol = 1e-3 (both paths share every kernel).  Reproduced here ON THE DEVICE
+    at that tolerance, every kernel call reaching libtinyllm_hip.so.  paged=True is NOT a reference assertion: the same loop with
+    the paged attention kernel in Week 3 (a different kernel from Week 2's dense decode attention), held at the same 1e-3 and
+    reported in profiles/ (the maximum is printed)."""
+    mx = _mx()
+    from tiny_llm_ref import Qwen3ModelWeek2, Qwen3ModelWeek3
+
+    with mx.stream(mx.gpu):
+        fake = _course_fake_model(mx)
+        week2 = Qwen3ModelWeek2(fake)
+        week3 = Qwen3ModelWeek3(fake, page_size=4, enable_paged_attention=paged)
+        tokens = mx.array([[1, 5, 7, 3, 9, 11]], dtype=mx.int32)
+        cache2, cache3 = week2.create_kv_cache(), week3.create_kv_cache()
+        worst = 0.0
+        for offset in range(tokens.shape[1]):
+            tok = tokens[:, offset:offset + 1]
+            a = week2(tok, offset, cache2)
+            b = week3(tok, offset, cache3)
+            assert a.is_cuda and b.is_cuda
+            a = np.array((a - mx.logsumexp(a, keepdims=True)).astype(mx.float32))
+            b = np.array((b - mx.logsumexp(b, keepdims=True)).astype(mx.float32))
+            worst = max(worst, float(np.max(np.abs(a - b))))
+            assert np.allclose(b, a, rtol=1e-3, atol=1e-3), (offset, worst)
+        print(f"PARITY week3_vs_week2_logsoftmax paged={paged} max_abs_diff={worst:.3e} (reference tolerance rtol=atol=1e-3)")

@@ -180,3 +180,23 @@ def test_profile_week2_kernels_harness_logic(monkeypatch):
     got = P.benchmark_groups([(n, builder(n)) for n in "abc"], warmup=2, iterations=3, evaluate=evaluate)
     assert got == {"a": 1e6, "b": 2e6, "c": 4e6}
     assert "".join(calls) == "abc" "bca" "cab" "abc" "bca", "order rotated by one every round, warm-up rounds included"
+
+
+def test_serve_replicas_starts_its_own_ranks_when_no_launcher_did():
+    """`python benches/serve_replicas.py --gpus 2 ...` without torch.distributed.run around it: the script launches its two ranks
+    itself (gloo control plane, schedule-only engine here) and rank 0 reports two replicas."""
+    import os
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = ROOT / "gpurun_out"
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        report = Path(tmp) / "report.json"
+        proc = subprocess.run([sys.executable, str(ROOT / "benches" / "serve_replicas.py"), "--gpus", "2", "--solution", "schedule-only",
+                               "--num-seqs", "24", "--batch-size", "8", "--json-output", str(report)], env=env, capture_output=True,
+                              text=True, timeout=300)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        data = json.loads(report.read_text())
+    text = json.dumps(data)
+    assert '"replicas": 2' in text, text[:500]
