@@ -17,6 +17,11 @@ for extra in (ROOT, ROOT / "tests", ROOT / "tiny-llm_amd", ROOT / "tiny-llm_amd"
         sys.path.insert(0, str(extra))
 
 
+# the reference's own test files staged by tools/stage_reference_tests.sh run in their own pytest process, with the facade on
+# the path (tests/test_zz_reference_tests_on_device_gpu.py): they are not part of this suite's collection
+collect_ignore = ["_reference_staged"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (pytest -m gpu)")
 

@@ -67,25 +67,50 @@ struct F32 {
 __device__ __forceinline__ float bf16_round(float f) { return BF16::to_float(BF16::from_float(f)); }
 
 // ---- wave helpers -----------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Reductions by DPP row rotations + four v_readlane (round 3).  __shfl_xor compiles to ds_bpermute_b32: a trip through the LDS
+// crossbar (~100 cycles) per step, six DEPENDENT steps for a wave-wide sum -- a quarter of a microsecond on the critical path of
+// every fused RMSNorm.  A DPP step is one VALU instruction.
+template <int N>
+__device__ __forceinline__ float dpp_row_ror(float v) {  // lane i of a 16-lane row reads lane (i + N) mod 16 of the same row
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+// all-reduce over aligned groups of 16 lanes (every lane of a group gets the group's sum)
+__device__ __forceinline__ float group16_sum(float v) {
+    v += dpp_row_ror<8>(v);
+    v += dpp_row_ror<4>(v);
+    v += dpp_row_ror<2>(v);
+    v += dpp_row_ror<1>(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+template <int N>
+__device__ __forceinline__ float dpp_row_ror_self(float v) {  // a disabled source lane yields the reader's own value
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float group16_max(float v) {
+    v = fmaxf(v, dpp_row_ror_self<8>(v));
+    v = fmaxf(v, dpp_row_ror_self<4>(v));
+    v = fmaxf(v, dpp_row_ror_self<2>(v));
+    v = fmaxf(v, dpp_row_ror_self<1>(v));
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = group16_sum(v);
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = group16_max(v);
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 // Softmax exponentials: the bare v_exp_f32.  exp2f() wraps it in denormal-range handling (compare, scale, select, ldexp: four
 // more VALU instructions per call); a weight below 2^-126 is zero at every precision the attention result is kept in.
 __device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }
-// reduce over aligned groups of 16 lanes
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));

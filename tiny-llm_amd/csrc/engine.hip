@@ -78,6 +78,9 @@ struct tl_engine {
     // is dropped and the wo GEMV forms the merged row from the split partials while it stages it (qmv3.h, PRO_ATTN_MERGE).  Off
     // until measured on the device.
     bool wo_merges_attn = false;
+    // TL_GEMV_PRODUCER_SS=0: the 1-4-row GEMVs re-derive the sum of squares of their input rows instead of adding the partials the
+    // producing GEMV left (qmv3.h, ss_in / ss_out).  On by default: qkv -0.44 us, gate|up -1.1 us per layer (abl_lab, bit 8)
+    bool gemv_producer_ss = true;
     bool fuse_norm = true;                   // TL_QMM3_FUSED_NORM=0: RMSNorm ahead of a skinny matmul always as its own launch
     int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
@@ -166,8 +169,13 @@ static int check_w4(const tl_w4 &w, int rows, int cols, const char *name) {
 }
 
 // GEMV with fused prologue/epilogue over M <= 8 rows; splits the rows when the activation tile exceeds LDS.
+// ss_in / ss_in_n: partial sums of squares of the rows of `a` ([M][ss_in_n]) when its producer left them; ss_out: where an
+// EPI_RESIDUAL GEMV leaves those of `out` ([M][rows / 16]); *ss_out_n = partials per row actually written (0 = none).
 static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
-                      const void *norm_w, const uint16_t *residual, ProfCtx *pc = nullptr, int kind = 0) {
+                      const void *norm_w, const uint16_t *residual, ProfCtx *pc = nullptr, int kind = 0,
+                      const float *ss_in = nullptr, int ss_in_n = 0, float *ss_out = nullptr, int *ss_out_n = nullptr) {
+    if (ss_out_n) *ss_out_n = 0;
+    bool all_emitted = ss_out != nullptr && epi == EPI_RESIDUAL && e->gemv_producer_ss;
     int step = std::min(M, 8);  // both GEMV kernels hold at most 8 activation rows (MR <= 8): more rows go in passes of 8
     const bool has_tiled = e->tiled.count(w.weight_dev) != 0;
     auto fits = [&](int rows) {
@@ -204,6 +212,10 @@ static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
             a3.N = args.N;
             a3.K = args.K;
             a3.prof = args.prof;
+            if (e->gemv_producer_ss) {
+                if (pro == PRO_RMSNORM && ss_in && ss_in_n > 0) a3.ss_in = ss_in + (size_t)m0 * ss_in_n, a3.ss_n = ss_in_n;
+                if (epi == EPI_RESIDUAL && ss_out) a3.ss_out = ss_out + (size_t)m0 * (w.rows / 16);
+            }
             if (launch_qmv3_bf16(a3, pro, epi, e->stream) != 0)
                 return fail(TL_ERR_UNSUPPORTED, "engine: MFMA GEMV launch failed");
             if (pc) prof_after(e, pc, kind, p3.blocks);
@@ -216,6 +228,7 @@ static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
             }
             continue;
         }
+        all_emitted = false;  // the packed-dot fallback leaves no partials
         if (launch_qmv_fused_bf16(args, pro, epi, e->stream) != 0)
             return fail(TL_ERR_UNSUPPORTED, "engine: no GEMV configuration for this shape");
         if (pc) prof_after(e, pc, kind, qmv_plan(args.M, args.N, args.K).blocks);
@@ -226,6 +239,7 @@ static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
         }
     }
     TL_CHECK_LAUNCH("engine gemv");
+    if (ss_out_n && all_emitted && w.rows % 16 == 0) *ss_out_n = w.rows / 16;
     return TL_OK;
 }
 
@@ -286,13 +300,18 @@ struct KeptPartials {
     long plane = 0;  // elements between slices (= rows * output columns)
 };
 static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
-                         const void *norm_w, const uint16_t *residual, ProfCtx *pc, int kind, const float *ss_in = nullptr,
-                         float *ss_out = nullptr, bool *ss_emitted = nullptr, KeptPartials *keep = nullptr) {
+                         const void *norm_w, const uint16_t *residual, ProfCtx *pc, int kind, const float *ss_in_any = nullptr,
+                         float *ss_out = nullptr, bool *ss_emitted = nullptr, KeptPartials *keep = nullptr, int ss_in_n = QM3_SS,
+                         int *ss_out_n = nullptr) {
+    // ss_in_any holds ss_in_n partials per row; the skinny matmul reads exactly QM3_SS of them, the GEMV any number.
+    // *ss_out_n (when asked for) = partials per row left in ss_out: QM3_SS by the slice reduction, rows / 16 by a GEMV, 0 = none
     if (ss_emitted) *ss_emitted = false;
+    if (ss_out_n) *ss_out_n = 0;
     if (keep) *keep = KeptPartials{};
-    if (e->force_linear == 1) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
+    const float *ss_in = ss_in_n == QM3_SS ? ss_in_any : nullptr;
+    if (e->force_linear == 1) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind, ss_in_any, ss_in_n, ss_out, ss_out_n);
     if (e->force_linear != 2 && (M < e->qmm3_min_rows || (M <= 8 && !e->use_qmm3)))
-        return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
+        return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind, ss_in_any, ss_in_n, ss_out, ss_out_n);
     const tl_engine_config &c = e->cfg;
     const uint16_t *in = a;
     // qmm3_min_rows .. 64 rows (batched decode): K-sliced skinny MFMA matmul over the tiled weights, then the slice
@@ -334,6 +353,7 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
             if (pc) prof_after(e, pc, kind, reduce_wg);
         }
         if (ss_emitted) *ss_emitted = ss_dst != nullptr;
+        if (ss_out_n) *ss_out_n = ss_dst != nullptr ? QM3_SS : 0;
         TL_CHECK_LAUNCH("engine skinny matmul");
         if (e->linfo) {
             tl_linear_info &li = *e->linfo;
@@ -346,7 +366,7 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
         return TL_OK;
     }
     if (e->force_linear == 2) return fail(TL_ERR_UNSUPPORTED, "engine: the skinny matmul does not cover this shape");
-    if (M <= 8) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind);
+    if (M <= 8) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind, ss_in_any, ss_in_n, ss_out, ss_out_n);
     if (pro == PRO_RMSNORM) {
         TL_TRY(tl_rms_norm(a, norm_w, e->xn, M, w.cols, c.rms_norm_eps, TL_BF16, e->stream));
         in = e->xn;
@@ -483,7 +503,9 @@ static bool wo_merge_applicable(const tl_engine *e, const tl_w4 &wo, int batch, 
     return pl.ok && pl.MR == 1 && shape && wo.cols / 8 <= 2 * pl.CW * 64;
 }
 // h = x + merge(attention partials) @ wo^T for one row.
-static int engine_wo_merge(tl_engine *e, const tl_w4 &wo, const uint16_t *residual, uint16_t *out, int n_splits, ProfCtx *pc) {
+static int engine_wo_merge(tl_engine *e, const tl_w4 &wo, const uint16_t *residual, uint16_t *out, int n_splits, ProfCtx *pc,
+                           float *ss_out = nullptr, int *ss_out_n = nullptr) {
+    if (ss_out_n) *ss_out_n = 0;
     const auto tiled = e->tiled.find(wo.weight_dev);
     Qmv3Args a3{};
     a3.wt = tiled->second.wt;
@@ -497,6 +519,10 @@ static int engine_wo_merge(tl_engine *e, const tl_w4 &wo, const uint16_t *residu
     a3.K = wo.rows;
     a3.prof = pc ? pc->buf : nullptr;
     a3.merge_ws = e->attn_ws;
+    if (ss_out && e->gemv_producer_ss && wo.rows % 16 == 0) {
+        a3.ss_out = ss_out;
+        if (ss_out_n) *ss_out_n = wo.rows / 16;
+    }
     if (launch_qmv3_attn_merge_bf16(a3, n_splits, e->stream) != 0)
         return fail(TL_ERR_UNSUPPORTED, "engine: no wo GEMV that merges the attention partials for this shape");
     if (pc) prof_after(e, pc, 1, qmv3_plan(1, wo.cols, wo.rows).blocks);
@@ -603,25 +629,25 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     const tl_engine_config &c = e->cfg;
     // x enters the step from the embedding gather (embed_slots_kernel / the previous step's step_end_kernel), which leaves the
     // per-row partial sums of squares in ss_x; every slice reduction that rewrites x or h refreshes them (or says it did not)
-    bool x_ss = true;
+    int x_ss = QM3_SS;  // partials per row in ss_x (0 = none): QM3_SS from the embedding kernels, then whatever the last writer of x left
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
         KeptPartials qkv_parts;
         const bool keep_qkv = e->attn_qkv_partials && sp.nw == 0 && attn_takes_qkv_partials(c.head_dim, sp.rq);
         TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0,
-                             x_ss ? e->ss_x : nullptr, nullptr, nullptr, keep_qkv ? &qkv_parts : nullptr));
+                             x_ss ? e->ss_x : nullptr, nullptr, nullptr, keep_qkv ? &qkv_parts : nullptr, x_ss));
         bool merge_left = false;
         TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, &qkv_parts,
                                 &w.wo, &merge_left));
-        bool h_ss = false;
-        if (merge_left) TL_TRY(engine_wo_merge(e, w.wo, e->x, e->h, sp.n_splits, pc));
-        else TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, &h_ss));
+        int h_ss = 0;
+        if (merge_left) TL_TRY(engine_wo_merge(e, w.wo, e->x, e->h, sp.n_splits, pc, e->ss_h, &h_ss));
+        else TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, nullptr, nullptr, QM3_SS, &h_ss));
         TL_TRY(engine_linear(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2,
-                             h_ss ? e->ss_h : nullptr));
-        TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, &x_ss));
+                             h_ss ? e->ss_h : nullptr, nullptr, nullptr, nullptr, h_ss));
+        TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, nullptr, nullptr, QM3_SS, &x_ss));
     }
     TL_TRY(engine_linear(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4,
-                         x_ss ? e->ss_x : nullptr));
+                         x_ss ? e->ss_x : nullptr, nullptr, nullptr, nullptr, x_ss));
     StepEndArgs s{};
     s.logits = e->logits;
     s.vocab = c.vocab_size;
@@ -813,8 +839,11 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const size_t o_act = carve(R * c.intermediate_size * 2);
     const size_t o_log = carve((size_t)std::max(c.max_batch, 8) * c.vocab_size * 2);  // decode rows, or 8 verification rows
     const size_t o_vid = carve(8 * 4);
-    const size_t o_ssx = carve((size_t)c.max_batch * QM3_SS * 4);
-    const size_t o_ssh = carve((size_t)c.max_batch * QM3_SS * 4);
+    // per-row partial sums of squares: QM3_SS per row from the skinny-matmul reduction / the embedding kernels, one per 16-row
+    // tile (hidden / 16) from the 1-4-row GEMVs
+    const size_t ss_per_row = (size_t)std::max(QM3_SS, c.hidden_size / 16 + 1);
+    const size_t o_ssx = carve((size_t)c.max_batch * ss_per_row * 4);
+    const size_t o_ssh = carve((size_t)c.max_batch * ss_per_row * 4);
     // attention partials: decode (batch*Hq rows x 64 splits) or the L<=8 operator path during short prefills
     // decode partials: at most 64 splits per row with many sequences, at most 256 split-rows per head with few (pick_decode_splits)
     e->attn_ws_bytes = std::max((size_t)std::max(c.max_batch * 64, 4 * 256) * c.num_heads * (c.head_dim + 2) * 4,
@@ -883,6 +912,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->ss_x = (float *)(A + o_ssx);
     e->ss_h = (float *)(A + o_ssh);
     if (const char *q = getenv("TL_QMM3_FUSED_NORM")) e->fuse_norm = atoi(q) != 0;
+    if (const char *q = getenv("TL_GEMV_PRODUCER_SS")) e->gemv_producer_ss = atoi(q) != 0;
     if (const char *q = getenv("TL_ATTN_QKV_PARTIALS")) e->attn_qkv_partials = atoi(q) != 0;
     if (const char *q = getenv("TL_WO_MERGES_ATTN")) e->wo_merges_attn = atoi(q) != 0;
     if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;

@@ -52,6 +52,14 @@ struct Qmv3Args {
     // sum; head dimension 128, N = heads * 128), formed while the row is staged -- attn_merge_kernel's arithmetic, term for
     // term, so the staged bf16 row has the bits that kernel would have written; its launch is dropped.
     const float *merge_ws;
+    // Producer-side sums of squares (round 3).  Every workgroup of a PRO_RMSNORM GEMV used to re-derive the row's sum of squares
+    // (sum per thread, wave reduction, LDS, a barrier) before it could normalise: 0.44 us of the qkv GEMV and 1.1 us of the
+    // 1,216-workgroup gate|up GEMV (tools/lab/abl_lab, bit 8).  The GEMV that WRITES the row (wo -> h, w_down -> x) now leaves,
+    // per activation row, one partial per 16-row tile: the sum of the squares of the bf16 values it stored (ss_out [M][K / 16]);
+    // the consumer adds ss_n partials in a fixed order (ss_in [M][ss_n]; 8 zero-padded partials from the embedding kernels).
+    const float *ss_in;
+    int ss_n;
+    float *ss_out;
 };
 
 #ifdef QMV3_LAB
@@ -140,6 +148,19 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
             for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) mval[k][s2][e] = *reinterpret_cast<const f32x2 *>(hb + s2 * 130 + (cc & 15) * 8 + 2 * e);
+        }
+    }
+    // producer-side sums of squares: the few partial loads go out first (they gate the normalisation of everything staged)
+    // (ONE 16-byte load per lane and row: up to 256 partials per row, i.e. hidden sizes up to 4,096)
+    const bool ss_given = PRO == PRO_RMSNORM && p.ss_in != nullptr && reg_path && p.ss_n <= 256 && (p.ss_n & 3) == 0;
+    f32x4 ssv[MR];
+    if constexpr (PRO == PRO_RMSNORM) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {  // unconditional load from a clamped address (no branch around a load), masked after
+            const bool ok = ss_given && m < p.M && 4 * lane < p.ss_n;
+            const float *src = ss_given ? p.ss_in : reinterpret_cast<const float *>(p.norm_w);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (ok ? (size_t)m * p.ss_n + 4 * lane : 0));
+            ssv[m] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 #pragma unroll
@@ -250,6 +271,14 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
 #pragma unroll
     for (int m = 0; m < MR; ++m) inv[m] = 1.0f;
     if constexpr (PRO == PRO_RMSNORM) {
+      if (ss_given) {  // uniform: every wave adds the row's partials in the same fixed order; no LDS, no barrier
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            float v = (ssv[m][0] + ssv[m][1]) + (ssv[m][2] + ssv[m][3]);  // partials 4 l .. 4 l + 3 of lane l
+            v = wave_sum(v);
+            inv[m] = rsqrtf(v / (float)N + p.eps);
+        }
+      } else if (!Q3_ABL(8)) {  // lab only, bit 8: pretend the inverse RMS is known
         float ss[MR];
 #pragma unroll
         for (int m = 0; m < MR; ++m) ss[m] = 0.f;
@@ -285,6 +314,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
             for (int w = 0; w < CW; ++w) tot += scratch[m * CW + w];
             inv[m] = rsqrtf(tot / (float)N + p.eps);
         }
+      }
     }
     if (reg_path && !Q3_ABL(2)) {
 #pragma unroll
@@ -385,9 +415,16 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
             if (live && (r & 1) == 0)
                 p.out[(size_t)arow * (K >> 1) + (orow >> 1)] = BF16::from_float((gv / (1.0f + expf(-gv))) * uv);
         } else if constexpr (EPI == EPI_RESIDUAL) {
+            float sq_v = 0.f;
             if (live) {
                 const size_t o = (size_t)arow * K + orow;
-                p.out[o] = BF16::from_float(BF16::to_float(p.residual[o]) + bf16_round(acc[i2]));
+                const uint16_t ov = BF16::from_float(BF16::to_float(p.residual[o]) + bf16_round(acc[i2]));
+                p.out[o] = ov;
+                sq_v = BF16::to_float(ov) * BF16::to_float(ov);
+            }
+            if (p.ss_out) {  // uniform.  One partial per (activation row, 16-row tile): the squares of the stored bf16 values
+                sq_v = group16_sum(sq_v);
+                if (r == 0 && tile_ok && arow < MR && arow < p.M) p.ss_out[(size_t)arow * tiles + tile_c] = sq_v;
             }
         } else {
             if (live) p.out[(size_t)arow * K + orow] = BF16::from_float(acc[i2]);
