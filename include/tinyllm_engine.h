@@ -88,6 +88,7 @@ typedef struct tl_engine_stats {
     long page_allocations, reused_page_allocations;
     long decode_steps, graph_captures, graph_replays, prefill_tokens;
     size_t kv_bytes, workspace_bytes;
+    long graph_cache_flushes; /* times the cache of captured decode graphs (48 plans) was emptied */
 } tl_engine_stats;
 
 /* embed: the quantized embedding table [vocab, hidden]; lm_head: NULL for tied
@@ -237,7 +238,6 @@ int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int
  * max_context: host upper bound of context_lens (sizes the context split exactly as tl_engine_decode does). */
 typedef struct tl_attention_info {
     int n_splits, tokens_per_split, heads_per_workgroup;
-    int wide_waves, wide_rows_in_flight, scalar_page_ids; /* wide one-head kernel: waves, K/V rows in flight per group, page ids by s_load */
     int launches;
 } tl_attention_info;
 size_t tl_decode_attention_fused_workspace_bytes(int batch, int num_heads, int head_dim);

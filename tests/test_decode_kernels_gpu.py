@@ -2,7 +2,7 @@
 
 The operator tests (test_ops_gpu.py) drive the public reference API; the engine, however, decodes through its own
 kernels: `qmv3_kernel` (fused MFMA GEMV over the tiled weights), `qmm3_kernel` + slice reduction (5..64 rows) and
-`attn_decode_wide_kernel` / `attn_decode_fused_kernel` (+ merge).  These tests call exactly that launch code through the
+`attn_decode_fused_kernel` (+ merge).  These tests call exactly that launch code through the
 kernel-level C entry points (`tl_decode_linear`, `tl_decode_attention_fused`, include/tinyllm_engine.h) and compare with
 the numpy oracle on the same seeded inputs:
 
@@ -284,100 +284,42 @@ def _check_attention(case, got, kp_after, vp_after, idle, what):
 
 
 @pytest.mark.parametrize("ctx", [0, 1, 63, 64, 127, 128, 255, 256, 300, 511, 512, 1000, 3000, 4095])
-@pytest.mark.parametrize("mode", ["default", "wide"])
-def test_decode_attention_contexts_up_to_4k(ext, ctx, mode, monkeypatch):
-    """One sequence.  default: the plan the engine picks (one query head and a 64-token window per workgroup, partials merged
-    by a second launch).  wide: the one-head kernel with the whole window in one workgroup (TL_ATTN_WIDE_MAX=512: no merge
-    launch up to 511 cached tokens, then 512-token windows + merge)."""
-    for name in ("TL_ATTN_WIDE_MAX", "TL_ATTN_NW", "TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_VECTOR_IDS"):
+def test_decode_attention_contexts_up_to_4k(ext, ctx, monkeypatch):
+    """One sequence, the plan the engine picks: one query head and a 64-token window per workgroup, partials merged by a second
+    launch at this kernel-level entry point (inside the engine the wo GEMV merges 2 / 4 / 8 windows itself)."""
+    for name in ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS"):
         monkeypatch.delenv(name, raising=False)
-    if mode == "wide":
-        monkeypatch.setenv("TL_ATTN_WIDE_MAX", "512")
     rng = np.random.default_rng(1000 + ctx)
     case = _attention_case(rng, [ctx])
     got, kpa, vpa, info = _run_attention(ext, case, ctx)
-    what = f"ctx={ctx} mode={mode} {info}"
-    assert info["heads_per_workgroup"] == 1 and (info["wide_waves"] > 0) == (mode == "wide"), what
+    what = f"ctx={ctx} {info}"
+    assert info["heads_per_workgroup"] == 1, what
     assert info["n_splits"] * info["tokens_per_split"] >= ctx + 1, what
-    if mode == "wide" and ctx + 1 <= 512:
-        assert info["n_splits"] == 1 and info["launches"] == 1, f"{what}: contexts up to 512 need no merge launch"
-        assert info["scalar_page_ids"] in (1, 2, 4), f"{what}: page 128 windows take their page ids through s_load"
-    if mode == "default":
-        assert info["tokens_per_split"] == 64 or info["n_splits"] == 64, what
-        assert info["launches"] == (1 if info["n_splits"] == 1 else 2), what
+    assert info["tokens_per_split"] == 64 or info["n_splits"] == 64, what
+    assert info["launches"] == (1 if info["n_splits"] == 1 else 2), what
     _check_attention(case, got, kpa, vpa, [False], what)
-    log_parity({"what": "decode_attention", "ctx": ctx, "mode": mode, **info})
-
-
-@pytest.mark.parametrize("ctx", [70, 300, 511])
-def test_decode_attention_in_kernel_merge_matches_merge_launch(ext, ctx, monkeypatch):
-    """The optional split merge inside the attention kernel (TL_ATTN_FUSED_MERGE=1: last-arriving workgroup, splits in index
-    order; off by default, measured neutral) against the merge launch: same partials, same order -- the bf16 outputs must be
-    IDENTICAL, call after call (the arrival counters return to zero)."""
-    rng = np.random.default_rng(77 + ctx)
-    case = _attention_case(rng, [ctx, 5, ctx - 3])
-    outs = {}
-    for fused in ("1", "0"):
-        monkeypatch.setenv("TL_ATTN_FUSED_MERGE", fused)
-        for rep in range(3):
-            got, kpa, vpa, info = _run_attention(ext, case, ctx)
-            assert info["launches"] == (1 if fused == "1" or info["n_splits"] == 1 else 2), info
-            outs[(fused, rep)] = got
-    ref = outs[("0", 0)]
-    for key, val in outs.items():
-        assert np.array_equal(val, ref), f"ctx={ctx}: run {key} differs from the merge-launch result in {int((val != ref).sum())} values"
-
-
-@pytest.mark.parametrize("nw", [4, 8, 16])
-@pytest.mark.parametrize("ctx", [200, 400])
-@pytest.mark.parametrize("vector_ids", [False, True])
-def test_decode_attention_wide_variants(ext, ctx, nw, vector_ids, monkeypatch):
-    """Every (waves, rows-in-flight) instantiation of the wide kernel that TL_ATTN_NW can select, with scalar and vector
-    page-id loads."""
-    monkeypatch.setenv("TL_ATTN_NW", str(nw))
-    monkeypatch.setenv("TL_ATTN_WIDE_MAX", "512")
-    if vector_ids:
-        monkeypatch.setenv("TL_ATTN_VECTOR_IDS", "1")
-    else:
-        monkeypatch.delenv("TL_ATTN_VECTOR_IDS", raising=False)
-    rng = np.random.default_rng(ctx * 31 + nw)
-    case = _attention_case(rng, [ctx, 17])
-    got, kpa, vpa, info = _run_attention(ext, case, ctx)
-    what = f"ctx={ctx} nw={nw} vector_ids={vector_ids} {info}"
-    assert info["wide_waves"] > 0 and (info["scalar_page_ids"] == 0) == vector_ids, what
-    _check_attention(case, got, kpa, vpa, [False, False], what)
+    log_parity({"what": "decode_attention", "ctx": ctx, "mode": "default", **info})
 
 
 @pytest.mark.parametrize("ctxs", [[8191], [8192, 5000, 129, -1], [32767], [32768, 1, 700, 20000]])
-@pytest.mark.parametrize("mode", ["default", "one_head_wide", "splits256", "legacy_rq1"])
+@pytest.mark.parametrize("mode", ["default", "splits256", "legacy_rq1"])
 def test_decode_attention_long_contexts(ext, ctxs, mode, monkeypatch):
     """BASELINE configs 3 and 5 (8k and 32k cached tokens, page 128), 1 and 4 sequences (ragged, one idle slot written as
-    -1): the default plan (one workgroup per GQA group walking 64-token stages, split + merge), the one-head wide kernel
-    forced onto long contexts, 256 context splits (attn_merge_many_kernel), and the one-head split kernel."""
-    for name in ("TL_ATTN_WIDE_MAX", "TL_ATTN_NW", "TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_RQ1_CTX", "TL_ATTN_RQ1_BATCH"):
+    -1): the default plan (one workgroup per GQA group walking 64-token stages, split + merge), 256 context splits
+    (attn_merge_cols_kernel over many groups), and the one-head split kernel."""
+    for name in ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_RQ1_CTX", "TL_ATTN_RQ1_BATCH"):
         monkeypatch.delenv(name, raising=False)
-    if mode == "one_head_wide":
-        monkeypatch.setenv("TL_ATTN_RQ1_CTX", "65536")
-        monkeypatch.setenv("TL_ATTN_RQ1_BATCH", "4")
+    if mode == "splits256":
         monkeypatch.setenv("TL_ATTN_MAX_SPLITS", "256")
-        monkeypatch.setenv("TL_ATTN_WIDE_MAX", "512")
-    elif mode == "splits256":
-        monkeypatch.setenv("TL_ATTN_MAX_SPLITS", "256")
-        monkeypatch.setenv("TL_ATTN_WIDE_MAX", "0")
     elif mode == "legacy_rq1":
         monkeypatch.setenv("TL_ATTN_RQ", "1")
-        monkeypatch.setenv("TL_ATTN_WIDE_MAX", "0")
     idle = [c < 0 for c in ctxs]
     rng = np.random.default_rng(abs(sum(ctxs)) + len(mode))
     case = _attention_case(rng, ctxs)
     got, kpa, vpa, info = _run_attention(ext, case, max(ctxs))
     what = f"ctxs={ctxs} mode={mode} {info}"
-    if mode == "one_head_wide":
-        assert info["wide_waves"] > 0, what
     if mode == "splits256" and max(ctxs) >= 32767 and len(ctxs) == 1:
         assert info["n_splits"] > 64, f"{what}: expected the many-split merge"
-    if mode in ("splits256", "legacy_rq1"):
-        assert info["wide_waves"] == 0, what
     _check_attention(case, got, kpa, vpa, idle, what)
     log_parity({"what": "decode_attention_long", "ctxs": ctxs, "mode": mode, **info})
 

@@ -19,11 +19,7 @@ LIB = ROOT / "tiny-llm_amd" / "extensions_hip" / "tiny_llm_ext_hip" / "libtinyll
 LLVM = Path("/opt/rocm/lib/llvm/bin")
 
 # kernels allowed to use scratch: (substring of the mangled name, reason)
-ALLOWED = [
-    ("attn_decode_wide_kernelILi8ELi16ELi8ELi0E", "16 waves x 8 rows with per-row page ids: known to spill, never launched (pick_decode_splits re-plans it onto 8 waves)"),
-    ("qmm3_kernelILi4ELi2ELi5E", "one-shot skinny matmul, 64 rows x 2 tiles per wave x 5-group slices (14 VGPRs spilled): only lm_head at 33..64 rows plans "
-                                 "it, and only with TL_QMM3_PERSISTENT=0 -- by default that shape takes the persistent grid (qmm3_prefers_persistent)"),
-]
+ALLOWED: list[tuple[str, str]] = []  # round 3 removed both former entries (the wide attention kernel and the spilling skinny-matmul candidate)
 
 
 def kernel_metadata():

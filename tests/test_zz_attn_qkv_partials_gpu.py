@@ -1,4 +1,4 @@
-"""GPU tier (collected last): TL_ATTN_QKV_PARTIALS=1 -- at 5..64 decode rows the qkv projection's slice-reduction launch is
+"""GPU tier (collected last): the default route at 5..64 decode rows (TL_ATTN_QKV_PARTIALS=0 turns it off) -- at 5..64 decode rows the qkv projection's slice-reduction launch is
 dropped and the decode-attention kernel adds the skinny matmul's fp32 slice partials itself (csrc/engine_kernels.h, QP; csrc/engine.hip
 engine_linear `keep`).  The kernel adds the slices in the reduction kernel's order and rounds once like it, so the two routes must
 agree BIT FOR BIT: same greedy tokens, same final logits, over several decode steps (the appended K/V rows feed later steps).
@@ -15,13 +15,9 @@ import torch
 from helpers import QWEN4B_CFG, TINY_CFG, to_mlx_shaped
 from oracle import tiny_oracle as O
 
-# The five TINY cases ran on the device with the round's last GPU seconds and passed
-# (profiles/r02_labs/qkv_partials_tiny_first_device_run.log: one slice per projection at that width).  The Qwen3-4B-shaped cases
-# (4 slices, launch count) have never run: a kernel nobody has rehearsed can do worse than fail (a memory fault ends the whole
-# pytest process), so they run only when TL_UNREHEARSED_GPU_TESTS=1 (tools/gpu_call_p.sh sets it) -- remove the gate after that run.
+# All cases have run on the device (round 3: profiles/r03_labs/opt_in_route_tests_first_run.log); the route is the default now,
+# and TL_ATTN_QKV_PARTIALS=0 is the route with the reduction launch it is compared with.
 pytestmark = [pytest.mark.gpu]
-unrehearsed = pytest.mark.skipif(os.environ.get("TL_UNREHEARSED_GPU_TESTS") != "1",
-                                 reason="never run on the device yet: TL_UNREHEARSED_GPU_TESTS=1 (tools/gpu_call_p.sh) runs it")
 
 
 def run(model, cfg, n_seq, steps, page_size, partials, profile=False):
@@ -30,8 +26,7 @@ def run(model, cfg, n_seq, steps, page_size, partials, profile=False):
     rng = np.random.default_rng(500 + n_seq)
     prompts = [[int(t) for t in rng.integers(1, cfg["vocab_size"], size=3 + (7 * i) % 19)] for i in range(n_seq)]
     old = os.environ.pop("TL_ATTN_QKV_PARTIALS", None)
-    if partials:
-        os.environ["TL_ATTN_QKV_PARTIALS"] = "1"  # read when the engine is created
+    os.environ["TL_ATTN_QKV_PARTIALS"] = "1" if partials else "0"  # read when the engine is created (default since round 3: 1)
     try:
         eng = DecodeEngine(model, page_size=page_size, num_pages=n_seq * 3 + 2, max_batch=n_seq, max_prefill_rows=32)
     finally:
@@ -67,7 +62,6 @@ def test_tiny_model_same_bits_with_and_without_the_reduction_launch(n_seq):
     assert torch.equal(a[2].view(torch.int16), b[2].view(torch.int16)), "final logits differ in their bits"
 
 
-@unrehearsed
 @pytest.mark.parametrize("n_seq", [5, 12, 40])
 def test_qwen3_4b_shapes_same_bits_and_one_launch_fewer_per_layer(n_seq):
     """Qwen3-4B's layer shapes (32 query heads on 8 KV heads, 2,560 wide: the qkv projection is cut into 4 slices), 3 layers,

@@ -792,6 +792,8 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
     TL_REQUIRE(dtype == TL_F32 || dtype == TL_BF16,
                "paged_attention: q, key_pages, and value_pages must have the same float32 or bfloat16 dtype");
     TL_REQUIRE(q && key_pages && value_pages && block_table && context_lens && out, "paged_attention: null pointer");
+    // the FlashAttention tiles take the maximum of the RAW scores and scale afterwards: only valid for a positive scale
+    TL_REQUIRE(scale > 0.f, "paged_attention: scale must be positive");
     TL_REQUIRE(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
                "paged_attention: num_heads must be divisible by num_kv_heads");
     TL_REQUIRE(N % num_heads == 0, "paged_attention: q.shape[0] must be divisible by num_heads");

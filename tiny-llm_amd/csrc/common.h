@@ -94,6 +94,23 @@ __device__ __forceinline__ float group16_max(float v) {
     v = fmaxf(v, dpp_row_ror_self<1>(v));
     return v;
 }
+// value of the lane whose index differs in bit 4 / bit 5 (gfx950 row / half swaps: one VALU instruction instead of ds_bpermute_b32)
+//   v_permlane16_swap a, b: a.row1 <-> b.row0, a.row3 <-> b.row2;  v_permlane32_swap a, b: a.lanes[32:63] <-> b.lanes[0:31]
+__device__ __forceinline__ float lane_xor16(float v, int lane) {
+    const int b = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);  // r[0] = {v0, v0, v2, v2}, r[1] = {v1, v1, v3, v3} by rows
+    return __builtin_bit_cast(float, (lane & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v, int lane) {
+    const int b = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);  // r[0] = {lo, lo}, r[1] = {hi, hi} by halves
+    return __builtin_bit_cast(float, (lane & 32) ? r[0] : r[1]);
+}
+// lane i reads lane i ^ 1 (DPP quad_perm [1, 0, 3, 2])
+__device__ __forceinline__ float lane_xor1(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0xB1, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
     v = group16_sum(v);
     const int b = __builtin_bit_cast(int, v);

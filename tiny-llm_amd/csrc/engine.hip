@@ -65,19 +65,17 @@ struct tl_engine {
              *attn = nullptr, *gu = nullptr, *act = nullptr, *tmp = nullptr, *logits = nullptr;
     float *attn_ws = nullptr;
     int last_attn_launches = 0;
-    unsigned int *attn_counters = nullptr;  // [max_batch][Hkv][4] arrival counters of the in-kernel split merge (zero at rest)
-    // TL_ATTN_FUSED_MERGE=1: 2 .. 8 splits merged by the last workgroup to arrive instead of a merge launch.  Off by default:
-    // measured neutral (r02: 913 vs 909 tok/s single stream, 1.97 vs 1.90 ms at 4 sequences) -- the arrival costs three
-    // dependent memory-side round trips (coherent stores acknowledged, counter, coherent loads), about what the launch costs.
-    bool attn_fused_merge = false;
     float *ss_x = nullptr, *ss_h = nullptr;  // [max_batch][QM3_SS] partial sums of squares of the rows of x / h (qmm3.h)
-    // TL_ATTN_QKV_PARTIALS=1: at 5 .. 64 decode rows the qkv projection's slice reduction is not launched; the decode-attention
-    // kernel adds the fp32 slice partials itself (engine_kernels.h, QP).  Off until measured on the device.
-    bool attn_qkv_partials = false;
-    // TL_WO_MERGES_ATTN=1: single-row decode with the context split 2 / 4 / 8 ways -- the merge launch behind the attention kernel
-    // is dropped and the wo GEMV forms the merged row from the split partials while it stages it (qmv3.h, PRO_ATTN_MERGE).  Off
-    // until measured on the device.
-    bool wo_merges_attn = false;
+    // At 5 .. 64 decode rows the qkv projection's slice reduction is not launched; the decode-attention kernel adds the fp32 slice
+    // partials itself (engine_kernels.h, QP).  Measured in round 3 (profiles/r03_labs/batched_decode_status.jsonl): 5 / 8 / 16 / 64
+    // sequences 1.87 -> 1.81, 1.91 -> 1.89, 2.08 -> 2.03, 3.63 -> 3.52 ms per step.  TL_ATTN_QKV_PARTIALS=0 launches the reduction.
+    bool attn_qkv_partials = true;
+    // Single-row decode with the context split 2 / 4 / 8 ways: no merge launch behind the attention kernel -- the wo GEMV forms the
+    // merged row from the split partials while it stages it (qmv3.h, PRO_ATTN_MERGE).  Measured in round 3
+    // (profiles/r03_labs/wo_merges_attn_ab_after_dpp.jsonl): 4 windows 1.023 -> 0.993 ms per token, 8 windows 1.033 -> 1.009 (the
+    // merging GEMV costs +0.9 / +2.0 us per layer, the merge launch cost 0.6 us + a boundary); 64-token windows stay the best
+    // (128-token windows: 1.022).  TL_WO_MERGES_ATTN=0 keeps the merge launch.
+    bool wo_merges_attn = true;
     // TL_GEMV_PRODUCER_SS=0: the 1-4-row GEMVs re-derive the sum of squares of their input rows instead of adding the partials the
     // producing GEMV left (qmv3.h, ss_in / ss_out).  On by default: qkv -0.44 us, gate|up -1.1 us per layer (abl_lab, bit 8)
     bool gemv_producer_ss = true;
@@ -90,12 +88,6 @@ struct tl_engine {
     int attn_rq1_batch = 2;      // ... and up to this many sequences (TL_ATTN_RQ1_BATCH); at 4 the re-read windows cost 261 vs 180 us
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
     int attn_max_splits = 64;    // most context splits per sequence (TL_ATTN_MAX_SPLITS, a power of two <= 256)
-    // largest window of the wide one-head kernel (TL_ATTN_WIDE_MAX: 0 = off, 64 .. 512).  Off by default: measured on the
-    // bench workload it costs 8.2 us per layer against 2.9 + 1.3 us for 64-token workgroups + merge (profiles/r02_labs):
-    // one CU keeps only ~32 KiB of L2 misses in flight (~16 GB/s), so a head's 128-256 KiB window has to be spread over CUs
-    int attn_wide_max = 0;
-    int attn_wide_nw = 0;        // waves per wide workgroup (TL_ATTN_NW: 4, 8 or 16; 0 = by window)
-    bool attn_wide_vector_ids = false;  // TL_ATTN_VECTOR_IDS=1: page ids by vector loads even where scalar loads apply
     tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
     int force_linear = 0;               // kernel-level entry points: 1 = fused GEMV, 2 = skinny matmul
     int qmm3_mode = -1;                 // skinny matmul grid: -1 by shape (qmm3_plan), 0 one-shot, 1 persistent
@@ -378,20 +370,16 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
 // Context split of the decode attention: power-of-two bucket >= context, fixed windows of C tokens per workgroup.
 struct SplitPlan {
     int n_splits, tokens_per_split;
-    int rq;      // query heads per workgroup
-    int nw = 0;  // > 0: the wide kernel (attn_decode_wide_kernel) with nw waves, u rows in flight per 16-lane group ...
-    int u = 0;
-    int npw = 0;  // ... and npw scalar page ids per window (0 = page ids by vector loads)
-    long key() const {
-        return ((long)nw << 56) | ((long)u << 50) | ((long)npw << 46) | ((long)rq << 40) | ((long)n_splits << 24) | (long)tokens_per_split;
-    }
+    int rq;  // query heads per workgroup
+    long key() const { return ((long)rq << 40) | ((long)n_splits << 24) | (long)tokens_per_split; }
 };
 // Measured on MI355X (profiles/README.md, profiles/r02_labs): a decode-attention workgroup is bound by its dependent latency
 // chain and by how many L2 misses ONE CU keeps in flight (~32 KiB), not by chip bandwidth.  Few sequences and short
-// contexts: one query head and a 64-token window (32 KiB of K/V) per workgroup, partials merged by a second launch.  Many
-// sequences or long contexts: one workgroup per GQA group walking 64-token stages, so that the K/V window is read from HBM
-// once.  The wide one-head kernel (whole 64..512-token window in one workgroup, no merge launch) is kept behind
-// TL_ATTN_WIDE_MAX: it lost on every context it was meant for.
+// contexts: one query head and a 64-token window (32 KiB of K/V) per workgroup, partials merged by the wo GEMV (2 / 4 / 8
+// windows of one sequence) or by a second launch.  Many sequences or long contexts: one workgroup per GQA group walking 64-token
+// stages, so that the K/V window is read from HBM once.  (A "wide" one-head kernel -- the whole 64..512-token window in one
+// workgroup, no merge -- was built in round 2, lost on every context it was meant for (8.2 us per layer against 2.9 + 1.3) and was
+// removed in round 3 together with the last-arriver in-kernel merge, which measured neutral.)
 static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
     const int rep = e->cfg.num_heads / e->cfg.num_kv_heads;
     int rq = e->attn_rq;
@@ -399,32 +387,6 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     if (rq != 1) rq = AD_RQ;
     int bucket = 64;
     while (bucket < max_ctx) bucket *= 2;
-    if (rq == 1 && e->attn_wide_max >= 64) {
-        int W = 64;
-        while (W < bucket && W < e->attn_wide_max) W *= 2;
-        const int n = bucket / W;
-        if (n <= e->attn_max_splits) {
-            SplitPlan sp{n, W, 1};
-            // waves per workgroup: TL_ATTN_NW, else 4 up to 256 tokens and 8 for 512 (rows in flight per group <= 16)
-            int nw = e->attn_wide_nw > 0 ? e->attn_wide_nw : (W <= 256 ? 4 : 8);
-            while (W / (4 * nw) > 16 && nw < 16) nw *= 2;
-            while (W / (4 * nw) < 4 && nw > 4) nw /= 2;
-            while (nw == 16 && W / (4 * nw) > 8) nw = 0;  // 16 waves hold at most 8 rows per group (128 VGPRs per lane)
-            const int u = nw > 0 ? W / (4 * nw) : 0;
-            if (nw > 0 && (u == 4 || u == 8 || u == 16)) {
-                sp.nw = nw;
-                sp.u = u;
-                const int ps = e->cfg.page_size;
-                const bool pow2 = ps > 0 && (ps & (ps - 1)) == 0;
-                if (e->cfg.head_dim == 128 && pow2 && ps >= 4 * nw && !e->attn_wide_vector_ids) {
-                    if (ps % W == 0) sp.npw = 1;
-                    else if (W % ps == 0 && (W / ps == 2 || W / ps == 4)) sp.npw = W / ps;
-                }
-                if (sp.nw == 16 && sp.u == 8 && sp.npw == 0) sp.nw = 8, sp.u = 16;  // that variant spills; same window on 8 waves
-                return sp;
-            }
-        }
-    }
     const int chunks = (rep + rq - 1) / rq;
     const int base = std::max(1, batch * e->cfg.num_kv_heads * chunks);
     int s = 1;
@@ -467,34 +429,10 @@ static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t s
     else launch_attn_decode_sp<VD, false>(a, grid, st, rq);
 }
 
-template <int VD, int NW, int U>
-static bool launch_attn_wide_npw(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int npw) {
-    const size_t lds = (size_t)NW * (16 * VD + 2) * sizeof(float);
-    if (npw == 0) hipLaunchKernelGGL((attn_decode_wide_kernel<VD, NW, U, 0>), grid, dim3(NW * 64), lds, st, a);
-    else if constexpr (VD == 8) {
-        if (npw == 1) hipLaunchKernelGGL((attn_decode_wide_kernel<VD, NW, U, 1>), grid, dim3(NW * 64), lds, st, a);
-        else if (npw == 2) hipLaunchKernelGGL((attn_decode_wide_kernel<VD, NW, U, 2>), grid, dim3(NW * 64), lds, st, a);
-        else if (npw == 4) hipLaunchKernelGGL((attn_decode_wide_kernel<VD, NW, U, 4>), grid, dim3(NW * 64), lds, st, a);
-        else return false;
-    } else return false;
-    return true;
-}
-template <int VD>
-static bool launch_attn_wide(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, const SplitPlan &sp) {
-#define TL_WIDE(NWv, Uv) \
-    if (sp.nw == NWv && sp.u == Uv) return launch_attn_wide_npw<VD, NWv, Uv>(a, grid, st, sp.npw);
-    TL_WIDE(4, 4) TL_WIDE(4, 8) TL_WIDE(4, 16)
-    if constexpr (VD == 8) {
-        TL_WIDE(8, 4) TL_WIDE(8, 8) TL_WIDE(8, 16) TL_WIDE(16, 4) TL_WIDE(16, 8)
-    }
-#undef TL_WIDE
-    return false;
-}
-
 // Can the wo GEMV of ONE decode row take the attention split partials instead of the merged row (qmv3.hip,
 // launch_qmv3_attn_merge_bf16: the instantiated plans)?
-static bool wo_merge_applicable(const tl_engine *e, const tl_w4 &wo, int batch, const SplitPlan &sp, bool fused_merge) {
-    if (!e->wo_merges_attn || batch != 1 || sp.nw != 0 || fused_merge || e->force_linear != 0) return false;
+static bool wo_merge_applicable(const tl_engine *e, const tl_w4 &wo, int batch, const SplitPlan &sp) {
+    if (!e->wo_merges_attn || batch != 1 || e->force_linear != 0) return false;
     if (sp.n_splits != 2 && sp.n_splits != 4 && sp.n_splits != 8) return false;
     if (e->cfg.head_dim != 128 || wo.cols != e->cfg.num_heads * 128 || e->tiled.count(wo.weight_dev) == 0) return false;
     if (1 >= e->qmm3_min_rows && e->use_qmm3) return false;  // a single row would not take the GEMV
@@ -569,12 +507,8 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
         if ((1 << sh) == c.page_size) a.page_shift = sh;
     a.rope_cur = e->rope_cur;
     a.prof = pc ? pc->buf : nullptr;
-    // 2 .. 8 splits of the looped kernel: merged by the last workgroup to arrive; more splits (long contexts) keep the
-    // column-parallel merge launch -- one workgroup folding hundreds of partial rows would be a serial tail
-    const bool fused_merge = e->attn_fused_merge && e->attn_counters != nullptr && sp.nw == 0 && n_splits > 1 && n_splits <= 8 && chunks <= 4;
-    a.merge_counters = fused_merge ? e->attn_counters : nullptr;
     if (qkv_parts && qkv_parts->partial) {
-        TL_REQUIRE(sp.nw == 0 && attn_takes_qkv_partials(D, sp.rq), "engine: this decode-attention plan does not read qkv slice partials");
+        TL_REQUIRE(attn_takes_qkv_partials(D, sp.rq), "engine: this decode-attention plan does not read qkv slice partials");
         a.qkv_partial = qkv_parts->partial;
         a.qkv_slices = qkv_parts->slices;
         a.qkv_plane = qkv_parts->plane;
@@ -582,29 +516,18 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
     TL_REQUIRE((size_t)batch * c.num_heads * n_splits * (D + 2) * sizeof(float) <= e->attn_ws_bytes || n_splits == 1,
                "engine: attention workspace too small for this split plan");
     const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
-    if (sp.nw > 0) {
-        bool ok = false;
-        switch (D) {
-            case 128: ok = launch_attn_wide<8>(a, grid, e->stream, sp); break;
-            case 64: ok = launch_attn_wide<4>(a, grid, e->stream, sp); break;
-            case 32: ok = launch_attn_wide<2>(a, grid, e->stream, sp); break;
-            default: break;
-        }
-        if (!ok) return fail(TL_ERR_UNSUPPORTED, "engine: no wide decode-attention kernel for this plan");
-    } else {
-        switch (D) {
-            case 128: launch_attn_decode<8>(a, grid, e->stream, sp.rq); break;
-            case 64: launch_attn_decode<4>(a, grid, e->stream, sp.rq); break;
-            case 32: launch_attn_decode<2>(a, grid, e->stream, sp.rq); break;
-            default: return fail(TL_ERR_UNSUPPORTED, "engine: head_dim must be 32, 64 or 128");
-        }
+    switch (D) {
+        case 128: launch_attn_decode<8>(a, grid, e->stream, sp.rq); break;
+        case 64: launch_attn_decode<4>(a, grid, e->stream, sp.rq); break;
+        case 32: launch_attn_decode<2>(a, grid, e->stream, sp.rq); break;
+        default: return fail(TL_ERR_UNSUPPORTED, "engine: head_dim must be 32, 64 or 128");
     }
     if (pc) prof_after(e, pc, 5, (int)(grid.x * grid.y * grid.z));
     // the consumer (the wo GEMV of a single row) merges the partials itself: no merge launch, `out` is not written
-    const bool leave_merge = merging_wo != nullptr && merge_left != nullptr && wo_merge_applicable(e, *merging_wo, batch, sp, fused_merge);
+    const bool leave_merge = merging_wo != nullptr && merge_left != nullptr && wo_merge_applicable(e, *merging_wo, batch, sp);
     if (leave_merge) *merge_left = true;
-    e->last_attn_launches = 1 + ((n_splits > 1 && !fused_merge && !leave_merge) ? 1 : 0);
-    if (n_splits > 1 && !fused_merge && !leave_merge) {
+    e->last_attn_launches = 1 + ((n_splits > 1 && !leave_merge) ? 1 : 0);
+    if (n_splits > 1 && !leave_merge) {
         const dim3 mg(batch * c.num_heads), mb(128);
         prof_t *pb = pc ? pc->buf : nullptr;
         int merge_wg = batch * c.num_heads;
@@ -633,7 +556,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
         KeptPartials qkv_parts;
-        const bool keep_qkv = e->attn_qkv_partials && sp.nw == 0 && attn_takes_qkv_partials(c.head_dim, sp.rq);
+        const bool keep_qkv = e->attn_qkv_partials && attn_takes_qkv_partials(c.head_dim, sp.rq);
         TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0,
                              x_ss ? e->ss_x : nullptr, nullptr, nullptr, keep_qkv ? &qkv_parts : nullptr, x_ss));
         bool merge_left = false;
@@ -853,7 +776,6 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
                                                                                          c.max_pages_per_seq, c.num_heads,
                                                                                          c.num_kv_heads, 0));
     const size_t o_ws = carve(e->attn_ws_bytes);
-    const size_t o_cnt = carve((size_t)c.max_batch * c.num_kv_heads * 4 * sizeof(unsigned int));
     e->arena_bytes = off;
 
     auto cleanup_fail = [&](const std::string &msg) {
@@ -904,10 +826,6 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->act = (uint16_t *)(A + o_act);
     e->logits = (uint16_t *)(A + o_log);
     e->attn_ws = (float *)(A + o_ws);
-    e->attn_counters = (unsigned int *)(A + o_cnt);
-    if (hipMemsetAsync(e->attn_counters, 0, (size_t)c.max_batch * c.num_kv_heads * 4 * sizeof(unsigned int), e->stream) != hipSuccess)
-        return cleanup_fail("engine_create: memset(attention counters) failed");
-    if (const char *q = getenv("TL_ATTN_FUSED_MERGE")) e->attn_fused_merge = atoi(q) != 0;
     e->verify_ids = (int32_t *)(A + o_vid);
     e->ss_x = (float *)(A + o_ssx);
     e->ss_h = (float *)(A + o_ssh);
@@ -923,9 +841,6 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e->attn_rq1_batch = atoi(q);
     if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q));
-    if (const char *q = getenv("TL_ATTN_WIDE_MAX")) e->attn_wide_max = std::min(512, std::max(0, atoi(q)));
-    if (const char *q = getenv("TL_ATTN_NW")) e->attn_wide_nw = (atoi(q) == 4 || atoi(q) == 8 || atoi(q) == 16) ? atoi(q) : 0;
-    e->attn_wide_vector_ids = getenv("TL_ATTN_VECTOR_IDS") != nullptr;
 
     // state words: zero everything up to the activations, then the block table to -1
     if (hipMemsetAsync(e->arena, 0, o_x, e->stream) != hipSuccess) return cleanup_fail("engine_create: memset failed");
@@ -1491,6 +1406,15 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
             const auto key = std::make_pair(batch, sp.key());
             auto it = e->graphs.find(key);
             if (it == e->graphs.end()) {
+                // The split plan (and with it the key) changes every 64 * n_splits tokens of context: a long run would keep one
+                // ~220-node executable graph per plan and row bucket for ever.  Plans are visited in order of growing context, so
+                // when the cache is full the old ones are dead: drop them all (a live plan is re-captured once, ~0.3 ms).
+                if (e->graphs.size() >= 48) {
+                    TL_HIP(hipStreamSynchronize(e->stream));
+                    for (auto &kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+                    e->graphs.clear();
+                    e->stats.graph_cache_flushes++;
+                }
                 hipGraph_t graph = nullptr;
                 TL_HIP(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
                 const int rc = enqueue_step(e, batch, sp);
@@ -1579,7 +1503,7 @@ extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *
     // largest grid of the step: the lm_head GEMV (4 rows per workgroup at worst) or the attention grid
     const int max_wg = std::max(c.vocab_size / 4 + 64, 64 * 4 * c.num_kv_heads * batch) + 1024;
     ProfCtx pc;
-    pc.cap = c.num_layers * 8 + 8;
+    pc.cap = c.num_layers * 12 + 8;  // up to 11 launches per layer at 5 .. 64 rows (four skinny matmuls + reductions, attention, merge, norms)
     TL_HIP(hipStreamSynchronize(e->stream));
     TL_HIP(hipMalloc((void **)&pc.buf, (size_t)max_wg * 2 * sizeof(prof_t)));
     TL_HIP(hipMalloc((void **)&pc.pairs, (size_t)pc.cap * 2 * sizeof(prof_t)));
@@ -1761,7 +1685,6 @@ __global__ __launch_bounds__(64) void rope_rows_kernel(const int32_t *__restrict
 extern "C" size_t tl_decode_attention_fused_workspace_bytes(int batch, int num_heads, int head_dim) {
     if (batch <= 0 || num_heads <= 0 || head_dim <= 0) return 0;
     return align_up((size_t)batch * (head_dim / 2) * sizeof(float2), 256) +
-           align_up((size_t)batch * num_heads * 4 * sizeof(unsigned int), 256) +  // arrival counters (<= Hq KV heads x 4 chunks)
            (size_t)batch * num_heads * 256 * (head_dim + 2) * sizeof(float);
 }
 
@@ -1793,20 +1716,13 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
     e.context_lens = const_cast<int32_t *>(context_lens_dev);
     e.rope_cur = (float2 *)workspace_dev;
     const size_t rc_bytes = align_up((size_t)batch * (head_dim / 2) * sizeof(float2), 256);
-    const size_t cnt_bytes = align_up((size_t)batch * num_heads * 4 * sizeof(unsigned int), 256);
-    e.attn_counters = (unsigned int *)((char *)workspace_dev + rc_bytes);
-    TL_REQUIRE(hipMemsetAsync(e.attn_counters, 0, cnt_bytes, e.stream) == hipSuccess, "decode_attention_fused: memset failed");
-    e.attn_ws = (float *)((char *)workspace_dev + rc_bytes + cnt_bytes);
-    e.attn_ws_bytes = workspace_bytes - rc_bytes - cnt_bytes;
-    if (const char *q = getenv("TL_ATTN_FUSED_MERGE")) e.attn_fused_merge = atoi(q) != 0;
+    e.attn_ws = (float *)((char *)workspace_dev + rc_bytes);
+    e.attn_ws_bytes = workspace_bytes - rc_bytes;
     if (const char *q = getenv("TL_ATTN_RQ")) e.attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e.attn_rq1_ctx = atoi(q);
     if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e.attn_rq1_batch = atoi(q);
     if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e.attn_max_splits = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e.attn_min_tokens = std::max(64, atoi(q));
-    if (const char *q = getenv("TL_ATTN_WIDE_MAX")) e.attn_wide_max = std::min(512, std::max(0, atoi(q)));
-    if (const char *q = getenv("TL_ATTN_NW")) e.attn_wide_nw = (atoi(q) == 4 || atoi(q) == 8 || atoi(q) == 16) ? atoi(q) : 0;
-    e.attn_wide_vector_ids = getenv("TL_ATTN_VECTOR_IDS") != nullptr;
     hipLaunchKernelGGL(rope_rows_kernel, dim3(batch), dim3(64), 0, e.stream, context_lens_dev, e.rope_cur, head_dim / 2, rope_theta);
     TL_CHECK_LAUNCH("decode_attention_fused rope");
     const SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
@@ -1817,9 +1733,6 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
         info->n_splits = sp.n_splits;
         info->tokens_per_split = sp.tokens_per_split;
         info->heads_per_workgroup = sp.rq;
-        info->wide_waves = sp.nw;
-        info->wide_rows_in_flight = sp.u;
-        info->scalar_page_ids = sp.npw;
         info->launches = e.last_attn_launches;
     }
     return rc;

@@ -76,7 +76,7 @@ __device__ __forceinline__ void head_norm_rope(const uint16_t *src, const uint16
 #pragma unroll
     for (int i = 0; i < VD; ++i) {
         const float n = bf16_round(f[i] * inv * g[i]);
-        const float partner = __shfl_xor(n, 8, 64);
+        const float partner = dpp_row_ror<8>(n);  // lane t ^ 8 of the 16-lane group
         const float r = (t < 8) ? (n * cs[i] - partner * sn[i]) : (n * cs[i] + partner * sn[i]);
         out[i] = bf16_round(r);
     }
@@ -136,7 +136,7 @@ __device__ __forceinline__ float group16_allsum(float v) {
 //   the append slot}; every load is unconditional from a clamped address (hipcc waits at the join of any divergent
 //   branch that contains a load).
 //   The token being decoded never round-trips through HBM: its K/V come from registers (split 0) and are written to
-//   the page by one group.  n_splits == 1 writes the output row, otherwise (m, l, acc) partials for the merge kernel.
+//   the page by one group.  n_splits == 1 writes the output row, otherwise (m, l, acc) partials for the merge kernel (or the merging wo GEMV, qmv3.h).
 //   reference semantics: paged_attention.metal:108-248 (decode), paged_cache_update :82-106,
 //   qwen3_week3.py:63-86 for the op order.
 // ---------------------------------------------------------------------------------------------
@@ -155,11 +155,7 @@ struct AttnDecodeArgs {
     int split_shift;  // log2(n_splits): the split count is a power of two
     int rep;          // query heads per KV head
     int page_shift;   // log2(page_size), or -1 when the page size is not a power of two (then: integer division)
-    // attn_decode_fused_kernel, 2 .. 8 splits: one arrival counter per (sequence, KV head, head chunk), zero between launches.
-    // The workgroup that arrives last merges the splits itself (no merge launch); nullptr = partials only.
-    unsigned int *merge_counters;
     prof_t *prof;
-    // (new members go below `prof`: the offsets of everything above are what the tuned kernels were compiled against)
     // attn_decode_fused_kernel<.., QP = true> (TL_ATTN_QKV_PARTIALS=1): the qkv projection ran as the K-sliced skinny matmul and
     // its slice reduction was NOT launched -- the rows arrive as qkv_slices fp32 planes [slice][batch][(Hq + 2 Hkv) D]
     // (plane stride qkv_plane elements), added here in slice order and rounded once, exactly as qmm3_reduce_kernel does.
@@ -563,18 +559,10 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             p.out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : vs / gl);
         } else {
             float *w = p.ws + (orow * p.n_splits + split) * STRIDE;
-            if (p.merge_counters != nullptr) {  // read by another workgroup of THIS launch: device-coherent stores (below)
-                __hip_atomic_store(w + d, vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (d == 0) {
-                    __hip_atomic_store(w + D, gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(w + D + 1, gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else {
-                w[d] = vs;
-                if (d == 0) {
-                    w[D] = gm;
-                    w[D + 1] = gl;
-                }
+            w[d] = vs;
+            if (d == 0) {
+                w[D] = gm;
+                w[D + 1] = gl;
             }
         }
     }
@@ -585,292 +573,6 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         const long off = (((long)wpage * Hkv + kvh) * p.page_size + wslot) * D + t * VD;
         store_row<VD>(p.key_pages + off, k_new);
         store_raw<VD>(p.value_pages + off, vraw_new);
-    }
-    // ---- 2 .. 8 splits: the last workgroup to arrive merges them (what attn_merge_kernel did in a launch of its own: one
-    // launch boundary and ~1.3 us of kernel per layer of a decode step).  The splits may run on other XCDs, behind other L2s.
-    // A device-scope release/acquire fence pair would make the partials visible, but it writes back and invalidates whole L2s
-    // per workgroup (measured: 105 -> 1,117 us of attention per step).  Instead only the partials themselves are coherent:
-    // relaxed device-scope atomic stores / loads (sc1: written through to, and read from, the memory side), and the arrival
-    // counter is bumped after the workgroup's stores have been acknowledged (vmcnt(0) + barrier).  The splits are folded in
-    // index order, whoever arrives last: the result does not depend on the timing.  The counter returns to zero.
-    if (p.merge_counters != nullptr && p.n_splits > 1) {
-        __shared__ int s_last;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned int *cnt = p.merge_counters + ((long)b * Hkv + kvh) * p.n_row_chunks + chunk;
-            const unsigned int prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = prev == (unsigned int)(p.n_splits - 1);
-            if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (s_last) {
-            for (int item = threadIdx.x; item < RQ * D; item += 256) {
-                const int r = item / D;
-                const int d = item - r * D;
-                const int hq = chunk * RQ + r;
-                if (hq >= rep) continue;
-                const long orow = (long)b * Hq + kvh * rep + hq;
-                const float *base = p.ws + orow * p.n_splits * STRIDE;
-                float ms[8], ls[8], vs[8];
-#pragma unroll
-                for (int s2 = 0; s2 < 8; ++s2) {
-                    const float *rowp = base + (long)min(s2, p.n_splits - 1) * STRIDE;
-                    ms[s2] = __hip_atomic_load(rowp + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ls[s2] = __hip_atomic_load(rowp + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vs[s2] = __hip_atomic_load(rowp + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                float gm = -1e30f;
-#pragma unroll
-                for (int s2 = 0; s2 < 8; ++s2)
-                    if (s2 < p.n_splits) gm = fmaxf(gm, ms[s2]);
-                float gl = 0.f, accm = 0.f;
-#pragma unroll
-                for (int s2 = 0; s2 < 8; ++s2) {
-                    if (s2 < p.n_splits) {
-                        const float f = exp2_hw(ms[s2] - gm);
-                        gl += ls[s2] * f;
-                        accm += vs[s2] * f;
-                    }
-                }
-                p.out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : accm / gl);
-            }
-        }
-    }
-    prof_end(p.prof, prof_t0);
-}
-
-// ---------------------------------------------------------------------------------------------
-// "Wide" decode attention (L = 1): ONE query head per workgroup, the WHOLE token window in flight at once, no loop.
-//   grid = (n_splits * rep, Hkv, batch); workgroup = NW waves = G = 4 NW groups of 16 lanes; window W = G * U tokens
-//   (= tokens_per_split); token (u, g) = window start + u * G + g, so a wave-load covers 4 consecutive 256-B rows.
-// Why it exists (profiles/README.md): at short context the split kernel above + its merge launch cost 2.9 + 1.05 us of
-// kernel time and two boundaries per layer; every extra 64-token window of its loop costs a further full memory round
-// trip because only one window is prefetched.  Here all 2 U row loads of a lane are issued back to back (K rows first:
-// the scores start while the V rows are still landing), contexts up to 512 tokens need no split and therefore no merge
-// launch, and the partial results meet inside the workgroup: the 4 groups of a wave by two xor-butterflies, the waves
-// through NW rows of LDS.
-//   NPW > 0: the window's NPW page ids are wave-uniform scalar loads (window = NPW whole pages, or a window inside one
-//   page): the K/V addresses then do not wait for a vector round trip.  NPW = 0: any page size, ids by vector loads.
-// Same arithmetic, rounding points and masks as attn_decode_fused_kernel (reference: paged_attention.metal:108-248,
-// paged_cache_update :82-106, qwen3_week3.py:63-86).
-// ---------------------------------------------------------------------------------------------
-template <int VD, int NW, int U, int NPW>
-__global__ __launch_bounds__(NW * 64) void attn_decode_wide_kernel(const AttnDecodeArgs p) {
-    constexpr int D = 16 * VD;
-    constexpr int STRIDE = D + 2;
-    constexpr int G = 4 * NW;
-    extern __shared__ __attribute__((aligned(16))) float psm[];  // [NW][STRIDE]
-    const prof_t prof_t0 = prof_begin(p.prof);
-    const int bx = __builtin_amdgcn_readfirstlane(blockIdx.x);
-    const int split = bx & (p.n_splits - 1);
-    const int hq_in = bx >> p.split_shift;  // query head inside the GQA group
-    const int kvh = __builtin_amdgcn_readfirstlane(blockIdx.y);
-    const int b = __builtin_amdgcn_readfirstlane(blockIdx.z);
-    const int Hq = p.num_heads, Hkv = p.num_kv_heads;
-    const int rep = p.rep;
-    auto page_of = [&](int tok) { return p.page_shift >= 0 ? (tok >> p.page_shift) : tok / p.page_size; };
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = threadIdx.x >> 4;
-    const int t = threadIdx.x & 15;
-    const int32_t *brow = p.block_table + (long)b * p.max_pages;
-    const uint16_t *row = p.qkv + (long)b * (Hq + 2 * Hkv) * D;
-    const float scale_log2 = p.scale * ENG_LOG2E;
-    const int t_begin = split * (G * U);
-    const int hq = kvh * rep + hq_in;
-
-    // ---- round trip 1 -------------------------------------------------------------------------------------------------
-    int ctx, first_page;
-    sload_i32(p.context_lens + b, ctx);
-    sload_i32(brow, first_page);
-    int pid_s[NPW > 0 ? NPW : 1];
-    const int fp = page_of(t_begin);
-    if constexpr (NPW > 0) {
-#pragma unroll
-        for (int j = 0; j < NPW; ++j) sload_i32(brow + min(fp + j, p.max_pages - 1), pid_s[j]);
-    }
-    int pid[U];
-    if constexpr (NPW == 0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) pid[u] = brow[min(page_of(t_begin + u * G + g), p.max_pages - 1)];
-    }
-    RawRow<VD> kraw_new, vraw_new, qraw, qw, kw;
-    load_raw<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
-    load_raw<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
-    load_raw<VD>(p.q_norm_w + t * VD, qw);
-    load_raw<VD>(p.k_norm_w + t * VD, kw);
-    load_raw<VD>(row + (long)hq * D + t * VD, qraw);
-    float cs[VD], sn[VD];
-    rope_from_table<VD>(p.rope_cur + (long)b * (D / 2), t, cs, sn);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NPW == 0) {
-        sload_wait(ctx, first_page);
-    } else if constexpr (NPW == 1) {
-        sload_wait(ctx, first_page, pid_s[0]);
-    } else if constexpr (NPW == 2) {
-        sload_wait(ctx, first_page, pid_s[0], pid_s[1]);
-    } else {
-        static_assert(NPW == 4, "NPW is 0, 1, 2 or 4");
-        sload_wait(ctx, first_page, pid_s[0], pid_s[1], pid_s[2], pid_s[3]);
-    }
-    const bool live = first_page >= 0;  // idle slots have an all -1 row and produce zeros
-
-    // ---- round trip 2: every K row, then every V row of the window -----------------------------------------------------
-    const int wp = page_of(ctx);
-    const int wslot = ctx - wp * p.page_size;
-    int wpage;
-    sload_i32(brow + min(wp, p.max_pages - 1), wpage);  // waited for at the very end of the kernel
-    RawRow<VD> kr[U], vr[U];
-    bool ok[U];
-    long off[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int tok = t_begin + u * G + g;
-        int id, lp;
-        if constexpr (NPW == 0) {
-            id = pid[u];
-            lp = page_of(tok);
-        } else if constexpr (NPW == 1) {
-            id = pid_s[0];
-            lp = fp;
-        } else {
-            const int j = (u * G) >> p.page_shift;  // wave-uniform: G divides the page size and the window is page aligned
-            id = pid_s[0];
-#pragma unroll
-            for (int q = 1; q < NPW; ++q) id = j == q ? pid_s[q] : id;
-            lp = fp + j;
-        }
-        const int slot = tok - lp * p.page_size;
-        ok[u] = tok < ctx && lp < p.max_pages && id >= 0;
-        off[u] = (((long)max(id, 0) * Hkv + kvh) * p.page_size + slot) * D + t * VD;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) load_raw<VD>(p.key_pages + off[u], kr[u]);
-#pragma unroll
-    for (int u = 0; u < U; ++u) load_raw<VD>(p.value_pages + off[u], vr[u]);
-
-    // ---- prologue math while the rows are in flight ---------------------------------------------------------------------
-    auto norm_rope = [&](const RawRow<VD> &x, const RawRow<VD> &w, float (&out)[VD]) {
-        float f[VD];
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < VD; ++i) {
-            f[i] = BF16::to_float(x.v[i]);
-            ss += f[i] * f[i];
-        }
-        ss = group16_allsum(ss);
-        const float inv = rsqrtf(ss / (float)D + p.eps);
-#pragma unroll
-        for (int i = 0; i < VD; ++i) {
-            const float n = bf16_round(f[i] * inv * BF16::to_float(w.v[i]));
-            const float partner = row_ror<8>(n);
-            const float r2 = (t < 8) ? (n * cs[i] - partner * sn[i]) : (n * cs[i] + partner * sn[i]);
-            out[i] = bf16_round(r2);
-        }
-    };
-    float k_new[VD], v_new[VD], qv[VD], acc[VD];
-    norm_rope(kraw_new, kw, k_new);
-    {
-        float qn[VD];
-        norm_rope(qraw, qw, qn);
-#pragma unroll
-        for (int i = 0; i < VD; ++i) {
-            v_new[i] = BF16::to_float(vraw_new.v[i]);
-            qv[i] = qn[i] * scale_log2;
-            acc[i] = 0.f;
-        }
-    }
-
-    // ---- scores of the whole window, one rescale, then the weighted V rows ------------------------------------------------
-    float sc[U];
-    float m = -1e30f;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        float part = 0.f;
-#pragma unroll
-        for (int i = 0; i < VD; ++i) part += qv[i] * BF16::to_float(kr[u].v[i]);
-        sc[u] = (ok[u] && live) ? group16_allsum(part) : -1e30f;
-        m = fmaxf(m, sc[u]);
-    }
-    float l = 0.f;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const float pw = (ok[u] && live) ? exp2_hw(sc[u] - m) : 0.f;
-        l += pw;
-#pragma unroll
-        for (int i = 0; i < VD; ++i) acc[i] += pw * BF16::to_float(vr[u].v[i]);
-    }
-    // the token being decoded (position ctx), straight from registers
-    if (split == 0) {
-        float part = 0.f;
-#pragma unroll
-        for (int i = 0; i < VD; ++i) part += qv[i] * k_new[i];
-        const float score = group16_allsum(part);
-        if (live && g == 0) {
-            const float nm = fmaxf(m, score);
-            const float of = exp2_hw(m - nm);
-            const float sf = exp2_hw(score - nm);
-            l = l * of + sf;
-#pragma unroll
-            for (int i = 0; i < VD; ++i) acc[i] = acc[i] * of + sf * v_new[i];
-            m = nm;
-        }
-    }
-
-    // ---- the 4 groups of a wave: two butterflies (every group ends with the wave's total) ---------------------------------
-#pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-        const float om = __shfl_xor(m, o, 64);
-        const float ol = __shfl_xor(l, o, 64);
-        const float nm = fmaxf(m, om);
-        const float f1 = exp2_hw(m - nm), f2 = exp2_hw(om - nm);
-        l = l * f1 + ol * f2;
-#pragma unroll
-        for (int i = 0; i < VD; ++i) acc[i] = acc[i] * f1 + __shfl_xor(acc[i], o, 64) * f2;
-        m = nm;
-    }
-    // ---- the NW waves: through LDS -----------------------------------------------------------------------------------------
-    if ((threadIdx.x & 63) < 16) {
-        float *dst = psm + (long)wave * STRIDE;
-#pragma unroll
-        for (int i = 0; i < VD; ++i) dst[t * VD + i] = acc[i];
-        if (t == 0) {
-            dst[D] = m;
-            dst[D + 1] = l;
-        }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < D) {
-        const int d = threadIdx.x;
-        float gm = -1e30f;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) gm = fmaxf(gm, psm[(long)j * STRIDE + D]);
-        float gl = 0.f, vs = 0.f;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const float *src = psm + (long)j * STRIDE;
-            const float f = exp2_hw(src[D] - gm);
-            gl += src[D + 1] * f;
-            vs += src[d] * f;
-        }
-        const long orow = (long)b * Hq + hq;
-        if (p.n_splits == 1) {
-            p.out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : vs / gl);
-        } else {
-            float *w = p.ws + (orow * p.n_splits + split) * STRIDE;
-            w[d] = vs;
-            if (d == 0) {
-                w[D] = gm;
-                w[D + 1] = gl;
-            }
-        }
-    }
-    // append the new token's K (normed + roped) and V to the slot's page, off the critical path
-    sload_wait(wpage);
-    if (live && wp < p.max_pages && wpage >= 0 && split == 0 && hq_in == 0 && g == 0) {
-        const long woff = (((long)wpage * Hkv + kvh) * p.page_size + wslot) * D + t * VD;
-        store_row<VD>(p.key_pages + woff, k_new);
-        store_raw<VD>(p.value_pages + woff, vraw_new);
     }
     prof_end(p.prof, prof_t0);
 }

@@ -513,6 +513,7 @@ inline Qmm3Plan qmm3_plan(int M, int N, int K, int mode = -1) {
         pl.LM = 4;
         for (int lm : cand) {
             if (qmm3_lds_bytes(pl.MB, lm) > 100 * 1024) continue;
+            if (pl.MB == 4 && pl.TW == 2 && lm == 5) continue;  // 64 rows x 2 tiles per wave x 5 groups spilled 14 VGPRs: removed in round 3
             const int slices = (G + lm - 1) / lm;
             pl.LM = lm;
             if ((long)slices * pl.tile_groups >= 192 || lm == 4) break;

@@ -153,7 +153,7 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
         return hipGetLastError() == hipSuccess ? 0 : -1;                                                            \
     }
 #define QM3_LM(MBv, TWv) QM3_CASE(MBv, TWv, 4) QM3_CASE(MBv, TWv, 5) QM3_CASE(MBv, TWv, 8) QM3_CASE(MBv, TWv, 10)
-    QM3_LM(1, 1) QM3_LM(2, 1) QM3_CASE(4, 1, 4) QM3_CASE(4, 1, 5) QM3_CASE(4, 2, 4) QM3_CASE(4, 2, 5)
+    QM3_LM(1, 1) QM3_LM(2, 1) QM3_CASE(4, 1, 4) QM3_CASE(4, 1, 5) QM3_CASE(4, 2, 4)
 #undef QM3_LM
 #undef QM3_CASE
     return -2;

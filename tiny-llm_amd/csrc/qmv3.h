@@ -411,7 +411,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
         const bool live = tile_ok && arow < MR && arow < p.M;
         if constexpr (EPI == EPI_SWIGLU) {
             const float gv = bf16_round(acc[i2]);  // rows interleaved: even = gate_i, odd = up_i
-            const float uv = __shfl_down(gv, 1, 64);
+            const float uv = lane_xor1(gv);  // the odd lane next door holds up_i (only even lanes store)
             if (live && (r & 1) == 0)
                 p.out[(size_t)arow * (K >> 1) + (orow >> 1)] = BF16::from_float((gv / (1.0f + expf(-gv))) * uv);
         } else if constexpr (EPI == EPI_RESIDUAL) {

@@ -90,7 +90,8 @@ class TlEngineStats(ctypes.Structure):
     _fields_ = [("pages_in_use", _c_int), ("pages_free", _c_int), ("peak_pages_in_use", _c_int),
                 ("page_allocations", ctypes.c_long), ("reused_page_allocations", ctypes.c_long),
                 ("decode_steps", ctypes.c_long), ("graph_captures", ctypes.c_long), ("graph_replays", ctypes.c_long),
-                ("prefill_tokens", ctypes.c_long), ("kv_bytes", _c_size_t), ("workspace_bytes", _c_size_t)]
+                ("prefill_tokens", ctypes.c_long), ("kv_bytes", _c_size_t), ("workspace_bytes", _c_size_t),
+                ("graph_cache_flushes", ctypes.c_long)]
 
 
 class TlStepProfile(ctypes.Structure):
@@ -104,7 +105,6 @@ class TlLinearInfo(ctypes.Structure):
 
 class TlAttentionInfo(ctypes.Structure):
     _fields_ = [("n_splits", _c_int), ("tokens_per_split", _c_int), ("heads_per_workgroup", _c_int),
-                ("wide_waves", _c_int), ("wide_rows_in_flight", _c_int), ("scalar_page_ids", _c_int),
                 ("launches", _c_int)]
 
 

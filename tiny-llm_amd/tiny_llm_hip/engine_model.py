@@ -90,6 +90,11 @@ class Qwen3ModelFused:
                  logits_to_keep: int | None = None) -> torch.Tensor:
         if inputs.dim() != 2 or inputs.shape[0] != 1:
             raise ValueError("Qwen3ModelFused: one request per call ([1, L] token ids); batches go through batch_generate_ids")
+        if logits_to_keep not in (None, 1):
+            raise ValueError("Qwen3ModelFused returns the logits of the LAST position only (logits_to_keep must be None or 1): "
+                             "multi-position verification of speculative decoding goes through DecodeEngine.verify")
+        if mask is not None and not (isinstance(mask, str) and mask == "causal"):
+            raise ValueError("Qwen3ModelFused applies the causal mask itself; explicit masks are not supported")
         if not cache or not isinstance(cache[0], _SlotHandle) or not cache[0]._state["live"]:
             raise ValueError("Qwen3ModelFused: cache must come from this model's create_kv_cache() and not be released")
         state = cache[0]._state
