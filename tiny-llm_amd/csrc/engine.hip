@@ -513,7 +513,7 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
         a.qkv_slices = qkv_parts->slices;
         a.qkv_plane = qkv_parts->plane;
     }
-    TL_REQUIRE((size_t)batch * c.num_heads * n_splits * (D + 2) * sizeof(float) <= e->attn_ws_bytes || n_splits == 1,
+    TL_REQUIRE((size_t)batch * c.num_heads * n_splits * (D + ATTN_WS_PAD) * sizeof(float) <= e->attn_ws_bytes || n_splits == 1,
                "engine: attention workspace too small for this split plan");
     const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
     switch (D) {
@@ -769,8 +769,8 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const size_t o_ssh = carve((size_t)c.max_batch * ss_per_row * 4);
     // attention partials: decode (batch*Hq rows x 64 splits) or the L<=8 operator path during short prefills
     // decode partials: at most 64 splits per row with many sequences, at most 256 split-rows per head with few (pick_decode_splits)
-    e->attn_ws_bytes = std::max((size_t)std::max(c.max_batch * 64, 4 * 256) * c.num_heads * (c.head_dim + 2) * 4,
-                                (size_t)c.num_heads * 8 * 64 * (c.head_dim + 2) * 4);
+    e->attn_ws_bytes = std::max((size_t)std::max(c.max_batch * 64, 4 * 256) * c.num_heads * (c.head_dim + ATTN_WS_PAD) * 4,
+                                (size_t)c.num_heads * 8 * 64 * (c.head_dim + ATTN_WS_PAD) * 4);
     for (int L = 1; L <= c.max_prefill_rows; ++L)  // the paged attention operator may split the context for any chunk length
         e->attn_ws_bytes = std::max(e->attn_ws_bytes, tl_paged_attention_workspace_bytes(c.num_heads, L, c.head_dim, c.page_size,
                                                                                          c.max_pages_per_seq, c.num_heads,
@@ -1685,7 +1685,7 @@ __global__ __launch_bounds__(64) void rope_rows_kernel(const int32_t *__restrict
 extern "C" size_t tl_decode_attention_fused_workspace_bytes(int batch, int num_heads, int head_dim) {
     if (batch <= 0 || num_heads <= 0 || head_dim <= 0) return 0;
     return align_up((size_t)batch * (head_dim / 2) * sizeof(float2), 256) +
-           (size_t)batch * num_heads * 256 * (head_dim + 2) * sizeof(float);
+           (size_t)batch * num_heads * 256 * (head_dim + ATTN_WS_PAD) * sizeof(float);
 }
 
 extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,

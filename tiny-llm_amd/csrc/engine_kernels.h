@@ -140,6 +140,9 @@ __device__ __forceinline__ float group16_allsum(float v) {
 //   reference semantics: paged_attention.metal:108-248 (decode), paged_cache_update :82-106,
 //   qwen3_week3.py:63-86 for the op order.
 // ---------------------------------------------------------------------------------------------
+// row of split partials in global memory: D value sums + (max, sum) + 2 floats of padding, so that rows start on 16 bytes (the wo GEMV
+// that merges them reads them with 16-byte loads); the LDS rows inside the kernels keep D + 2
+constexpr int ATTN_WS_PAD = 4;
 struct AttnDecodeArgs {
     const uint16_t *qkv;  // [batch, (Hq + 2 Hkv) * D]
     const uint16_t *q_norm_w, *k_norm_w;
@@ -147,7 +150,7 @@ struct AttnDecodeArgs {
     const int32_t *block_table;         // [max_batch, max_pages]
     const int32_t *context_lens;        // [max_batch] tokens already cached (= position of the new token)
     uint16_t *out;                      // [batch, Hq * D]
-    float *ws;                          // [batch * Hq, n_splits, D + 2]
+    float *ws;                          // [batch * Hq, n_splits, D + 4]: D value sums, running max, running sum, 2 pad (16-byte rows)
     const float2 *rope_cur;             // [max_batch, D / 2] (cos, sin) of each slot's NEXT position, kept by step_end
     int page_size, max_pages, num_heads, num_kv_heads;
     float scale, eps, rope_base;
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         if (p.n_splits == 1) {
             p.out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : vs / gl);
         } else {
-            float *w = p.ws + (orow * p.n_splits + split) * STRIDE;
+            float *w = p.ws + (orow * p.n_splits + split) * (D + ATTN_WS_PAD);
             w[d] = vs;
             if (d == 0) {
                 w[D] = gm;
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict
                                                          int D, prof_t *prof) {
     const prof_t prof_t0 = prof_begin(prof);
     const long orow = blockIdx.x;
-    const int stride = D + 2;
+    const int stride = D + ATTN_WS_PAD;
     const float *base = ws + orow * NS * stride;
     const int d = threadIdx.x < D ? threadIdx.x : 0;
     float ms[NS], ls[NS], vs[NS];
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(256) void attn_merge_cols_kernel(const float *__res
     const long orow = blockIdx.x;
     const int c = threadIdx.x & 31, sg = threadIdx.x >> 5;
     const int d = min((int)blockIdx.y * 32 + c, D - 1);
-    const int stride = D + 2;
+    const int stride = D + ATTN_WS_PAD;
     const float *base = ws + orow * n_splits * stride;
     float m = -1e30f, l = 0.f, acc = 0.f;
     for (int s0 = sg; s0 < n_splits; s0 += 64) {

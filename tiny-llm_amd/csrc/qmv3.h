@@ -48,7 +48,7 @@ struct Qmv3Args {
     int ablate;  // lab only: 1 = skip MFMA math, 2 = skip the staging arithmetic / LDS stores, 4 = skip the activation loads
 #endif
     // PRO_ATTN_MERGE (the wo projection of a single decode row, TL_WO_MERGES_ATTN=1): `a` is not read; the activation row is
-    // the merge of the decode-attention kernel's split partials merge_ws [head][NS][128 + 2] (value sums, running max, running
+    // the merge of the decode-attention kernel's split partials merge_ws [head][NS][128 + 4] (value sums, running max, running
     // sum; head dimension 128, N = heads * 128), formed while the row is staged -- attn_merge_kernel's arithmetic, term for
     // term, so the staged bf16 row has the bits that kernel would have written; its launch is dropped.
     const float *merge_ws;
@@ -136,18 +136,20 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
     // PRO_ATTN_MERGE: chunk cc = 8 columns of head cc / 16; per split its 8 value sums and the head's (max, sum) pair
     constexpr int MS = PRO == PRO_ATTN_MERGE ? NS : 1;
     constexpr int MCCU = PRO == PRO_ATTN_MERGE ? 2 : 1;  // chunk sets a merging thread owns: the launcher admits N / 8 <= 2 T only
-    f32x2 mval[MCCU][MS][4], mml[MCCU][MS];
+    constexpr int MWS = 128 + 4;  // floats per partial row in merge_ws (engine_kernels.h, ATTN_WS_PAD): rows start on 16 bytes
+    f32x4 mval[MCCU][MS][2];
+    f32x2 mml[MCCU][MS];
     if constexpr (PRO == PRO_ATTN_MERGE) {
 #pragma unroll
         for (int k = 0; k < MCCU; ++k) {  // no branch around these loads: every thread reads from a clamped address
             const int cc = min(tid + k * T, cpr - 1);
-            const float *hb = p.merge_ws + (size_t)(cc >> 4) * NS * 130;
+            const float *hb = p.merge_ws + (size_t)(cc >> 4) * NS * MWS;
 #pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) mml[k][s2] = *reinterpret_cast<const f32x2 *>(hb + s2 * 130 + 128);
+            for (int s2 = 0; s2 < NS; ++s2) mml[k][s2] = *reinterpret_cast<const f32x2 *>(hb + s2 * MWS + 128);
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mval[k][s2][e] = *reinterpret_cast<const f32x2 *>(hb + s2 * 130 + (cc & 15) * 8 + 2 * e);
+                for (int e = 0; e < 2; ++e) mval[k][s2][e] = *reinterpret_cast<const f32x4 *>(hb + s2 * MWS + (cc & 15) * 8 + 4 * e);
         }
     }
     // producer-side sums of squares: the few partial loads go out first (they gate the normalisation of everything staged)
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
             for (int e = 0; e < 8; ++e) {
                 float acc1 = 0.f;
 #pragma unroll
-                for (int s2 = 0; s2 < NS; ++s2) acc1 += mval[k][s2][e >> 1][e & 1] * f2[s2];
+                for (int s2 = 0; s2 < NS; ++s2) acc1 += mval[k][s2][e >> 2][e & 3] * f2[s2];
                 o[e] = gl == 0.f ? 0.f : acc1 / gl;
             }
             const bool okc = reg_path && tid + k * T < cpr;
