@@ -81,6 +81,37 @@ def assert_bf16_close(got, want, ulps: float = 2.0, abs_floor: float = 0.0, what
                              f"worst at {i}: got {got[i]!r}, want {want[i]!r}")
 
 
+def ulp_of(x, dtype: str) -> np.ndarray:
+    """Spacing of `dtype` ("bf16" / "f16" / "f32") at |x| (f16 subnormals: the fixed spacing 2^-24)."""
+    x = np.maximum(np.abs(np.asarray(x, dtype=np.float64)), 2.0 ** -126)
+    e = np.floor(np.log2(x))
+    if dtype == "bf16":
+        return 2.0 ** (e - 7)
+    if dtype == "f16":
+        return 2.0 ** (np.maximum(e, -14) - 10)
+    return 2.0 ** (e - 23)
+
+
+def assert_rounded_close(got, want, dtype: str, ulps: float = 1.0, floor=0.0, what: str = ""):
+    """Per-element operator tolerance (replaces a whole-tensor atol scaled by the largest output, which hid relative errors on
+    small outputs): |got - want| <= ulps * ulp_dtype(want) + floor.  `want` is the oracle's result -- float64 accumulation, ONE
+    rounding to `dtype`; the kernel accumulates in fp32 in another order and rounds once, so it lands within one ulp of `want`
+    wherever the value is not small against the partial sums it was formed from.  That case is `floor`, which the caller
+    derives from the magnitudes that were summed (e.g. 2^-20 * sum |a_k w_k| = 16 fp32 steps of the absolute sum)."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    assert_within(got, want, ulps * ulp_of(want, dtype) + np.asarray(floor, dtype=np.float64), what)
+
+
+def w4_abs_dot(a, packed, scales, biases, dtype: str) -> np.ndarray:
+    """sum_k |a[m, k]| |w[n, k]| in float64 for W4 weights: the absolute sum a dot product's fp32 accumulation error scales with."""
+    from oracle import tiny_oracle as O
+
+    w = np.abs(np.asarray(O.dequantize_weights(packed, scales, biases, dtype=dtype), dtype=np.float64))
+    return np.abs(np.asarray(a, dtype=np.float64)) @ w.T
+
+
 def assert_within(got, want, allowed, what: str = ""):
     """|got - want| <= allowed elementwise (allowed: an array derived by the caller from the magnitudes that were rounded)."""
     got = np.asarray(got, dtype=np.float64)

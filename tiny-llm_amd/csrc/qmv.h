@@ -60,6 +60,7 @@ template <>
 struct Dot2<BF16> {
     static constexpr uint32_t MAGIC = 0x43004300u;
     static constexpr float OFFSET = 128.0f;
+    __device__ __forceinline__ static uint32_t unbias(uint32_t w) { return w; }
     __device__ __forceinline__ static float dot(uint32_t w, uint32_t x, float acc) {
         return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, x), acc,
                                                false);
@@ -67,8 +68,15 @@ struct Dot2<BF16> {
 };
 template <>
 struct Dot2<F16> {
+    // 0x6400 | q = 1024 + q.  Left in place, the offset costs ten of the fp32 accumulator's bits (sum a (1024 + q) - 1024 sum a
+    // cancels to a value 2^-10 of its operands): a few f16 steps of error in the result, found by the per-element tolerances of
+    // round 3.  One packed f16 add takes the offset out exactly (1024 + q and q are both f16 values), so the dot product runs on q.
     static constexpr uint32_t MAGIC = 0x64006400u;
-    static constexpr float OFFSET = 1024.0f;
+    static constexpr float OFFSET = 0.0f;
+    __device__ __forceinline__ static uint32_t unbias(uint32_t w) {
+        const f16x2_t off = {(_Float16)-1024.0f, (_Float16)-1024.0f};
+        return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2_t, w) + off);
+    }
     __device__ __forceinline__ static float dot(uint32_t w, uint32_t x, float acc) {
         return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w), __builtin_bit_cast(f16x2_t, x), acc, false);
     }
@@ -269,10 +277,10 @@ __global__ __launch_bounds__(256) void qmv_kernel(const QmvArgs p_in) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t w = cur.w[u][rp][q];
-                    pw[rp][q * 4 + 0] = (w & 0x000f000fu) | D2::MAGIC;
-                    pw[rp][q * 4 + 1] = ((w >> 4) & 0x000f000fu) | D2::MAGIC;
-                    pw[rp][q * 4 + 2] = ((w >> 8) & 0x000f000fu) | D2::MAGIC;
-                    pw[rp][q * 4 + 3] = ((w >> 12) & 0x000f000fu) | D2::MAGIC;
+                    pw[rp][q * 4 + 0] = D2::unbias((w & 0x000f000fu) | D2::MAGIC);
+                    pw[rp][q * 4 + 1] = D2::unbias(((w >> 4) & 0x000f000fu) | D2::MAGIC);
+                    pw[rp][q * 4 + 2] = D2::unbias(((w >> 8) & 0x000f000fu) | D2::MAGIC);
+                    pw[rp][q * 4 + 3] = D2::unbias(((w >> 12) & 0x000f000fu) | D2::MAGIC);
                 }
                 sc[rp] = TT::to_float(cur.s[u][rp]);
                 bo[rp] = TT::to_float(cur.b[u][rp]) - D2::OFFSET * sc[rp];
