@@ -164,16 +164,10 @@ def aggregate_value(n_gpus: int, steps: int, elapsed_max_s: float) -> float:
     return n_gpus * steps / elapsed_max_s
 
 
-def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_steps: int) -> dict:
-    """Time the plain-C port (oracle/) on the host cores on a bounded sample and use it as a checker."""
+def host_weights(mlx_model) -> dict:
+    """The checkpoint as host numpy arrays in the layout oracle/c_oracle.py takes."""
     import numpy as np
     import torch
-
-    from oracle import c_oracle
-
-    if not c_oracle.available():
-        return {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
-                "sample": "oracle/libqwen3_oracle.so missing (run __graft_entry__.build())"}
 
     def host_w4(layer):
         return (layer.weight.cpu().numpy().view(np.uint32), layer.scales.view(torch.int16).cpu().numpy().view(np.uint16),
@@ -190,7 +184,21 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
                            q_norm=host_norm(a.q_norm.weight), k_norm=host_norm(a.k_norm.weight),
                            input_norm=host_norm(layer.input_layernorm.weight),
                            post_norm=host_norm(layer.post_attention_layernorm.weight)))
-    weights = dict(embed=host_w4(mlx_model.model.embed_tokens), layers=layers, norm=host_norm(mlx_model.model.norm.weight))
+    return dict(embed=host_w4(mlx_model.model.embed_tokens), layers=layers, norm=host_norm(mlx_model.model.norm.weight))
+
+
+def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_steps: int) -> dict:
+    """Time the plain-C port (oracle/) on the host cores on a bounded sample and use it as a checker."""
+    import numpy as np
+    import torch
+
+    from oracle import c_oracle
+
+    if not c_oracle.available():
+        return {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
+                "sample": "oracle/libqwen3_oracle.so missing (run __graft_entry__.build())"}
+
+    weights = host_weights(mlx_model)
     # OpenMP fork/join per matvec (7 x 36 per token) stops scaling long before a 2-socket host runs out of cores
     cores = min(os.cpu_count() or 1, 32)
     model = c_oracle.COracleQwen3(cfg, weights, max_ctx=sample_prompt + sample_steps + 1, threads=cores)
@@ -255,6 +263,50 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
             "max_abs_logit_gpu_vs_cpu": round(worst_logit, 5), "gpu_vs_cpu_max_logprob_diff": round(worst, 4),
             "gpu_greedy_ids_vs_truth": f"{exact}/{len(truth_logits)} are the truth's argmax, {near}/{len(truth_logits)} within "
                                        f"2 x the engine's measured error of it"}
+
+
+def peaked_checkpoint_leg(cfg: dict, device: str, seed: int, steps: int = 8) -> dict:
+    """Greedy ids on a PEAKED synthetic checkpoint (tiny_llm_hip/synthetic.py: larger embedding, damped residual writers) must EQUAL
+    the float64 truth's: with N(0, 0.02) weights the top two of 151,936 logits lie within a rounding error of each other and id
+    agreement says little; here the margin is tens of bf16 steps.  The engine and the truth each follow their OWN greedy ids."""
+    import numpy as np
+
+    from oracle import c_oracle
+    from tiny_llm_hip.engine import DecodeEngine
+    from tiny_llm_hip.synthetic import synthetic_qwen3
+
+    if not c_oracle.available():
+        return {"checked": False, "why": "oracle/libqwen3_oracle.so missing"}
+    model = synthetic_qwen3(cfg, seed=seed + 7, sigma=0.02, device=device, embed_sigma=0.25, residual_gain=0.02)
+    prompt = build_prompt(random.Random(4321), 8, cfg["vocab_size"])
+    eng = DecodeEngine(model, page_size=128, num_pages=4, max_batch=1, max_prefill_rows=8)
+    try:
+        eng.begin(0)
+        eng.prefill(0, prompt, chunk=8)
+        gpu_logits = [eng.logits(1)[0].float().cpu().numpy()]
+        eng.decode(steps, batch=1)
+        gpu_ids = eng.read_tokens(0, steps + 1)
+        eng.release(0)
+    finally:
+        eng.close()
+    cores = min(os.cpu_count() or 1, 32)
+    truth = c_oracle.CTruthQwen3(cfg, host_weights(model), max_ctx=len(prompt) + steps + 2, threads=cores)
+    tid, tl = 0, None
+    for t in prompt:
+        tid, tl = truth.step(t)
+    truth_ids, margins = [tid], []
+    first_err = float(np.abs(gpu_logits[0].astype(np.float64) - tl).max())
+    for _ in range(steps):
+        top2 = np.partition(tl, -2)[-2:]
+        margins.append(float(top2[1] - top2[0]))
+        tid, tl = truth.step(truth_ids[-1])
+        truth_ids.append(tid)
+    truth.close()
+    same = sum(int(a == b) for a, b in zip(gpu_ids, truth_ids))
+    return {"checked": True, "recipe": "embed_sigma 0.25, residual_gain 0.02 (o_proj, down_proj), else N(0, 0.02); W4 g128",
+            "greedy_ids_equal_truth": f"{same}/{len(truth_ids)}", "all_equal": same == len(truth_ids),
+            "min_top2_margin_of_truth": round(min(margins), 3), "max_abs_logit_gpu_vs_truth_first_step": round(first_err, 4),
+            "gpu_ids": gpu_ids, "truth_ids": [int(t) for t in truth_ids]}
 
 
 def main() -> None:
@@ -422,6 +474,7 @@ def main() -> None:
     cpu = None
     if args.gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_leg(mlx_model, cfg, engine, sample_prompt=8, sample_steps=16)
+        cpu["peaked_checkpoint"] = peaked_checkpoint_leg(cfg, device, args.seed)
 
     out = {
         "metric": "Qwen3-4B int4 decode tokens/sec/GPU; achieved HBM GB/s vs roofline",

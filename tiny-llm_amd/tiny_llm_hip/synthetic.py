@@ -64,14 +64,20 @@ def _qlayer(weight: torch.Tensor) -> SimpleNamespace:
 
 
 def synthetic_qwen3(config: dict | str, seed: int = 0, sigma: float = 0.02, device: str = "cuda",
-                    norm_jitter: float = 0.05) -> SimpleNamespace:
-    """Random-weight Qwen3 in the mlx_lm object shape.  w ~ N(0, sigma) in bf16 -> W4 g128."""
+                    norm_jitter: float = 0.05, embed_sigma: float | None = None, residual_gain: float = 1.0) -> SimpleNamespace:
+    """Random-weight Qwen3 in the mlx_lm object shape.  w ~ N(0, sigma) in bf16 -> W4 g128.
+
+    embed_sigma / residual_gain build a PEAKED checkpoint: N(0, sigma) everywhere gives flat logits (the layers' outputs swamp the
+    embedding, the top two logits of 151,936 lie within a rounding error of each other, and "the greedy id equals the truth's" is
+    a coin toss there).  With a larger embedding (embed_sigma) and the two projections that write the residual stream (o_proj,
+    down_proj) scaled by residual_gain < 1, the stream keeps a clear component along the input token's embedding row and the tied
+    head answers with a margin far above any rounding error: greedy ids can be REQUIRED to equal the float64 truth's."""
     cfg = dict(QWEN3_CONFIGS[config]) if isinstance(config, str) else dict(config)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
 
-    def linear(out_dim: int, in_dim: int) -> SimpleNamespace:
-        w = (torch.randn((out_dim, in_dim), generator=gen, device=device, dtype=torch.float32) * sigma)
+    def linear(out_dim: int, in_dim: int, scale: float = sigma) -> SimpleNamespace:
+        w = (torch.randn((out_dim, in_dim), generator=gen, device=device, dtype=torch.float32) * scale)
         return _qlayer(w.to(torch.bfloat16))
 
     def norm(n: int) -> SimpleNamespace:
@@ -85,10 +91,11 @@ def synthetic_qwen3(config: dict | str, seed: int = 0, sigma: float = 0.02, devi
         layers.append(SimpleNamespace(
             self_attn=SimpleNamespace(
                 q_proj=linear(hq * hd, hs), k_proj=linear(hkv * hd, hs), v_proj=linear(hkv * hd, hs),
-                o_proj=linear(hs, hq * hd), q_norm=norm(hd), k_norm=norm(hd)),
-            mlp=SimpleNamespace(gate_proj=linear(inter, hs), up_proj=linear(inter, hs), down_proj=linear(hs, inter)),
+                o_proj=linear(hs, hq * hd, sigma * residual_gain), q_norm=norm(hd), k_norm=norm(hd)),
+            mlp=SimpleNamespace(gate_proj=linear(inter, hs), up_proj=linear(inter, hs), down_proj=linear(hs, inter, sigma * residual_gain)),
             input_layernorm=norm(hs), post_attention_layernorm=norm(hs)))
-    model = SimpleNamespace(embed_tokens=linear(cfg["vocab_size"], hs), layers=layers, norm=norm(hs))
+    model = SimpleNamespace(embed_tokens=linear(cfg["vocab_size"], hs, embed_sigma if embed_sigma is not None else sigma), layers=layers,
+                            norm=norm(hs))
     out = SimpleNamespace(args=SimpleNamespace(**cfg), model=model)
     if not cfg.get("tie_word_embeddings", True):
         out.lm_head = linear(cfg["vocab_size"], hs)
