@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Copy the artefacts of an evidence run (tools/gpu_call_n.sh -> gpurun_out/call_n) into profiles/ under their tracked names,
+"""Copy the artefacts of an evidence run (tools/gpu_evidence.sh -> gpurun_out/evidence) into profiles/ under their tracked names,
 and recompute each bench line's `roofline.rocprof` block from the rocprofv3 summary of the SAME run (bench.py on the GPU box
 reads the previously committed summary).
 
-    python tools/collect_evidence.py [--round r02] [--src gpurun_out/call_n]
+    python tools/collect_evidence.py [--round r02] [--src gpurun_out/evidence]
 """
 import argparse
 import json
@@ -13,12 +13,13 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tiny-llm_amd"))
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r02")
-    ap.add_argument("--src", type=Path, default=ROOT / "gpurun_out" / "call_n")
+    ap.add_argument("--round", default="r03")
+    ap.add_argument("--src", type=Path, default=ROOT / "gpurun_out" / "evidence")
     args = ap.parse_args()
     import bench
 
@@ -52,9 +53,18 @@ def main() -> None:
     for name, cfg in (("bench.json", 2), ("bench_c3.json", 3), ("bench_c5.json", 5)):
         line = json.loads((src / name).read_text().strip().splitlines()[-1])
         r = line["roofline"]
-        g_bytes = r["bytes_per_launch_avg"] * r["launches_per_step"]
-        rp = bench.rocprof_gemv_rate(traces / f"bench_config{cfg}_kernel_stats.csv", g_bytes)
+        from tiny_llm_hip.synthetic import QWEN3_CONFIGS
+
+        c = QWEN3_CONFIGS["qwen3-4b"]
+        w4 = lambda rows, cols: rows * cols / 2 + rows * (cols / 128) * 4
+        hs, inter, L = c["hidden_size"], c["intermediate_size"], c["num_hidden_layers"]
+        qkv_rows = (c["num_attention_heads"] + 2 * c["num_key_value_heads"]) * c["head_dim"]
+        kinds = {"gemv_qkv": {"bytes": L * w4(qkv_rows, hs)}, "gemv_o": {"bytes": L * w4(hs, c["num_attention_heads"] * c["head_dim"])},
+                 "gemv_gate_up": {"bytes": L * w4(2 * inter, hs)}, "gemv_down": {"bytes": L * w4(hs, inter)},
+                 "gemv_lm_head": {"bytes": w4(c["vocab_size"], hs)}}
+        rp = bench.rocprof_gemv_rate(traces / f"bench_config{cfg}_kernel_stats.csv", kinds, L)
         if rp:
+            rp["source"] = "rocprofv3 --kernel-trace --stats of the same command in the same evidence run (its own process; tools/evidence_run.sh)"
             rp["stamp_minus_rocprof_us_per_launch"] = round(rp["avg_launch_us"] - r["avg_launch_us"], 3)
             r["rocprof"] = rp
         (prof / f"{rnd}_bench_config{cfg}.json").write_text(json.dumps(line) + "\n")

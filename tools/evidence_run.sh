@@ -1,8 +1,9 @@
 #!/bin/bash
-# r02 call N (= call J re-run after the FlashAttention and stage-page changes): evidence run -- whole GPU suite, smoke, bench configs 2/3/5 (+ rocprofv3 kernel stats of each), batched decode
+# Evidence run of a round (copied into profiles/ by tools/collect_evidence.py): whole GPU suite (with the reference's own tests when staged:
+# tools/stage_reference_tests.sh), smoke, bench configs 2/3/5 (+ rocprofv3 kernel stats of each), batched decode
 # table, serving (one GPU, reference admission and packed admission), acceptance run, operator / attention microbenches.
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/call_n
+OUT=$R/gpurun_out/evidence
 mkdir -p $OUT
 cd $R
 export TMPDIR=/tmp
@@ -18,7 +19,7 @@ python - <<'PY'
 import json
 for c in ("bench","bench_c3","bench_c5"):
     try:
-        b=json.loads(open(f"gpurun_out/call_n/{c}.json").read().strip().splitlines()[-1]); r=b["roofline"]
+        b=json.loads(open(f"gpurun_out/evidence/{c}.json").read().strip().splitlines()[-1]); r=b["roofline"]
         print(c,b["value"],b["ms_per_step"],"prefill",b["prefill_tokens_per_s"],"frac",r["frac"],"step_frac",r["step_frac"],r.get("rocprof",{}).get("frac"),r["attention_kv"]["frac"])
     except Exception as e: print(c,"failed",e)
 PY
@@ -28,7 +29,7 @@ for B in 2 4 8 16 32 64; do
 done
 python - <<'PY'
 import json
-for l in open("gpurun_out/call_n/ab_batched.jsonl"):
+for l in open("gpurun_out/evidence/ab_batched.jsonl"):
     r=json.loads(l); print("batch",r["batch"],"ms/step",r["ms_per_step"],"tok/s",r["tokens_per_s"],"launches",r.get("launches"))
 PY
 timeout 900 python benches/serve_replicas.py --num-seqs 128 --batch-size 64 --json-output $OUT/replicas_n1.json > $OUT/replicas_n1.log 2>&1
