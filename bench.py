@@ -258,6 +258,9 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
             "sample": f"{sample_steps} decode steps after a {sample_prompt}-token prompt, same Qwen3-4B W4 checkpoint, "
                       f"oracle/qwen3_decode.c with OpenMP on {cores} threads",
             "truth": f"oracle/qwen3_truth.c (float64, no intermediate rounding), first {len(truth_logits)} steps",
+            "oracle_pins": "the numpy / C checkers are bit-identical in 16 bits to the reference's own Metal kernels compiled for the host (oracle/_ref) for the "
+                           "vanilla matmul, decode matvec, embedding, split-K reduce, RMSNorm, RoPE, SwiGLU, dense and paged decode attention; the tile GEMM and "
+                           "the MMA FlashAttention restatements follow the .metal text and are pinned by PyTorch only (MLX's steel headers are not in the reference tree)",
             "max_abs_logit_gpu_vs_truth": round(e_gpu, 5), "max_abs_logit_cpu_vs_truth": round(e_cpu, 5),
             "gpu_error_over_cpu_error": round(e_gpu / e_cpu, 3) if e_cpu > 0 else None,
             "max_abs_logit_gpu_vs_cpu": round(worst_logit, 5), "gpu_vs_cpu_max_logprob_diff": round(worst, 4),
