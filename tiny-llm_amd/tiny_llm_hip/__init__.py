@@ -22,3 +22,4 @@ from .models import *  # noqa: F401,F403
 from .moe import *  # noqa: F401,F403
 from .loader import load, load_weights, TokenizerWrapper  # noqa: F401
 from .week2_kernels import *  # noqa: F401,F403
+from .prefix import AgentError, KvPrefixGenerator, ModelCheckpoint, PrefixReuse  # noqa: F401

@@ -94,6 +94,7 @@ class DecodeEngine:
             args.head_dim, args.intermediate_size, args.vocab_size, float(args.rope_theta), float(args.rms_norm_eps),
             page_size, num_pages, max_batch, max_pages_per_seq, max_prefill_rows)
         self.page_size, self.max_batch, self.vocab_size = page_size, max_batch, args.vocab_size
+        self.num_hidden_layers = int(args.num_hidden_layers)
         self.device = emb.weight.device
         handle = ctypes.c_void_p()
         embed_c = embed.c()
