@@ -1553,6 +1553,16 @@ extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *
     out->n_splits = n_splits;
     const double us_per_tick = 1e3 / (double)rate_khz;
     prof_t first = ~0ull, last = 0;
+    // TL_PROFILE_DUMP=<file>: the raw (kind, first workgroup start, last wave end) stamps of this step, one line per launch, in
+    // ticks of the constant-rate device wall clock -- to be laid beside a rocprofv3 kernel trace of the same process (lab use)
+    if (const char *dump = getenv("TL_PROFILE_DUMP")) {
+        if (FILE *f = fopen(dump, "a")) {
+            fprintf(f, "step clock_khz %d launches %zu\n", rate_khz, pc.kinds.size());
+            for (size_t i = 0; i < pc.kinds.size(); ++i)
+                fprintf(f, "%d %llu %llu\n", pc.kinds[i], (unsigned long long)pairs[2 * i], (unsigned long long)pairs[2 * i + 1]);
+            fclose(f);
+        }
+    }
     for (size_t i = 0; i < pc.kinds.size(); ++i) {
         const prof_t t0 = pairs[2 * i], t1 = pairs[2 * i + 1];
         const double us = (t1 > t0 ? (double)(t1 - t0) : 0.0) * us_per_tick;
