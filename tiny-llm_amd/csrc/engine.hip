@@ -88,6 +88,7 @@ struct tl_engine {
     int attn_rq1_batch = 2;      // ... and up to this many sequences (TL_ATTN_RQ1_BATCH); at 4 the re-read windows cost 261 vs 180 us
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
     int attn_max_splits = 64;    // most context splits per sequence (TL_ATTN_MAX_SPLITS, a power of two <= 256)
+    int attn_max_splits_gqa = 32;  // ... when a workgroup takes a whole GQA group (TL_ATTN_MAX_SPLITS sets both)
     tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
     int force_linear = 0;               // kernel-level entry points: 1 = fused GEMV, 2 = skinny matmul
     int qmm3_mode = -1;                 // skinny matmul grid: -1 by shape (qmm3_plan), 0 one-shot, 1 persistent
@@ -394,7 +395,10 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // few sequences: split for latency (up to 2048 short-lived workgroups); many sequences: the chip is already full, longer
     // windows amortise the per-workgroup prologue and skip the merge launch (measured at 16 and 64 sequences)
     const int wg_cap = batch <= 4 ? 2048 : 512;
-    while (s * 2 <= bucket / min_tokens && s * 2 * base <= wg_cap && s * 2 <= e->attn_max_splits) s *= 2;  // >= min_tokens per workgroup
+    // a whole GQA group per workgroup (long contexts / several sequences): at most 32 windows -- one workgroup per CU for one sequence;
+    // measured at 8k 666 -> 680 tok/s against 64 windows, 32k unchanged (round 3)
+    const int max_splits = rq == AD_RQ ? e->attn_max_splits_gqa : e->attn_max_splits;
+    while (s * 2 <= bucket / min_tokens && s * 2 * base <= wg_cap && s * 2 <= max_splits) s *= 2;  // >= min_tokens per workgroup
     // Windows sized to the context, not to its power-of-two bucket: a workgroup walks its whole window in 64-token stages
     // whether or not the tokens exist, so a 33k context on a 64k bucket spent half of every window on masked loads (r02:
     // 63 us per layer in the step against 44 us for the same kernel on an exactly filled bucket).  The split COUNT stays a
@@ -839,7 +843,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (const char *q = getenv("TL_ATTN_RQ")) e->attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e->attn_rq1_ctx = atoi(q);
     if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e->attn_rq1_batch = atoi(q);
-    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = std::min(256, std::max(1, atoi(q)));
+    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = e->attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q));
 
     // state words: zero everything up to the activations, then the block table to -1
@@ -1731,7 +1735,7 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
     if (const char *q = getenv("TL_ATTN_RQ")) e.attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e.attn_rq1_ctx = atoi(q);
     if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e.attn_rq1_batch = atoi(q);
-    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e.attn_max_splits = std::min(256, std::max(1, atoi(q)));
+    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e.attn_max_splits = e.attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e.attn_min_tokens = std::max(64, atoi(q));
     hipLaunchKernelGGL(rope_rows_kernel, dim3(batch), dim3(64), 0, e.stream, context_lens_dev, e.rope_cur, head_dim / 2, rope_theta);
     TL_CHECK_LAUNCH("decode_attention_fused rope");
