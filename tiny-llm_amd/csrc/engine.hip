@@ -79,6 +79,11 @@ struct tl_engine {
     // TL_GEMV_PRODUCER_SS=0: the 1-4-row GEMVs re-derive the sum of squares of their input rows instead of adding the partials the
     // producing GEMV left (qmv3.h, ss_in / ss_out).  On by default: qkv -0.44 us, gate|up -1.1 us per layer (abl_lab, bit 8)
     bool gemv_producer_ss = true;
+    // The wo GEMV of 1-4 decode rows also leaves h * post_attention_layernorm (bf16) and the gate|up GEMV stages THAT row and
+    // multiplies its sums by the row's 1 / rms at the end (qmv3.h, PRO_RMS_WEIGHTED): the 1,216 workgroups of gate|up no longer
+    // fetch the norm weights and normalise the whole row each.  tools/lab/trace_lab, back to back: gate|up 7.82 -> 7.08 us, wo
+    // 3.91 -> 4.06; the qkv and lm_head GEMVs gain nothing from it and keep the fused RMSNorm.  TL_GEMV_WEIGHTED_ROWS=0: off.
+    bool gemv_weighted_rows = true;
     bool fuse_norm = true;                   // TL_QMM3_FUSED_NORM=0: RMSNorm ahead of a skinny matmul always as its own launch
     int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
@@ -166,7 +171,10 @@ static int check_w4(const tl_w4 &w, int rows, int cols, const char *name) {
 // EPI_RESIDUAL GEMV leaves those of `out` ([M][rows / 16]); *ss_out_n = partials per row actually written (0 = none).
 static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
                       const void *norm_w, const uint16_t *residual, ProfCtx *pc = nullptr, int kind = 0,
-                      const float *ss_in = nullptr, int ss_in_n = 0, float *ss_out = nullptr, int *ss_out_n = nullptr) {
+                      const float *ss_in = nullptr, int ss_in_n = 0, float *ss_out = nullptr, int *ss_out_n = nullptr,
+                      const void *norm_out = nullptr, uint16_t *out_w = nullptr) {
+    // norm_out / out_w (EPI_RESIDUAL): also leave out * norm_out for a PRO_RMS_WEIGHTED consumer; the caller has checked
+    // (weighted_rows_apply) that the MFMA GEMV takes all rows in one pass -- anything else is an error, not a silent fallback
     if (ss_out_n) *ss_out_n = 0;
     bool all_emitted = ss_out != nullptr && epi == EPI_RESIDUAL && e->gemv_producer_ss;
     int step = std::min(M, 8);  // both GEMV kernels hold at most 8 activation rows (MR <= 8): more rows go in passes of 8
@@ -206,8 +214,13 @@ static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
             a3.K = args.K;
             a3.prof = args.prof;
             if (e->gemv_producer_ss) {
-                if (pro == PRO_RMSNORM && ss_in && ss_in_n > 0) a3.ss_in = ss_in + (size_t)m0 * ss_in_n, a3.ss_n = ss_in_n;
+                if ((pro == PRO_RMSNORM || pro == PRO_RMS_WEIGHTED) && ss_in && ss_in_n > 0) a3.ss_in = ss_in + (size_t)m0 * ss_in_n, a3.ss_n = ss_in_n;
                 if (epi == EPI_RESIDUAL && ss_out) a3.ss_out = ss_out + (size_t)m0 * (w.rows / 16);
+            }
+            if (out_w) {
+                TL_REQUIRE(epi == EPI_RESIDUAL && norm_out && step == M, "engine: weighted rows need the residual epilogue and one pass");
+                a3.norm_out = (const uint16_t *)norm_out;
+                a3.out_w = out_w;
             }
             if (launch_qmv3_bf16(a3, pro, epi, e->stream) != 0)
                 return fail(TL_ERR_UNSUPPORTED, "engine: MFMA GEMV launch failed");
@@ -222,6 +235,7 @@ static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
             continue;
         }
         all_emitted = false;  // the packed-dot fallback leaves no partials
+        TL_REQUIRE(out_w == nullptr && pro != PRO_RMS_WEIGHTED, "engine: weighted rows are a route of the MFMA GEMV only");
         if (launch_qmv_fused_bf16(args, pro, epi, e->stream) != 0)
             return fail(TL_ERR_UNSUPPORTED, "engine: no GEMV configuration for this shape");
         if (pc) prof_after(e, pc, kind, qmv_plan(args.M, args.N, args.K).blocks);
@@ -287,6 +301,19 @@ static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
 // else nullptr.  ss_out / *ss_emitted: where the slice reduction should leave the partials of `out`, and whether it did.
 // keep (EPI_STORE only): the caller's consumer adds the slices itself -- the reduction launch is skipped and *keep says where the
 // fp32 planes are; `out` is then NOT written.  Left empty (partial == nullptr) when another kernel took the projection.
+// rows that engine_linear hands to the GEMV before it considers anything else
+static bool gemv_takes_rows(const tl_engine *e, int M) {
+    return e->force_linear == 1 || (e->force_linear != 2 && (M < e->qmm3_min_rows || (M <= 8 && !e->use_qmm3)));
+}
+// Can `producer` (EPI_RESIDUAL) leave its rows weighted for `consumer` (PRO_RMS_WEIGHTED)?  Both must be single-pass MFMA GEMVs,
+// the producer must leave the sums of squares, and the consumer's row must sit in its register chunks (qmv3.h, reg_path).
+static bool weighted_rows_apply(const tl_engine *e, const tl_w4 &producer, const tl_w4 &consumer, int M) {
+    if (!e->gemv_weighted_rows || !e->gemv_producer_ss || !gemv_takes_rows(e, M) || M > 8) return false;
+    if (e->tiled.count(producer.weight_dev) == 0 || e->tiled.count(consumer.weight_dev) == 0) return false;
+    const Qmv3Plan pp = qmv3_plan(M, producer.cols, producer.rows), pcn = qmv3_plan(M, consumer.cols, consumer.rows);
+    if (!pp.ok || !pcn.ok || producer.rows != consumer.cols) return false;
+    return qmv3_takes_weighted_rows(pcn, consumer.cols, producer.rows / 16);
+}
 struct KeptPartials {
     const float *partial = nullptr;
     int slices = 0;
@@ -295,16 +322,16 @@ struct KeptPartials {
 static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
                          const void *norm_w, const uint16_t *residual, ProfCtx *pc, int kind, const float *ss_in_any = nullptr,
                          float *ss_out = nullptr, bool *ss_emitted = nullptr, KeptPartials *keep = nullptr, int ss_in_n = QM3_SS,
-                         int *ss_out_n = nullptr) {
+                         int *ss_out_n = nullptr, const void *norm_out = nullptr, uint16_t *out_w = nullptr) {
     // ss_in_any holds ss_in_n partials per row; the skinny matmul reads exactly QM3_SS of them, the GEMV any number.
     // *ss_out_n (when asked for) = partials per row left in ss_out: QM3_SS by the slice reduction, rows / 16 by a GEMV, 0 = none
     if (ss_emitted) *ss_emitted = false;
     if (ss_out_n) *ss_out_n = 0;
     if (keep) *keep = KeptPartials{};
     const float *ss_in = ss_in_n == QM3_SS ? ss_in_any : nullptr;
-    if (e->force_linear == 1) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind, ss_in_any, ss_in_n, ss_out, ss_out_n);
-    if (e->force_linear != 2 && (M < e->qmm3_min_rows || (M <= 8 && !e->use_qmm3)))
-        return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind, ss_in_any, ss_in_n, ss_out, ss_out_n);
+    if (gemv_takes_rows(e, M))
+        return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind, ss_in_any, ss_in_n, ss_out, ss_out_n, norm_out, out_w);
+    TL_REQUIRE(out_w == nullptr && pro != PRO_RMS_WEIGHTED, "engine: weighted rows are a route of the GEMV only");
     const tl_engine_config &c = e->cfg;
     const uint16_t *in = a;
     // qmm3_min_rows .. 64 rows (batched decode): K-sliced skinny MFMA matmul over the tiled weights, then the slice
@@ -446,7 +473,7 @@ static bool wo_merge_applicable(const tl_engine *e, const tl_w4 &wo, int batch, 
 }
 // h = x + merge(attention partials) @ wo^T for one row.
 static int engine_wo_merge(tl_engine *e, const tl_w4 &wo, const uint16_t *residual, uint16_t *out, int n_splits, ProfCtx *pc,
-                           float *ss_out = nullptr, int *ss_out_n = nullptr) {
+                           float *ss_out = nullptr, int *ss_out_n = nullptr, const void *norm_out = nullptr, uint16_t *out_w = nullptr) {
     if (ss_out_n) *ss_out_n = 0;
     const auto tiled = e->tiled.find(wo.weight_dev);
     Qmv3Args a3{};
@@ -465,6 +492,7 @@ static int engine_wo_merge(tl_engine *e, const tl_w4 &wo, const uint16_t *residu
         a3.ss_out = ss_out;
         if (ss_out_n) *ss_out_n = wo.rows / 16;
     }
+    if (out_w) a3.norm_out = (const uint16_t *)norm_out, a3.out_w = out_w;
     if (launch_qmv3_attn_merge_bf16(a3, n_splits, e->stream) != 0)
         return fail(TL_ERR_UNSUPPORTED, "engine: no wo GEMV that merges the attention partials for this shape");
     if (pc) prof_after(e, pc, 1, qmv3_plan(1, wo.cols, wo.rows).blocks);
@@ -567,8 +595,16 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
         TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, &qkv_parts,
                                 &w.wo, &merge_left));
         int h_ss = 0;
-        if (merge_left) TL_TRY(engine_wo_merge(e, w.wo, e->x, e->h, sp.n_splits, pc, e->ss_h, &h_ss));
-        else TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, nullptr, nullptr, QM3_SS, &h_ss));
+        // h leaves the wo GEMV twice when the gate|up GEMV can take it weighted: as the residual stream and, in xn, times the
+        // post-attention norm weight
+        const bool weighted = weighted_rows_apply(e, w.wo, w.wgu, batch);
+        uint16_t *hw = weighted ? e->xn : nullptr;
+        if (merge_left) TL_TRY(engine_wo_merge(e, w.wo, e->x, e->h, sp.n_splits, pc, e->ss_h, &h_ss, w.post_norm_dev, hw));
+        else TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, nullptr, nullptr, QM3_SS, &h_ss, w.post_norm_dev, hw));
+        if (weighted) {
+            TL_REQUIRE(h_ss > 0, "engine: the wo GEMV left no sums of squares for its weighted rows");
+            TL_TRY(engine_linear(e, w.wgu, e->xn, e->act, batch, PRO_RMS_WEIGHTED, EPI_SWIGLU, nullptr, nullptr, pc, 2, e->ss_h, nullptr, nullptr, nullptr, h_ss));
+        } else
         TL_TRY(engine_linear(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2,
                              h_ss ? e->ss_h : nullptr, nullptr, nullptr, nullptr, h_ss));
         TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, nullptr, nullptr, QM3_SS, &x_ss));
@@ -835,6 +871,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->ss_h = (float *)(A + o_ssh);
     if (const char *q = getenv("TL_QMM3_FUSED_NORM")) e->fuse_norm = atoi(q) != 0;
     if (const char *q = getenv("TL_GEMV_PRODUCER_SS")) e->gemv_producer_ss = atoi(q) != 0;
+    if (const char *q = getenv("TL_GEMV_WEIGHTED_ROWS")) e->gemv_weighted_rows = atoi(q) != 0;
     if (const char *q = getenv("TL_ATTN_QKV_PARTIALS")) e->attn_qkv_partials = atoi(q) != 0;
     if (const char *q = getenv("TL_WO_MERGES_ATTN")) e->wo_merges_attn = atoi(q) != 0;
     if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;

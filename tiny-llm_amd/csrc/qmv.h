@@ -32,7 +32,7 @@
 
 namespace tl {
 
-enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN_MERGE = 2 };  // PRO_ATTN_MERGE: qmv3.h only (Qmv3Args::merge_ws)
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN_MERGE = 2, PRO_RMS_WEIGHTED = 3 };  // the last two: qmv3.h only (Qmv3Args::merge_ws / ::ss_in)
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2 };
 
 struct QmvArgs {

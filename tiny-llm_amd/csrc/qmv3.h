@@ -44,8 +44,16 @@ struct Qmv3Args {
     float eps;
     int M, N, K;
     prof_t *prof;
+#ifdef QMV3_TRACE  // lab only (tools/lab/trace_lab): wall-clock stamps of wave 0 at the phase boundaries, p.trace [blocks][8]
+#define Q3_STAMP(i) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define Q3_STAMP(i) do { } while (0)
+#endif
 #ifdef QMV3_LAB
     int ablate;  // lab only: 1 = skip MFMA math, 2 = skip the staging arithmetic / LDS stores, 4 = skip the activation loads
+#endif
+#ifdef QMV3_TRACE
+    unsigned long long *trace;  // lab only
 #endif
     // PRO_ATTN_MERGE (the wo projection of a single decode row, TL_WO_MERGES_ATTN=1): `a` is not read; the activation row is
     // the merge of the decode-attention kernel's split partials merge_ws [head][NS][128 + 4] (value sums, running max, running
@@ -60,8 +68,30 @@ struct Qmv3Args {
     const float *ss_in;
     int ss_n;
     float *ss_out;
+    // Rows weighted by their producer (round 3).  With the sums of squares handed over, what is left of the fused RMSNorm is work
+    // every workgroup repeats on the whole row: fetch the norm weights, multiply, round.  RMSNorm is x * inv * w with ONE scalar
+    // inv per row, so the GEMV is linear in it: out = inv * sum_n bf16(x_n w_n) W_kn.  An EPI_RESIDUAL GEMV therefore also
+    // leaves the row its consumer stages, out_w = bf16(out * norm_out) (the next RMSNorm's weight; 2 bytes more per element
+    // written once), and the consumer (PRO_RMS_WEIGHTED: `a` = out_w, ss_in required) stages it like a plain row and multiplies
+    // its accumulators by inv at the end -- the partial sums are not even waited for until then.  One bf16 rounding per staged
+    // element as in the reference (there of x * inv * w, here of x * w): same error bound, not the same bits.
+    const uint16_t *norm_out;  // [K]      EPI_RESIDUAL, optional
+    uint16_t *out_w;           // [M, K]   EPI_RESIDUAL, optional
 };
 
+// output stores (lab: -DQ3_STORE_MODE=1 nontemporal, 2 = system-scope atomic store, i.e. write-through)
+#ifndef Q3_STORE_MODE
+#define Q3_STORE_MODE 0
+#endif
+template <typename T> __device__ __forceinline__ void q3_store(T *ptr, T v) {
+#if Q3_STORE_MODE == 1
+    __builtin_nontemporal_store(v, ptr);
+#elif Q3_STORE_MODE == 2
+    __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    *ptr = v;
+#endif
+}
 #ifdef QMV3_LAB
 #define Q3_ABL(bit) (p.ablate & (bit))
 #else
@@ -105,6 +135,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
     constexpr int WR = CW / KS;
     constexpr int ROWS = MR < 4 ? MR : 4;  // accumulator rows a lane actually needs (lanes c > 0 only when MR > 4)
     const prof_t prof_t0 = prof_begin(p.prof);
+    Q3_STAMP(0);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the slice arithmetic on the SALU
     const int lane = tid & 63;
@@ -152,11 +183,24 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
                 for (int e = 0; e < 2; ++e) mval[k][s2][e] = *reinterpret_cast<const f32x4 *>(hb + s2 * MWS + (cc & 15) * 8 + 4 * e);
         }
     }
+    // EPI_RESIDUAL: the residual values and the consumer's norm weight of this lane's output element are fetched now, not by a
+    // dependent load in the tail of the kernel
+    const int orow = (tile_c << 4) + r;
+    uint16_t resv[ROWS], nwo = 0;
+    if constexpr (EPI == EPI_RESIDUAL) {
+#pragma unroll
+        for (int i2 = 0; i2 < ROWS; ++i2) {
+            const int arow = 4 * c + i2;
+            resv[i2] = p.residual[(size_t)((arow < MR && arow < p.M) ? arow : 0) * K + orow];
+        }
+        nwo = (p.out_w ? p.norm_out : p.residual)[orow];
+    }
     // producer-side sums of squares: the few partial loads go out first (they gate the normalisation of everything staged)
     // (ONE 16-byte load per lane and row: up to 256 partials per row, i.e. hidden sizes up to 4,096)
-    const bool ss_given = PRO == PRO_RMSNORM && p.ss_in != nullptr && reg_path && p.ss_n <= 256 && (p.ss_n & 3) == 0;
+    constexpr bool NORMED = PRO == PRO_RMSNORM || PRO == PRO_RMS_WEIGHTED;
+    const bool ss_given = NORMED && p.ss_in != nullptr && reg_path && p.ss_n <= 256 && (p.ss_n & 3) == 0;  // PRO_RMS_WEIGHTED: the launcher insists
     f32x4 ssv[MR];
-    if constexpr (PRO == PRO_RMSNORM) {
+    if constexpr (NORMED) {
 #pragma unroll
         for (int m = 0; m < MR; ++m) {  // unconditional load from a clamped address (no branch around a load), masked after
             const bool ok = ss_given && m < p.M && 4 * lane < p.ss_n;
@@ -189,6 +233,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
         else
             nwv[k] = u32x4{0u, 0u, 0u, 0u};
     }
+    Q3_STAMP(1);  // activation / partial loads issued
     __builtin_amdgcn_sched_barrier(0);  // activations first: vmcnt retires in issue order, and they are needed first
     u32x4 wq[LM];
     uint32_t sq[LM];
@@ -201,6 +246,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
         for (int i = 0; i < LM; ++i) wq[i] = __builtin_nontemporal_load(wp + (size_t)min(g0 + i, G - 1) * 64);
     }
     __builtin_amdgcn_sched_barrier(0);
+    Q3_STAMP(2);  // weight loads issued
 
     // ---- 2. activation rows -> LDS (bf16, natural order) + per-group sums; fused RMSNorm ----------------------------
     {
@@ -272,14 +318,17 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
     float inv[MR];
 #pragma unroll
     for (int m = 0; m < MR; ++m) inv[m] = 1.0f;
-    if constexpr (PRO == PRO_RMSNORM) {
-      if (ss_given) {  // uniform: every wave adds the row's partials in the same fixed order; no LDS, no barrier
+    auto inv_from_partials = [&]() {  // uniform: every wave adds the row's partials in the same fixed order; no LDS, no barrier
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
             float v = (ssv[m][0] + ssv[m][1]) + (ssv[m][2] + ssv[m][3]);  // partials 4 l .. 4 l + 3 of lane l
             v = wave_sum(v);
             inv[m] = rsqrtf(v / (float)N + p.eps);
         }
+    };
+    if constexpr (PRO == PRO_RMSNORM) {
+      if (ss_given) {
+        inv_from_partials();
       } else if (!Q3_ABL(8)) {  // lab only, bit 8: pretend the inverse RMS is known
         float ss[MR];
 #pragma unroll
@@ -346,6 +395,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
         }
     }
     __syncthreads();  // activations are staged
+    Q3_STAMP(3);  // activations staged
 
     float acc[ROWS];
 #pragma unroll
@@ -384,6 +434,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
         }
     }
 
+    Q3_STAMP(4);  // unpack + MFMA done (all weights landed)
     if constexpr (KS > 1) {
 #pragma unroll
         for (int i2 = 0; i2 < ROWS; ++i2) {
@@ -405,8 +456,12 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
         }
     }
 
+    if constexpr (PRO == PRO_RMS_WEIGHTED) {  // the rows were staged as x * w: the row's 1 / rms multiplies the finished sums
+        inv_from_partials();
+#pragma unroll
+        for (int i2 = 0; i2 < ROWS; ++i2) acc[i2] *= (MR > 4 && c == 1) ? inv[(4 + i2) % MR] : inv[i2 % MR];
+    }
     // epilogue: lane (weight row r, c) holds activation rows 4c .. 4c + ROWS - 1
-    const int orow = (tile_c << 4) + r;
 #pragma unroll
     for (int i2 = 0; i2 < ROWS; ++i2) {
         const int arow = 4 * c + i2;
@@ -415,23 +470,25 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
             const float gv = bf16_round(acc[i2]);  // rows interleaved: even = gate_i, odd = up_i
             const float uv = lane_xor1(gv);  // the odd lane next door holds up_i (only even lanes store)
             if (live && (r & 1) == 0)
-                p.out[(size_t)arow * (K >> 1) + (orow >> 1)] = BF16::from_float((gv / (1.0f + expf(-gv))) * uv);
+                q3_store(&p.out[(size_t)arow * (K >> 1) + (orow >> 1)], BF16::from_float((gv / (1.0f + expf(-gv))) * uv));
         } else if constexpr (EPI == EPI_RESIDUAL) {
             float sq_v = 0.f;
             if (live) {
                 const size_t o = (size_t)arow * K + orow;
-                const uint16_t ov = BF16::from_float(BF16::to_float(p.residual[o]) + bf16_round(acc[i2]));
-                p.out[o] = ov;
+                const uint16_t ov = BF16::from_float(BF16::to_float(resv[i2]) + bf16_round(acc[i2]));
+                q3_store(&p.out[o], ov);
                 sq_v = BF16::to_float(ov) * BF16::to_float(ov);
+                if (p.out_w) q3_store(&p.out_w[o], BF16::from_float(BF16::to_float(ov) * BF16::to_float(nwo)));
             }
             if (p.ss_out) {  // uniform.  One partial per (activation row, 16-row tile): the squares of the stored bf16 values
                 sq_v = group16_sum(sq_v);
-                if (r == 0 && tile_ok && arow < MR && arow < p.M) p.ss_out[(size_t)arow * tiles + tile_c] = sq_v;
+                if (r == 0 && tile_ok && arow < MR && arow < p.M) q3_store(&p.ss_out[(size_t)arow * tiles + tile_c], sq_v);
             }
         } else {
-            if (live) p.out[(size_t)arow * K + orow] = BF16::from_float(acc[i2]);
+            if (live) q3_store(&p.out[(size_t)arow * K + orow], BF16::from_float(acc[i2]));
         }
     }
+    Q3_STAMP(5);  // reduced and stored
     prof_end(p.prof, prof_t0);
 }
 
@@ -467,6 +524,11 @@ inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0, int force_cw = 
     pl.ok = K > 0 && K % 16 == 0 && N % 128 == 0 && M >= 1 && M <= 8 && (G + ks - 1) / ks <= Q3_LMAX &&
             pl.lds <= 150 * 1024;
     return pl;
+}
+
+// PRO_RMS_WEIGHTED: the row must sit in the staging registers of one pass and its sums of squares in one 16-byte load per lane
+inline bool qmv3_takes_weighted_rows(const Qmv3Plan &pl, int N, int ss_n) {
+    return pl.ok && N / 8 <= (pl.MR <= 2 ? 3 : 2) * pl.CW * 64 && ss_n > 0 && ss_n <= 256 && (ss_n & 3) == 0;
 }
 
 // qmv3.hip

@@ -108,6 +108,10 @@ int launch_qmv3_bf16(const Qmv3Args &args, int pro, int epi, hipStream_t st, int
     if (pro == PRO_RMSNORM && epi == EPI_STORE) return launch_variant3<PRO_RMSNORM, EPI_STORE>(args, st, force_ks, force_cw);
     if (pro == PRO_NONE && epi == EPI_RESIDUAL) return launch_variant3<PRO_NONE, EPI_RESIDUAL>(args, st, force_ks, force_cw);
     if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) return launch_variant3<PRO_RMSNORM, EPI_SWIGLU>(args, st, force_ks, force_cw);
+    if (pro == PRO_RMS_WEIGHTED && epi == EPI_SWIGLU) {  // the one consumer of weighted rows there is: gate|up
+        if (!args.ss_in || !qmv3_takes_weighted_rows(qmv3_plan(args.M, args.N, args.K, force_ks, force_cw), args.N, args.ss_n)) return -1;
+        return launch_variant3<PRO_RMS_WEIGHTED, EPI_SWIGLU>(args, st, force_ks, force_cw);
+    }
     return -2;
 }
 
