@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ key_pages, const uint16_t *__restrict__ value_pages,
     const int32_t *__restrict__ block_table, const int32_t *__restrict__ context_lens, uint16_t *__restrict__ out,
     float *__restrict__ ws, int n_splits, int L, int page_size, int page_shift, int max_pages, int num_heads, int num_kv_heads,
-    float scale, int is_causal) {
+    float scale, int is_causal, int xcd_remap) {
     constexpr int D = 128;
     __shared__ __attribute__((aligned(16))) uint16_t ks[FA_BK * D];     // [token][dim] swizzled
     __shared__ __attribute__((aligned(16))) uint16_t vt[D * FA_LDV];     // [dim][token]
@@ -354,15 +354,26 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     const int lane = tid & 63;
     const int l32 = lane & 31;
     const int h = lane >> 5;
-    const int kvh = blockIdx.y;
+    // XCD-aware order (xcd_remap): workgroups are dealt to the 8 XCDs round-robin in launch order, so in launch order the K/V
+    // pages of ONE kv head are streamed through all 8 L2s (4 MiB each; one head's K + V at 8k tokens is 4 MiB).  Remapped, the
+    // workgroups an XCD receives are one contiguous range of the (kv head, x) order: with 8 kv heads, one head per XCD.
+    int bx = blockIdx.x, kvh = blockIdx.y;
+    if (xcd_remap) {
+        const int gx = gridDim.x, T = gx * (int)gridDim.y;
+        const int l = blockIdx.x + gx * blockIdx.y;
+        const int c = l & 7;
+        const int t = c * (T >> 3) + min(c, T & 7) + (l >> 3);
+        kvh = t / gx;
+        bx = t - kvh * gx;
+    }
     const int b = blockIdx.z;
     const int rep = num_heads / num_kv_heads;
     const int QB = (L + 31) / 32;
     const int items = rep * QB;
-    // blockIdx.x = item block * n_splits + context split: with few query rows (chunked prefill of a long prompt) the KV
+    // bx = item block * n_splits + context split: with few query rows (chunked prefill of a long prompt) the KV
     // range is cut into n_splits pieces, one workgroup each, merged by paged_merge_kernel (flash-decoding style)
-    const int split = blockIdx.x % n_splits;
-    const int item_block = blockIdx.x / n_splits;
+    const int split = bx % n_splits;
+    const int item_block = bx / n_splits;
     const int item = item_block * 4 + wave;
     const bool wave_live = item < items;
     const int hq = wave_live ? item % rep : 0;
@@ -814,6 +825,7 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
         const size_t fa_need = fa_splits > 1 ? (size_t)N * L * fa_splits * (D + 2) * sizeof(float) : 0;
         if (fa_need > 0 && (!workspace || workspace_bytes < fa_need)) fa_splits = 1;  // no workspace: one pass, still correct
         const dim3 grid(item_blocks * fa_splits, num_kv_heads, B);
+        static const int fa_xcd_remap = getenv("TL_FA_XCD_REMAP") ? atoi(getenv("TL_FA_XCD_REMAP")) : 1;  // 0: launch order (lab A/B)
         int page_shift = -1;
         for (int sh = 0; sh < 30; ++sh)
             if ((1 << sh) == page_size) page_shift = sh;
@@ -821,12 +833,12 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
             hipLaunchKernelGGL(paged_fa_bf16_d128_kernel<true>, grid, dim3(256), 0, st, (const uint16_t *)q,
                                (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,
                                (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, page_shift, max_pages, num_heads,
-                               num_kv_heads, scale, is_causal);
+                               num_kv_heads, scale, is_causal, fa_xcd_remap);
         else
             hipLaunchKernelGGL(paged_fa_bf16_d128_kernel<false>, grid, dim3(256), 0, st, (const uint16_t *)q,
                                (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,
                                (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, page_shift, max_pages, num_heads,
-                               num_kv_heads, scale, is_causal);
+                               num_kv_heads, scale, is_causal, fa_xcd_remap);
         TL_CHECK_LAUNCH("paged_attention(prefill)");
         if (fa_splits > 1) {
             hipLaunchKernelGGL((paged_merge_kernel<BF16>), dim3(N * L), dim3(128), 0, st, (const float *)workspace,

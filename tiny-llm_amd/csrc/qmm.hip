@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
                                                        const uint16_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                        uint16_t *__restrict__ out, int M, int N, int K,
                                                        int partition_size, size_t partition_stride,
-                                                       const uint16_t *__restrict__ residual = nullptr) {
+                                                       const uint16_t *__restrict__ residual = nullptr, int xcd_remap = 0) {
     constexpr int NT = 64 * NW;
     constexpr int AQ = 32 * MT * 8 / NT;  // 16-byte activation chunks per thread and 64-wide reduction step
     static_assert(AQ >= 1 && AQ * NT == 32 * MT * 8, "the activation tile must divide evenly over the threads");
@@ -128,8 +128,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
     const int lane = tid & 63;
     const int l32 = lane & 31;
     const int h = lane >> 5;
-    const int bn0 = blockIdx.x * (32 * NW);
-    const int bm0 = blockIdx.y * BM;
+    // XCD-aware tile order (xcd_remap): workgroups go to the 8 XCDs round-robin in launch order and every XCD has its own 4 MiB L2.
+    // In launch order the column tiles of one row band are dealt over all 8 L2s and every L2 sees every activation row; remapped,
+    // the workgroups an XCD receives form one contiguous range of a band-major order (bands of gridDim.y / 8 row tiles, column
+    // by column inside a band): an XCD keeps a 256-row band of a 2,048-row chunk (1.3 MiB of activations) in its L2 and the weight
+    // tile of a column is fetched once per band.  A bijection of the tiles for any grid; only locality relies on the deal order.
+    int tx = blockIdx.x, ty = blockIdx.y;
+    if (xcd_remap) {
+        const int gx = gridDim.x, gy = gridDim.y, T = gx * gy;
+        const int l = blockIdx.x + gx * blockIdx.y;  // launch order inside this reduction slice: every 8th workgroup shares an XCD
+        const int c = l & 7;
+        const int t = c * (T >> 3) + min(c, T & 7) + (l >> 3);  // class c takes one contiguous range of the band-major order
+        const int R = max(1, gy >> 3);
+        const int band = t / (R * gx), rem = t - band * (R * gx);
+        const int rows = min(R, gy - band * R);
+        tx = rem / rows;
+        ty = band * R + (rem - tx * rows);
+    }
+    const int bn0 = tx * (32 * NW);
+    const int bm0 = ty * BM;
     const int red0 = blockIdx.z * partition_size;
     const int j0 = red0 >> 6;
     const int j1 = (red0 + partition_size) >> 6;
@@ -288,6 +305,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const uint16_t *
     }
 }
 
+// TL_QMM_XCD_REMAP=0: tiles in launch order (lab A/B of the XCD-aware order, qmm_mfma_kernel)
+static int qmm_xcd_remap() {
+    static const int v = getenv("TL_QMM_XCD_REMAP") ? atoi(getenv("TL_QMM_XCD_REMAP")) : 1;
+    return v;
+}
 static int mfma_mt(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
 // 8 waves (a 128 x 256 tile) for the widest projection at full chunks only -- r02 lab at 2,048 rows: gate|up 710 -> 781
 // TFLOP/s, but qkv 767 -> 660 and the split-K projections (o, down) 531 / 596 -> 470 / 517, and everything slower at 512 rows
@@ -378,12 +400,12 @@ static int run_qmm(const void *scales, const void *biases, const void *a, const 
         const int psize = N / split;
         const size_t pstride = (size_t)M * K;
         if (nw == 8) {
-            hipLaunchKernelGGL((qmm_mfma_kernel<TT, 4, 8>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride);
+            hipLaunchKernelGGL((qmm_mfma_kernel<TT, 4, 8>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr, qmm_xcd_remap());
         } else {
             switch (mt) {
-                case 1: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 1>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
-                case 2: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 2>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
-                default: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 4>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride); break;
+                case 1: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 1>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr, qmm_xcd_remap()); break;
+                case 2: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 2>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr, qmm_xcd_remap()); break;
+                default: hipLaunchKernelGGL((qmm_mfma_kernel<TT, 4>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr, qmm_xcd_remap()); break;
             }
         }
         if (split > 1) {
@@ -418,10 +440,10 @@ int qmm_bf16_epilogue(const void *scales, const void *biases, const uint16_t *A,
         const size_t need = (size_t)split * M * K * 2;
         if (!workspace || workspace_bytes < need) return fail(TL_ERR_INVALID, "qmm_bf16_epilogue: split-K workspace is missing or too small");
         uint16_t *dst = (uint16_t *)workspace;
-        if (nw == 8) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4, 8>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr);
-        else if (mt == 1) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 1>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr);
-        else if (mt == 2) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 2>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr);
-        else hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr);
+        if (nw == 8) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4, 8>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr, qmm_xcd_remap());
+        else if (mt == 1) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 1>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr, qmm_xcd_remap());
+        else if (mt == 2) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 2>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr, qmm_xcd_remap());
+        else hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr, qmm_xcd_remap());
         const size_t elements = (size_t)M * K;
         const dim3 rg(ceil_div(elements / 2, 256));
         if (epi == EPI_SWIGLU) hipLaunchKernelGGL((splitk_reduce_epi_kernel<BF16, EPI_SWIGLU>), rg, dim3(256), 0, st, dst, O, elements, split, residual);
@@ -429,10 +451,10 @@ int qmm_bf16_epilogue(const void *scales, const void *biases, const uint16_t *A,
         return TL_OK;
     }
 #define QMM_EPI_LAUNCH(EPIv)                                                                                                     \
-    if (nw == 8) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4, 8, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual); \
-    else if (mt == 1) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 1, 4, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual); \
-    else if (mt == 2) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 2, 4, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual); \
-    else hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4, 4, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual);
+    if (nw == 8) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4, 8, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual, qmm_xcd_remap()); \
+    else if (mt == 1) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 1, 4, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual, qmm_xcd_remap()); \
+    else if (mt == 2) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 2, 4, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual, qmm_xcd_remap()); \
+    else hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4, 4, EPIv>), grid, block, 0, st, S, Bi, A, b, O, M, N, K, psize, pstride, residual, qmm_xcd_remap());
     if (epi == EPI_SWIGLU) {
         QMM_EPI_LAUNCH(EPI_SWIGLU)
     } else {

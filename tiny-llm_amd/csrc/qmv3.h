@@ -507,11 +507,13 @@ inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0, int force_cw = 
     while (ks < 8 && (G + ks - 1) / ks > Q3_LMAX) ks *= 2;
     {
         // a grid of 1 .. 4 workgroups per CU with a ragged last round (gate|up: 608 workgroups on 256 CUs = 3 rounds for
-        // 2.4 rounds of work) runs faster cut twice as fine (measured 7.3 -> 6.9 us); smaller and larger grids do not
+        // 2.4 rounds of work) runs faster cut twice as fine (measured 7.3 -> 6.9 us); smaller and larger grids do not.
+        // Up to 4 rows since round 3 (tools/lab/plan_lab, gate|up with weighted rows: 2 rows 8.32 -> 7.47 us, 4 rows 10.05 -> 9.39;
+        // qkv and wo do not meet the condition and would lose: profiles/r03_labs/gemv_plan_sweep_rows_1_2_4.log)
         const int blocks = (tiles + (4 / ks) - 1) / (4 / (ks > 4 ? 4 : ks));
         const double x = blocks / 256.0;
         const double rounds = (double)(int)(x + 0.999999);
-        if (M == 1 && ks < 4 && x >= 1.0 && x < 4.0 && rounds / x > 1.2 && (G + 2 * ks - 1) / (2 * ks) >= 4) ks *= 2;
+        if (M <= 4 && ks < 4 && x >= 1.0 && x < 4.0 && rounds / x > 1.2 && (G + 2 * ks - 1) / (2 * ks) >= 4) ks *= 2;
     }
     if (force_ks > 0) ks = force_ks;
     pl.KS = ks;
