@@ -515,6 +515,10 @@ inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0, int force_cw = 
         const double rounds = (double)(int)(x + 0.999999);
         if (M <= 4 && ks < 4 && x >= 1.0 && x < 4.0 && rounds / x > 1.2 && (G + 2 * ks - 1) / (2 * ks) >= 4) ks *= 2;
     }
+    // four rows over a long reduction (w_down: 76 groups): 16 waves with 5 groups each stage the 4 x 9,728 activations and run
+    // their chains twice as fast as 8 waves with 10 (tools/lab/plan_lab: 9.50 -> 7.65 us; at 1 / 2 rows the 8-wave cut wins,
+    // 5.66 / 6.27 against 5.86 / 6.58)
+    if (pl.MR == 4 && ks == 8 && (G + 15) / 16 >= 4) ks = 16;
     if (force_ks > 0) ks = force_ks;
     pl.KS = ks;
     pl.CW = ks >= 8 ? ks : 4;

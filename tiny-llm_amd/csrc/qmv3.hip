@@ -66,6 +66,7 @@ static int launch_variant3(const Qmv3Args &args, hipStream_t st, int force_ks, i
 #define Q3_LM(MRv, KSv, CWv) Q3_CASE(MRv, KSv, CWv, 4) Q3_CASE(MRv, KSv, CWv, 5) Q3_CASE(MRv, KSv, CWv, 8) Q3_CASE(MRv, KSv, CWv, 10)
 #define Q3_MR(MRv) Q3_LM(MRv, 1, 4) Q3_LM(MRv, 2, 4) Q3_LM(MRv, 4, 4) Q3_LM(MRv, 8, 8) Q3_LM(MRv, 2, 8) Q3_LM(MRv, 4, 8)
     Q3_MR(1) Q3_MR(2) Q3_MR(4) Q3_MR(8)
+    Q3_CASE(4, 16, 16, 4) Q3_CASE(4, 16, 16, 5)  // qmv3_plan: four rows over a long reduction (8 x <= 10 groups cut 16 x <= 5)
 #undef Q3_LM
 #undef Q3_MR
 #undef Q3_CASE

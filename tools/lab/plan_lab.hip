@@ -60,4 +60,20 @@ template <int MR> void sweep() {
     run<MR, 2, 4, PRO_RMSNORM, EPI_SWIGLU, 10>("gate_up rms", 19456, 2560);
     run<MR, 8, 8, PRO_NONE, EPI_RESIDUAL, 10>("down", 2560, 9728);
 }
-int main() { sweep<1>(); sweep<2>(); sweep<4>(); return 0; }
+int main(int argc, char **argv) {
+    if (argc > 1) {  // the 16-wave question: w_down cut 16 ways along the reduction (5 groups per wave) against the planner's 8 x 10
+        run<1, 8, 8, PRO_NONE, EPI_RESIDUAL, 10>("down", 2560, 9728);
+        run<1, 16, 16, PRO_NONE, EPI_RESIDUAL, 5>("down", 2560, 9728);
+        run<2, 8, 8, PRO_NONE, EPI_RESIDUAL, 10>("down", 2560, 9728);
+        run<2, 16, 16, PRO_NONE, EPI_RESIDUAL, 5>("down", 2560, 9728);
+        run<4, 8, 8, PRO_NONE, EPI_RESIDUAL, 10>("down", 2560, 9728);
+        run<4, 16, 16, PRO_NONE, EPI_RESIDUAL, 5>("down", 2560, 9728);
+        run<1, 4, 4, PRO_NONE, EPI_RESIDUAL, 8>("wo", 2560, 4096);
+        run<1, 8, 8, PRO_NONE, EPI_RESIDUAL, 4>("wo", 2560, 4096);
+        run<1, 16, 16, PRO_NONE, EPI_RESIDUAL, 4>("wo", 2560, 4096);
+        run<1, 8, 8, PRO_NONE, EPI_RESIDUAL, 10>("down", 2560, 9728);
+        run<1, 16, 16, PRO_NONE, EPI_RESIDUAL, 5>("down", 2560, 9728);
+        return 0;
+    }
+    sweep<1>(); sweep<2>(); sweep<4>(); return 0;
+}
