@@ -46,6 +46,10 @@ PROJECTIONS = {
 # qmv3 template parameters the planner picks at ONE row (MR, KS, CW, LM): what bench.py's roofline kernel is
 GEMV_PLAN_M1 = {"qkv": (1, 2, 4, 10), "wo": (1, 4, 4, 8), "gate_up": (1, 4, 4, 5), "down": (1, 8, 8, 10),
                 "lm_head": (1, 2, 4, 10)}
+# ... and at 2 and 4 rows where they differ from one row by more than MR (round 3, tools/lab/plan_lab: gate|up keeps the finer cut up to
+# 4 rows, w_down takes 16 waves of 5 groups at 3-4 rows)
+GEMV_PLAN_ROWS = {("gate_up", 2): (2, 4, 4, 5), ("gate_up", 4): (4, 4, 4, 5), ("down", 2): (2, 8, 8, 10), ("down", 4): (4, 16, 16, 5),
+                  ("qkv", 2): (2, 2, 4, 10), ("qkv", 4): (4, 2, 4, 10), ("wo", 2): (2, 4, 4, 8), ("wo", 4): (4, 4, 4, 8)}
 MAX_ROWS = 64
 
 
@@ -151,6 +155,8 @@ def test_fused_gemv_at_qwen3_4b_shapes(ext, projection, M):
         assert info["kernel"] == 1, f"{what}: fell back to {info['kernel_name']}"
         if M == 1:
             assert tuple(info["p"][:4]) == GEMV_PLAN_M1[p.name], what
+        if (p.name, M) in GEMV_PLAN_ROWS and info["rows_per_pass"] == M:
+            assert tuple(info["p"][:4]) == GEMV_PLAN_ROWS[(p.name, M)], what
         if info["rows_per_pass"] == M:
             assert info["launches"] == 1, what
         _check(p, got, M, variant, what)

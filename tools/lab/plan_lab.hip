@@ -61,6 +61,22 @@ template <int MR> void sweep() {
     run<MR, 8, 8, PRO_NONE, EPI_RESIDUAL, 10>("down", 2560, 9728);
 }
 int main(int argc, char **argv) {
+    if (argc > 1 && atoi(argv[1]) == 8) {  // eight rows on the GEMV (the engine hands 5+ rows to the K-sliced skinny matmul instead)
+        run<8, 2, 4, PRO_RMSNORM, EPI_STORE, 10>("qkv", 6144, 2560);
+        run<8, 4, 4, PRO_RMSNORM, EPI_STORE, 5>("qkv", 6144, 2560);
+        run<8, 2, 8, PRO_RMSNORM, EPI_STORE, 10>("qkv", 6144, 2560);
+        run<8, 4, 8, PRO_RMSNORM, EPI_STORE, 5>("qkv", 6144, 2560);
+        run<8, 4, 4, PRO_NONE, EPI_RESIDUAL, 8>("wo", 2560, 4096);
+        run<8, 8, 8, PRO_NONE, EPI_RESIDUAL, 4>("wo", 2560, 4096);
+        run<8, 4, 8, PRO_NONE, EPI_RESIDUAL, 8>("wo", 2560, 4096);
+        run<8, 4, 4, PRO_RMS_WEIGHTED, EPI_SWIGLU, 5>("gate_up w", 19456, 2560);
+        run<8, 2, 4, PRO_RMS_WEIGHTED, EPI_SWIGLU, 10>("gate_up w", 19456, 2560);
+        run<8, 4, 8, PRO_RMS_WEIGHTED, EPI_SWIGLU, 5>("gate_up w", 19456, 2560);
+        run<8, 2, 8, PRO_RMS_WEIGHTED, EPI_SWIGLU, 10>("gate_up w", 19456, 2560);
+        run<8, 8, 8, PRO_RMS_WEIGHTED, EPI_SWIGLU, 4>("gate_up w", 19456, 2560);
+        run<8, 8, 8, PRO_NONE, EPI_RESIDUAL, 10>("down", 2560, 9728);
+        return 0;
+    }
     if (argc > 1) {  // the 16-wave question: w_down cut 16 ways along the reduction (5 groups per wave) against the planner's 8 x 10
         run<1, 8, 8, PRO_NONE, EPI_RESIDUAL, 10>("down", 2560, 9728);
         run<1, 16, 16, PRO_NONE, EPI_RESIDUAL, 5>("down", 2560, 9728);
