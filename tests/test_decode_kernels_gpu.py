@@ -291,9 +291,10 @@ def _check_attention(case, got, kp_after, vp_after, idle, what):
 
 @pytest.mark.parametrize("ctx", [0, 1, 63, 64, 127, 128, 255, 256, 300, 511, 512, 1000, 3000, 4095])
 def test_decode_attention_contexts_up_to_4k(ext, ctx, monkeypatch):
-    """One sequence, the plan the engine picks: one query head and a 64-token window per workgroup, partials merged by a second
-    launch at this kernel-level entry point (inside the engine the wo GEMV merges 2 / 4 / 8 windows itself)."""
-    for name in ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS"):
+    """One sequence, the plan the engine picks: one query head per workgroup and windows of a quarter of the context's power-of-two
+    bucket, between 64 and 256 tokens (round 3: 64-token windows up to 256 tokens of context, 8 windows at 2k, 16 at 4k), partials
+    merged by a second launch at this kernel-level entry point (inside the engine the wo GEMV merges 2 / 4 / 8 windows itself)."""
+    for name in ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS"):
         monkeypatch.delenv(name, raising=False)
     rng = np.random.default_rng(1000 + ctx)
     case = _attention_case(rng, [ctx])
@@ -301,7 +302,11 @@ def test_decode_attention_contexts_up_to_4k(ext, ctx, monkeypatch):
     what = f"ctx={ctx} {info}"
     assert info["heads_per_workgroup"] == 1, what
     assert info["n_splits"] * info["tokens_per_split"] >= ctx + 1, what
-    assert info["tokens_per_split"] == 64 or info["n_splits"] == 64, what
+    bucket = 64
+    while bucket < ctx + 1:
+        bucket *= 2
+    window = max(64, min(256, bucket // 4))
+    assert info["n_splits"] == max(1, bucket // window) and info["tokens_per_split"] <= window, what
     assert info["launches"] == (1 if info["n_splits"] == 1 else 2), what
     _check_attention(case, got, kpa, vpa, [False], what)
     log_parity({"what": "decode_attention", "ctx": ctx, "mode": "default", **info})

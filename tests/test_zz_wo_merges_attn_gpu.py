@@ -34,7 +34,7 @@ def run(model, prompt, steps, merging):
     old = os.environ.pop("TL_WO_MERGES_ATTN", None)
     os.environ["TL_WO_MERGES_ATTN"] = "1" if merging else "0"  # read when the engine is created (default since round 3: 1)
     try:
-        eng = DecodeEngine(model, page_size=128, num_pages=8, max_batch=1, max_prefill_rows=1024)
+        eng = DecodeEngine(model, page_size=128, num_pages=24, max_batch=1, max_prefill_rows=1024)
     finally:
         os.environ.pop("TL_WO_MERGES_ATTN", None)
         if old is not None:
@@ -53,10 +53,11 @@ def run(model, prompt, steps, merging):
     return first, tokens, logits, prof
 
 
-@pytest.mark.parametrize("prompt_len,splits", [(40, 1), (100, 2), (200, 4), (300, 8), (600, 16)])
+@pytest.mark.parametrize("prompt_len,splits", [(40, 1), (100, 2), (200, 4), (300, 4), (600, 4), (1200, 8), (2500, 16)])
 def test_same_bits_with_and_without_the_merge_launch(model, prompt_len, splits):
-    """Context buckets 64 / 128 / 256 / 512 / 1,024 tokens = 1 / 2 / 4 / 8 / 16 windows of 64 tokens: the wo GEMV merges 2, 4 and 8
-    partials; one window has nothing to merge and 16 keep the column-parallel merge launch (both routes then run the same kernels)."""
+    """Context buckets 64 / 128 / 256 tokens = 1 / 2 / 4 windows of 64 tokens, 512 / 1,024 = 4 windows of 128 / 256, 2,048 = 8 windows
+    of 256, 4,096 = 16 (windows are a quarter of the bucket, 64 .. 256 tokens): the wo GEMV merges 2, 4 and 8 partials; one window
+    has nothing to merge and 16 keep the column-parallel merge launch (both routes then run the same kernels)."""
     rng = np.random.default_rng(prompt_len)
     prompt = [int(t) for t in rng.integers(256, CFG["vocab_size"], size=prompt_len)]
     a = run(model, prompt, steps=5, merging=False)

@@ -92,6 +92,7 @@ struct tl_engine {
     int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup (TL_ATTN_RQ1_CTX)
     int attn_rq1_batch = 2;      // ... and up to this many sequences (TL_ATTN_RQ1_BATCH); at 4 the re-read windows cost 261 vs 180 us
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
+    bool attn_min_tokens_auto = true;  // ... unless one sequence with one query head per workgroup: by context (pick_decode_splits)
     int attn_max_splits = 64;    // most context splits per sequence (TL_ATTN_MAX_SPLITS, a power of two <= 256)
     int attn_max_splits_gqa = 32;  // ... when a workgroup takes a whole GQA group (TL_ATTN_MAX_SPLITS sets both)
     tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
@@ -418,7 +419,13 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     const int chunks = (rep + rq - 1) / rq;
     const int base = std::max(1, batch * e->cfg.num_kv_heads * chunks);
     int s = 1;
-    const int min_tokens = e->attn_min_tokens;
+    // One sequence, one query head per workgroup: windows grow with the context -- bucket / 4, between 64 and 256 tokens -- so that
+    // the wo GEMV can still merge them (2 / 4 / 8 windows, no merge launch) up to 2k tokens and 16 windows stand where 64 stood
+    // at 4k.  Round 3, decode_ab at contexts 300 / 700 / 1,500 / 3,000 (profiles/r03_labs/attention_window_size_by_context*.jsonl):
+    // 1.018 -> 1.014, 1.078 -> 1.060, 1.218 -> 1.143, 1.386 -> 1.246 ms per step; up to 256 tokens of context 64-token windows stay
+    // the best (128: 1.022 against 0.993).  TL_ATTN_MIN_TOKENS pins one size (lab).
+    int min_tokens = e->attn_min_tokens;
+    if (e->attn_min_tokens_auto && rq == 1 && batch == 1) min_tokens = std::max(64, std::min(256, bucket / 4));
     // few sequences: split for latency (up to 2048 short-lived workgroups); many sequences: the chip is already full, longer
     // windows amortise the per-workgroup prologue and skip the merge launch (measured at 16 and 64 sequences)
     const int wg_cap = batch <= 4 ? 2048 : 512;
@@ -881,7 +888,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e->attn_rq1_ctx = atoi(q);
     if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e->attn_rq1_batch = atoi(q);
     if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = e->attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
-    if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q));
+    if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q)), e->attn_min_tokens_auto = false;
 
     // state words: zero everything up to the activations, then the block table to -1
     if (hipMemsetAsync(e->arena, 0, o_x, e->stream) != hipSuccess) return cleanup_fail("engine_create: memset failed");
@@ -1773,7 +1780,7 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
     if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e.attn_rq1_ctx = atoi(q);
     if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e.attn_rq1_batch = atoi(q);
     if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e.attn_max_splits = e.attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
-    if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e.attn_min_tokens = std::max(64, atoi(q));
+    if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e.attn_min_tokens = std::max(64, atoi(q)), e.attn_min_tokens_auto = false;
     hipLaunchKernelGGL(rope_rows_kernel, dim3(batch), dim3(64), 0, e.stream, context_lens_dev, e.rope_cur, head_dim / 2, rope_theta);
     TL_CHECK_LAUNCH("decode_attention_fused rope");
     const SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
