@@ -92,7 +92,7 @@ struct tl_engine {
     int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup (TL_ATTN_RQ1_CTX)
     int attn_rq1_batch = 2;      // ... and up to this many sequences (TL_ATTN_RQ1_BATCH); at 4 the re-read windows cost 261 vs 180 us
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
-    bool attn_min_tokens_auto = true;  // ... unless one sequence with one query head per workgroup: by context (pick_decode_splits)
+    bool attn_min_tokens_auto = true;  // ... or more, by context and sequences (pick_decode_splits)
     int attn_max_splits = 64;    // most context splits per sequence (TL_ATTN_MAX_SPLITS, a power of two <= 256)
     int attn_max_splits_gqa = 32;  // ... when a workgroup takes a whole GQA group (TL_ATTN_MAX_SPLITS sets both)
     tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
@@ -419,13 +419,18 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     const int chunks = (rep + rq - 1) / rq;
     const int base = std::max(1, batch * e->cfg.num_kv_heads * chunks);
     int s = 1;
-    // One sequence, one query head per workgroup: windows grow with the context -- bucket / 4, between 64 and 256 tokens -- so that
-    // the wo GEMV can still merge them (2 / 4 / 8 windows, no merge launch) up to 2k tokens and 16 windows stand where 64 stood
-    // at 4k.  Round 3, decode_ab at contexts 300 / 700 / 1,500 / 3,000 (profiles/r03_labs/attention_window_size_by_context*.jsonl):
-    // 1.018 -> 1.014, 1.078 -> 1.060, 1.218 -> 1.143, 1.386 -> 1.246 ms per step; up to 256 tokens of context 64-token windows stay
-    // the best (128: 1.022 against 0.993).  TL_ATTN_MIN_TOKENS pins one size (lab).
+    // Windows grow with the context (round 3, tools/decode_ab.py; profiles/r03_labs/attention_window_size_*.jsonl).  Up to 512 tokens of
+    // context 64-token windows are the best at 1-4 sequences (one sequence at 200 tokens: 128-token windows 1.022 against 0.993 ms).
+    // Beyond, 256-token windows: one sequence 700 / 1,500 / 3,000 tokens 1.078 -> 1.060, 1.218 -> 1.143, 1.386 -> 1.246 ms per step (the wo
+    // GEMV still merges the 4 / 8 windows up to 2k tokens, 16 stand where 64 stood at 4k), two sequences 1.310 -> 1.245, 1.510 -> 1.361,
+    // 1.666 -> 1.540, four sequences at 1,000 tokens 1.762 -> 1.610.  Two exceptions at 257..512 tokens, both measured: one sequence
+    // 128-token windows (4 instead of 8 partials for the wo GEMV: 1.018 -> 1.014), 5-8 sequences 128 (1.882 -> 1.824 at 8).
+    // TL_ATTN_MIN_TOKENS pins one size (lab).
     int min_tokens = e->attn_min_tokens;
-    if (e->attn_min_tokens_auto && rq == 1 && batch == 1) min_tokens = std::max(64, std::min(256, bucket / 4));
+    if (e->attn_min_tokens_auto) {
+        if (bucket > 512 && batch <= 4) min_tokens = 256;
+        else if (bucket == 512 && (batch == 1 || (batch >= 5 && batch <= 8))) min_tokens = 128;
+    }
     // few sequences: split for latency (up to 2048 short-lived workgroups); many sequences: the chip is already full, longer
     // windows amortise the per-workgroup prologue and skip the merge launch (measured at 16 and 64 sequences)
     const int wg_cap = batch <= 4 ? 2048 : 512;
