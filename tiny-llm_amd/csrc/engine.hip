@@ -92,6 +92,7 @@ struct tl_engine {
     int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup (TL_ATTN_RQ1_CTX)
     int attn_rq1_batch = 2;      // ... and up to this many sequences (TL_ATTN_RQ1_BATCH); at 4 the re-read windows cost 261 vs 180 us
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
+    int attn_wg_cap = 0;         // most attention workgroups per launch; 0 = by sequences (pick_decode_splits)
     bool attn_min_tokens_auto = true;  // ... or more, by context and sequences (pick_decode_splits)
     int attn_max_splits = 64;    // most context splits per sequence (TL_ATTN_MAX_SPLITS, a power of two <= 256)
     int attn_max_splits_gqa = 32;  // ... when a workgroup takes a whole GQA group (TL_ATTN_MAX_SPLITS sets both)
@@ -435,7 +436,7 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     }
     // few sequences: split for latency (up to 2048 short-lived workgroups); many sequences: the chip is already full, longer
     // windows amortise the per-workgroup prologue and skip the merge launch (measured at 16 and 64 sequences)
-    const int wg_cap = batch <= 4 ? 2048 : 512;
+    const int wg_cap = e->attn_wg_cap > 0 ? e->attn_wg_cap : (batch <= 4 ? 2048 : 512);  // TL_ATTN_WG_CAP pins it (lab)
     // a whole GQA group per workgroup (long contexts / several sequences): at most 32 windows -- one workgroup per CU for one sequence;
     // measured at 8k 666 -> 680 tok/s against 64 windows, 32k unchanged (round 3)
     const int max_splits = rq == AD_RQ ? e->attn_max_splits_gqa : e->attn_max_splits;
@@ -896,6 +897,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e->attn_rq1_batch = atoi(q);
     if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = e->attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q)), e->attn_min_tokens_auto = false;
+    if (const char *q = getenv("TL_ATTN_WG_CAP")) e->attn_wg_cap = std::max(0, atoi(q));
 
     // state words: zero everything up to the activations, then the block table to -1
     if (hipMemsetAsync(e->arena, 0, o_x, e->stream) != hipSuccess) return cleanup_fail("engine_create: memset failed");
@@ -1788,6 +1790,7 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
     if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e.attn_rq1_batch = atoi(q);
     if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e.attn_max_splits = e.attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e.attn_min_tokens = std::max(64, atoi(q)), e.attn_min_tokens_auto = false;
+    if (const char *q = getenv("TL_ATTN_WG_CAP")) e.attn_wg_cap = std::max(0, atoi(q));
     hipLaunchKernelGGL(rope_rows_kernel, dim3(batch), dim3(64), 0, e.stream, context_lens_dev, e.rope_cur, head_dim / 2, rope_theta);
     TL_CHECK_LAUNCH("decode_attention_fused rope");
     const SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
