@@ -91,6 +91,20 @@ typedef struct tl_engine_stats {
     long graph_cache_flushes; /* times the cache of captured decode graphs (48 plans) was emptied */
 } tl_engine_stats;
 
+/* A Qwen3-MoE layer (reference: src/tiny_llm_ref/qwen3_week3.py:209-214, 258-272 builds a Moe block for it; moe.py:39-89 is the
+ * block: router softmax in fp32 -> top_k experts -> gathered gate / up / down W4 products -> probability-weighted sum).
+ * router [E, hidden]; experts stacked on a leading axis: gate / up [E, I, hidden/8] words, down [E, hidden, I/8] words, scales /
+ * biases [E, rows, cols/128] bf16.  W4, group 128.  Borrowed memory, like every weight. */
+typedef struct tl_moe_weights {
+    tl_w4 router;
+    const uint32_t *gate_dev, *up_dev, *down_dev;
+    const void *gate_scales_dev, *gate_biases_dev, *up_scales_dev, *up_biases_dev, *down_scales_dev, *down_biases_dev;
+    int num_experts;        /* E <= 1024 */
+    int experts_per_token;  /* top_k <= 16 */
+    int intermediate_size;  /* I (moe_intermediate_size), a multiple of 128 */
+    int norm_topk_prob;     /* renormalise the selected probabilities (Qwen3-MoE: true) */
+} tl_moe_weights;
+
 /* embed: the quantized embedding table [vocab, hidden]; lm_head: NULL for tied
  * embeddings (reference qwen3_week3.py:314-318).  Weight memory is borrowed and
  * must outlive the engine.  `stream` is the hipStream_t all work is issued on;
@@ -98,6 +112,11 @@ typedef struct tl_engine_stats {
  * stream cannot be graph-captured) after a device-wide synchronise. */
 int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weights *layers, const tl_w4 *embed,
                      const void *final_norm_dev, const tl_w4 *lm_head, void *stream, tl_engine **out);
+/* Make `layer` a mixture-of-experts layer (after tl_engine_create, before the first prefill / decode of the engine).  The layer's
+ * dense wgu / wdown may be null in tl_engine_create's `layers` then; a layer with neither is an error at its first use.  The MoE
+ * MLP runs as the reference's op sequence inside the captured step: RMSNorm, router GEMV, route kernel, gathered gate and up
+ * GEMVs (one launch each, an expert per row), SiLU x up, gathered down GEMV, weighted sum + residual. */
+int tl_engine_set_moe_layer(tl_engine *e, int layer, const tl_moe_weights *w);
 void tl_engine_destroy(tl_engine *e);
 /* Block the host until everything enqueued on the engine stream has finished. */
 int tl_engine_synchronize(tl_engine *e);

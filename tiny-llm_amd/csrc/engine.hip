@@ -116,6 +116,14 @@ struct tl_engine {
 
     bool warmed = false;
     std::map<std::pair<int, long>, hipGraphExec_t> graphs;  // (batch, n_splits << 32 | tokens_per_split)
+    // Qwen3-MoE layers (tl_engine_set_moe_layer): router + stacked experts instead of the dense gate|up / w_down of that layer
+    std::vector<tl_moe_weights> moe;  // per layer; num_experts == 0: dense
+    int moe_k_max = 0, moe_e_max = 0, moe_i_max = 0;
+    char *moe_ws = nullptr;  // one allocation: router logits, ids, scores, gate / up / act rows, expert outputs
+    size_t moe_ws_bytes = 0;
+    uint16_t *moe_logits = nullptr, *moe_scores = nullptr, *moe_gate = nullptr, *moe_up = nullptr, *moe_act = nullptr, *moe_y = nullptr;
+    int32_t *moe_ids = nullptr;
+    bool is_moe(int l) const { return l < (int)moe.size() && moe[l].num_experts > 0; }
     float2 *rope_table = nullptr, *rope_cur = nullptr;
     int rope_positions = 0;
     int logits_rows = 0;
@@ -594,6 +602,27 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
     return TL_OK;
 }
 
+// The MLP of a Qwen3-MoE layer over `rows` activation rows: xn = RMSNorm(h) is given; out = h + sum_j score_j * expert_j(xn)
+// (reference: moe.py:69-89 inside qwen3_week3.py:204-205).  Every launch reads device-resident ids: graph-capturable.
+static int engine_moe_mlp(tl_engine *e, int l, const uint16_t *xn, const uint16_t *h, uint16_t *out, int rows, ProfCtx *pc) {
+    const tl_moe_weights &m = e->moe[l];
+    const int D = e->cfg.hidden_size, E = m.num_experts, k = m.experts_per_token, I = m.intermediate_size;
+    TL_REQUIRE(e->moe_ws != nullptr && rows <= e->rows_cap && (long)rows * k <= 65535, "engine: MoE workspace missing or too many expert rows");
+    // router logits [rows, E] through the reference-semantics matmul (quantized_linear of the router, moe.py:44)
+    TL_TRY(engine_qmm(e, m.router, xn, e->moe_logits, rows));
+    hipLaunchKernelGGL(moe_route_kernel, dim3(rows), dim3(256), 0, e->stream, e->moe_logits, E, k, m.norm_topk_prob, e->moe_ids, e->moe_scores);
+    const int er = rows * k;  // expert rows: token-major, the token's top_k experts in descending probability
+    TL_TRY(gather_qmv_bf16(m.gate_scales_dev, m.gate_biases_dev, xn, m.gate_dev, e->moe_ids, e->moe_gate, er, D, I, E, k, e->stream));
+    TL_TRY(gather_qmv_bf16(m.up_scales_dev, m.up_biases_dev, xn, m.up_dev, e->moe_ids, e->moe_up, er, D, I, E, k, e->stream));
+    const long n8 = (long)er * I / 8;
+    hipLaunchKernelGGL(moe_silu_mul_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, e->moe_gate, e->moe_up, e->moe_act, n8);
+    TL_TRY(gather_qmv_bf16(m.down_scales_dev, m.down_biases_dev, e->moe_act, m.down_dev, e->moe_ids, e->moe_y, er, I, D, E, 1, e->stream));
+    hipLaunchKernelGGL(moe_combine_kernel, dim3(rows), dim3(256), 0, e->stream, e->moe_y, e->moe_scores, h, out, D, k);
+    (void)pc;  // the MoE launches carry no in-kernel stamps: tl_engine_profile_step leaves them out of its kinds
+    TL_CHECK_LAUNCH("engine MoE layer");
+    return TL_OK;
+}
+
 // One fused decode step over slots [0, batch).
 static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nullptr) {
     const tl_engine_config &c = e->cfg;
@@ -610,6 +639,15 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
         TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, &qkv_parts,
                                 &w.wo, &merge_left));
         int h_ss = 0;
+        if (e->is_moe(l)) {  // wo + residual, then the MoE MLP as its own launches (no producer-side sums for the next layer)
+            if (merge_left) TL_TRY(engine_wo_merge(e, w.wo, e->x, e->h, sp.n_splits, pc, nullptr, nullptr));
+            else TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1));
+            TL_TRY(tl_rms_norm(e->h, w.post_norm_dev, e->xn, batch, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
+            TL_TRY(engine_moe_mlp(e, l, e->xn, e->h, e->x, batch, pc));
+            x_ss = 0;
+            continue;
+        }
+        TL_REQUIRE(w.wgu.weight_dev != nullptr, "engine: a layer has neither a dense MLP nor experts (tl_engine_set_moe_layer)");
         // h leaves the wo GEMV twice when the gate|up GEMV can take it weighted: as the residual stream and, in xn, times the
         // post-attention norm weight
         const bool weighted = weighted_rows_apply(e, w.wo, w.wgu, batch);
@@ -762,8 +800,11 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     for (int l = 0; l < c.num_layers; ++l) {
         TL_TRY(check_w4(layers[l].wqkv, qkv_dim, c.hidden_size, "wqkv"));
         TL_TRY(check_w4(layers[l].wo, c.hidden_size, q_dim, "wo"));
-        TL_TRY(check_w4(layers[l].wgu, 2 * c.intermediate_size, c.hidden_size, "wgu"));
-        TL_TRY(check_w4(layers[l].wdown, c.hidden_size, c.intermediate_size, "wdown"));
+        // a layer without a dense MLP (both null) must get its experts through tl_engine_set_moe_layer before the first step
+        if (layers[l].wgu.weight_dev != nullptr || layers[l].wdown.weight_dev != nullptr) {
+            TL_TRY(check_w4(layers[l].wgu, 2 * c.intermediate_size, c.hidden_size, "wgu"));
+            TL_TRY(check_w4(layers[l].wdown, c.hidden_size, c.intermediate_size, "wdown"));
+        }
         TL_REQUIRE(layers[l].input_norm_dev && layers[l].post_norm_dev && layers[l].q_norm_dev && layers[l].k_norm_dev,
                    "engine_create: null norm weight");
     }
@@ -942,7 +983,10 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
             return true;
         };
         bool ok = true;
-        for (const auto &l : e->layers) ok = ok && add_tiled(l.wqkv) && add_tiled(l.wo) && add_tiled(l.wgu) && add_tiled(l.wdown);
+        for (const auto &l : e->layers) {
+            ok = ok && add_tiled(l.wqkv) && add_tiled(l.wo);
+            if (l.wgu.weight_dev) ok = ok && add_tiled(l.wgu) && add_tiled(l.wdown);
+        }
         ok = ok && add_tiled(e->head());
         if (!ok) return cleanup_fail("engine_create: hipMalloc(tiled weights) failed");
     }
@@ -952,8 +996,15 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
         // (qmm3_min_rows .. 64 decode rows, any of the five matrices) and split-K partials of the prefill GEMM (9 ..
         // rows_cap rows).  Graphs captured later hold this address, so it is never reallocated.
         size_t need = 0;
-        const tl_w4 *mats[5] = {&e->layers[0].wqkv, &e->layers[0].wo, &e->layers[0].wgu, &e->layers[0].wdown, &e->head()};
+        const tl_layer_weights *dense = &e->layers[0];  // the first layer that has a dense MLP sizes the MLP workspaces
+        for (const auto &l : e->layers)
+            if (l.wgu.weight_dev) {
+                dense = &l;
+                break;
+            }
+        const tl_w4 *mats[5] = {&e->layers[0].wqkv, &e->layers[0].wo, &dense->wgu, &dense->wdown, &e->head()};
         for (const tl_w4 *w : mats) {
+            if (!w->weight_dev) continue;
             for (int M = 1; M <= std::min(64, e->rows_cap); ++M) {
                 const Qmm3Plan p3 = qmm3_plan(M, w->cols, w->rows);
                 if (p3.ok) need = std::max(need, p3.partial_bytes);
@@ -967,6 +1018,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
         }
     }
 
+    e->moe.assign(c.num_layers, tl_moe_weights{});
     e->slot_pages.assign(c.max_batch, {});
     e->slot_ctx.assign(c.max_batch, 0);
     e->slot_live.assign(c.max_batch, 0);
@@ -982,9 +1034,61 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     return TL_OK;
 }
 
+extern "C" int tl_engine_set_moe_layer(tl_engine *e, int layer, const tl_moe_weights *w) {
+    TL_REQUIRE(e && w, "engine_set_moe_layer: null argument");
+    const tl_engine_config &c = e->cfg;
+    TL_REQUIRE(layer >= 0 && layer < c.num_layers, "engine_set_moe_layer: layer out of range");
+    TL_REQUIRE(e->graphs.empty() && e->stats.decode_steps == 0 && e->stats.prefill_tokens == 0,
+               "engine_set_moe_layer: call it before the first prefill / decode");
+    TL_REQUIRE(w->num_experts > 0 && w->num_experts <= 1024 && w->experts_per_token > 0 && w->experts_per_token <= 16 &&
+                   w->experts_per_token <= w->num_experts,
+               "engine_set_moe_layer: need 1 <= experts_per_token <= min(16, num_experts) and num_experts <= 1024");
+    TL_REQUIRE(w->intermediate_size > 0 && w->intermediate_size % 128 == 0, "engine_set_moe_layer: intermediate_size must be a positive multiple of 128");
+    TL_TRY(check_w4(w->router, w->num_experts, c.hidden_size, "moe router"));
+    TL_REQUIRE(w->gate_dev && w->up_dev && w->down_dev && w->gate_scales_dev && w->gate_biases_dev && w->up_scales_dev &&
+                   w->up_biases_dev && w->down_scales_dev && w->down_biases_dev,
+               "engine_set_moe_layer: null expert tensor");
+    TL_REQUIRE((long)e->rows_cap * w->experts_per_token <= 65535, "engine_set_moe_layer: max_prefill_rows x experts_per_token must stay below 65536 (one grouped launch)");
+    // the router's matmul must fit the workspace sized at tl_engine_create (it does for every E <= the widest projection)
+    for (int M : {1, 8, 9, e->rows_cap})
+        TL_REQUIRE(tl_quantized_matmul_workspace_bytes(std::min(M, e->rows_cap), c.hidden_size, w->num_experts, TL_BF16, 1, 1) <= e->splitk_ws_bytes,
+                   "engine_set_moe_layer: the router matmul does not fit the engine's matmul workspace");
+    const int k = std::max(e->moe_k_max, w->experts_per_token), E = std::max(e->moe_e_max, w->num_experts),
+              I = std::max(e->moe_i_max, w->intermediate_size);
+    if (k != e->moe_k_max || E != e->moe_e_max || I != e->moe_i_max) {  // (re)size the workspace: nothing captured holds it yet
+        const size_t R = (size_t)e->rows_cap;
+        size_t off = 0;
+        auto carve = [&](size_t bytes) {
+            const size_t at = off;
+            off = align_up(off + bytes, 256);
+            return at;
+        };
+        const size_t o_log = carve(R * E * 2), o_ids = carve(R * k * 4), o_sc = carve(R * k * 2), o_g = carve(R * k * I * 2),
+                     o_u = carve(R * k * I * 2), o_a = carve(R * k * I * 2), o_y = carve(R * k * c.hidden_size * 2);
+        TL_HIP(hipStreamSynchronize(e->stream));
+        if (e->moe_ws) (void)hipFree(e->moe_ws);
+        e->moe_ws = nullptr;
+        TL_HIP(hipMalloc((void **)&e->moe_ws, off));
+        e->moe_ws_bytes = off;
+        char *A = e->moe_ws;
+        e->moe_logits = (uint16_t *)(A + o_log);
+        e->moe_ids = (int32_t *)(A + o_ids);
+        e->moe_scores = (uint16_t *)(A + o_sc);
+        e->moe_gate = (uint16_t *)(A + o_g);
+        e->moe_up = (uint16_t *)(A + o_u);
+        e->moe_act = (uint16_t *)(A + o_a);
+        e->moe_y = (uint16_t *)(A + o_y);
+        e->moe_k_max = k, e->moe_e_max = E, e->moe_i_max = I;
+        e->stats.workspace_bytes = e->arena_bytes + e->tiled_bytes + e->moe_ws_bytes;
+    }
+    e->moe[layer] = *w;
+    return TL_OK;
+}
+
 extern "C" void tl_engine_destroy(tl_engine *e) {
     if (!e) return;
     (void)hipStreamSynchronize(e->stream);
+    if (e->moe_ws) (void)hipFree(e->moe_ws);
     for (auto &kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     if (e->arena) (void)hipFree(e->arena);
     if (e->kpool) (void)hipFree(e->kpool);
@@ -1238,8 +1342,13 @@ static int prefill_impl(tl_engine *e, int slot, const int32_t *tokens, int n, in
         }
         TL_TRY(engine_gemm(e, w.wo, e->attn, e->h, n, EPI_RESIDUAL, e->x));
         TL_TRY(tl_rms_norm(e->h, w.post_norm_dev, e->xn, n, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
-        TL_TRY(engine_gemm(e, w.wgu, e->xn, e->act, n, EPI_SWIGLU, nullptr));
-        TL_TRY(engine_gemm(e, w.wdown, e->act, e->x, n, EPI_RESIDUAL, e->h));
+        if (e->is_moe(l)) {
+            TL_TRY(engine_moe_mlp(e, l, e->xn, e->h, e->x, n, nullptr));
+        } else {
+            TL_REQUIRE(w.wgu.weight_dev != nullptr, "engine: a layer has neither a dense MLP nor experts (tl_engine_set_moe_layer)");
+            TL_TRY(engine_gemm(e, w.wgu, e->xn, e->act, n, EPI_SWIGLU, nullptr));
+            TL_TRY(engine_gemm(e, w.wdown, e->act, e->x, n, EPI_RESIDUAL, e->h));
+        }
         TL_CHECK_LAUNCH("engine prefill layer");
     }
     e->slot_ctx[slot] = start + n;
@@ -1369,8 +1478,13 @@ static int prefill_packed_impl(tl_engine *e, int n_seqs, const int *slots, const
         }
         TL_TRY(engine_gemm(e, w.wo, e->attn, e->h, total, EPI_RESIDUAL, e->x));
         TL_TRY(tl_rms_norm(e->h, w.post_norm_dev, e->xn, total, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
-        TL_TRY(engine_gemm(e, w.wgu, e->xn, e->act, total, EPI_SWIGLU, nullptr));
-        TL_TRY(engine_gemm(e, w.wdown, e->act, e->x, total, EPI_RESIDUAL, e->h));
+        if (e->is_moe(l)) {
+            TL_TRY(engine_moe_mlp(e, l, e->xn, e->h, e->x, total, nullptr));
+        } else {
+            TL_REQUIRE(w.wgu.weight_dev != nullptr, "engine: a layer has neither a dense MLP nor experts (tl_engine_set_moe_layer)");
+            TL_TRY(engine_gemm(e, w.wgu, e->xn, e->act, total, EPI_SWIGLU, nullptr));
+            TL_TRY(engine_gemm(e, w.wdown, e->act, e->x, total, EPI_RESIDUAL, e->h));
+        }
         TL_CHECK_LAUNCH("engine packed prefill layer");
     }
     int n_logits = 0;

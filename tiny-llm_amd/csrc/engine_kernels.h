@@ -1021,4 +1021,106 @@ __global__ void fill_i32_kernel(int32_t *dst, int32_t value, int n) {
     if (i < n) dst[i] = value;
 }
 
+// ---- Qwen3-MoE layers inside the engine (reference: src/tiny_llm_ref/moe.py:39-89, qwen3_week3.py:258-272) ----------------------
+// Router: softmax over the E router logits of a row in fp32, rounded to bf16 (the activations' dtype, moe.py:45-46), the top_k
+// largest probabilities in descending order (equal probabilities: the lower expert index first) and their scores, renormalised over
+// the selection when `norm` (bf16 arithmetic as the reference's arrays: the sum rounded once, the quotient rounded once).
+// One workgroup per activation row; E <= 1024, top_k <= 16.
+__global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t *__restrict__ logits, int E, int top_k, int norm,
+                                                        int32_t *__restrict__ ids, uint16_t *__restrict__ scores) {
+    __shared__ float red[4];
+    __shared__ int red_i[4];
+    __shared__ uint16_t probs[1024];
+    __shared__ uint16_t picked[16];
+    const int row = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint16_t *lr = logits + (long)row * E;
+    float mx = -INFINITY;
+    for (int i = tid; i < E; i += 256) mx = fmaxf(mx, BF16::to_float(lr[i]));
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < E; i += 256) sum += expf(BF16::to_float(lr[i]) - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int i = tid; i < E; i += 256) probs[i] = BF16::from_float(expf(BF16::to_float(lr[i]) - mx) / sum);
+    __syncthreads();
+    for (int j = 0; j < top_k; ++j) {  // top_k rounds of a workgroup-wide arg-max; a picked expert leaves the pool
+        float best = -1.f;
+        int best_i = 0x7fffffff;
+        for (int i = tid; i < E; i += 256) {
+            const float v = BF16::to_float(probs[i]);
+            if (probs[i] != 0xffffu && (v > best || (v == best && i < best_i))) best = v, best_i = i;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off);
+            const int oi = __shfl_xor(best_i, off);
+            if (ov > best || (ov == best && oi < best_i)) best = ov, best_i = oi;
+        }
+        if (lane == 0) red[wave] = best, red_i[wave] = best_i;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (red[w] > best || (red[w] == best && red_i[w] < best_i)) best = red[w], best_i = red_i[w];
+            ids[(long)row * top_k + j] = best_i;
+            picked[j] = probs[best_i];
+            probs[best_i] = 0xffffu;  // a NaN pattern no probability takes: out of the pool
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int j = 0; j < top_k; ++j) tot += BF16::to_float(picked[j]);
+        const float den = BF16::to_float(BF16::from_float(tot));
+        for (int j = 0; j < top_k; ++j)
+            scores[(long)row * top_k + j] = norm ? BF16::from_float(BF16::to_float(picked[j]) / den) : picked[j];
+    }
+}
+
+// act = bf16(bf16(silu(gate)) * up), 8 elements per thread (moe.py:83-84: silu(gate) * up on bf16 arrays, two roundings)
+__global__ __launch_bounds__(256) void moe_silu_mul_kernel(const uint16_t *__restrict__ gate, const uint16_t *__restrict__ up,
+                                                           uint16_t *__restrict__ act, long n8) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n8) return;
+    uint16_t g[8], u[8], o[8];
+    *reinterpret_cast<uint4 *>(g) = reinterpret_cast<const uint4 *>(gate)[idx];
+    *reinterpret_cast<uint4 *>(u) = reinterpret_cast<const uint4 *>(up)[idx];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float gt = BF16::to_float(g[e]);
+        o[e] = BF16::from_float(bf16_round(gt / (1.0f + expf(-gt))) * BF16::to_float(u[e]));
+    }
+    reinterpret_cast<uint4 *>(act)[idx] = *reinterpret_cast<const uint4 *>(o);
+}
+
+// out[m] = bf16(h[m] + bf16(sum_j bf16(y[m, j] * score[m, j])))   (moe.py:89 then the layer's residual add, qwen3_week3.py:204-205);
+// the sum over the top_k expert rows accumulates in fp32 in expert order.  grid = rows, D % 8 == 0.
+__global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t *__restrict__ y, const uint16_t *__restrict__ scores,
+                                                          const uint16_t *__restrict__ h, uint16_t *__restrict__ out, int D,
+                                                          int top_k) {
+    const int m = blockIdx.x;
+    for (int c = threadIdx.x; c < D / 8; c += 256) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int j = 0; j < top_k; ++j) {
+            const float sc = BF16::to_float(scores[(long)m * top_k + j]);
+            uint16_t v[8];
+            *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(y + ((long)m * top_k + j) * D + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf16_round(BF16::to_float(v[e]) * sc);
+        }
+        uint16_t r[8], o[8];
+        *reinterpret_cast<uint4 *>(r) = *reinterpret_cast<const uint4 *>(h + (long)m * D + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = BF16::from_float(BF16::to_float(r[e]) + bf16_round(acc[e]));
+        *reinterpret_cast<uint4 *>(out + (long)m * D + c * 8) = *reinterpret_cast<const uint4 *>(o);
+    }
+}
+
 }  // namespace tl

@@ -467,7 +467,7 @@ int qmm_bf16_epilogue(const void *scales, const void *biases, const uint16_t *A,
 // one GEMV per activation row, each against the weights of its own expert (grid.y = rows)
 template <typename TT>
 static int run_gather_qmv(const void *scales, const void *biases, const void *a, const uint32_t *b, const int32_t *expert_ids,
-                          void *out, int M, int N, int K, int num_experts, hipStream_t st) {
+                          void *out, int M, int N, int K, int num_experts, hipStream_t st, int a_rows_div = 1) {
     QmvArgs args{};
     args.scales = (const uint16_t *)scales;
     args.biases = (const uint16_t *)biases;
@@ -479,6 +479,7 @@ static int run_gather_qmv(const void *scales, const void *biases, const void *a,
     args.K = K;
     args.expert_ids = expert_ids;
     args.num_experts = num_experts;
+    args.a_rows_div = a_rows_div;
     const QmvPlan pl = qmv_plan(1, N, K);
     if (pl.lds > 150 * 1024) return fail(TL_ERR_UNSUPPORTED, "gather_quantized_matvec: reduction dimension too large");
     const dim3 grid(pl.blocks, M), block(256);
@@ -493,6 +494,13 @@ static int run_gather_qmv(const void *scales, const void *biases, const void *a,
     GQ_CASE(1, 2) GQ_CASE(1, 1) GQ_CASE(2, 1) GQ_CASE(4, 1)
 #undef GQ_CASE
     return fail(TL_ERR_UNSUPPORTED, "gather_quantized_matvec: no GEMV configuration for this shape");
+}
+
+int gather_qmv_bf16(const void *scales, const void *biases, const uint16_t *a, const uint32_t *b, const int32_t *expert_ids,
+                    uint16_t *out, int M, int N, int K, int num_experts, int a_rows_div, hipStream_t st) {
+    if (M > 65535) return fail(TL_ERR_INVALID, "grouped-expert matvec: at most 65535 rows per launch");
+    if (M == 0 || K == 0) return TL_OK;
+    return run_gather_qmv<BF16>(scales, biases, a, b, expert_ids, out, M, N, K, num_experts, st, a_rows_div);
 }
 
 }  // namespace tl

@@ -52,6 +52,8 @@ struct QmvArgs {
     // scales / biases [E, K, N/128].  The kernel then runs as M = 1 on that row.
     const int32_t *expert_ids;
     int num_experts;
+    int a_rows_div;  // grouped-expert mode: output row m reads activation row m / a_rows_div (0 or 1: its own row) -- the top_k
+                     // expert rows of one token share the token's activation row, which is then not replicated (engine MoE layers)
 };
 
 template <typename TT>
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void qmv_kernel(const QmvArgs p_in) {
         p.b += e * (long)p.K * (p.N >> 3);
         p.scales += e * (long)p.K * (p.N >> 7);
         p.biases += e * (long)p.K * (p.N >> 7);
-        p.a += (long)m * p.N;
+        p.a += (long)(p.a_rows_div > 1 ? m / p.a_rows_div : m) * p.N;
         p.out += (long)m * p.K;
         p.M = 1;
     }
@@ -408,6 +410,9 @@ inline QmvPlan qmv_plan(int M, int N, int K) {
 // Returns 0, or -1 when the activation tile does not fit in LDS, -2 for an unknown plan.
 int launch_qmv_fused_bf16(const QmvArgs &args, int pro, int epi, hipStream_t st);
 
+// qmm.hip: grouped-expert GEMV (bf16): out[m] = a[m / a_rows_div] @ dequant(b[expert_ids[m]])^T, one launch, grid.y = M rows
+int gather_qmv_bf16(const void *scales, const void *biases, const uint16_t *a, const uint32_t *b, const int32_t *expert_ids,
+                    uint16_t *out, int M, int N, int K, int num_experts, int a_rows_div, hipStream_t st);
 // qmm.hip: the prefill W4 GEMM with the engine's epilogue folded in (rows > 8; epi = EPI_RESIDUAL / EPI_SWIGLU)
 int qmm_bf16_epilogue(const void *scales, const void *biases, const uint16_t *a, const uint32_t *b, uint16_t *out, int M, int N, int K,
                       int epi, const uint16_t *residual, void *workspace, size_t workspace_bytes, hipStream_t st);

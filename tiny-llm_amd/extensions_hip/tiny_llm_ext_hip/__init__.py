@@ -78,6 +78,14 @@ class TlLayerWeights(ctypes.Structure):
                 ("q_norm_dev", _c_void_p), ("k_norm_dev", _c_void_p)]
 
 
+class TlMoeWeights(ctypes.Structure):
+    _fields_ = [("router", TlW4), ("gate_dev", _c_void_p), ("up_dev", _c_void_p), ("down_dev", _c_void_p),
+                ("gate_scales_dev", _c_void_p), ("gate_biases_dev", _c_void_p), ("up_scales_dev", _c_void_p),
+                ("up_biases_dev", _c_void_p), ("down_scales_dev", _c_void_p), ("down_biases_dev", _c_void_p),
+                ("num_experts", _c_int), ("experts_per_token", _c_int), ("intermediate_size", _c_int),
+                ("norm_topk_prob", _c_int)]
+
+
 class TlEngineConfig(ctypes.Structure):
     _fields_ = [("hidden_size", _c_int), ("num_layers", _c_int), ("num_heads", _c_int), ("num_kv_heads", _c_int),
                 ("head_dim", _c_int), ("intermediate_size", _c_int), ("vocab_size", _c_int),
@@ -121,6 +129,7 @@ _SIGNATURES.update({
     "tl_engine_profile_step": (_c_int, [_c_void_p, _c_int, _P(TlStepProfile)]),
     "tl_engine_create": (_c_int, [_P(TlEngineConfig), _P(TlLayerWeights), _P(TlW4), _c_void_p, _P(TlW4), _c_void_p,
                                   _P(_c_void_p)]),
+    "tl_engine_set_moe_layer": (_c_int, [_c_void_p, _c_int, _P(TlMoeWeights)]),
     "tl_engine_destroy": (None, [_c_void_p]),
     "tl_engine_synchronize": (_c_int, [_c_void_p]),
     "tl_engine_begin": (_c_int, [_c_void_p, _c_int]),

@@ -66,15 +66,23 @@ class DecodeEngine:
         self.args = args
         self._keep: list[Any] = []
         layers = (_ext.TlLayerWeights * args.num_hidden_layers)()
+        moe_layers: dict[int, Any] = {}  # Qwen3-MoE layers (reference qwen3_week3.py:209-214, 258-272): attached after create
         for i, layer in enumerate(mlx_model.model.layers):
             attn, mlp = layer.self_attn, layer.mlp
             qkv = _Fused.concat([attn.q_proj, attn.k_proj, attn.v_proj])
             wo = _Fused(attn.o_proj.weight, attn.o_proj.scales, attn.o_proj.biases)
-            gu = _Fused.interleave(mlp.gate_proj, mlp.up_proj)
-            down = _Fused(mlp.down_proj.weight, mlp.down_proj.scales, mlp.down_proj.biases)
             norms = [layer.input_layernorm.weight, layer.post_attention_layernorm.weight, attn.q_norm.weight,
                      attn.k_norm.weight]
             norms = [n.to(torch.bfloat16).contiguous() for n in norms]
+            if hasattr(mlp, "switch_mlp"):  # router + stacked experts: no dense MLP in this layer
+                moe_layers[i] = mlp
+                none = _ext.TlW4(None, None, None, 0, 0)
+                self._keep += [qkv, wo, norms]
+                layers[i] = _ext.TlLayerWeights(qkv.c(), wo.c(), none, none, norms[0].data_ptr(), norms[1].data_ptr(),
+                                                norms[2].data_ptr(), norms[3].data_ptr())
+                continue
+            gu = _Fused.interleave(mlp.gate_proj, mlp.up_proj)
+            down = _Fused(mlp.down_proj.weight, mlp.down_proj.scales, mlp.down_proj.biases)
             self._keep += [qkv, wo, gu, down, norms]
             layers[i] = _ext.TlLayerWeights(qkv.c(), wo.c(), gu.c(), down.c(), norms[0].data_ptr(),
                                             norms[1].data_ptr(), norms[2].data_ptr(), norms[3].data_ptr())
@@ -103,6 +111,27 @@ class DecodeEngine:
             ctypes.byref(cfg), layers, ctypes.byref(embed_c), final_norm.data_ptr(),
             ctypes.byref(head_c) if head_c is not None else None, None, ctypes.byref(handle)))
         self._h = handle
+        for i, mlp in moe_layers.items():
+            self._attach_moe(i, mlp, args)
+
+    def _attach_moe(self, layer: int, mlp: Any, args: Any) -> None:
+        """Hand the router and the stacked experts of one sparse layer to the engine (tl_engine_set_moe_layer)."""
+        router = _Fused(mlp.gate.weight, mlp.gate.scales, mlp.gate.biases)
+        sw = mlp.switch_mlp
+        experts = {}
+        for name in ("gate_proj", "up_proj", "down_proj"):
+            p = getattr(sw, name)
+            w = _bits(p.weight).contiguous()
+            if w.dim() != 3:
+                raise ValueError(f"layer {layer}: switch_mlp.{name}.weight must be [experts, rows, words]")
+            experts[name] = (w, p.scales.to(torch.bfloat16).contiguous(), p.biases.to(torch.bfloat16).contiguous())
+        n_experts, inter, _ = experts["gate_proj"][0].shape
+        self._keep += [router, experts]
+        g, u, d = experts["gate_proj"], experts["up_proj"], experts["down_proj"]
+        w = _ext.TlMoeWeights(router.c(), g[0].data_ptr(), u[0].data_ptr(), d[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
+                              u[1].data_ptr(), u[2].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), int(n_experts),
+                              int(args.num_experts_per_tok), int(inter), int(bool(getattr(args, "norm_topk_prob", False))))
+        _ext.check(_lib.tl_engine_set_moe_layer(self._h, layer, ctypes.byref(w)))
 
     @classmethod
     def from_model(cls, mlx_model: Any, **kwargs) -> "DecodeEngine":
