@@ -18,9 +18,9 @@ def load(path):
 
 fetch = load(src / "fetch" / "lab_counter_collection.csv")
 write = load(src / "write" / "lab_counter_collection.csv")
-shapes = {"qkv": (6144, 2560, "tl::qmv3_kernel<1, 2, 4, 1, 0, 10>", 192 * 256), "o": (2560, 4096, "tl::qmv3_kernel<1, 4, 4, 0, 1, 8>", 160 * 256),
-          "gate_up": (19456, 2560, "tl::qmv3_kernel<1, 4, 4, 1, 2, 5>", 1216 * 256), "down": (2560, 9728, "tl::qmv3_kernel<1, 8, 8, 0, 1, 10>", 160 * 512),
-          "lm_head": (151936, 2560, "tl::qmv3_kernel<1, 2, 4, 1, 0, 10>", 4748 * 256)}
+shapes = {"qkv": (6144, 2560, "tl::qmv3_kernel<1, 2, 4, 1, 0, 10, 0>", 192 * 256), "o": (2560, 4096, "tl::qmv3_kernel<1, 4, 4, 0, 1, 8, 0>", 160 * 256),
+          "gate_up": (19456, 2560, "tl::qmv3_kernel<1, 4, 4, 1, 2, 5, 0>", 1216 * 256), "down": (2560, 9728, "tl::qmv3_kernel<1, 8, 8, 0, 1, 10, 0>", 160 * 512),
+          "lm_head": (151936, 2560, "tl::qmv3_kernel<1, 2, 4, 1, 0, 10, 0>", 4748 * 256)}
 # calibration on stream_kernel<4, true> (tools/lab/gemv_lab.hip, pmc mode): a pure 16 B/lane non-temporal stream whose
 # byte count is known exactly -- per shape 2 grids x iters dispatches of K*N/2 bytes each (the lab's own loop bounds)
 known = 0.0
