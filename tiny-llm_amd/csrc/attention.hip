@@ -332,7 +332,8 @@ __global__ __launch_bounds__(128) void paged_merge_kernel(const float *__restric
 constexpr int FA_BK = 64;            // tokens staged per barrier phase (two 32-token MFMA sub-tiles)
 constexpr int FA_SUB = FA_BK / 32;
 constexpr int FA_CPT = FA_BK / 16;    // 16-byte K (and V) chunks per thread and stage
-constexpr int FA_LDV = FA_BK + 4;    // row length of the transposed V tile
+constexpr int FA_VROW = 128 + 32;    // bf16 elements per row of the row-major V tile: rows 320 B apart put the 4 rows x 16 dims a
+                                     // 16-lane group gathers with ds_read_b64_tr_b16 on distinct banks (16 r + 8 g + 2 q + {0, 1})
 
 // ONEPAGE: the page size is a power of two >= FA_BK, so a 64-token stage lies inside ONE page.  Its page id is then a single
 // wave-uniform word and every K/V address of the stage is (uniform base of the page's rows) + (a per-thread offset fixed for
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     float scale, int is_causal, int xcd_remap) {
     constexpr int D = 128;
     __shared__ __attribute__((aligned(16))) uint16_t ks[FA_BK * D];     // [token][dim] swizzled
-    __shared__ __attribute__((aligned(16))) uint16_t vt[D * FA_LDV];     // [dim][token]
+    __shared__ __attribute__((aligned(16))) uint16_t vs[FA_BK * FA_VROW];  // [token][dim] as it lies in the page; read transposed
     __shared__ int tile_page[2][FA_BK];
 
     const int tid = threadIdx.x;
@@ -431,30 +432,25 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     u32x4 kreg[FA_CPT], vreg[FA_CPT];
     // page ids travel one stage ahead of the K/V rows they address: a stage's loads are then ONE global round trip behind
     // the MFMAs of the previous stage instead of two dependent ones (block table, then rows)
-    // K chunk c = tid + 256 i  ->  (token c / 16, 16-byte chunk c % 16): coalesced rows, b128 stores into the swizzled K tile.
-    // V (below)            ->  a token pair and two chunks per thread: consecutive lanes hold consecutive token pairs of one
-    // chunk, so the stores into the transposed tile vt[dim][token] hit consecutive words (the K mapping would put 16 lanes
-    // on two LDS banks).  The price is a strided global read of V (rows 256 B apart), absorbed by the L1.
-    int pid_reg[FA_CPT], pidv_reg[FA_CPT];
-    bool kv_ok[FA_CPT], v_ok[FA_CPT];
+    // K and V chunk c = tid + 256 i  ->  (token c / 16, 16-byte chunk c % 16): coalesced rows, b128 stores into the swizzled K tile
+    // and into the row-major V tile (round 3: the PV fragments are gathered by ds_read_b64_tr_b16; until then V was stored
+    // transposed with 16 ds_write_b32 per thread and stage).
+    int pid_reg[FA_CPT];
+    bool kv_ok[FA_CPT];
 #pragma unroll
-    for (int i = 0; i < FA_CPT; ++i) kv_ok[i] = v_ok[i] = false;
+    for (int i = 0; i < FA_CPT; ++i) kv_ok[i] = false;
     // page_shift = log2(page_size), or -1 (integer division, ~30 VALU ops each, 16 of them per stage and thread)
     auto logical_page = [&](int tok) { return page_shift >= 0 ? (tok >> page_shift) : tok / page_size; };
     // The id is NOT touched here (no "in ? id : -1"): any use of the loaded word right behind the load makes the compiler wait
     // for it on the spot -- and, loads returning in issue order, for the K/V rows of the next stage requested just before it,
     // i.e. the stage prefetch stopped overlapping the MFMAs (r02: found in the ISA as vmcnt(0) behind load_pids).  Whether the
     // token has a page at all is kept as a flag computed from the token index alone and applied where the id is used.
-    bool pid_in[FA_CPT], pidv_in[FA_CPT];
+    bool pid_in[FA_CPT];
     auto page_of_token = [&](int tok, bool &in) {
         const int lp = logical_page(tok);
         in = tok < ctx && lp < max_pages;
         return block_table[(long)b * max_pages + (in ? lp : 0)];  // unconditional load from a clamped address
     };
-    // V: thread -> token PAIR (2p, 2p + 1), p = tid & 31, and chunks chv = (tid >> 5) + 8 i (i < 2): the pair's values of one
-    // dim land in ONE 32-bit word of the transposed tile vt[dim][token], so a stage costs 16 ds_write_b32 per thread instead of
-    // 32 ds_write_b16 (the LDS store path is per instruction, not per byte).  vreg[2 i + t], pidv_reg[t] for token 2p + t.
-    const int vp = tid & 31, vch0 = tid >> 5;
     int page_next = -1;  // ONEPAGE: the (uniform) page id of the stage whose rows are requested next
     bool stage_full = false;  // ONEPAGE: every row of the stage in the registers is a live token (no zeroing at the store)
     auto load_pids = [&](int stage) {
@@ -466,8 +462,6 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
         } else {
 #pragma unroll
             for (int i = 0; i < FA_CPT; ++i) pid_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) >> 4), pid_in[i]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) pidv_reg[t] = page_of_token(stage * FA_BK + 2 * vp + t, pidv_in[t]);
         }
     };
     auto stage_load = [&](int stage) {
@@ -486,12 +480,7 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
                 if ((c & 15) == 0) tile_page[stage & 1][c >> 4] = kv_ok[i] ? page : -1;
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    vreg[2 * i + t] = *reinterpret_cast<const u32x4 *>(vbase + (size_t)(2 * vp + t) * D + (vch0 + 8 * i) * 8);
-                    v_ok[2 * i + t] = page >= 0 && stage * FA_BK + 2 * vp + t < ctx;
-                }
+            for (int i = 0; i < FA_CPT; ++i) vreg[i] = *reinterpret_cast<const u32x4 *>(vbase + (size_t)(tid + i * 256) * 8);
             return;
         }
 #pragma unroll
@@ -507,21 +496,9 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
             // join, i.e. before the MFMAs it should overlap); rows of unused pages are zeroed when they are stored to LDS
             const long off = (((long)max(page_id, 0) * num_kv_heads + kvh) * page_size + slot) * D + ch * 8;
             kreg[i] = *reinterpret_cast<const u32x4 *>(key_pages + off);
+            vreg[i] = *reinterpret_cast<const u32x4 *>(value_pages + off);
             kv_ok[i] = page_id >= 0;
             if (ch == 0) tile_page[stage & 1][tok_in] = page_id;  // read one iteration later, after two barriers
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int tokv = stage * FA_BK + 2 * vp + t;
-            const int lpv = logical_page(tokv);
-            const int slotv = tokv - lpv * page_size;
-            const int page_idv = pidv_in[t] ? pidv_reg[t] : -1;
-            const long rowv = (((long)max(page_idv, 0) * num_kv_heads + kvh) * page_size + slotv) * D;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                vreg[2 * i + t] = *reinterpret_cast<const u32x4 *>(value_pages + rowv + (vch0 + 8 * i) * 8);
-                v_ok[2 * i + t] = page_idv >= 0;
-            }
         }
     };
 
@@ -534,21 +511,18 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
             if (!(ONEPAGE && stage_full) && !kv_ok[i]) kreg[i] = u32x4{0u, 0u, 0u, 0u};
             *reinterpret_cast<u32x4 *>(&ks[tok_in * D + ((ch ^ (tok_in & 15)) * 8)]) = kreg[i];
         }
-        uint32_t *vt32 = reinterpret_cast<uint32_t *>(vt);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool keep = ONEPAGE && stage_full;
-            const u32x4 v0 = (keep || v_ok[2 * i]) ? vreg[2 * i] : u32x4{0u, 0u, 0u, 0u};
-            const u32x4 v1 = (keep || v_ok[2 * i + 1]) ? vreg[2 * i + 1] : u32x4{0u, 0u, 0u, 0u};
-            const int chv = vch0 + 8 * i;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {  // word e of a chunk = dims 2e (low half) and 2e + 1 (high half) of its token
-                vt32[((chv * 8 + 2 * e) * FA_LDV) / 2 + vp] = (v0[e] & 0xffffu) | (v1[e] << 16);
-                vt32[((chv * 8 + 2 * e + 1) * FA_LDV) / 2 + vp] = (v0[e] >> 16) | (v1[e] & 0xffff0000u);
-            }
+        for (int i = 0; i < FA_CPT; ++i) {  // V rows as they lie in the page: one b128 store per chunk (the PV fragments are read transposed)
+            const int c = tid + i * 256;
+            if (!(ONEPAGE && stage_full) && !kv_ok[i]) vreg[i] = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4 *>(&vs[(c >> 4) * FA_VROW + (c & 15) * 8]) = vreg[i];
         }
     };
 
+    // this lane's corner of the [4 tokens][16 dims] block its 16-lane group gathers (group = (dim half g, token half h))
+    typedef short v4s16 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s16 lds_v4s16;
+    uint16_t *vtr = vs + (4 * h + ((lane & 15) >> 2)) * FA_VROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     // splits are whole stages; tile counts (total / mine / the block's) stay in 32-token units
     const int total_stages = (total_tiles + FA_SUB - 1) / FA_SUB;
     const int blk_stages = (blk_tiles + FA_SUB - 1) / FA_SUB;
@@ -653,10 +627,13 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
         for (int db = 0; db < 4; ++db) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int d = db * 32 + l32;
-                const u32x2 lo = *reinterpret_cast<const u32x2 *>(&vt[d * FA_LDV + tb + 16 * s + 4 * h]);
-                const u32x2 hi = *reinterpret_cast<const u32x2 *>(&vt[d * FA_LDV + tb + 16 * s + 4 * h + 8]);
-                const u32x4 vf = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                // A fragment of V^T: lane (dim db*32 + l32, half h) needs tokens tb + 16 s + 4 h + {0..3} and + 8 + {0..3} of its dim.
+                // ds_read_b64_tr_b16: in a 16-lane group lane c hands in the address of [row c >> 2][4 dims from 4 (c & 3)] of a
+                // [4 tokens][16 dims] block and receives the block's column c (tools/lab/tr_probe.hip) -- V stays row-major.
+                const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16 *)(vtr + (tb + 16 * s) * FA_VROW + db * 32));
+                const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16 *)(vtr + (tb + 16 * s + 8) * FA_VROW + db * 32));
+                const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+                const u32x4 vf = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
                 if constexpr (FA_ABL & 2) o[db][s] += __uint_as_float((vf[0] ^ pf[s][1]) & 0x3f800000u);
                 else
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
