@@ -709,15 +709,27 @@ __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
     float best = -INFINITY;
     int best_i = 0x7fffffff;
     const int vec_end = ((uintptr_t)lg % 16 == 0) ? (p.vocab & ~7) : 0;
-    for (int c = threadIdx.x * 8; c < vec_end; c += 1024 * 8) {
-        uint16_t raw[8];
-        *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(lg + c);
+    // ONE workgroup reads the whole row (304 KB at Qwen3's vocabulary): a plain loop is a chain of 19 dependent L2 round trips
+    // (12 us in the step profile).  The loads go out ten 16-byte chunks at a time, from clamped addresses, and are looked at after:
+    // two round trips.
+    constexpr int SE_NB = 10;
+    for (int c0 = threadIdx.x * 8; c0 < vec_end; c0 += 1024 * 8 * SE_NB) {
+        uint4 rawv[SE_NB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = BF16::to_float(raw[e]);
-            if (v > best) {  // strictly greater: the earliest index of a tie stays
-                best = v;
-                best_i = c + e;
+        for (int j = 0; j < SE_NB; ++j) rawv[j] = *reinterpret_cast<const uint4 *>(lg + min(c0 + j * 8192, vec_end - 8));
+#pragma unroll
+        for (int j = 0; j < SE_NB; ++j) {
+            const int c = c0 + j * 8192;
+            if (c >= vec_end) continue;
+            uint16_t raw[8];
+            *reinterpret_cast<uint4 *>(raw) = rawv[j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = BF16::to_float(raw[e]);
+                if (v > best) {  // strictly greater: the earliest index of a tie stays
+                    best = v;
+                    best_i = c + e;
+                }
             }
         }
     }
@@ -728,14 +740,13 @@ __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
             best_i = c;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(best_i, o, 64);
-        if (ov > best || (ov == best && oi < best_i)) {
-            best = ov;
-            best_i = oi;
-        }
+    {   // wave-wide (maximum, lowest index that holds it) by DPP rotations instead of twelve ds_bpermute round trips: indices are
+        // below 2^24, exact as floats, so the lowest index is -max(-index) over the lanes that hold the maximum
+        const float m = wave_max(best);
+        const float cand = (best == m && best_i != 0x7fffffff) ? (float)best_i : 3.0e38f;
+        const float lowest = -wave_max(-cand);
+        best = m;
+        best_i = lowest < 1.0e30f ? (int)lowest : 0x7fffffff;
     }
     if ((threadIdx.x & 63) == 0) {
         s_val[threadIdx.x >> 6] = best;
