@@ -255,6 +255,13 @@ int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int
  *   qkv [batch, (Hq + 2 Hkv) D] bf16, pages [P, Hkv, page_size, D] bf16, block_table [batch, max_pages] int32,
  *   context_lens [batch] int32 (tokens already cached), out [batch, Hq D] bf16.
  * max_context: host upper bound of context_lens (sizes the context split exactly as tl_engine_decode does). */
+/* Host-only (no device, no launch): the plans the decode path picks.  tl_decode_gemv_plan: MFMA GEMV of M rows against a
+ * [rows, cols] W4 matrix -> out5 = {activation rows per workgroup, reduction split, waves, groups per wave, workgroups}; returns 1
+ * when the MFMA GEMV takes the shape (0: the packed-dot GEMV would).  tl_decode_attention_plan: `batch` sequences whose longest
+ * holds max_context tokens before this step -> out3 = {windows per sequence, tokens per window, query heads per workgroup}. */
+int tl_decode_gemv_plan(int M, int rows, int cols, int *out5);
+int tl_decode_attention_plan(int batch, int max_context, int num_heads, int num_kv_heads, int *out3);
+
 typedef struct tl_attention_info {
     int n_splits, tokens_per_split, heads_per_workgroup;
     int launches;

@@ -1,0 +1,75 @@
+"""CPU tier: the plans the decode path picks, read through the host-only entry points (include/tinyllm_engine.h:
+tl_decode_gemv_plan, tl_decode_attention_plan) -- no device, no launch.  The numbers behind each rule are in
+profiles/r03_labs/README.md (plan sweeps, window sizes, switch points); the same GEMV plans are asserted on the device against the
+kernels that actually ran (tests/test_decode_kernels_gpu.py)."""
+
+import ctypes
+
+import pytest
+
+QWEN3_4B = {"qkv": (6144, 2560), "wo": (2560, 4096), "gate_up": (19456, 2560), "down": (2560, 9728), "lm_head": (151936, 2560)}
+
+
+@pytest.fixture(scope="module")
+def lib(built_libs):
+    import tiny_llm_ext_hip as ext
+
+    return ext.lib()
+
+
+def gemv_plan(lib, M, name):
+    rows, cols = QWEN3_4B[name]
+    out = (ctypes.c_int * 5)()
+    ok = lib.tl_decode_gemv_plan(M, rows, cols, out)
+    return ok, tuple(out)
+
+
+def attention_plan(lib, batch, ctx, heads=32, kv_heads=8):
+    out = (ctypes.c_int * 3)()
+    assert lib.tl_decode_attention_plan(batch, ctx, heads, kv_heads, out) == 1
+    return tuple(out)
+
+
+def test_gemv_plans_at_the_qwen3_4b_projections(lib):
+    """(activation rows per workgroup, reduction split, waves, groups per wave, workgroups): one row -- the kernels bench.py's roofline
+    names; 2 and 4 rows -- gate|up keeps the finer cut, w_down takes 16 waves of 5 groups at 3-4 rows (round 3, tools/lab/plan_lab)."""
+    want = {
+        (1, "qkv"): (1, 2, 4, 10, 192), (1, "wo"): (1, 4, 4, 8, 160), (1, "gate_up"): (1, 4, 4, 5, 1216), (1, "down"): (1, 8, 8, 10, 160),
+        (1, "lm_head"): (1, 2, 4, 10, 4748),
+        (2, "qkv"): (2, 2, 4, 10, 192), (2, "gate_up"): (2, 4, 4, 5, 1216), (2, "down"): (2, 8, 8, 10, 160),
+        (3, "down"): (4, 16, 16, 5, 160), (4, "gate_up"): (4, 4, 4, 5, 1216), (4, "down"): (4, 16, 16, 5, 160), (4, "wo"): (4, 4, 4, 8, 160),
+    }
+    for (M, name), plan in want.items():
+        ok, got = gemv_plan(lib, M, name)
+        assert ok == 1 and got == plan, f"{name} at {M} rows: {got}"
+    assert lib.tl_decode_gemv_plan(1, 100, 2560, (ctypes.c_int * 5)()) == 0, "rows that are not a multiple of 16 go to the packed-dot GEMV"
+    assert lib.tl_decode_gemv_plan(1, 2560, 9728 * 4, (ctypes.c_int * 5)()) == 0, "a reduction of 304 groups does not fit 8 x 10 groups per wave"
+    assert lib.tl_decode_gemv_plan(0, 2560, 2560, (ctypes.c_int * 5)()) == 0
+
+
+@pytest.mark.parametrize("batch,ctx,windows,heads_per_wg,max_window", [
+    (1, 40, 1, 1, 64), (1, 100, 2, 1, 64), (1, 150, 4, 1, 64), (1, 255, 4, 1, 64),   # up to 256 tokens: 64-token windows
+    (1, 300, 4, 1, 128), (1, 511, 4, 1, 128),                                        # 257..512: 128 (4 partials for the wo GEMV, not 8)
+    (1, 700, 4, 1, 256), (1, 1500, 8, 1, 256), (1, 3000, 16, 1, 256),                # beyond: 256-token windows
+    (1, 5000, 32, 4, 256), (1, 32768, 32, 4, 2048),                                  # above 4,096 tokens a GQA group per workgroup, 32 windows
+    (2, 300, 8, 1, 64), (2, 700, 4, 1, 256), (2, 1500, 8, 1, 256), (2, 3000, 16, 4, 256),  # two sequences switch at 2,048 tokens
+    (4, 256, 8, 4, 64), (4, 1000, 4, 4, 256),                                        # 3+ sequences: always the GQA-group walk
+    (8, 300, 4, 4, 128), (8, 1000, 8, 4, 128), (64, 300, 1, 4, 512),                 # 5-8: 128 at 257..512; many sequences: one window each
+])
+def test_attention_plans_by_context_and_sequences(lib, monkeypatch, batch, ctx, windows, heads_per_wg, max_window):
+    for name in ("TL_ATTN_RQ", "TL_ATTN_RQ1_CTX", "TL_ATTN_RQ1_BATCH", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS", "TL_ATTN_WG_CAP"):
+        monkeypatch.delenv(name, raising=False)
+    n_splits, per_split, rq = attention_plan(lib, batch, ctx)
+    assert (n_splits, rq) == (windows, heads_per_wg), f"{batch} sequences, {ctx} tokens: {n_splits} windows of {per_split}, {rq} heads per workgroup"
+    assert per_split % 64 == 0 and 64 <= per_split <= max_window and n_splits * per_split >= ctx + 1
+
+
+def test_attention_plan_knobs_are_read(lib, monkeypatch):
+    monkeypatch.setenv("TL_ATTN_MIN_TOKENS", "64")
+    assert attention_plan(lib, 1, 3000)[0] == 64  # the round-2 plan: 64-token windows whatever the context
+    monkeypatch.setenv("TL_ATTN_MAX_SPLITS", "8")
+    assert attention_plan(lib, 1, 3000)[0] == 8
+    monkeypatch.delenv("TL_ATTN_MIN_TOKENS")
+    monkeypatch.delenv("TL_ATTN_MAX_SPLITS")
+    monkeypatch.setenv("TL_ATTN_RQ", "4")
+    assert attention_plan(lib, 1, 300)[2] == 4

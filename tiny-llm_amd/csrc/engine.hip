@@ -418,6 +418,15 @@ struct SplitPlan {
 // stages, so that the K/V window is read from HBM once.  (A "wide" one-head kernel -- the whole 64..512-token window in one
 // workgroup, no merge -- was built in round 2, lost on every context it was meant for (8.2 us per layer against 2.9 + 1.3) and was
 // removed in round 3 together with the last-arriver in-kernel merge, which measured neutral.)
+// the attention plan's lab knobs (environment, read when an engine -- or the standalone operator's stand-in for one -- is set up)
+static void read_attention_knobs(tl_engine *e) {
+    if (const char *q = getenv("TL_ATTN_RQ")) e->attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
+    if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e->attn_rq1_ctx = atoi(q);
+    if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e->attn_rq1_batch = atoi(q);
+    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = e->attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
+    if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q)), e->attn_min_tokens_auto = false;
+    if (const char *q = getenv("TL_ATTN_WG_CAP")) e->attn_wg_cap = std::max(0, atoi(q));
+}
 static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
     const int rep = e->cfg.num_heads / e->cfg.num_kv_heads;
     int rq = e->attn_rq;
@@ -933,12 +942,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
-    if (const char *q = getenv("TL_ATTN_RQ")) e->attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
-    if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e->attn_rq1_ctx = atoi(q);
-    if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e->attn_rq1_batch = atoi(q);
-    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = e->attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
-    if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q)), e->attn_min_tokens_auto = false;
-    if (const char *q = getenv("TL_ATTN_WG_CAP")) e->attn_wg_cap = std::max(0, atoi(q));
+    read_attention_knobs(e);
 
     // state words: zero everything up to the activations, then the block table to -1
     if (hipMemsetAsync(e->arena, 0, o_x, e->stream) != hipSuccess) return cleanup_fail("engine_create: memset failed");
@@ -1899,12 +1903,7 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
     const size_t rc_bytes = align_up((size_t)batch * (head_dim / 2) * sizeof(float2), 256);
     e.attn_ws = (float *)((char *)workspace_dev + rc_bytes);
     e.attn_ws_bytes = workspace_bytes - rc_bytes;
-    if (const char *q = getenv("TL_ATTN_RQ")) e.attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
-    if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e.attn_rq1_ctx = atoi(q);
-    if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e.attn_rq1_batch = atoi(q);
-    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e.attn_max_splits = e.attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
-    if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e.attn_min_tokens = std::max(64, atoi(q)), e.attn_min_tokens_auto = false;
-    if (const char *q = getenv("TL_ATTN_WG_CAP")) e.attn_wg_cap = std::max(0, atoi(q));
+    read_attention_knobs(&e);
     hipLaunchKernelGGL(rope_rows_kernel, dim3(batch), dim3(64), 0, e.stream, context_lens_dev, e.rope_cur, head_dim / 2, rope_theta);
     TL_CHECK_LAUNCH("decode_attention_fused rope");
     const SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
@@ -1918,4 +1917,22 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
         info->launches = e.last_attn_launches;
     }
     return rc;
+}
+
+// ---- host-only: the plans the decode path would pick (no device, no launch): what the CPU tests and a binding's dry run read -------
+extern "C" int tl_decode_gemv_plan(int M, int rows, int cols, int *out5) {
+    if (!out5 || M < 1 || rows <= 0 || cols <= 0) return 0;
+    const Qmv3Plan pl = qmv3_plan(M, cols, rows);
+    out5[0] = pl.MR, out5[1] = pl.KS, out5[2] = pl.CW, out5[3] = pl.LM, out5[4] = pl.blocks;
+    return pl.ok ? 1 : 0;
+}
+extern "C" int tl_decode_attention_plan(int batch, int max_context, int num_heads, int num_kv_heads, int *out3) {
+    if (!out3 || batch < 1 || max_context < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0) return 0;
+    tl_engine e;
+    e.cfg.num_heads = num_heads;
+    e.cfg.num_kv_heads = num_kv_heads;
+    read_attention_knobs(&e);
+    const SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
+    out3[0] = sp.n_splits, out3[1] = sp.tokens_per_split, out3[2] = sp.rq;
+    return 1;
 }

@@ -130,6 +130,8 @@ _SIGNATURES.update({
     "tl_engine_create": (_c_int, [_P(TlEngineConfig), _P(TlLayerWeights), _P(TlW4), _c_void_p, _P(TlW4), _c_void_p,
                                   _P(_c_void_p)]),
     "tl_engine_set_moe_layer": (_c_int, [_c_void_p, _c_int, _P(TlMoeWeights)]),
+    "tl_decode_gemv_plan": (_c_int, [_c_int, _c_int, _c_int, _P(_c_int)]),
+    "tl_decode_attention_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _P(_c_int)]),
     "tl_engine_destroy": (None, [_c_void_p]),
     "tl_engine_synchronize": (_c_int, [_c_void_p]),
     "tl_engine_begin": (_c_int, [_c_void_p, _c_int]),
