@@ -339,8 +339,10 @@ constexpr int FA_VROW = 128 + 32;    // bf16 elements per row of the row-major V
 // wave-uniform word and every K/V address of the stage is (uniform base of the page's rows) + (a per-thread offset fixed for
 // the whole kernel): the per-chunk page lookups (8 vector loads per thread and stage) and the 64-bit address chains behind them
 // (~20 VALU instructions per chunk, as much as the softmax of the stage) disappear.
-template <bool ONEPAGE>
-__global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
+// QR = 32-row query blocks per wave (round 3): with two, every K and V fragment read from LDS feeds two MFMAs and a workgroup
+// covers 4 heads x 64 query rows per K/V tile it stages -- half the staging, half the fragment reads per flop; one wave per SIMD.
+template <bool ONEPAGE, int QR = 1>
+__global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ key_pages, const uint16_t *__restrict__ value_pages,
     const int32_t *__restrict__ block_table, const int32_t *__restrict__ context_lens, uint16_t *__restrict__ out,
     float *__restrict__ ws, int n_splits, int L, int page_size, int page_shift, int max_pages, int num_heads, int num_kv_heads,
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     }
     const int b = blockIdx.z;
     const int rep = num_heads / num_kv_heads;
-    const int QB = (L + 31) / 32;
+    const int QB = (L + 32 * QR - 1) / (32 * QR);  // query blocks of 32 QR rows: one per wave
     const int items = rep * QB;
     // bx = item block * n_splits + context split: with few query rows (chunked prefill of a long prompt) the KV
     // range is cut into n_splits pieces, one workgroup each, merged by paged_merge_kernel (flash-decoding style)
@@ -382,32 +384,37 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
     const int n = b * num_heads + kvh * rep + hq;
     const int ctx = context_lens[b];
     const float scale_log2 = scale * LOG2E;
-    const int qrow = qb * 32 + l32;
-    const bool q_valid = wave_live && qrow < L;
-
+    int qrow[QR];
+    bool q_valid[QR];
     // Q^T fragments (B operand): lane (qrow, half h), step s -> dims 16s + 8h .. +8
-    u32x4 qf[8];
+    u32x4 qf[QR][8];
+    f32x16 o[QR][4];
+    float run_max[QR], run_sum[QR];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        if (q_valid) {
-            qf[s] = *reinterpret_cast<const u32x4 *>(q + ((long)n * L + qrow) * D + 16 * s + 8 * h);
-        } else {
-            qf[s] = u32x4{0u, 0u, 0u, 0u};
+    for (int rb = 0; rb < QR; ++rb) {
+        qrow[rb] = (qb * QR + rb) * 32 + l32;
+        q_valid[rb] = wave_live && qrow[rb] < L;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (q_valid[rb]) {
+                qf[rb][s] = *reinterpret_cast<const u32x4 *>(q + ((long)n * L + qrow[rb]) * D + 16 * s + 8 * h);
+            } else {
+                qf[rb][s] = u32x4{0u, 0u, 0u, 0u};
+            }
         }
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[rb][db][r] = 0.f;
+        run_max[rb] = -INFINITY;
+        run_sum[rb] = 0.f;
     }
-
-    f32x16 o[4];
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float run_max = -INFINITY, run_sum = 0.f;
 
     // tile range: block-level limit = max over this block's items
     const int total_tiles = (ctx + 31) / 32;
     int my_tiles = total_tiles;
     if (is_causal) {
-        const int last_query = min((qb + 1) * 32, L) - 1;
+        const int last_query = min((qb + 1) * 32 * QR, L) - 1;
         const int last_key = last_query + (ctx - L);
         my_tiles = min(max((last_key + 1 + 31) / 32, 0), total_tiles);
     }
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
         const int last_item = min(item_block * 4 + 3, items - 1);
         const int last_qb = last_item / rep;
         if (is_causal) {
-            const int lq = min((last_qb + 1) * 32, L) - 1;
+            const int lq = min((last_qb + 1) * 32 * QR, L) - 1;
             const int lk = lq + (ctx - L);
             blk_tiles = min(max((lk + 1 + 31) / 32, 0), total_tiles);
         } else {
@@ -548,81 +555,89 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
         if (tile >= my_tiles) continue;  // wave-uniform: this wave's rows see nothing here
         const int tb = sub * 32;         // token offset of the sub-tile inside the stage
 
-        // S^T = K Q^T
-        f32x16 sacc;
+        // S^T = K Q^T: a K fragment read from LDS feeds the MFMA of every row block of the wave
+        f32x16 sacc[QR];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        for (int rb = 0; rb < QR; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[rb][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int ch = (2 * s + h) ^ (l32 & 15);
             const u32x4 kf = *reinterpret_cast<const u32x4 *>(&ks[(tb + l32) * D + ch * 8]);
-            if constexpr (FA_ABL & 4) sacc[s] += __uint_as_float((kf[0] ^ qf[s][1]) & 0x3f800000u);
-            else
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
-                                                           __builtin_bit_cast(bf16x8_t, qf[s]), sacc, 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < QR; ++rb) {
+                if constexpr (FA_ABL & 4) sacc[rb][s] += __uint_as_float((kf[0] ^ qf[rb][s][1]) & 0x3f800000u);
+                else
+                sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                                   __builtin_bit_cast(bf16x8_t, qf[rb][s]), sacc[rb], 0, 0, 0);
+            }
         }
-        // mask + scale ; lane holds tokens (r&3)+8(r>>2)+4h of query row qrow.
+        u32x4 pf[QR][2];
+#pragma unroll
+        for (int rb = 0; rb < QR; ++rb) {
+        // mask + scale ; lane holds tokens (r&3)+8(r>>2)+4h of query row qrow[rb].
         // Interior tiles (wave-uniform test: every token is inside the context, on one live page, and at or below the causal
-        // diagonal of the block's FIRST query row) need no per-element test: most tiles of a long context are interior.
+        // diagonal of the row block's FIRST query row) need no per-element test: most tiles of a long context are interior.
         float tmax = -INFINITY;
         const bool interior = page_shift >= 5 && tile * 32 + 31 < ctx && tile_page[stage & 1][tb] >= 0 &&
-                              (!is_causal || tile * 32 + 31 <= qb * 32 + (ctx - L));
+                              (!is_causal || tile * 32 + 31 <= (qb * QR + rb) * 32 + (ctx - L));
         if (interior) {  // raw scores here; the scale goes into the exponent's FMA below (16 multiplies fewer per tile)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[r]);
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[rb][r]);
             tmax *= scale_log2;  // scale > 0: max and scaling commute
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tok = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                bool valid = q_valid && tok < ctx && tile_page[stage & 1][tb + (r & 3) + 8 * (r >> 2) + 4 * h] >= 0;
-                if (is_causal) valid = valid && tok <= qrow + (ctx - L);
-                sacc[r] = valid ? sacc[r] * scale_log2 : -INFINITY;
-                tmax = fmaxf(tmax, sacc[r]);
+                bool valid = q_valid[rb] && tok < ctx && tile_page[stage & 1][tb + (r & 3) + 8 * (r >> 2) + 4 * h] >= 0;
+                if (is_causal) valid = valid && tok <= qrow[rb] + (ctx - L);
+                sacc[rb][r] = valid ? sacc[rb][r] * scale_log2 : -INFINITY;
+                tmax = fmaxf(tmax, sacc[rb][r]);
             }
         }
         if constexpr (FA_ABL & 1) {
-            run_sum += sacc[0];
+            run_sum[rb] += sacc[rb][0];
         } else {
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float new_max = fmaxf(run_max, tmax);
+        const float new_max = fmaxf(run_max[rb], tmax);
         float prev_scale, tsum = 0.f;
         if (interior) {  // every score is finite: exp2f(-inf) of the first tile's running maximum is the wanted 0
-            prev_scale = exp2_hw(run_max - new_max);
+            prev_scale = exp2_hw(run_max[rb] - new_max);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sacc[r] = exp2_hw(fmaf(sacc[r], scale_log2, -new_max));
-                tsum += sacc[r];
+                sacc[rb][r] = exp2_hw(fmaf(sacc[rb][r], scale_log2, -new_max));
+                tsum += sacc[rb][r];
             }
         } else {
-            const bool finite_row = q_valid && new_max != -INFINITY;
-            prev_scale = (run_max == -INFINITY || !finite_row) ? 0.f : exp2_hw(run_max - new_max);
+            const bool finite_row = q_valid[rb] && new_max != -INFINITY;
+            prev_scale = (run_max[rb] == -INFINITY || !finite_row) ? 0.f : exp2_hw(run_max[rb] - new_max);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = (sacc[r] == -INFINITY || !finite_row) ? 0.f : exp2_hw(sacc[r] - new_max);
-                sacc[r] = p;
+                const float p = (sacc[rb][r] == -INFINITY || !finite_row) ? 0.f : exp2_hw(sacc[rb][r] - new_max);
+                sacc[rb][r] = p;
                 tsum += p;
             }
         }
         tsum += __shfl_xor(tsum, 32, 64);
-        run_max = new_max;
-        run_sum = prev_scale * run_sum + tsum;
+        run_max[rb] = new_max;
+        run_sum[rb] = prev_scale * run_sum[rb] + tsum;
         if (!__all(prev_scale == 1.0f)) {  // once the running maxima have settled the rescale is the identity for the whole wave
 #pragma unroll
             for (int db = 0; db < 4; ++db)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] *= prev_scale;
+                for (int r = 0; r < 16; ++r) o[rb][db][r] *= prev_scale;
         }
         }  // FA_ABL & 1
 
         // P^T fragments (B operand), step s uses regs 8s..8s+7
-        u32x4 pf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pf[s][e] = BF16::pack2(sacc[8 * s + 2 * e], sacc[8 * s + 2 * e + 1]);
+            for (int e = 0; e < 4; ++e) pf[rb][s][e] = BF16::pack2(sacc[rb][8 * s + 2 * e], sacc[rb][8 * s + 2 * e + 1]);
+        }  // row block
 
-        // O^T += V^T P^T
+        // O^T += V^T P^T: a V fragment (gathered transposed from the row-major tile) feeds every row block
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
 #pragma unroll
@@ -634,42 +649,48 @@ __global__ __launch_bounds__(256, 2) void paged_fa_bf16_d128_kernel(
                 const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16 *)(vtr + (tb + 16 * s + 8) * FA_VROW + db * 32));
                 const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
                 const u32x4 vf = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
-                if constexpr (FA_ABL & 2) o[db][s] += __uint_as_float((vf[0] ^ pf[s][1]) & 0x3f800000u);
-                else
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
-                                                                __builtin_bit_cast(bf16x8_t, pf[s]), o[db], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < QR; ++rb) {
+                    if constexpr (FA_ABL & 2) o[rb][db][s] += __uint_as_float((vf[0] ^ pf[rb][s][1]) & 0x3f800000u);
+                    else
+                    o[rb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
+                                                                        __builtin_bit_cast(bf16x8_t, pf[rb][s]), o[rb][db], 0, 0, 0);
+                }
             }
         }
         }  // sub-tile
     }
 
-    if (!q_valid) return;
-    if (n_splits > 1) {
-        // un-normalised partial: D values, running max (log2 domain), running sum
-        float *w = ws + (((long)n * L + qrow) * n_splits + split) * (D + 2);
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+    for (int rb = 0; rb < QR; ++rb) {
+        if (!q_valid[rb]) continue;
+        if (n_splits > 1) {
+            // un-normalised partial: D values, running max (log2 domain), running sum
+            float *w = ws + (((long)n * L + qrow[rb]) * n_splits + split) * (D + 2);
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
+            for (int db = 0; db < 4; ++db)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[db * 32 + 8 * rg + 4 * h + e] = o[db][4 * rg + e];
-        if (h == 0) {
-            w[D] = run_max == -INFINITY ? -1e30f : run_max;
-            w[D + 1] = run_sum;
+                for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[db * 32 + 8 * rg + 4 * h + e] = o[rb][db][4 * rg + e];
+            if (h == 0) {
+                w[D] = run_max[rb] == -INFINITY ? -1e30f : run_max[rb];
+                w[D + 1] = run_sum[rb];
+            }
+            continue;
         }
-        return;
-    }
-    uint16_t *orow = out + ((long)n * L + qrow) * D;
-    const float inv = run_sum == 0.f ? 0.f : 1.0f / run_sum;
+        uint16_t *orow = out + ((long)n * L + qrow[rb]) * D;
+        const float inv = run_sum[rb] == 0.f ? 0.f : 1.0f / run_sum[rb];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
+        for (int db = 0; db < 4; ++db) {
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            // regs 4rg..4rg+3 -> dims db*32 + 8rg + 4h + 0..3
-            u32x2 pk;
-            pk[0] = BF16::pack2(o[db][4 * rg + 0] * inv, o[db][4 * rg + 1] * inv);
-            pk[1] = BF16::pack2(o[db][4 * rg + 2] * inv, o[db][4 * rg + 3] * inv);
-            *reinterpret_cast<u32x2 *>(orow + db * 32 + 8 * rg + 4 * h) = pk;
+            for (int rg = 0; rg < 4; ++rg) {
+                // regs 4rg..4rg+3 -> dims db*32 + 8rg + 4h + 0..3
+                u32x2 pk;
+                pk[0] = BF16::pack2(o[rb][db][4 * rg + 0] * inv, o[rb][db][4 * rg + 1] * inv);
+                pk[1] = BF16::pack2(o[rb][db][4 * rg + 2] * inv, o[rb][db][4 * rg + 3] * inv);
+                *reinterpret_cast<u32x2 *>(orow + db * 32 + 8 * rg + 4 * h) = pk;
+            }
         }
     }
 }
@@ -795,7 +816,11 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
 
     if (L > 8 && dtype == TL_BF16) {
         if (D != 128) return fail(TL_ERR_UNSUPPORTED, "paged_attention: bfloat16 prefill requires head dimension 128");
-        const int items = rep * ((L + 31) / 32);
+        // (the kernel is templated on QR, 32-row query blocks per wave; two of them -- every K / V fragment read feeds two MFMAs, half
+        // the K/V staging per flop -- were measured in round 3 and lose at one wave per SIMD: 392 -> 573 us at 2,048 x 8,192,
+        // profiles/r03_labs/prefill_fa_two_row_blocks.log; only QR = 1 is instantiated)
+        constexpr int qr = 1;
+        const int items = rep * ((L + 32 * qr - 1) / (32 * qr));
         const int item_blocks = (items + 3) / 4;
         const int max_ctx_fa = max_context_hint > 0 ? max_context_hint : max_pages * page_size;
         int fa_splits = pick_fa_splits(B, num_kv_heads, item_blocks, max_ctx_fa);
@@ -806,16 +831,14 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
         int page_shift = -1;
         for (int sh = 0; sh < 30; ++sh)
             if ((1 << sh) == page_size) page_shift = sh;
-        if (page_shift >= 6)  // a 64-token stage never straddles pages
-            hipLaunchKernelGGL(paged_fa_bf16_d128_kernel<true>, grid, dim3(256), 0, st, (const uint16_t *)q,
-                               (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,
-                               (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, page_shift, max_pages, num_heads,
-                               num_kv_heads, scale, is_causal, fa_xcd_remap);
-        else
-            hipLaunchKernelGGL(paged_fa_bf16_d128_kernel<false>, grid, dim3(256), 0, st, (const uint16_t *)q,
-                               (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,
-                               (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, page_shift, max_pages, num_heads,
-                               num_kv_heads, scale, is_causal, fa_xcd_remap);
+#define FA_LAUNCH(ONEP, QRv)                                                                                                    \
+        hipLaunchKernelGGL((paged_fa_bf16_d128_kernel<ONEP, QRv>), grid, dim3(256), 0, st, (const uint16_t *)q,                 \
+                           (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,                \
+                           (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, page_shift, max_pages, num_heads,      \
+                           num_kv_heads, scale, is_causal, fa_xcd_remap)
+        if (page_shift >= 6) FA_LAUNCH(true, 1);  // a 64-token stage never straddles pages
+        else FA_LAUNCH(false, 1);
+#undef FA_LAUNCH
         TL_CHECK_LAUNCH("paged_attention(prefill)");
         if (fa_splits > 1) {
             hipLaunchKernelGGL((paged_merge_kernel<BF16>), dim3(N * L), dim3(128), 0, st, (const float *)workspace,
