@@ -250,6 +250,33 @@ int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int
                      const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,
                      size_t workspace_bytes, void *stream, tl_linear_info *info);
 
+/* The routes of the fused GEMV that only a whole engine step reached before round 4 -- the kernels BASELINE configs[1] times
+ * (csrc/qmv3.h): the wo projection of ONE row forming its input row from the decode-attention split partials, the gate|up
+ * projection over rows its producer left weighted, and the producer / consumer hand-over of RMSNorm sums of squares.  The
+ * reference tests its matvec per shape against the dequantised product (tests_refsol/test_week_2_day_3.py:89-118); these
+ * entry points let tests/test_decode_kernels_gpu.py do the same for exactly those instantiations.
+ *   prologue 2 (with epilogue 1, M = 1, kernel 1): `a_dev` is not read; the activation row is the merge of
+ *     merge_ws_dev [cols / 128 heads][n_splits][128 + 4] fp32 (128 value sums, running max in log2 units, running sum, 2 pad;
+ *     n_splits 2 / 4 / 8): per column  bf16(sum_s v_s 2^(m_s - max m) / sum_s l_s 2^(m_s - max m)),  zero where the sum is zero.
+ *   prologue 3 (with epilogue 2, M <= 8, kernel 1): a_dev holds bf16(x * norm_weight) (what a producer's out_w_dev holds) and
+ *     ss_in_dev the sums of squares of x; out = SwiGLU(bf16(rsqrt(mean x^2 + eps) * (a @ W^T))).
+ *   ss_in_dev [M][ss_in_n] (prologues 1 and 3): partial sums of squares of each row, added instead of re-derived (the GEMV: any
+ *     multiple of 4 up to 256 partials; the skinny matmul: exactly 8).
+ *   epilogue 1 through the GEMV: ss_out_dev [M][rows / 16] receives the sum of squares of every 16 stored bf16 outputs;
+ *     norm_out_dev [rows] + out_w_dev [M][rows]: also store bf16(out * norm_out). */
+typedef struct tl_linear_ex {
+    const float *merge_ws_dev;
+    int n_splits;
+    const float *ss_in_dev;
+    int ss_in_n;
+    float *ss_out_dev;
+    const void *norm_out_dev;
+    void *out_w_dev;
+} tl_linear_ex;
+int tl_decode_linear_ex(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
+                        const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,
+                        size_t workspace_bytes, void *stream, const tl_linear_ex *ex, tl_linear_info *info);
+
 /* The attention launch of one decode layer: q/k-RMSNorm + RoPE at position context_lens[b] + append of the new K/V row to
  * the pages (IN PLACE) + GQA attention over context_lens[b] + 1 tokens (+ the merge launch when the context is split).
  *   qkv [batch, (Hq + 2 Hkv) D] bf16, pages [P, Hkv, page_size, D] bf16, block_table [batch, max_pages] int32,
@@ -260,6 +287,9 @@ int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int
  * when the MFMA GEMV takes the shape (0: the packed-dot GEMV would).  tl_decode_attention_plan: `batch` sequences whose longest
  * holds max_context tokens before this step -> out3 = {windows per sequence, tokens per window, query heads per workgroup}. */
 int tl_decode_gemv_plan(int M, int rows, int cols, int *out5);
+/* 1 when the library holds a fused-GEMV kernel for (rows per workgroup, reduction split, waves, groups per wave): a plan is only
+ * ever "taken" (tl_decode_gemv_plan returns 1) for such a combination; anything else decodes through the packed-dot GEMV. */
+int tl_decode_gemv_variant_compiled(int MR, int KS, int CW, int LM);
 int tl_decode_attention_plan(int batch, int max_context, int num_heads, int num_kv_heads, int *out3);
 
 typedef struct tl_attention_info {

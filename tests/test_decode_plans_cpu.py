@@ -47,6 +47,50 @@ def test_gemv_plans_at_the_qwen3_4b_projections(lib):
     assert lib.tl_decode_gemv_plan(0, 2560, 2560, (ctypes.c_int * 5)()) == 0
 
 
+# (hidden, Hq * D, (Hq + 2 Hkv) * D, intermediate, vocab) of the dense Qwen3 family and of Qwen2-7B (public configs; head_dim 128)
+MODEL_SHAPES = {
+    "qwen3-0.6b": (1024, 2048, 4096, 3072, 151936), "qwen3-1.7b": (2048, 2048, 4096, 6144, 151936),
+    "qwen3-4b": (2560, 4096, 6144, 9728, 151936), "qwen3-8b": (4096, 4096, 6144, 12288, 151936),
+    "qwen3-14b": (5120, 5120, 7168, 17408, 151936), "qwen3-32b": (5120, 8192, 10240, 25600, 151936),
+    "qwen2-7b": (3584, 3584, 4608, 18944, 152064),
+}
+
+
+@pytest.mark.parametrize("model", list(MODEL_SHAPES))
+def test_every_taken_gemv_plan_has_a_compiled_kernel(lib, model):
+    """Round-3 advisor finding: a planner rule promoted w_down of Qwen3-8B / 14B / Qwen2-7B at 3-4 rows to 16 waves x 8 / 10 groups,
+    which no kernel is compiled for (the engine then failed instead of decoding).  A plan is "taken" only for a combination in the
+    instantiation table (csrc/qmv3.hip Q3_TABLE); every other shape decodes through the packed-dot GEMV."""
+    hidden, q_dim, qkv_dim, inter, vocab = MODEL_SHAPES[model]
+    projections = {"qkv": (qkv_dim, hidden), "wo": (hidden, q_dim), "gate_up": (2 * inter, hidden), "down": (hidden, inter),
+                   "lm_head": (vocab, hidden)}
+    for name, (rows, cols) in projections.items():
+        for M in range(1, 9):
+            out = (ctypes.c_int * 5)()
+            ok = lib.tl_decode_gemv_plan(M, rows, cols, out)
+            MR, KS, CW, LM, blocks = tuple(out)
+            compiled = lib.tl_decode_gemv_variant_compiled(MR, KS, CW, LM)
+            assert ok == 0 or compiled == 1, f"{model} {name} at {M} rows: plan {tuple(out)} is taken but not compiled"
+            if ok:
+                assert MR >= M or MR == 8, f"{model} {name} at {M} rows: {tuple(out)}"
+                assert KS * LM * 128 >= cols and blocks >= 1, f"{model} {name} at {M} rows: the plan does not cover the reduction: {tuple(out)}"
+    # the cases the finding named: four rows against reductions of 96 / 136 groups (w_down of Qwen3-8B / 14B) are beyond 8 waves x 10
+    # groups and no 16-wave kernel with 8 / 10 groups per wave exists: not taken (packed-dot GEMV), as before round 3
+    out = (ctypes.c_int * 5)()
+    assert lib.tl_decode_gemv_plan(4, 4096, 12288, out) == 0 and lib.tl_decode_gemv_plan(4, 5120, 17408, out) == 0
+    assert lib.tl_decode_gemv_plan(4, 2560, 9728, out) == 1 and tuple(out)[:4] == (4, 16, 16, 5)  # the shape the rule was measured on
+
+
+def test_the_planners_variant_predicate_is_the_instantiation_table(lib):
+    """qmv3_has_variant (header, used by qmv3_plan) against the macro table the launcher is generated from."""
+    import itertools
+
+    table = {(mr, ks, cw, lm) for mr, ks, cw, lm in itertools.product(range(1, 17), range(1, 17), (4, 8, 16), range(1, 12))
+             if lib.tl_decode_gemv_variant_compiled(mr, ks, cw, lm)}
+    assert len(table) == 4 * 6 * 4 + 2
+    assert (4, 16, 16, 5) in table and (4, 16, 16, 8) not in table and (1, 8, 8, 10) in table and (1, 8, 4, 10) not in table
+
+
 @pytest.mark.parametrize("batch,ctx,windows,heads_per_wg,max_window", [
     (1, 40, 1, 1, 64), (1, 100, 2, 1, 64), (1, 150, 4, 1, 64), (1, 255, 4, 1, 64),   # up to 256 tokens: 64-token windows
     (1, 300, 4, 1, 128), (1, 511, 4, 1, 128),                                        # 257..512: 128 (4 partials for the wo GEMV, not 8)

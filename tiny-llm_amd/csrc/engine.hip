@@ -1814,21 +1814,25 @@ extern "C" size_t tl_decode_linear_workspace_bytes(int M, int rows, int cols) {
     return need + partial;
 }
 
-extern "C" int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
-                                const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,
-                                size_t workspace_bytes, void *stream, tl_linear_info *info) {
-    TL_REQUIRE(w && a_dev && out_dev, "decode_linear: null argument");
+static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
+                              const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,
+                              size_t workspace_bytes, void *stream, const tl_linear_ex *ex, tl_linear_info *info) {
+    TL_REQUIRE(w && out_dev, "decode_linear: null argument");
     TL_REQUIRE(M >= 1 && M <= 64, "decode_linear: between 1 and 64 activation rows");
-    TL_REQUIRE(prologue == PRO_NONE || prologue == PRO_RMSNORM, "decode_linear: prologue is 0 (none) or 1 (RMSNorm)");
+    TL_REQUIRE(prologue == PRO_NONE || prologue == PRO_RMSNORM || (ex && (prologue == PRO_ATTN_MERGE || prologue == PRO_RMS_WEIGHTED)),
+               "decode_linear: prologue is 0 (none) or 1 (RMSNorm); tl_decode_linear_ex also takes 2 (merge of attention partials) and 3 (weighted rows)");
     TL_REQUIRE(epilogue == EPI_STORE || epilogue == EPI_RESIDUAL || epilogue == EPI_SWIGLU,
                "decode_linear: epilogue is 0 (store), 1 (residual add) or 2 (SwiGLU over interleaved rows)");
+    TL_REQUIRE(prologue == PRO_ATTN_MERGE || a_dev, "decode_linear: null activation rows");
     TL_REQUIRE(prologue != PRO_RMSNORM || norm_w_dev, "decode_linear: the RMSNorm prologue needs its weight");
     TL_REQUIRE(epilogue != EPI_RESIDUAL || residual_dev, "decode_linear: the residual epilogue needs the residual rows");
     TL_REQUIRE(kernel >= 0 && kernel <= 4,
                "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV), 2 (skinny matmul), 3 / 4 (its one-shot / persistent grid)");
     TL_REQUIRE(epilogue != EPI_SWIGLU || w->w.rows % 2 == 0, "decode_linear: SwiGLU needs an even number of weight rows");
-    // the engine's own fused variants: RMSNorm+store (qkv, lm_head), residual (wo, w_down), RMSNorm+SwiGLU (gate|up), plain
-    TL_REQUIRE((prologue == PRO_NONE && epilogue != EPI_SWIGLU) || (prologue == PRO_RMSNORM && epilogue != EPI_RESIDUAL),
+    // the engine's own fused variants: RMSNorm+store (qkv, lm_head), residual (wo, w_down), RMSNorm+SwiGLU (gate|up), plain;
+    // through tl_decode_linear_ex also: merged attention partials + residual (wo of one row), weighted rows + SwiGLU (gate|up)
+    TL_REQUIRE((prologue == PRO_NONE && epilogue != EPI_SWIGLU) || (prologue == PRO_RMSNORM && epilogue != EPI_RESIDUAL) ||
+                   (prologue == PRO_ATTN_MERGE && epilogue == EPI_RESIDUAL) || (prologue == PRO_RMS_WEIGHTED && epilogue == EPI_SWIGLU),
                "decode_linear: no fused variant for this prologue / epilogue pair");
     const size_t need = tl_decode_linear_workspace_bytes(M, w->w.rows, w->w.cols);
     TL_REQUIRE(workspace_dev && workspace_bytes >= need, "decode_linear: workspace is missing or too small");
@@ -1845,12 +1849,75 @@ extern "C" int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *o
     tl_linear_info li{};
     e.linfo = &li;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e.qmm3_min_rows = std::max(1, atoi(q));
-    const int rc = engine_linear(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, prologue, epilogue, norm_w_dev,
-                                 (const uint16_t *)residual_dev, nullptr, 0);
-    e.splitk_ws = nullptr;  // borrowed
-    e.tiled.clear();
-    if (info) *info = li;
-    return rc;
+    int rc = TL_OK;
+    auto done = [&](int code) {
+        e.splitk_ws = nullptr;  // borrowed
+        e.tiled.clear();
+        if (info) *info = li;
+        return code;
+    };
+    if (!ex) {
+        rc = engine_linear(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, prologue, epilogue, norm_w_dev,
+                           (const uint16_t *)residual_dev, nullptr, 0);
+        return done(rc);
+    }
+    // ---- the routes only the engine could reach before round 4 (qmv3.h: PRO_ATTN_MERGE, PRO_RMS_WEIGHTED, ss_in / ss_out, out_w)
+    const bool gemv_only = prologue == PRO_ATTN_MERGE || prologue == PRO_RMS_WEIGHTED || ex->ss_out_dev || ex->out_w_dev;
+    if (gemv_only && !(kernel == 1 || (kernel == 0 && M < e.qmm3_min_rows)))
+        return done(fail(TL_ERR_INVALID, "decode_linear_ex: merged partials, weighted rows, ss_out and out_w are routes of the fused GEMV (kernel 1, or 0 with fewer than 5 rows)"));
+    if ((ex->out_w_dev != nullptr) != (ex->norm_out_dev != nullptr) || (ex->out_w_dev && epilogue != EPI_RESIDUAL) ||
+        (ex->ss_out_dev && epilogue != EPI_RESIDUAL))
+        return done(fail(TL_ERR_INVALID, "decode_linear_ex: ss_out / (norm_out, out_w) belong to the residual epilogue; norm_out and out_w come together"));
+    if (ex->ss_in_dev && (ex->ss_in_n <= 0 || !(prologue == PRO_RMSNORM || prologue == PRO_RMS_WEIGHTED)))
+        return done(fail(TL_ERR_INVALID, "decode_linear_ex: ss_in needs ss_in_n > 0 and a normalising prologue (1 or 3)"));
+    int ss_n = 0;
+    if (prologue == PRO_ATTN_MERGE) {
+        if (M != 1 || !ex->merge_ws_dev) return done(fail(TL_ERR_INVALID, "decode_linear_ex: the merging prologue takes ONE row and the split partials (merge_ws_dev)"));
+        e.attn_ws = const_cast<float *>(ex->merge_ws_dev);
+        rc = engine_wo_merge(&e, w->w, (const uint16_t *)residual_dev, (uint16_t *)out_dev, ex->n_splits, nullptr, ex->ss_out_dev, &ss_n,
+                             ex->norm_out_dev, (uint16_t *)ex->out_w_dev);
+        e.attn_ws = nullptr;  // borrowed
+        if (rc == TL_OK) {
+            const Qmv3Plan pl = qmv3_plan(1, w->w.cols, w->w.rows);
+            li.kernel = 1, li.launches = 1, li.rows_per_pass = 1;
+            li.p[0] = pl.MR, li.p[1] = pl.KS, li.p[2] = pl.CW, li.p[3] = pl.LM, li.p[4] = pl.blocks;
+        }
+        return done(rc);
+    }
+    if (prologue == PRO_RMS_WEIGHTED) {
+        const Qmv3Plan pl = qmv3_plan(std::min(M, 8), w->w.cols, w->w.rows);
+        if (!ex->ss_in_dev || M > 8 || !qmv3_takes_weighted_rows(pl, w->w.cols, ex->ss_in_n))
+            return done(fail(TL_ERR_INVALID, "decode_linear_ex: weighted rows need ss_in (a multiple of 4, at most 256 partials per row), at most 8 rows and a row that fits the staging registers"));
+    }
+    if (gemv_only || kernel == 1 || (kernel == 0 && M < e.qmm3_min_rows)) {
+        if (M > 8) return done(fail(TL_ERR_INVALID, "decode_linear_ex: the fused GEMV takes at most 8 rows"));
+        rc = engine_qmv(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, prologue, epilogue, norm_w_dev,
+                        (const uint16_t *)residual_dev, nullptr, 0, ex->ss_in_dev, ex->ss_in_n, ex->ss_out_dev, &ss_n, ex->norm_out_dev,
+                        (uint16_t *)ex->out_w_dev);
+        if (rc == TL_OK && ex->ss_out_dev && ss_n != w->w.rows / 16)
+            rc = fail(TL_ERR_UNSUPPORTED, "decode_linear_ex: the GEMV that ran left no sums of squares (packed-dot fallback or several passes)");
+        return done(rc);
+    }
+    // skinny matmul with its fused RMSNorm: QM3_SS partials per row
+    if (ex->ss_in_dev && ex->ss_in_n != QM3_SS) return done(fail(TL_ERR_INVALID, "decode_linear_ex: the skinny matmul reads exactly 8 partial sums of squares per row"));
+    rc = engine_linear(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, prologue, epilogue, norm_w_dev,
+                       (const uint16_t *)residual_dev, nullptr, 0, ex->ss_in_dev, nullptr, nullptr, nullptr, QM3_SS);
+    return done(rc);
+}
+
+extern "C" int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
+                                const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,
+                                size_t workspace_bytes, void *stream, tl_linear_info *info) {
+    return decode_linear_impl(w, a_dev, out_dev, M, prologue, epilogue, norm_w_dev, residual_dev, eps, kernel, workspace_dev,
+                              workspace_bytes, stream, nullptr, info);
+}
+
+extern "C" int tl_decode_linear_ex(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
+                                   const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,
+                                   size_t workspace_bytes, void *stream, const tl_linear_ex *ex, tl_linear_info *info) {
+    TL_REQUIRE(ex, "decode_linear_ex: null extension block (use tl_decode_linear)");
+    return decode_linear_impl(w, a_dev, out_dev, M, prologue, epilogue, norm_w_dev, residual_dev, eps, kernel, workspace_dev,
+                              workspace_bytes, stream, ex, info);
 }
 
 // (cos, sin) of each row's position = its context length, the same expression as rope_table_kernel
@@ -1926,6 +1993,7 @@ extern "C" int tl_decode_gemv_plan(int M, int rows, int cols, int *out5) {
     out5[0] = pl.MR, out5[1] = pl.KS, out5[2] = pl.CW, out5[3] = pl.LM, out5[4] = pl.blocks;
     return pl.ok ? 1 : 0;
 }
+extern "C" int tl_decode_gemv_variant_compiled(int MR, int KS, int CW, int LM) { return qmv3_variant_in_table(MR, KS, CW, LM) ? 1 : 0; }
 extern "C" int tl_decode_attention_plan(int batch, int max_context, int num_heads, int num_kv_heads, int *out3) {
     if (!out3 || batch < 1 || max_context < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0) return 0;
     tl_engine e;

@@ -497,6 +497,14 @@ struct Qmv3Plan {
     size_t lds;
     bool ok;
 };
+// The (MR, KS, CW, LM) combinations qmv3.hip instantiates (its Q3_CASE table, restated): 1 / 2 / 4 / 8 rows x {1, 2, 4 reduction
+// splits on 4 waves, 2, 4, 8 on 8 waves} x {4, 5, 8, 10} groups per wave, and 4 rows x 16 splits on 16 waves x {4, 5} groups.
+inline bool qmv3_has_variant(int MR, int KS, int CW, int LM) {
+    const bool lm = LM == 4 || LM == 5 || LM == 8 || LM == 10;
+    const bool mr = MR == 1 || MR == 2 || MR == 4 || MR == 8;
+    const bool cut = (CW == 4 && (KS == 1 || KS == 2 || KS == 4)) || (CW == 8 && (KS == 2 || KS == 4 || KS == 8));
+    return (mr && lm && cut) || (MR == 4 && KS == 16 && CW == 16 && (LM == 4 || LM == 5));
+}
 inline int qmv3_round_lm(int lper) { return lper <= 4 ? 4 : (lper <= 5 ? 5 : (lper <= 8 ? 8 : Q3_LMAX)); }
 inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0, int force_cw = 0) {
     Qmv3Plan pl{};
@@ -518,7 +526,8 @@ inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0, int force_cw = 
     // four rows over a long reduction (w_down: 76 groups): 16 waves with 5 groups each stage the 4 x 9,728 activations and run
     // their chains twice as fast as 8 waves with 10 (tools/lab/plan_lab: 9.50 -> 7.65 us; at 1 / 2 rows the 8-wave cut wins,
     // 5.66 / 6.27 against 5.86 / 6.58)
-    if (pl.MR == 4 && ks == 8 && (G + 15) / 16 >= 4) ks = 16;
+    // (only where a 16-wave kernel exists: 4 or 5 groups per wave, i.e. reductions of up to 80 groups; longer ones keep 8 waves)
+    if (pl.MR == 4 && ks == 8 && (G + 15) / 16 >= 4 && (G + 15) / 16 <= 5) ks = 16;
     if (force_ks > 0) ks = force_ks;
     pl.KS = ks;
     pl.CW = ks >= 8 ? ks : 4;
@@ -527,8 +536,9 @@ inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0, int force_cw = 
     const int wr = pl.CW / pl.KS;
     pl.blocks = (tiles + wr - 1) / wr;
     pl.lds = qmv3_lds_bytes(pl.MR, N, pl.KS, pl.CW);
+    // ok = the shape fits AND a kernel is compiled for (MR, KS, CW, LM): everything else goes to the packed-dot GEMV (qmv.h)
     pl.ok = K > 0 && K % 16 == 0 && N % 128 == 0 && M >= 1 && M <= 8 && (G + ks - 1) / ks <= Q3_LMAX &&
-            pl.lds <= 150 * 1024;
+            pl.lds <= 150 * 1024 && qmv3_has_variant(pl.MR, pl.KS, pl.CW, pl.LM);
     return pl;
 }
 
@@ -538,6 +548,7 @@ inline bool qmv3_takes_weighted_rows(const Qmv3Plan &pl, int N, int ss_n) {
 }
 
 // qmv3.hip
+bool qmv3_variant_in_table(int MR, int KS, int CW, int LM);  // the instantiation table itself (CPU test vs qmv3_has_variant)
 int launch_qmv3_bf16(const Qmv3Args &args, int pro, int epi, hipStream_t st, int force_ks = 0, int force_cw = 0);  // -1: not applicable
 int launch_qmv3_attn_merge_bf16(const Qmv3Args &args, int n_splits, hipStream_t st);  // -1: not applicable, nothing launched
 // standard checkpoint layout -> tiled layout (device to device, stream ordered)

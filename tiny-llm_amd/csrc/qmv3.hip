@@ -50,6 +50,20 @@ int repack_w4_tiled(const uint32_t *w, const uint16_t *scales, const uint16_t *b
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// The instantiation table, written once: Q3_TABLE(X) expands X(MR, KS, CW, LM) for every compiled combination.
+#define Q3_LM(X, MRv, KSv, CWv) X(MRv, KSv, CWv, 4) X(MRv, KSv, CWv, 5) X(MRv, KSv, CWv, 8) X(MRv, KSv, CWv, 10)
+#define Q3_MR(X, MRv) Q3_LM(X, MRv, 1, 4) Q3_LM(X, MRv, 2, 4) Q3_LM(X, MRv, 4, 4) Q3_LM(X, MRv, 8, 8) Q3_LM(X, MRv, 2, 8) Q3_LM(X, MRv, 4, 8)
+#define Q3_TABLE(X) Q3_MR(X, 1) Q3_MR(X, 2) Q3_MR(X, 4) Q3_MR(X, 8) \
+    X(4, 16, 16, 4) X(4, 16, 16, 5)  /* qmv3_plan: four rows over a long reduction (8 x <= 10 groups cut 16 x <= 5) */
+
+// what the table holds, for the CPU test that keeps qmv3_has_variant (qmv3.h, used by the planner) in step with it
+bool qmv3_variant_in_table(int MR, int KS, int CW, int LM) {
+#define Q3_MEMBER(MRv, KSv, CWv, LMv) if (MR == MRv && KS == KSv && CW == CWv && LM == LMv) return true;
+    Q3_TABLE(Q3_MEMBER)
+#undef Q3_MEMBER
+    return false;
+}
+
 template <int PRO, int EPI>
 static int launch_variant3(const Qmv3Args &args, hipStream_t st, int force_ks, int force_cw) {
     const Qmv3Plan pl = qmv3_plan(args.M, args.N, args.K, force_ks, force_cw);
@@ -63,12 +77,7 @@ static int launch_variant3(const Qmv3Args &args, hipStream_t st, int force_ks, i
         hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                                    \
         return 0;                                                                                                   \
     }
-#define Q3_LM(MRv, KSv, CWv) Q3_CASE(MRv, KSv, CWv, 4) Q3_CASE(MRv, KSv, CWv, 5) Q3_CASE(MRv, KSv, CWv, 8) Q3_CASE(MRv, KSv, CWv, 10)
-#define Q3_MR(MRv) Q3_LM(MRv, 1, 4) Q3_LM(MRv, 2, 4) Q3_LM(MRv, 4, 4) Q3_LM(MRv, 8, 8) Q3_LM(MRv, 2, 8) Q3_LM(MRv, 4, 8)
-    Q3_MR(1) Q3_MR(2) Q3_MR(4) Q3_MR(8)
-    Q3_CASE(4, 16, 16, 4) Q3_CASE(4, 16, 16, 5)  // qmv3_plan: four rows over a long reduction (8 x <= 10 groups cut 16 x <= 5)
-#undef Q3_LM
-#undef Q3_MR
+    Q3_TABLE(Q3_CASE)
 #undef Q3_CASE
     return -2;
 }

@@ -111,6 +111,11 @@ class TlLinearInfo(ctypes.Structure):
     _fields_ = [("kernel", _c_int), ("launches", _c_int), ("rows_per_pass", _c_int), ("p", _c_int * 5)]
 
 
+class TlLinearEx(ctypes.Structure):
+    _fields_ = [("merge_ws_dev", _c_void_p), ("n_splits", _c_int), ("ss_in_dev", _c_void_p), ("ss_in_n", _c_int),
+                ("ss_out_dev", _c_void_p), ("norm_out_dev", _c_void_p), ("out_w_dev", _c_void_p)]
+
+
 class TlAttentionInfo(ctypes.Structure):
     _fields_ = [("n_splits", _c_int), ("tokens_per_split", _c_int), ("heads_per_workgroup", _c_int),
                 ("launches", _c_int)]
@@ -123,6 +128,9 @@ _SIGNATURES.update({
     "tl_decode_linear_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "tl_decode_linear": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_float,
                                   _c_int, _c_void_p, _c_size_t, _c_void_p, _P(TlLinearInfo)]),
+    "tl_decode_linear_ex": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_float,
+                                     _c_int, _c_void_p, _c_size_t, _c_void_p, _P(TlLinearEx), _P(TlLinearInfo)]),
+    "tl_decode_gemv_variant_compiled": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
     "tl_decode_attention_fused_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "tl_decode_attention_fused": (_c_int, [_c_void_p] * 8 + [_c_int] * 6 + [_c_float, _c_float, _c_int, _c_void_p, _c_size_t,
                                                              _c_void_p, _P(TlAttentionInfo)]),
@@ -558,8 +566,9 @@ __all__ = [
 
 
 # ---- kernel-level entry points of the decode path (include/tinyllm_engine.h, last section) -------------------------
-PRO_NONE, PRO_RMSNORM = 0, 1
+PRO_NONE, PRO_RMSNORM, PRO_ATTN_MERGE, PRO_RMS_WEIGHTED = 0, 1, 2, 3
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2
+ATTN_PARTIAL_ROW = 128 + 4  # floats per (head, split) row of decode-attention split partials: 128 value sums, max, sum, 2 pad
 # values of tl_linear_info.kernel (what RAN); the `kernel` argument of decode_linear selects: 0 engine routing, 1 GEMV,
 # 2 skinny matmul (grid by shape), 3 / 4 skinny matmul on its one-shot / persistent grid
 LINEAR_KERNELS = {1: "qmv3 (fused MFMA GEMV)", 2: "qmm3 (skinny MFMA matmul + slice reduction)",
@@ -597,32 +606,68 @@ class TiledW4:
             pass
 
 
-def decode_linear(w: TiledW4, a: torch.Tensor, *, prologue: int = PRO_NONE, epilogue: int = EPI_STORE,
+def decode_linear(w: TiledW4, a: torch.Tensor | None, *, prologue: int = PRO_NONE, epilogue: int = EPI_STORE,
                   norm_weight: torch.Tensor | None = None, residual: torch.Tensor | None = None, eps: float = 1e-6,
-                  kernel: int = 0) -> tuple[torch.Tensor, dict]:
+                  kernel: int = 0, merge_partials: torch.Tensor | None = None, ss_in: torch.Tensor | None = None,
+                  want_ss_out: bool = False, norm_out: torch.Tensor | None = None):
     """One projection of a decode step over ``a`` [M <= 64, cols] bf16 (tl_decode_linear).  Returns (out, info) where info
-    names the kernel that ran and its launch parameters."""
-    _require_gpu("decode_linear", a)
-    if a.dtype != torch.bfloat16 or a.dim() != 2 or a.shape[1] != w.cols or not a.is_contiguous():
-        raise RuntimeError("decode_linear: a must be a contiguous bfloat16 [M, cols] tensor")
-    M = int(a.shape[0])
+    names the kernel that ran and its launch parameters.
+
+    The keyword arguments after ``kernel`` reach the routes of tl_decode_linear_ex (include/tinyllm_engine.h):
+    ``merge_partials`` [cols / 128, n_splits, 132] fp32 with prologue PRO_ATTN_MERGE (``a`` is None, one row);
+    ``ss_in`` [M, n] fp32 partial sums of squares for prologue PRO_RMSNORM / PRO_RMS_WEIGHTED; ``want_ss_out`` /
+    ``norm_out`` [rows] with the residual epilogue -- info then carries "ss_out" [M, rows / 16] and "out_w" [M, rows]."""
+    extended = merge_partials is not None or ss_in is not None or want_ss_out or norm_out is not None \
+        or prologue in (PRO_ATTN_MERGE, PRO_RMS_WEIGHTED)
+    if prologue == PRO_ATTN_MERGE:
+        if merge_partials is None or a is not None:
+            raise RuntimeError("decode_linear: the merging prologue takes merge_partials and no activation rows")
+        _require_gpu("decode_linear", merge_partials)
+        if merge_partials.dtype != torch.float32 or merge_partials.dim() != 3 or not merge_partials.is_contiguous() \
+                or merge_partials.shape[0] * 128 != w.cols or merge_partials.shape[2] != ATTN_PARTIAL_ROW:
+            raise RuntimeError("decode_linear: merge_partials must be contiguous float32 [cols / 128, n_splits, 132]")
+        M, device = 1, merge_partials.device
+    else:
+        _require_gpu("decode_linear", a)
+        if a.dtype != torch.bfloat16 or a.dim() != 2 or a.shape[1] != w.cols or not a.is_contiguous():
+            raise RuntimeError("decode_linear: a must be a contiguous bfloat16 [M, cols] tensor")
+        M, device = int(a.shape[0]), a.device
     out_cols = w.rows // 2 if epilogue == EPI_SWIGLU else w.rows
-    out = torch.empty((M, out_cols), dtype=torch.bfloat16, device=a.device)
+    out = torch.empty((M, out_cols), dtype=torch.bfloat16, device=device)
     if residual is not None and (residual.dtype != torch.bfloat16 or tuple(residual.shape) != (M, w.rows)
                                  or not residual.is_contiguous()):
         raise RuntimeError("decode_linear: residual must be a contiguous bfloat16 [M, rows] tensor")
     if norm_weight is not None and (norm_weight.dtype != torch.bfloat16 or tuple(norm_weight.shape) != (w.cols,)):
         raise RuntimeError("decode_linear: norm_weight must be bfloat16 [cols]")
     ws_bytes = _lib.tl_decode_linear_workspace_bytes(M, w.rows, w.cols)
-    ws = _workspace(ws_bytes, a.device)
+    ws = _workspace(ws_bytes, device)
     info = TlLinearInfo()
-    _check(_lib.tl_decode_linear(w._h, _ptr(a), _ptr(out), M, int(prologue), int(epilogue),
-                                 _ptr(norm_weight) if norm_weight is not None else None,
-                                 _ptr(residual) if residual is not None else None, float(eps), int(kernel),
-                                 _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, _stream(),
-                                 ctypes.byref(info)))
+    common = (w._h, _ptr(a) if a is not None else None, _ptr(out), M, int(prologue), int(epilogue),
+              _ptr(norm_weight) if norm_weight is not None else None, _ptr(residual) if residual is not None else None,
+              float(eps), int(kernel), _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, _stream())
+    extra = {}
+    if not extended:
+        _check(_lib.tl_decode_linear(*common, ctypes.byref(info)))
+    else:
+        ex = TlLinearEx()
+        if merge_partials is not None:
+            ex.merge_ws_dev, ex.n_splits = _ptr(merge_partials), int(merge_partials.shape[1])
+        if ss_in is not None:
+            if ss_in.dtype != torch.float32 or ss_in.dim() != 2 or ss_in.shape[0] != M or not ss_in.is_contiguous():
+                raise RuntimeError("decode_linear: ss_in must be contiguous float32 [M, partials]")
+            _require_gpu("decode_linear", ss_in)
+            ex.ss_in_dev, ex.ss_in_n = _ptr(ss_in), int(ss_in.shape[1])
+        if want_ss_out:
+            extra["ss_out"] = torch.full((M, w.rows // 16), float("nan"), dtype=torch.float32, device=device)
+            ex.ss_out_dev = _ptr(extra["ss_out"])
+        if norm_out is not None:
+            if norm_out.dtype != torch.bfloat16 or tuple(norm_out.shape) != (w.rows,):
+                raise RuntimeError("decode_linear: norm_out must be bfloat16 [rows]")
+            extra["out_w"] = torch.empty((M, w.rows), dtype=torch.bfloat16, device=device)
+            ex.norm_out_dev, ex.out_w_dev = _ptr(norm_out), _ptr(extra["out_w"])
+        _check(_lib.tl_decode_linear_ex(*common, ctypes.byref(ex), ctypes.byref(info)))
     return out, {"kernel": info.kernel, "kernel_name": LINEAR_KERNELS.get(info.kernel, "?"), "launches": info.launches,
-                 "rows_per_pass": info.rows_per_pass, "p": list(info.p)}
+                 "rows_per_pass": info.rows_per_pass, "p": list(info.p), **extra}
 
 
 def decode_attention_fused(qkv: torch.Tensor, q_norm: torch.Tensor, k_norm: torch.Tensor, key_pages: torch.Tensor,
