@@ -32,7 +32,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 EPS = 1e-6
 
-PRO_NONE, PRO_RMSNORM = 0, 1
+PRO_NONE, PRO_RMSNORM, PRO_ATTN_MERGE, PRO_RMS_WEIGHTED = 0, 1, 2, 3
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2
 
 # name: (weight rows K, reduction N, prologue, epilogue) -- the fused pair the engine uses for that projection
@@ -86,6 +86,8 @@ class _Projection:
         # oracle, float64 accumulation, one rounding per reference op
         hp = packed.cpu().numpy().view(np.uint32)
         hs, hb = _bf16_host(scales), _bf16_host(biases)
+        self.packed_host, self.scales_host, self.biases_host = hp, hs, hb
+        self._w4_dev = (packed, scales, biases)
         a, nw, res = _bf16_host(self.a), _bf16_host(self.norm_w), _bf16_host(self.residual)
         # one pass over the weights for both activation sets (unpacking 389 M nibbles dominates the lm_head oracle)
         stacked = np.concatenate([a, O.rms_norm_fast(a, nw, EPS)], axis=0) if pro == PRO_RMSNORM else a
@@ -116,12 +118,21 @@ class _Projection:
             # bf16(residual + bf16(acc)): one ulp of the projection's value, then one ulp of the sum
             self.allowed[(pro, epi)] = bf16_ulp(plain) + floor + bf16_ulp(out)
 
-    def run(self, ext, M, variant, kernel):
+    def squared_dot(self, a: np.ndarray) -> np.ndarray:
+        """sum_n (a[m, n] W[k, n])^2 in float64 (on the device: W is up to 19,456 x 2,560), W = the dequantised weights."""
+        packed, scales, biases = self._w4_dev
+        shifts = torch.arange(0, 32, 4, device=DEV, dtype=torch.int32)
+        q = ((packed.to(torch.int32).unsqueeze(-1) >> shifts) & 0xF).reshape(self.K, self.N).double()
+        w = q * scales.double().repeat_interleave(128, dim=1) + biases.double().repeat_interleave(128, dim=1)
+        a2 = torch.from_numpy(np.asarray(a, dtype=np.float64)).to(DEV) ** 2
+        return (a2 @ (w * w).T).cpu().numpy()
+
+    def run(self, ext, M, variant, kernel, clear_counters=True):
         pro, epi = variant
         return ext.decode_linear(self.tiled, self.a[:M].contiguous(), prologue=pro, epilogue=epi,
                                  norm_weight=self.norm_w if pro == PRO_RMSNORM else None,
                                  residual=self.residual[:M].contiguous() if epi == EPI_RESIDUAL else None, eps=EPS,
-                                 kernel=kernel)
+                                 kernel=kernel, clear_counters=clear_counters)
 
 
 _cache = {}
@@ -171,9 +182,11 @@ PERSISTENT_FROM_MB = {"qkv": None, "wo": None, "gate_up": 1, "down": 2, "lm_head
 @pytest.mark.parametrize("M", [5, 9, 16, 17, 32, 33, 64])
 @pytest.mark.parametrize("projection", list(PROJECTIONS), indirect=True)
 def test_skinny_matmul_at_qwen3_4b_shapes(ext, projection, M):
-    """qmm3_kernel / qmm3p_kernel + qmm3_reduce_kernel (batched decode, 5..64 rows): fp32 slice partials summed in slice order,
-    the engine's epilogues applied by the reduction; includes the 64-row lm_head whose partials are the largest workspace.
-    Both grids are held against the oracle for every projection and row count; the grid the planner picks is asserted."""
+    """qmm3_kernel / qmm3p_kernel (batched decode, 5..64 rows): fp32 slice partials summed in slice order and the engine's epilogues
+    applied -- by the wave that stores a tile's last partial, inside the launch (kernels 6 / 7: the engine's default since round 4),
+    or by qmm3_reduce_kernel in a launch of its own (kernels 3 / 4); includes the 64-row lm_head whose partials are the largest
+    workspace.  Both grids and both reductions are held against the oracle for every projection and row count, the two reductions
+    must agree to the BIT (same sums in the same order), and the grid the planner picks is asserted."""
     p = projection
     MB = 1 if M <= 16 else (2 if M <= 32 else 4)
     for grid in (3, 4):
@@ -185,12 +198,58 @@ def test_skinny_matmul_at_qwen3_4b_shapes(ext, projection, M):
             if grid == 4:
                 assert info["p"][2] in (4, 8) and info["p"][4] <= 256, f"{what}: at most one workgroup per CU"
             _check(p, got, M, variant, what)
+            for rep in range(2):  # twice: the second launch finds the arrival counters as the first one left them
+                fixed, finfo = p.run(ext, M, variant, kernel=grid + 3, clear_counters=rep == 0)
+                fwhat = f"qmm3 grid {grid} reducing in the launch (run {rep}) {p.name} M={M} variant={variant} {finfo}"
+                assert finfo["kernel"] == 2 and finfo["p"][:5] == info["p"][:5], fwhat
+                assert finfo["launches"] == info["launches"] - 1, f"{fwhat}: the reduction launch must be gone"
+                assert torch.equal(fixed, got), f"{fwhat}: differs from the reduction launch ({int((fixed != got).sum())} elements)"
     _, info = p.run(ext, M, (p.pro, p.epi), kernel=2)
     want_persistent = PERSISTENT_FROM_MB[p.name] is not None and MB >= PERSISTENT_FROM_MB[p.name] and not (p.name == "lm_head" and MB == 1)
     assert info["kernel"] == 2 and (info["p"][1] == 0) == want_persistent, f"planner's grid for {p.name} at M={M}: {info}"
     if M > 8:  # the engine's own routing sends more than 8 rows here as well
         _, info = p.run(ext, M, (p.pro, p.epi), kernel=0)
         assert info["kernel"] == 2, f"routing at M={M}: {info}"
+
+
+@pytest.mark.parametrize("M", [5, 8, 16, 33, 64])
+@pytest.mark.parametrize("name", ["wo", "down"])
+def test_skinny_matmul_hands_over_sums_of_squares(ext, name, M):
+    """The producer side at 5-64 rows: the tile's last arriver leaves the sum of squares of its 16 stored bf16 values per row
+    (ss_out [M][K / 16]), which the next projection's fused RMSNorm adds (below)."""
+    if name not in _cache:
+        _cache[name] = _Projection(ext, name)
+    p = _cache[name]
+    got, info = ext.decode_linear(p.tiled, p.a[:M].contiguous(), prologue=PRO_NONE, epilogue=EPI_RESIDUAL,
+                                  residual=p.residual[:M].contiguous(), eps=EPS, kernel=5, want_ss_out=True)
+    what = f"skinny matmul with hand-over {name} M={M} {info['p']}"
+    assert info["kernel"] == 2 and info["launches"] == 1, what
+    _check(p, got, M, (PRO_NONE, EPI_RESIDUAL), what)
+    g64 = got.double()
+    assert torch.allclose(info["ss_out"].double(), (g64 * g64).reshape(M, p.K // 16, 16).sum(dim=2), rtol=1e-5, atol=1e-9), what
+
+
+@pytest.mark.parametrize("M", [5, 8, 16, 33, 64])
+@pytest.mark.parametrize("name", ["qkv", "gate_up", "lm_head"])
+@pytest.mark.parametrize("partials", [8, 160])
+def test_skinny_matmul_normalises_with_the_producers_sums_of_squares(ext, name, M, partials):
+    """The consumer side: PRO_RMSNORM of the skinny matmul from `partials` sums of squares per row -- 8 (the embedding kernels: the
+    total in entry 0) or 160 (hidden / 16: a producer that reduced its own slices) -- against the oracle with the plain allowance."""
+    if name not in _cache:
+        _cache[name] = _Projection(ext, name)
+    p = _cache[name]
+    x = p.a[:M].double()
+    if partials == 8:
+        ss = torch.zeros((M, 8), dtype=torch.float32, device=DEV)
+        ss[:, 0] = (x * x).sum(dim=1).float()
+    else:
+        ss = (x * x).reshape(M, p.N // 16, 16).sum(dim=2).float().contiguous()
+    for kernel in (5, 2):  # reducing in the launch / with the reduction launch
+        got, info = ext.decode_linear(p.tiled, p.a[:M].contiguous(), prologue=PRO_RMSNORM, epilogue=p.epi, norm_weight=p.norm_w,
+                                      eps=EPS, kernel=kernel, ss_in=ss)
+        what = f"skinny matmul, fused RMSNorm from {partials} partials, {name} M={M} kernel={kernel} {info}"
+        assert info["kernel"] == 2 and info["launches"] == (1 if kernel == 5 else 2), f"{what}: the RMSNorm must be fused"
+        _check(p, got, M, (PRO_RMSNORM, p.epi), what)
 
 
 @pytest.mark.parametrize("projection", list(PROJECTIONS), indirect=True)
@@ -206,6 +265,152 @@ def test_engine_routing_between_gemv_and_skinny_matmul(ext, projection):
         got, info = p.run(ext, M, variant, kernel=0)
         assert info["kernel"] == 2, f"{p.name} M={M}: {info}"
         _check(p, got, M, variant, f"routing {p.name} M={M}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The instantiations BASELINE configs[1] TIMES (bench.py at a 128-token prompt: 4 attention windows): the wo GEMV that forms its
+# input row from the split partials, qmv3_kernel<1,4,4,PRO_ATTN_MERGE,EPI_RESIDUAL,8,NS>, and the gate|up GEMV over rows its
+# producer left weighted, qmv3_kernel<1,4,4,PRO_RMS_WEIGHTED,EPI_SWIGLU,5> -- each against the numpy oracle at the real shapes,
+# through tl_decode_linear_ex, the way the reference tests its matvec per shape (tests_refsol/test_week_2_day_3.py:89-118).
+# ---------------------------------------------------------------------------------------------------------------------
+PARTIAL_ROW = 128 + 4  # floats per (head, split): 128 value sums, running max (log2 units), running sum, 2 pad
+
+
+def _split_partials(rng, heads, n_splits):
+    """What attn_decode_fused_kernel leaves per (head, split): (sum_j p_j v_j, max score, sum_j p_j) with p_j = 2^(score_j - max).
+    Built from random scores / values of 40 tokens per window; head 3 has an EMPTY last window (max -1e30, sums 0: a window past the
+    context), head 5 has no token at all (every window empty: the merged row must be zero there)."""
+    ws = np.zeros((heads, n_splits, PARTIAL_ROW), dtype=np.float32)
+    for h in range(heads):
+        for s2 in range(n_splits):
+            empty = (h == 3 and s2 == n_splits - 1) or h == 5
+            if empty:
+                ws[h, s2, 128] = -1e30
+                continue
+            scores = rng.standard_normal(40) * 4.0 + rng.standard_normal() * 6.0
+            vals = O.bf16(rng.standard_normal((40, 128), dtype=np.float32))
+            m = scores.max()
+            pj = np.exp2(scores - m)
+            ws[h, s2, :128] = (pj[:, None] * vals).sum(axis=0)
+            ws[h, s2, 128] = m
+            ws[h, s2, 129] = pj.sum()
+    return ws
+
+
+def _merged_row(ws):
+    """attn_merge_kernel's definition in float64 (engine_kernels.h; reference: the online-softmax merge of
+    paged_attention.metal:214-236): out = sum_s v_s f_s / sum_s l_s f_s, f_s = 2^(m_s - max m); zero where the denominator is zero."""
+    w = ws.astype(np.float64)
+    m, l, v = w[:, :, 128], w[:, :, 129], w[:, :, :128]
+    f = np.exp2(m - m.max(axis=1, keepdims=True))
+    den = (l * f).sum(axis=1)
+    num = (v * f[:, :, None]).sum(axis=1)
+    out = np.where(den[:, None] == 0.0, 0.0, num / np.where(den == 0.0, 1.0, den)[:, None])
+    return O.bf16(out.reshape(1, -1).astype(np.float32))
+
+
+@pytest.mark.parametrize("n_splits", [2, 4, 8])
+@pytest.mark.parametrize("projection", ["wo"], indirect=True)
+def test_wo_gemv_that_merges_the_attention_windows_against_the_oracle(ext, projection, n_splits):
+    """h = x + bf16(merge(partials) @ wo^T), the sums of squares of h per 16-row tile and h * post_attention_layernorm: the launch
+    bench.py's single stream runs 36 times per token (PRO_ATTN_MERGE; NS = 4 at the bench's 128..256-token context)."""
+    p = projection
+    rng = np.random.default_rng(40 + n_splits)
+    ws = _split_partials(rng, p.N // 128, n_splits)
+    row = _merged_row(ws)
+    assert not row[0, 5 * 128:6 * 128].any() and row[0, 3 * 128:4 * 128].any()
+    hp = p.packed_host
+    plain = O.quantized_matmul(p.scales_host, p.biases_host, row, hp, "bf16")
+    res = _bf16_host(p.residual[:1])
+    want = O.bf16(res + plain)
+    # allowance: one ulp of the projection's value + one of the sum (as for the plain wo variant) + the merged row itself: an element
+    # whose float64 quotient lies within fp32 noise of a bf16 rounding boundary may land on the other side in the kernel (fp32
+    # division, hardware exp2) -- 16 such flips of the largest |a| ulp against the largest |w| bound it
+    flips = 16 * float(bf16_ulp(np.abs(row)).max()) * float(np.abs(O.dequantize_weights(hp[:64], p.scales_host[:64], p.biases_host[:64], dtype="bf16")).max())
+    allowed = bf16_ulp(plain) + 2e-4 * max(1.0, float(np.sqrt(np.mean(plain.astype(np.float64) ** 2)))) + bf16_ulp(want) + flips
+    norm_out = (1.0 + 0.05 * torch.randn((p.K,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))).to(torch.bfloat16)
+    got, info = ext.decode_linear(p.tiled, None, prologue=PRO_ATTN_MERGE, epilogue=EPI_RESIDUAL, residual=p.residual[:1].contiguous(),
+                                  eps=EPS, kernel=1, merge_partials=torch.from_numpy(ws).to(DEV), want_ss_out=True, norm_out=norm_out)
+    what = f"merging wo GEMV, {n_splits} windows {info['p']}"
+    assert info["kernel"] == 1 and tuple(info["p"][:4]) == GEMV_PLAN_M1["wo"] and info["launches"] == 1, what
+    assert_within(_bf16_host(got), want, allowed, what=what)
+    # the hand-over to the consumer: partial sums of squares of the STORED bf16 values, and the weighted row -- both functions of `got`
+    g64 = got.double()
+    ss_want = (g64 * g64).reshape(1, p.K // 16, 16).sum(dim=2)
+    assert torch.allclose(info["ss_out"].double(), ss_want, rtol=1e-5, atol=1e-9), f"{what}: ss_out is not the sum of squares of the stored outputs"
+    assert torch.equal(info["out_w"], (got.float() * norm_out.float()).to(torch.bfloat16)), f"{what}: out_w is not bf16(out * norm_out)"
+    log_parity({"what": "wo_gemv_attn_merge", "n_splits": n_splits, "max_abs_err": float(np.abs(_bf16_host(got) - want).max()),
+                "max_allowed": float(np.max(allowed)), "p": info["p"]})
+
+
+def _weighted_rows_case(p, M):
+    """Rows as the wo GEMV hands them to gate|up: a = bf16(x * w_norm) and per-16-column sums of squares of x (160 partials)."""
+    x = p.a[:M].float()
+    a_w = (x * p.norm_w.float()).to(torch.bfloat16).contiguous()
+    ss = (x.double() ** 2).reshape(M, p.N // 16, 16).sum(dim=2).float().contiguous()
+    return a_w, ss
+
+
+@pytest.mark.parametrize("M", [1, 2, 4])
+@pytest.mark.parametrize("projection", ["gate_up"], indirect=True)
+def test_gate_up_gemv_over_weighted_rows_against_the_oracle(ext, projection, M):
+    """SwiGLU(bf16(inv * (bf16(x w) @ W^T))) against the reference's order SwiGLU(bf16(bf16(x inv w) @ W^T)) (FastRMSNorm then the
+    matvec, week2_kernels.metal:41-47 + quantized_matmul.metal:441-538).  The staged element is rounded once on both sides -- of
+    x w here, of x inv w there -- so the two pre-activations differ by a sum of N independent rounding differences:
+    sigma^2 = 2 (u^2 / 12) sum_n (a_n W_kn)^2 with u <= 2^-7 relative; 6 sigma is allowed on top of the plain variant's allowance."""
+    p = projection
+    a_w, ss = _weighted_rows_case(p, M)
+    got, info = ext.decode_linear(p.tiled, a_w, prologue=PRO_RMS_WEIGHTED, epilogue=EPI_SWIGLU, eps=EPS, kernel=1, ss_in=ss)
+    what = f"weighted-row gate|up GEMV M={M} {info['p']}"
+    assert info["kernel"] == 1 and info["launches"] == 1 and tuple(info["p"][:4]) == (M, 4, 4, 5), what
+    normed = O.rms_norm_fast(_bf16_host(p.a[:M]), _bf16_host(p.norm_w), EPS)
+    pre = O.quantized_matmul(p.scales_host, p.biases_host, normed, p.packed_host, "bf16")
+    sq = p.squared_dot(normed)  # sum_n (a_n W_kn)^2, [M, K]
+    sigma = np.sqrt(2.0 / 12.0) * 2.0 ** -7 * np.sqrt(sq)
+    g, u = pre[:, 0::2].astype(np.float64), pre[:, 1::2].astype(np.float64)
+    dg, du = 6.0 * sigma[:, 0::2], 6.0 * sigma[:, 1::2]
+    want = O.swiglu(pre[:, 0::2], pre[:, 1::2])
+    floor = 2e-4 * max(1.0, p.scale)
+    allowed = 1.1 * (bf16_ulp(g) + floor + dg) * np.abs(u) + (bf16_ulp(u) + floor + du) * np.abs(g / (1 + np.exp(-g))) + bf16_ulp(want)
+    assert_within(_bf16_host(got), want, allowed, what=what)
+    # and it is as close to the UNROUNDED product (activations not rounded at all) as the reference's order is: both carry one rounding
+    err = np.abs(_bf16_host(got) - want)
+    log_parity({"what": "gate_up_gemv_weighted_rows", "M": M, "max_abs_err": float(err.max()), "max_allowed": float(allowed.max()),
+                "share_of_allowance_max": float((err / allowed).max()), "p": info["p"]})
+
+
+@pytest.mark.parametrize("name,M", [("qkv", 1), ("qkv", 4), ("lm_head", 1), ("gate_up", 2)])
+def test_rmsnorm_gemv_with_the_producers_sums_of_squares(ext, name, M):
+    """PRO_RMSNORM with ss_in (the engine's default for qkv and lm_head: w_down's epilogue leaves 160 partials per row): the same
+    values as the self-derived norm, held against the oracle with the plain allowance."""
+    if name not in _cache:
+        _cache[name] = _Projection(ext, name)
+    p = _cache[name]
+    _, ss = _weighted_rows_case(p, M)
+    got, info = ext.decode_linear(p.tiled, p.a[:M].contiguous(), prologue=PRO_RMSNORM, epilogue=p.epi, norm_weight=p.norm_w, eps=EPS,
+                                  kernel=1, ss_in=ss)
+    what = f"RMSNorm GEMV with producer partials {name} M={M} {info['p']}"
+    assert info["kernel"] == 1 and info["launches"] == 1, what
+    _check(p, got, M, (PRO_RMSNORM, p.epi), what)
+
+
+@pytest.mark.parametrize("name,M", [("wo", 1), ("wo", 4), ("down", 1), ("down", 2), ("down", 4)])
+def test_residual_gemv_leaves_sums_of_squares_and_the_weighted_row(ext, name, M):
+    """EPI_RESIDUAL with ss_out (+ out_w for wo): the producer side of the hand-over, for the plain (non-merging) GEMV."""
+    if name not in _cache:
+        _cache[name] = _Projection(ext, name)
+    p = _cache[name]
+    norm_out = (1.0 + 0.05 * torch.randn((p.K,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))).to(torch.bfloat16)
+    got, info = ext.decode_linear(p.tiled, p.a[:M].contiguous(), prologue=PRO_NONE, epilogue=EPI_RESIDUAL,
+                                  residual=p.residual[:M].contiguous(), eps=EPS, kernel=1, want_ss_out=True,
+                                  norm_out=norm_out if name == "wo" else None)
+    what = f"residual GEMV with hand-over {name} M={M} {info['p']}"
+    assert info["kernel"] == 1 and info["launches"] == 1, what
+    _check(p, got, M, (PRO_NONE, EPI_RESIDUAL), what)
+    g64 = got.double()
+    assert torch.allclose(info["ss_out"].double(), (g64 * g64).reshape(M, p.K // 16, 16).sum(dim=2), rtol=1e-5, atol=1e-9), what
+    if name == "wo":
+        assert torch.equal(info["out_w"], (got.float() * norm_out.float()).to(torch.bfloat16)), what
 
 
 # ---------------------------------------------------------------------------------------------------------------------

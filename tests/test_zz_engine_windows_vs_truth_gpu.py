@@ -1,0 +1,78 @@
+"""GPU tier: the fused engine at 2 / 4 / 8 / 16 attention windows against the float64 truth.
+
+BASELINE configs[1] (bench.py, 128-token prompt) decodes with FOUR 64-token attention windows merged by the wo GEMV itself
+(csrc/qmv3.h PRO_ATTN_MERGE) and with gate|up over weighted rows (PRO_RMS_WEIGHTED).  tests/test_engine_qwen4b_gpu.py holds the
+engine against the truth at an 8-token prompt only (one window, no merge); here the same check runs behind prompts of 100 / 130 /
+300 / 1,200 / 2,500 tokens = 2 / 4 (of 64 tokens: the bench's plan) / 4 (of 128) / 8 windows merged by the wo GEMV and 16 merged by
+the column-parallel launch, on a model with
+Qwen3-4B LAYER shapes (so the planner picks the bench's own instantiations; 2 layers, vocabulary 8,192).
+
+The truth and the bf16 oracle's distance from it come from tests/golden/engine_window_vectors.npz, generated in the build
+container by tests/golden/make_engine_window_vectors.py with oracle.TruthQwen3 / OracleQwen3 (the numpy restatements pinned in
+DESIGN.md section 2); the checkpoint is rebuilt here from numpy's seeded generator and checked against the committed checksum.
+Reference bar: tests_refsol/test_week_3_day_4.py:204-245 (paged decode against the dense path), test_week_2_day_6.py:92-109
+(full-model log-probs)."""
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import check_against_truth, log_parity, to_mlx_shaped
+from oracle import tiny_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = Path(__file__).resolve().parent / "golden" / "engine_window_vectors.npz"
+sys.path.insert(0, str(GOLDEN.parent))
+
+# prompt tokens -> (attention windows of the decode steps behind it, merged by the wo GEMV?)
+PLANS = {100: (2, True), 130: (4, True), 300: (4, True), 1200: (8, True), 2500: (16, False)}
+
+
+@pytest.fixture(scope="module")
+def checkpoint():
+    import make_engine_window_vectors as G
+
+    vec = np.load(GOLDEN)
+    weights = O.make_qwen3_weights(G.CFG, seed=int(vec["seed"]), sigma=float(vec["sigma"]))
+    assert np.array_equal(G.checksum(weights), vec["checksum"]), "the rebuilt checkpoint is not the one the fixture was generated on"
+    return G.CFG, to_mlx_shaped(G.CFG, weights), vec
+
+
+@pytest.mark.parametrize("prompt_len", list(PLANS))
+def test_engine_logits_behind_long_prompts_against_the_truth(checkpoint, prompt_len):
+    from tiny_llm_hip.engine import DecodeEngine
+
+    cfg, model, vec = checkpoint
+    windows, merged_by_wo = PLANS[prompt_len]
+    prompt = [int(t) for t in vec[f"prompt_{prompt_len}"]]
+    fed = [int(t) for t in vec[f"fed_{prompt_len}"]]
+    truth = vec[f"truth_{prompt_len}"].astype(np.float64)
+    oracle = O.from_bf16_bits(vec[f"oracle_bits_{prompt_len}"]).astype(np.float64)
+    eng = DecodeEngine(model, page_size=128, num_pages=24, max_batch=1, max_prefill_rows=1024)
+    try:
+        eng.begin(0)
+        eng.prefill(0, prompt, chunk=1024)
+        got = [eng.logits(1)[0].float().cpu().numpy()]
+        for i, tok in enumerate(fed):  # teacher-forced on the TRUTH's greedy ids: every row is compared at the same inputs
+            eng.set_token(0, tok)
+            eng.decode(1, batch=1)     # step 0 eager (warm-up), the others through the captured graph
+            got.append(eng.logits(1)[0].float().cpu().numpy())
+        st = eng.stats()
+        prof = eng.profile_step(1)
+        eng.release(0)
+    finally:
+        eng.close()
+    merges = prof["kinds"]["attention_merge"]["launches"]
+    what = f"Qwen3-4B layer shapes x {cfg['num_hidden_layers']}, prompt {prompt_len}: {prof['n_splits']} windows, {merges} merge launches per step"
+    assert prof["n_splits"] == windows, what
+    assert merges == (0 if merged_by_wo else cfg["num_hidden_layers"]), what
+    assert st["graph_replays"] >= len(fed) - 1, "the decode steps must run through the captured graph"
+    got = np.stack(got)
+    # row 0 comes out of the prefill path (GEMM + FlashAttention), rows 1.. out of the fused decode step
+    check_against_truth(got[:1], oracle[:1], truth[:1], what=what + " [prefill row]")
+    rec = check_against_truth(got[1:], oracle[1:], truth[1:], what=what + " [decode rows]")
+    log_parity({"what": "engine_windows_vs_truth", "prompt": prompt_len, "windows": windows, "wo_merges": merged_by_wo, **rec})
