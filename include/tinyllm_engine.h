@@ -243,9 +243,7 @@ typedef struct tl_linear_info {
  *   prologue 0 none | 1 RMSNorm(a, norm_w, eps) rounded to bf16;  epilogue 0 store | 1 residual + bf16(acc) |
  *   2 SwiGLU over interleaved (gate_i, up_i) rows -> out [M, rows/2].
  *   kernel 0 = the engine's routing by M and matrix size, 1 = force the fused GEMV (M <= 8), 2 = force the skinny matmul
- *   (grid chosen by shape as the engine does) followed by its slice-reduction launch, 3 / 4 = that on the one-shot / persistent
- *   grid, 5 = the skinny matmul adding its slices inside the launch (the engine's default since round 4), 6 / 7 = that on the
- *   one-shot / persistent grid.
+ *   (grid chosen by shape as the engine does), 3 / 4 = the skinny matmul on its one-shot / persistent grid.
  * The engine uses the pairs (1,0) qkv / lm_head, (0,1) wo / w_down, (1,2) gate|up, (0,0). */
 size_t tl_decode_linear_workspace_bytes(int M, int rows, int cols);
 int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
@@ -263,10 +261,9 @@ int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int
  *   prologue 3 (with epilogue 2, M <= 8, kernel 1): a_dev holds bf16(x * norm_weight) (what a producer's out_w_dev holds) and
  *     ss_in_dev the sums of squares of x; out = SwiGLU(bf16(rsqrt(mean x^2 + eps) * (a @ W^T))).
  *   ss_in_dev [M][ss_in_n] (prologues 1 and 3): partial sums of squares of each row, added instead of re-derived (the GEMV: any
- *     multiple of 4 up to 256 partials; the skinny matmul: exactly 8).
- *   epilogue 1 through the GEMV (or the skinny matmul that reduces its slices in the launch): ss_out_dev [M][rows / 16] receives
- *     the sum of squares of every 16 stored bf16 outputs;  GEMV only: norm_out_dev [rows] + out_w_dev [M][rows]: also store
- *     bf16(out * norm_out). */
+ *     multiple of 4 up to 256 partials, and so does the skinny matmul).
+ *   epilogue 1 through the GEMV: ss_out_dev [M][rows / 16] receives the sum of squares of every 16 stored bf16 outputs;
+ *     norm_out_dev [rows] + out_w_dev [M][rows]: also store bf16(out * norm_out). */
 typedef struct tl_linear_ex {
     const float *merge_ws_dev;
     int n_splits;
@@ -275,8 +272,6 @@ typedef struct tl_linear_ex {
     float *ss_out_dev;
     const void *norm_out_dev;
     void *out_w_dev;
-    int keep_counters; /* skinny matmul reducing its slices in the launch (kernel 5 / 6 / 7): 1 = the arrival counters at the end of
-                          `workspace_dev` are as a previous call over the SAME workspace left them (zero) -- do not clear them */
 } tl_linear_ex;
 int tl_decode_linear_ex(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
                         const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,

@@ -85,12 +85,6 @@ struct tl_engine {
     // 3.91 -> 4.06; the qkv and lm_head GEMVs gain nothing from it and keep the fused RMSNorm.  TL_GEMV_WEIGHTED_ROWS=0: off.
     bool gemv_weighted_rows = true;
     bool fuse_norm = true;                   // TL_QMM3_FUSED_NORM=0: RMSNorm ahead of a skinny matmul always as its own launch
-    // Round 4: the slices of a skinny matmul are added inside its own launch by the wave that stores a tile's last partial
-    // (qmm3.h, FX) -- no slice-reduction launches (3 per layer at 5-64 rows), the qkv rows reach the attention kernel as bf16 rows
-    // again.  TL_QMM3_FIXUP=0 keeps the reduction launches (and the attention kernel adding the qkv slices).
-    bool qmm3_fixup = true;
-    int qmm3_fixup_max_rows = 64;            // TL_QMM3_FIXUP_MAX_ROWS (lab): more rows keep the reduction launch
-    unsigned int *fix_counters = nullptr;    // [widest matrix rows / 16] arrival counters, zero between launches
     int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
     bool use_qmm3 = true;   // TL_NO_QMM3=1 at create: rows > 8 go through the prefill GEMM path instead
@@ -374,32 +368,9 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
         q.ss = ss_in;
         q.ss_n = ss_in_n;
         q.eps = c.rms_norm_eps;
-        const bool fixup = e->qmm3_fixup && e->fix_counters != nullptr && M <= e->qmm3_fixup_max_rows;
-        if (fixup) {  // slices added and the epilogue applied inside the launch: no reduction launch behind it
-            q.fix_counters = e->fix_counters;
-            q.fix_slices = p3.slices;
-            q.epi = epi;
-            q.residual = residual;
-            q.out = out;
-            q.ss_out = (ss_out && e->fuse_norm && qmm3_fixup_can_emit_ss(epi, w.rows)) ? ss_out : nullptr;
-        }
         if (launch_qmm3_bf16(q, e->stream, fused_norm ? PRO_RMSNORM : PRO_NONE, e->qmm3_mode) != 0)
             return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul launch failed");
         if (pc) prof_after(e, pc, kind, p3.persistent ? p3.grid_x : p3.grid_x * p3.slices);
-        if (fixup) {
-            if (ss_emitted) *ss_emitted = q.ss_out != nullptr;
-            if (ss_out_n) *ss_out_n = q.ss_out != nullptr ? w.rows / 16 : 0;
-            TL_CHECK_LAUNCH("engine skinny matmul");
-            if (e->linfo) {
-                tl_linear_info &li = *e->linfo;
-                li.kernel = 2;
-                li.launches += 1 + (pro == PRO_RMSNORM && !fused_norm ? 1 : 0);
-                li.rows_per_pass = M;
-                li.p[0] = p3.MB, li.p[1] = p3.persistent ? 0 : p3.TW, li.p[2] = p3.LM, li.p[3] = p3.slices;
-                li.p[4] = p3.persistent ? p3.grid_x : p3.grid_x * p3.slices;
-            }
-            return TL_OK;
-        }
         float *ss_dst = (ss_out && e->fuse_norm && qmm3_reduce_can_emit_ss(epi, w.rows)) ? ss_out : nullptr;
         const bool kept = keep != nullptr && epi == EPI_STORE && ss_dst == nullptr;
         if (kept) {
@@ -671,9 +642,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
         KeptPartials qkv_parts;
-        // (with the in-launch slice reduction the qkv rows arrive as bf16 rows: nothing to hand over)
-        const bool keep_qkv = e->attn_qkv_partials && attn_takes_qkv_partials(c.head_dim, sp.rq) &&
-                              !(e->qmm3_fixup && batch <= e->qmm3_fixup_max_rows);
+        const bool keep_qkv = e->attn_qkv_partials && attn_takes_qkv_partials(c.head_dim, sp.rq);
         TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0,
                              x_ss ? e->ss_x : nullptr, nullptr, nullptr, keep_qkv ? &qkv_parts : nullptr, x_ss));
         bool merge_left = false;
@@ -886,7 +855,6 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const size_t o_prod = carve((size_t)c.max_batch * 4);
     const size_t o_ring = carve((size_t)c.max_batch * e->ring_cap * 4);
     const size_t o_sctx = carve(64);
-    const size_t o_fix = carve((size_t)(std::max({c.vocab_size, 2 * c.intermediate_size, qkv_dim, c.hidden_size}) / 16 + 64) * 4);
     const size_t o_ptok = carve(R * 4);
     const size_t o_x = carve(R * c.hidden_size * 2);
     const size_t o_h = carve(R * c.hidden_size * 2);
@@ -951,7 +919,6 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->produced = (int32_t *)(A + o_prod);
     e->ring = (int32_t *)(A + o_ring);
     e->scratch_ctx = (int32_t *)(A + o_sctx);
-    e->fix_counters = (unsigned int *)(A + o_fix);  // zeroed with the state words below
     e->prefill_tokens = (int32_t *)(A + o_ptok);
     e->x = (uint16_t *)(A + o_x);
     e->h = (uint16_t *)(A + o_h);
@@ -969,8 +936,6 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->ss_x = (float *)(A + o_ssx);
     e->ss_h = (float *)(A + o_ssh);
     if (const char *q = getenv("TL_QMM3_FUSED_NORM")) e->fuse_norm = atoi(q) != 0;
-    if (const char *q = getenv("TL_QMM3_FIXUP")) e->qmm3_fixup = atoi(q) != 0;
-    if (const char *q = getenv("TL_QMM3_FIXUP_MAX_ROWS")) e->qmm3_fixup_max_rows = std::max(0, atoi(q));
     if (const char *q = getenv("TL_GEMV_PRODUCER_SS")) e->gemv_producer_ss = atoi(q) != 0;
     if (const char *q = getenv("TL_GEMV_WEIGHTED_ROWS")) e->gemv_weighted_rows = atoi(q) != 0;
     if (const char *q = getenv("TL_ATTN_QKV_PARTIALS")) e->attn_qkv_partials = atoi(q) != 0;
@@ -1847,7 +1812,7 @@ extern "C" size_t tl_decode_linear_workspace_bytes(int M, int rows, int cols) {
         const Qmm3Plan p3 = qmm3_plan(std::min(M, 64), cols, rows, mode);
         if (p3.ok) partial = std::max(partial, p3.partial_bytes);
     }
-    return need + align_up(partial, 256) + align_up((size_t)(rows / 16 + 64) * 4, 256);  // + arrival counters of the in-launch reduction
+    return need + partial;
 }
 
 static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
@@ -1862,9 +1827,8 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
     TL_REQUIRE(prologue == PRO_ATTN_MERGE || a_dev, "decode_linear: null activation rows");
     TL_REQUIRE(prologue != PRO_RMSNORM || norm_w_dev, "decode_linear: the RMSNorm prologue needs its weight");
     TL_REQUIRE(epilogue != EPI_RESIDUAL || residual_dev, "decode_linear: the residual epilogue needs the residual rows");
-    TL_REQUIRE(kernel >= 0 && kernel <= 7,
-               "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV), 2 (skinny matmul + reduction launch), 3 / 4 (its one-shot / "
-               "persistent grid), 5 (skinny matmul reducing its slices in the launch), 6 / 7 (its one-shot / persistent grid)");
+    TL_REQUIRE(kernel >= 0 && kernel <= 4,
+               "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV), 2 (skinny matmul), 3 / 4 (its one-shot / persistent grid)");
     TL_REQUIRE(epilogue != EPI_SWIGLU || w->w.rows % 2 == 0, "decode_linear: SwiGLU needs an even number of weight rows");
     // the engine's own fused variants: RMSNorm+store (qkv, lm_head), residual (wo, w_down), RMSNorm+SwiGLU (gate|up), plain;
     // through tl_decode_linear_ex also: merged attention partials + residual (wo of one row), weighted rows + SwiGLU (gate|up)
@@ -1879,22 +1843,16 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
     e.tiled[w->w.weight_dev] = w->t;
     e.xn = (uint16_t *)workspace_dev;
     const size_t xn_bytes = align_up((size_t)M * w->w.cols * 2, 256);
-    const size_t fix_bytes = align_up((size_t)(w->w.rows / 16 + 64) * 4, 256);
     e.splitk_ws = (char *)workspace_dev + xn_bytes;
-    e.splitk_ws_bytes = workspace_bytes - xn_bytes - fix_bytes;
-    e.fix_counters = (unsigned int *)((char *)workspace_dev + workspace_bytes - fix_bytes);
-    if (!(ex && ex->keep_counters)) TL_HIP(hipMemsetAsync(e.fix_counters, 0, fix_bytes, (hipStream_t)stream));
+    e.splitk_ws_bytes = workspace_bytes - xn_bytes;
     e.force_linear = kernel >= 2 ? 2 : kernel;
-    e.qmm3_mode = (kernel == 3 || kernel == 6) ? 0 : ((kernel == 4 || kernel == 7) ? 1 : -1);
-    if (const char *q = getenv("TL_QMM3_FIXUP")) e.qmm3_fixup = atoi(q) != 0;  // kernel 0: the engine's routing and defaults
-    if (kernel >= 2) e.qmm3_fixup = kernel >= 5;
+    e.qmm3_mode = kernel == 3 ? 0 : (kernel == 4 ? 1 : -1);
     tl_linear_info li{};
     e.linfo = &li;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e.qmm3_min_rows = std::max(1, atoi(q));
     int rc = TL_OK;
     auto done = [&](int code) {
         e.splitk_ws = nullptr;  // borrowed
-        e.fix_counters = nullptr;
         e.tiled.clear();
         if (info) *info = li;
         return code;
@@ -1905,8 +1863,7 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
         return done(rc);
     }
     // ---- the routes only the engine could reach before round 4 (qmv3.h: PRO_ATTN_MERGE, PRO_RMS_WEIGHTED, ss_in / ss_out, out_w)
-    const bool skinny_fixup = kernel >= 5 || (kernel == 0 && M >= e.qmm3_min_rows && e.qmm3_fixup);
-    const bool gemv_only = prologue == PRO_ATTN_MERGE || prologue == PRO_RMS_WEIGHTED || (ex->ss_out_dev && !skinny_fixup) || ex->out_w_dev;
+    const bool gemv_only = prologue == PRO_ATTN_MERGE || prologue == PRO_RMS_WEIGHTED || ex->ss_out_dev || ex->out_w_dev;
     if (gemv_only && !(kernel == 1 || (kernel == 0 && M < e.qmm3_min_rows)))
         return done(fail(TL_ERR_INVALID, "decode_linear_ex: merged partials, weighted rows, ss_out and out_w are routes of the fused GEMV (kernel 1, or 0 with fewer than 5 rows)"));
     if ((ex->out_w_dev != nullptr) != (ex->norm_out_dev != nullptr) || (ex->out_w_dev && epilogue != EPI_RESIDUAL) ||
@@ -1942,16 +1899,11 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
             rc = fail(TL_ERR_UNSUPPORTED, "decode_linear_ex: the GEMV that ran left no sums of squares (packed-dot fallback or several passes)");
         return done(rc);
     }
-    // skinny matmul with its fused RMSNorm (any multiple of 4 up to 256 partials per row) and, reducing its slices in the launch,
-    // the producer side of the hand-over (ss_out [M][rows / 16])
+    // skinny matmul with its fused RMSNorm (any multiple of 4 up to 256 partials per row)
     if (ex->ss_in_dev && !qmm3_takes_ss(ex->ss_in_n))
         return done(fail(TL_ERR_INVALID, "decode_linear_ex: the skinny matmul reads a multiple of 4, at most 256, partial sums of squares per row"));
-    bool emitted = false;
     rc = engine_linear(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, prologue, epilogue, norm_w_dev,
-                       (const uint16_t *)residual_dev, nullptr, 0, ex->ss_in_dev, ex->ss_out_dev, &emitted, nullptr,
-                       ex->ss_in_dev ? ex->ss_in_n : 0, &ss_n);
-    if (rc == TL_OK && ex->ss_out_dev && (!emitted || ss_n != w->w.rows / 16))
-        rc = fail(TL_ERR_UNSUPPORTED, "decode_linear_ex: the skinny matmul left no per-tile sums of squares (needs the in-launch reduction and rows / 16 <= 256)");
+                       (const uint16_t *)residual_dev, nullptr, 0, ex->ss_in_dev, nullptr, nullptr, nullptr, ex->ss_in_dev ? ex->ss_in_n : 0);
     return done(rc);
 }
 

@@ -47,20 +47,11 @@ struct Qmm3Args {
     int M, N, K;
     prof_t *prof;
     // PRO_RMSNORM only: a holds the UN-normalised rows; ss [M][ss_n] partial sums of squares of each row (ss_n a multiple of 4, at
-    // most 256: 8 from the embedding kernels / the slice reduction, K / 16 from a producer that reduced its own slices, below)
+    // most 256: 8 from the embedding kernels / the slice reduction, rows / 16 from a GEMV producer)
     const uint16_t *norm_w;
     const float *ss;
     float eps;
     int ss_n;
-    // FX (round 4): the slices of a 16-column tile are added IN THIS LAUNCH by the wave that stores the tile's last partial --
-    // qmm3_reduce_kernel's arithmetic (slices in index order, then the epilogue), without its launch: at 5-16 rows the three
-    // reductions of a layer were 108 of a step's 296 launches (~4.7 us of kernel + a ~2 us boundary each).
-    unsigned int *fix_counters;  // [K / 16] arrival counters, zero between launches (the last arriver resets its counter)
-    int fix_slices;              // partial planes per tile (= the plan's slices)
-    int epi;                     // EPI_STORE / EPI_RESIDUAL / EPI_SWIGLU
-    const uint16_t *residual;    // [M][K]      EPI_RESIDUAL
-    uint16_t *out;               // [M][K] bf16 (EPI_SWIGLU: [M][K / 2])
-    float *ss_out;               // [M][K / 16] EPI_RESIDUAL, optional: sums of squares of the 16 stored bf16 values of (row, tile)
 };
 
 __host__ __device__ inline size_t qmm3_lds_bytes(int MB, int LM) {
@@ -176,83 +167,7 @@ __device__ __forceinline__ void qmm3_stage_slice(const Qmm3Args &p, int g0, int 
     }
 }
 
-// FX: in-launch slice reduction of ONE 16-column tile, called by a whole wave right after it has stored its partial tile with
-// device-coherent stores (sc1: written through to the memory side -- the other slices of the tile may run on other XCDs, behind
-// other L2s; a device-scope fence pair would write back and invalidate whole L2s per wave, measured in round 2 at 10x the kernel).
-// The wave waits for its stores to be acknowledged and bumps the tile's arrival counter; the wave that finds slices - 1 there is
-// the last: every plane of the tile is complete, it reads them back with device-coherent loads IN SLICE ORDER (its own included:
-// the result does not depend on who arrives last), applies qmm3_reduce_kernel's epilogue and returns the counter to zero.
-// Lane (r, c) owns (activation rows 16 mb + 4 c + j, column 16 tile + r), as in the accumulators.
-template <int MB>
-__device__ __forceinline__ void qmm3_fixup_tile(const Qmm3Args &p, int tile, int lane) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned int prev = 0;
-    if (lane == 0) prev = __hip_atomic_fetch_add(p.fix_counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    prev = (unsigned int)__builtin_amdgcn_readfirstlane((int)prev);
-    if (prev != (unsigned int)(p.fix_slices - 1)) return;
-    if (lane == 0) __hip_atomic_store(p.fix_counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int r = lane & 15, c = lane >> 4;
-    const int K = p.K, M = p.M, tiles = K >> 4;
-    const int col = (tile << 4) + r;
-    const size_t plane = (size_t)M * K;
-    // One 16-row block at a time (a loop, not unrolled: the register footprint of this rarely-run tail must not depend on MB --
-    // it sits inside the main loop of the persistent kernel, whose accumulators and weight sets stay live across it).
-    constexpr int INFL = MB == 1 ? 8 : (MB == 2 ? 4 : 2);  // slices in flight together (x 4 values per lane)
-#pragma unroll 1
-    for (int mb = 0; mb < MB; ++mb) {
-        uint32_t off[4];  // element offsets inside a plane: M * K < 2^32 (64 rows x 151,936 columns)
-        bool live[4];
-        uint16_t resv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = mb * 16 + 4 * c + j;
-            live[j] = row < M;
-            off[j] = (uint32_t)(live[j] ? row : 0) * (uint32_t)K + (uint32_t)col;  // every load is unconditional, from a clamped address
-            resv[j] = p.epi == EPI_RESIDUAL ? p.residual[off[j]] : (uint16_t)0;
-        }
-        float sum[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < p.fix_slices; s0 += INFL) {
-            float x[INFL][4];
-#pragma unroll
-            for (int i = 0; i < INFL; ++i) {
-                const float *pl = p.partial + (size_t)min(s0 + i, p.fix_slices - 1) * plane;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[i][j] = __hip_atomic_load(pl + off[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int i = 0; i < INFL; ++i)
-                if (s0 + i < p.fix_slices) {  // uniform; no load inside
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) sum[j] += x[i][j];
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = mb * 16 + 4 * c + j;
-            if (p.epi == EPI_SWIGLU) {  // rows interleaved: even column = gate_i, odd = up_i; the even lane stores
-                const float gv = bf16_round(sum[j]);
-                const float uv = lane_xor1(gv);
-                if (live[j] && (r & 1) == 0)
-                    p.out[(size_t)row * (K >> 1) + (col >> 1)] = BF16::from_float((gv / (1.0f + expf(-gv))) * uv);
-            } else if (p.epi == EPI_RESIDUAL) {
-                const uint16_t ov = BF16::from_float(BF16::to_float(resv[j]) + bf16_round(sum[j]));
-                float sq = 0.f;
-                if (live[j]) {
-                    p.out[off[j]] = ov;
-                    sq = BF16::to_float(ov) * BF16::to_float(ov);
-                }
-                if (p.ss_out) {  // uniform
-                    sq = group16_sum(sq);
-                    if (r == 0 && live[j]) p.ss_out[(size_t)row * tiles + tile] = sq;
-                }
-            } else {
-                if (live[j]) p.out[off[j]] = BF16::from_float(sum[j]);
-            }
-        }
-    }
-}
-
-template <int MB, int TW, int LM, int PRO = PRO_NONE, bool FX = false>
+template <int MB, int TW, int LM, int PRO = PRO_NONE>
 __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = MB * 16;
@@ -358,13 +273,8 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = mb * 16 + 4 * c + j;
-                if (row < p.M && (!(QMM3_ABL & 4) || acc[tw][mb][j] == 123.f)) {
-                    float *dst = &p.partial[((size_t)slice * p.M + row) * K + ocol];
-                    if constexpr (FX) __hip_atomic_store(dst, acc[tw][mb][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else *dst = acc[tw][mb][j];
-                }
+                if (row < p.M && (!(QMM3_ABL & 4) || acc[tw][mb][j] == 123.f)) p.partial[((size_t)slice * p.M + row) * K + ocol] = acc[tw][mb][j];
             }
-        if constexpr (FX) qmm3_fixup_tile<MB>(p, tile[tw], lane);  // wave-uniform tile: the whole wave arrives together
     }
     prof_end(p.prof, prof_t0);
 }
@@ -381,7 +291,7 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
 #ifndef QMM3P_SB
 #define QMM3P_SB 8  // staging chunks in flight per thread
 #endif
-template <int MB, int NU, int PRO, bool FX>
+template <int MB, int NU, int PRO>
 __device__ __forceinline__ void qmm3p_body(const Qmm3Args &p, char *smem, const int slice, const int g0, const int gn, const int wg,
                                            const int tiles_per_wg) {
     constexpr int LM = 4 * NU;
@@ -519,9 +429,7 @@ __device__ __forceinline__ void qmm3p_body(const Qmm3Args &p, char *smem, const 
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (!(QMM3_ABL & 4) || acc[mb][j] == 123.f)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mb][j]), prs, base + (uint32_t)(mb * 16 + j) * (uint32_t)K * 4u, 0,
-                                                              FX ? 16 : 0);  // FX: sc1, device-coherent (qmm3_fixup_tile)
-            if constexpr (FX) qmm3_fixup_tile<MB>(p, __builtin_amdgcn_readfirstlane(tile), lane);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mb][j]), prs, base + (uint32_t)(mb * 16 + j) * (uint32_t)K * 4u, 0, 0);
         }
     };
     using U0 = std::integral_constant<int, 0>;
@@ -565,7 +473,7 @@ struct Qmm3pGrid {
     int full_slices, wgs_full, tpw_full;  // slices of 4*NU groups: workgroups and tiles per workgroup of each
     int last_groups, wgs_last, tpw_last;  // the short last slice (0 groups = none)
 };
-template <int MB, int NU, int PRO = PRO_NONE, bool FX = false>
+template <int MB, int NU, int PRO = PRO_NONE>
 __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3p_kernel(const Qmm3Args p, const Qmm3pGrid gr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #if QMM3_ABL & 64
@@ -577,11 +485,11 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3p_kernel(const Qmm3Args p,
     const int nfull = gr.full_slices * gr.wgs_full;
     if (bid < nfull) {
         const int slice = bid / gr.wgs_full;
-        qmm3p_body<MB, NU, PRO, FX>(p, smem, slice, slice * 4 * NU, 4 * NU, bid - slice * gr.wgs_full, gr.tpw_full);
+        qmm3p_body<MB, NU, PRO>(p, smem, slice, slice * 4 * NU, 4 * NU, bid - slice * gr.wgs_full, gr.tpw_full);
     } else if (NU == 2 && gr.last_groups <= 4) {
-        qmm3p_body<MB, 1, PRO, FX>(p, smem, gr.full_slices, gr.full_slices * 4 * NU, gr.last_groups, bid - nfull, gr.tpw_last);
+        qmm3p_body<MB, 1, PRO>(p, smem, gr.full_slices, gr.full_slices * 4 * NU, gr.last_groups, bid - nfull, gr.tpw_last);
     } else {
-        qmm3p_body<MB, NU, PRO, FX>(p, smem, gr.full_slices, gr.full_slices * 4 * NU, gr.last_groups, bid - nfull, gr.tpw_last);
+        qmm3p_body<MB, NU, PRO>(p, smem, gr.full_slices, gr.full_slices * 4 * NU, gr.last_groups, bid - nfull, gr.tpw_last);
     }
 #if !(QMM3_ABL & 64)
     prof_end(p.prof, prof_t0);
@@ -665,7 +573,6 @@ inline Qmm3Plan qmm3_plan(int M, int N, int K, int mode = -1) {
 }
 
 // qmm3.hip
-// args.fix_counters != nullptr selects the FX kernels (in-launch slice reduction + epilogue: no launch_qmm3_reduce_bf16 behind it)
 int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro = PRO_NONE, int mode = -1);
 // out = epilogue(sum over slices); epi = EPI_STORE / EPI_RESIDUAL (residual [M,K]) / EPI_SWIGLU (out [M,K/2]).
 // ss_out (optional, EPI_STORE / EPI_RESIDUAL with K <= QM3_SS * 1024): [M][QM3_SS] partial sums of squares of the bf16 output rows
@@ -675,6 +582,4 @@ int launch_qmm3_reduce_bf16(const float *partial, int slices, int M, int K, int 
 inline bool qmm3_reduce_can_emit_ss(int epi, int K) { return epi != EPI_SWIGLU && K % 4 == 0 && (K / 4 + 255) / 256 <= QM3_SS; }
 // the fused RMSNorm of the skinny matmul takes any ss_n the staging prologue can fetch in four 16-byte loads per lane
 inline bool qmm3_takes_ss(int ss_n) { return ss_n > 0 && ss_n <= QM3_SS_MAX && ss_n % 4 == 0; }
-// FX: can the tile's last arriver leave the sums of squares the consumer wants ([M][K / 16])?
-inline bool qmm3_fixup_can_emit_ss(int epi, int K) { return epi == EPI_RESIDUAL && qmm3_takes_ss(K / 16); }
 }  // namespace tl

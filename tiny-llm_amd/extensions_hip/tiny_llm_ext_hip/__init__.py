@@ -113,7 +113,7 @@ class TlLinearInfo(ctypes.Structure):
 
 class TlLinearEx(ctypes.Structure):
     _fields_ = [("merge_ws_dev", _c_void_p), ("n_splits", _c_int), ("ss_in_dev", _c_void_p), ("ss_in_n", _c_int),
-                ("ss_out_dev", _c_void_p), ("norm_out_dev", _c_void_p), ("out_w_dev", _c_void_p), ("keep_counters", _c_int)]
+                ("ss_out_dev", _c_void_p), ("norm_out_dev", _c_void_p), ("out_w_dev", _c_void_p)]
 
 
 class TlAttentionInfo(ctypes.Structure):
@@ -609,17 +609,16 @@ class TiledW4:
 def decode_linear(w: TiledW4, a: torch.Tensor | None, *, prologue: int = PRO_NONE, epilogue: int = EPI_STORE,
                   norm_weight: torch.Tensor | None = None, residual: torch.Tensor | None = None, eps: float = 1e-6,
                   kernel: int = 0, merge_partials: torch.Tensor | None = None, ss_in: torch.Tensor | None = None,
-                  want_ss_out: bool = False, norm_out: torch.Tensor | None = None, clear_counters: bool = True):
+                  want_ss_out: bool = False, norm_out: torch.Tensor | None = None):
     """One projection of a decode step over ``a`` [M <= 64, cols] bf16 (tl_decode_linear).  Returns (out, info) where info
     names the kernel that ran and its launch parameters.
 
     The keyword arguments after ``kernel`` reach the routes of tl_decode_linear_ex (include/tinyllm_engine.h):
     ``merge_partials`` [cols / 128, n_splits, 132] fp32 with prologue PRO_ATTN_MERGE (``a`` is None, one row);
     ``ss_in`` [M, n] fp32 partial sums of squares for prologue PRO_RMSNORM / PRO_RMS_WEIGHTED; ``want_ss_out`` /
-    ``norm_out`` [rows] with the residual epilogue -- info then carries "ss_out" [M, rows / 16] and "out_w" [M, rows];
-    ``clear_counters=False`` (kernels 5-7): trust the arrival counters a previous call over the same shape left in the workspace."""
+    ``norm_out`` [rows] with the residual epilogue -- info then carries "ss_out" [M, rows / 16] and "out_w" [M, rows]."""
     extended = merge_partials is not None or ss_in is not None or want_ss_out or norm_out is not None \
-        or prologue in (PRO_ATTN_MERGE, PRO_RMS_WEIGHTED) or not clear_counters
+        or prologue in (PRO_ATTN_MERGE, PRO_RMS_WEIGHTED)
     if prologue == PRO_ATTN_MERGE:
         if merge_partials is None or a is not None:
             raise RuntimeError("decode_linear: the merging prologue takes merge_partials and no activation rows")
@@ -651,7 +650,6 @@ def decode_linear(w: TiledW4, a: torch.Tensor | None, *, prologue: int = PRO_NON
         _check(_lib.tl_decode_linear(*common, ctypes.byref(info)))
     else:
         ex = TlLinearEx()
-        ex.keep_counters = 0 if clear_counters else 1  # the workspace (and the counters at its end) is the cached one of the last call
         if merge_partials is not None:
             ex.merge_ws_dev, ex.n_splits = _ptr(merge_partials), int(merge_partials.shape[1])
         if ss_in is not None:

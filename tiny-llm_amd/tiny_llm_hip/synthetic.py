@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from types import SimpleNamespace
 
+import math
+
 import torch
 
 QWEN3_CONFIGS = {
@@ -64,14 +66,22 @@ def _qlayer(weight: torch.Tensor) -> SimpleNamespace:
 
 
 def synthetic_qwen3(config: dict | str, seed: int = 0, sigma: float = 0.02, device: str = "cuda",
-                    norm_jitter: float = 0.05, embed_sigma: float | None = None, residual_gain: float = 1.0) -> SimpleNamespace:
+                    norm_jitter: float = 0.05, embed_sigma: float | None = None, residual_gain: float = 1.0,
+                    head_permutation: tuple[int, int] | None = None) -> SimpleNamespace:
     """Random-weight Qwen3 in the mlx_lm object shape.  w ~ N(0, sigma) in bf16 -> W4 g128.
 
     embed_sigma / residual_gain build a PEAKED checkpoint: N(0, sigma) everywhere gives flat logits (the layers' outputs swamp the
     embedding, the top two logits of 151,936 lie within a rounding error of each other, and "the greedy id equals the truth's" is
     a coin toss there).  With a larger embedding (embed_sigma) and the two projections that write the residual stream (o_proj,
     down_proj) scaled by residual_gain < 1, the stream keeps a clear component along the input token's embedding row and the tied
-    head answers with a margin far above any rounding error: greedy ids can be REQUIRED to equal the float64 truth's."""
+    head answers with a margin far above any rounding error: greedy ids can be REQUIRED to equal the float64 truth's.
+
+    head_permutation = (a, b), a coprime to the vocabulary: an UNTIED head whose row (a t + b) mod V is the embedding row of token t
+    (the quantised tensors, moved row-wise: exact).  A tied head on such a checkpoint echoes its input token for ever (round 3's
+    checker produced nine copies of one id with a margin of 460 logit units -- it could not see a kernel that is wrong by a hundred);
+    with the permuted head the stream's component along embedding row t votes for token a t + b: the greedy sequence walks the
+    permutation, every step answers with a different id, and residual_gain sets how far the top-2 margin stands above the rounding
+    error (bench.py / tests/test_engine_qwen4b_gpu.py want 5-50 x the engine's measured error)."""
     cfg = dict(QWEN3_CONFIGS[config]) if isinstance(config, str) else dict(config)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -96,7 +106,20 @@ def synthetic_qwen3(config: dict | str, seed: int = 0, sigma: float = 0.02, devi
             input_layernorm=norm(hs), post_attention_layernorm=norm(hs)))
     model = SimpleNamespace(embed_tokens=linear(cfg["vocab_size"], hs, embed_sigma if embed_sigma is not None else sigma), layers=layers,
                             norm=norm(hs))
+    if head_permutation is not None:
+        cfg["tie_word_embeddings"] = False
     out = SimpleNamespace(args=SimpleNamespace(**cfg), model=model)
-    if not cfg.get("tie_word_embeddings", True):
+    if head_permutation is not None:
+        a, b = head_permutation
+        V = cfg["vocab_size"]
+        if math.gcd(a, V) != 1:
+            raise ValueError("head_permutation: a must be coprime to the vocabulary size")
+        target = (torch.arange(V, dtype=torch.int64, device=device) * a + b) % V  # row of the head that holds embedding row t
+        e = model.embed_tokens
+        head = SimpleNamespace(weight=torch.empty_like(e.weight), scales=torch.empty_like(e.scales), biases=torch.empty_like(e.biases),
+                               group_size=128, bits=4)
+        head.weight[target], head.scales[target], head.biases[target] = e.weight, e.scales, e.biases
+        out.lm_head = head
+    elif not cfg.get("tie_word_embeddings", True):
         out.lm_head = linear(cfg["vocab_size"], hs)
     return out
