@@ -56,6 +56,7 @@ class ServingMetrics:
     # not in the reference: what the scheduler did
     prefill_chunks: int = 0
     turns: int = 0
+    decode_bytes: int = 0  # algorithmic HBM bytes of all decode steps: per step W + 147,456 B x sum of live contexts
     decode_step_ms: list = field(default_factory=list, repr=False)
 
 
@@ -161,6 +162,7 @@ def serve_requests(engine, requests, *, batch_size: int, prefill_step: int, pref
                 last_completion = None  # idle time without an active decode request is not a fairness gap
                 continue
             rows = min(next((b for b in ROW_BUCKETS if b >= active[-1] + 1), batch_size), batch_size)
+            m.decode_bytes += int(engine.step_bytes(rows)) if hasattr(engine, "step_bytes") else 0
             t0 = clock()
             engine.decode(1, batch=rows)  # the occupied prefix of the slots; idle rows inside it produce nothing
             engine.synchronize()
@@ -286,6 +288,7 @@ def _serve_requests_packed(engine, requests, *, batch_size, prefill_step, prefil
                 last_completion = None
                 continue
             rows = min(next((b for b in ROW_BUCKETS if b >= active[-1] + 1), batch_size), batch_size)
+            m.decode_bytes += int(engine.step_bytes(rows)) if hasattr(engine, "step_bytes") else 0
             t0 = clock()
             engine.decode(1, batch=rows)
             engine.synchronize()
@@ -403,6 +406,10 @@ class ScheduleOnlyEngine:
 
     def synchronize(self):
         pass
+
+    def step_bytes(self, batch=None):
+        """W + 147,456 B x the live contexts of the step (Qwen3-4B W4: W = 2,136,832,000 B)."""
+        return 2_136_832_000 + 147_456 * sum(c for c in self.slots[:batch] if c is not None)
 
     def stats(self):
         return {"reused_page_allocations": 0, "pages_in_use": 0}

@@ -86,3 +86,8 @@ def test_bench_py_starts_its_own_ranks_when_no_launcher_did():
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["value"] == pytest.approx(2 * 6 / (out["ms_per_step"] * 6 / 1e3), rel=1e-3)  # whole-job aggregate over both ranks
     assert out["data"].startswith("none") and out["config"]["parallelism"].startswith("request-parallel x2")
+    # every rank's own clock, gathered once after the timed region: a straggler GPU must be visible in the driver's record
+    pr = out["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and len(pr["tokens_per_s"]) == 2 and pr["slowest_rank"] in (0, 1)
+    assert pr["min_tokens_per_s"] == min(pr["tokens_per_s"]) and pr["max_tokens_per_s"] == max(pr["tokens_per_s"])
+    assert max(pr["ms_per_step"]) == pytest.approx(out["ms_per_step"], rel=0.05), "the job's step time is its slowest rank's"

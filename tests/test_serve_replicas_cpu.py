@@ -97,6 +97,19 @@ def test_two_replicas_over_gloo_match_one_replica_serving_everything(tmp_path):
     assert a["requests"] == b["requests"] == 96 and a["generated_tokens"] == b["generated_tokens"]
     assert [r["requests"] for r in b["per_replica"]] == [48, 48]
     assert 0.4 < b["wall_s"] / a["wall_s"] < 0.75
+    # the driver-shaped record: ONE JSON line, the last of rank 0's stdout, in bench.py's shape with BASELINE.json configs[3] named
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and proc.stdout.strip().splitlines()[-1] == lines[0]
+    line = json.loads(lines[0])
+    assert line["metric"] == json.loads((ROOT / "BASELINE.json").read_text())["metric"]
+    assert line["n_gpus"] == 2 and line["unit"] == "tokens/s" and line["higher_is_better"] is True and line["scaling"] == "strong"
+    assert "configs[3]" in line["config"]["workload"] and "continuous batching" in line["config"]["workload"]
+    assert line["value"] == pytest.approx(b["output_tok_s"], rel=1e-3), "value is the whole-job aggregate over both replicas"
+    assert [g["rank"] for g in line["per_gpu"]] == [0, 1] and all(g["output_tokens_per_s"] > 0 for g in line["per_gpu"])
+    assert sum(g["output_tokens_per_s"] for g in line["per_gpu"]) >= line["value"] * 0.999  # the job ends with its slowest replica
+    # bytes per decode step follow SURVEY 8d: the weights once + 147,456 B per live context token
+    assert line["roofline"]["bytes_per_decode_step"] > 2_136_832_000 and len(line["roofline"]["achieved_per_gpu"]) == 2
+    assert line["data"].startswith("none"), "a cost-model run must not read as a measurement"
 
 
 def test_config1_week1_cpu_runner_smoke():
