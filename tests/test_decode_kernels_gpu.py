@@ -492,6 +492,42 @@ def test_decode_attention_contexts_up_to_4k(ext, ctx, monkeypatch):
     log_parity({"what": "decode_attention", "ctx": ctx, "mode": "default", **info})
 
 
+@pytest.mark.parametrize("ctx", [0, 1, 63, 64, 127, 128, 129, 255, 300, 1000, 3000, 4095, 8191, 32767])
+def test_decode_attention_of_one_contiguous_sequence_computes_its_page_ids(ext, ctx, monkeypatch):
+    """Round 4: ONE sequence whose pages are consecutive ids (a fresh pool: what bench.py's single stream decodes on).  The kernel
+    takes `first page` as an argument and computes page ids instead of loading block-table words, so the first K/V rows go out in
+    its first round trip.  Same arithmetic: the outputs and the appended K/V rows must equal the block-table route's to the BIT,
+    and both are held against the oracle.  The pool here is larger than the sequence and starts at page 3."""
+    for name in ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS"):
+        monkeypatch.delenv(name, raising=False)
+    rng = np.random.default_rng(5000 + ctx)
+    need = (ctx + 1 + PAGE - 1) // PAGE
+    first, P = 3, need + 6
+    table = -np.ones((1, need + 1), dtype=np.int32)
+    table[0, :need] = first + np.arange(need)
+    kp = O.bf16(rng.standard_normal((P, HKV, PAGE, D), dtype=np.float32))
+    vp = O.bf16(rng.standard_normal((P, HKV, PAGE, D), dtype=np.float32))
+    qkv = O.bf16(rng.standard_normal((1, (HQ + 2 * HKV) * D), dtype=np.float32))
+    qn = O.bf16(1.0 + 0.1 * rng.standard_normal((D,), dtype=np.float32))
+    kn = O.bf16(1.0 + 0.1 * rng.standard_normal((D,), dtype=np.float32))
+    case = (kp, vp, table, np.asarray([ctx], dtype=np.int32), qkv, qn, kn)
+    got_t, kpa_t, vpa_t, info_t = _run_attention(ext, case, ctx)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV, torch.bfloat16)
+    kpd, vpd = t(kp), t(vp)
+    out, info = ext.decode_attention_fused(t(qkv), t(qn), t(kn), kpd, vpd, torch.from_numpy(table).to(DEV), torch.from_numpy(case[3]).to(DEV),
+                                           num_heads=HQ, num_kv_heads=HKV, rope_theta=THETA, eps=EPS, max_context=ctx,
+                                           contiguous_first_page=first)
+    torch.cuda.synchronize()
+    got, kpa, vpa = _bf16_host(out), _bf16_host(kpd), _bf16_host(vpd)
+    what = f"contiguous ctx={ctx} {info}"
+    assert {k: info[k] for k in ("n_splits", "tokens_per_split", "heads_per_workgroup")} == \
+           {k: info_t[k] for k in ("n_splits", "tokens_per_split", "heads_per_workgroup")}, what
+    np.testing.assert_array_equal(got, got_t, err_msg=f"{what}: output differs from the block-table route")
+    np.testing.assert_array_equal(kpa, kpa_t, err_msg=f"{what}: key pages differ from the block-table route")
+    np.testing.assert_array_equal(vpa, vpa_t, err_msg=f"{what}: value pages differ from the block-table route")
+    _check_attention(case, got, kpa, vpa, [False], what)
+
+
 @pytest.mark.parametrize("ctxs", [[8191], [8192, 5000, 129, -1], [32767], [32768, 1, 700, 20000]])
 @pytest.mark.parametrize("mode", ["default", "splits256", "legacy_rq1"])
 def test_decode_attention_long_contexts(ext, ctxs, mode, monkeypatch):

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/tinyllm_engine.h"
@@ -65,6 +66,11 @@ struct tl_engine {
              *attn = nullptr, *gu = nullptr, *act = nullptr, *tmp = nullptr, *logits = nullptr;
     float *attn_ws = nullptr;
     int last_attn_launches = 0;
+    // lm_head GEMV of a 1-4-row decode step: per 16-logit tile (max, lowest index) pairs for step_end_kernel (qmv3.h tile_max);
+    // TL_LMHEAD_TILE_MAX=0: step_end reads the logits row again
+    f32x2 *lm_tile_max = nullptr;            // [8][vocab / 16]
+    bool lm_tile_max_on = true, want_tile_max = false;
+    int tile_max_rows = 0;                   // rows of the last lm_head launch that left pairs (0 = none)
     float *ss_x = nullptr, *ss_h = nullptr;  // [max_batch][QM3_SS] partial sums of squares of the rows of x / h (qmm3.h)
     // At 5 .. 64 decode rows the qkv projection's slice reduction is not launched; the decode-attention kernel adds the fp32 slice
     // partials itself (engine_kernels.h, QP).  Measured in round 3 (profiles/r03_labs/batched_decode_status.jsonl): 5 / 8 / 16 / 64
@@ -115,7 +121,10 @@ struct tl_engine {
     tl_engine_stats stats{};
 
     bool warmed = false;
-    std::map<std::pair<int, long>, hipGraphExec_t> graphs;  // (batch, n_splits << 32 | tokens_per_split)
+    std::map<std::tuple<int, long, long>, hipGraphExec_t> graphs;  // (batch, split plan, first page of a contiguous single sequence or -1)
+    // One sequence on consecutive page ids: the decode-attention kernel computes page ids instead of loading them (engine_kernels.h, CG).
+    // TL_ATTN_CONTIG=0: always through the block table.
+    bool attn_contig = true;
     // Qwen3-MoE layers (tl_engine_set_moe_layer): router + stacked experts instead of the dense gate|up / w_down of that layer
     std::vector<tl_moe_weights> moe;  // per layer; num_experts == 0: dense
     int moe_k_max = 0, moe_e_max = 0, moe_i_max = 0;
@@ -226,6 +235,10 @@ static int engine_qmv(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
             if (e->gemv_producer_ss) {
                 if ((pro == PRO_RMSNORM || pro == PRO_RMS_WEIGHTED) && ss_in && ss_in_n > 0) a3.ss_in = ss_in + (size_t)m0 * ss_in_n, a3.ss_n = ss_in_n;
                 if (epi == EPI_RESIDUAL && ss_out) a3.ss_out = ss_out + (size_t)m0 * (w.rows / 16);
+            }
+            if (e->want_tile_max && e->lm_tile_max && epi == EPI_STORE && step == M && w.rows % 16 == 0) {
+                a3.tile_max = e->lm_tile_max;
+                e->tile_max_rows = M;
             }
             if (out_w) {
                 TL_REQUIRE(epi == EPI_RESIDUAL && norm_out && step == M, "engine: weighted rows need the residual epilogue and one pass");
@@ -410,7 +423,12 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
 struct SplitPlan {
     int n_splits, tokens_per_split;
     int rq;  // query heads per workgroup
+    // One sequence whose pages are the consecutive ids contig_first, contig_first + 1, ... (contig_pages of them; -1: use the block
+    // table): the attention kernel then takes its page ids from this kernel argument (engine_kernels.h, CG).  Part of a captured
+    // graph's identity, like the split plan.
+    int contig_first = -1, contig_pages = 0;
     long key() const { return ((long)rq << 40) | ((long)n_splits << 24) | (long)tokens_per_split; }
+    long key2() const { return contig_first < 0 ? -1L : (((long)contig_first << 24) | (long)contig_pages); }
 };
 // Measured on MI355X (profiles/README.md, profiles/r02_labs): a decode-attention workgroup is bound by its dependent latency
 // chain and by how many L2 misses ONE CU keeps in flight (~32 KiB), not by chip bandwidth.  Few sequences and short
@@ -467,20 +485,34 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     return SplitPlan{s, std::max(64, std::min(per_split, bucket / s)), rq};
 }
 
+// One live sequence (slot 0) whose pages are consecutive ids: the plan carries the first id and how many pages lie between it and the
+// end of the pool (the kernel clamps masked, out-of-context page indices there: finite memory of the pool, weight zero).  Checked on
+// the host mirror before EVERY step; a sequence that stops being contiguous simply takes the block-table kernel (another graph).
+static void mark_contiguous(const tl_engine *e, int batch, SplitPlan &sp) {
+    sp.contig_first = -1, sp.contig_pages = 0;
+    if (!e->attn_contig || batch != 1 || e->slot_pages.empty() || !e->slot_live[0]) return;
+    const auto &pages = e->slot_pages[0];
+    if (pages.empty()) return;
+    for (size_t j = 1; j < pages.size(); ++j)
+        if (pages[j] != pages[0] + (int)j) return;
+    sp.contig_first = pages[0];
+    sp.contig_pages = e->cfg.num_pages - pages[0];
+}
+
 // head_dim 128 with a whole GQA group per workgroup is the only shape that takes qkv slice partials (batched decode of 5+ rows)
 static bool attn_takes_qkv_partials(int head_dim, int rq) { return head_dim == 128 && rq == AD_RQ; }
-template <int VD, bool SP, bool IP = false>
+template <int VD, bool SP, bool IP = false, bool CG = false>
 static void launch_attn_decode_sp(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq) {
     const size_t lds = (size_t)16 * rq * (16 * VD + 2) * sizeof(float);
-    if constexpr (VD == 8) {
+    if constexpr (VD == 8 && !CG) {
         if (a.qkv_partial != nullptr && rq == AD_RQ) {
             const size_t staged = (size_t)(2 + AD_RQ) * 16 * VD * sizeof(uint16_t);
             hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP, true>), grid, dim3(256), lds + staged, st, a);
             return;
         }
     }
-    if (rq == 1) hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, 1, SP, IP>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP>), grid, dim3(256), lds, st, a);
+    if (rq == 1) hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, 1, SP, IP, false, CG>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP, false, CG>), grid, dim3(256), lds, st, a);
 }
 template <int VD>
 static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq) {
@@ -488,7 +520,11 @@ static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t s
     // every 64-token stage of a window inside one page: windows are multiples of 64 tokens, pages a power of two >= 64
     static const bool stage_pages_off = getenv("TL_ATTN_STAGE_PAGES") && atoi(getenv("TL_ATTN_STAGE_PAGES")) == 0;
     const bool stage_page = !single_page && !stage_pages_off && a.page_shift >= 6 && a.tokens_per_split % 64 == 0;
-    if (single_page) launch_attn_decode_sp<VD, true>(a, grid, st, rq);
+    // one sequence on consecutive page ids (AttnDecodeArgs::contig_first): page ids by arithmetic, the first K/V rows in the first round trip
+    const bool contig = a.contig_first >= 0 && a.contig_pages > 0 && a.qkv_partial == nullptr && grid.z == 1 && (single_page || stage_page);
+    if (contig && single_page) launch_attn_decode_sp<VD, true, false, true>(a, grid, st, rq);
+    else if (contig) launch_attn_decode_sp<VD, false, true, true>(a, grid, st, rq);
+    else if (single_page) launch_attn_decode_sp<VD, true>(a, grid, st, rq);
     else if (stage_page) launch_attn_decode_sp<VD, false, true>(a, grid, st, rq);
     else launch_attn_decode_sp<VD, false>(a, grid, st, rq);
 }
@@ -572,6 +608,8 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
         if ((1 << sh) == c.page_size) a.page_shift = sh;
     a.rope_cur = e->rope_cur;
     a.prof = pc ? pc->buf : nullptr;
+    a.contig_first = batch == 1 ? sp.contig_first : -1;
+    a.contig_pages = sp.contig_pages;
     if (qkv_parts && qkv_parts->partial) {
         TL_REQUIRE(attn_takes_qkv_partials(D, sp.rq), "engine: this decode-attention plan does not read qkv slice partials");
         a.qkv_partial = qkv_parts->partial;
@@ -672,9 +710,14 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
                              h_ss ? e->ss_h : nullptr, nullptr, nullptr, nullptr, h_ss));
         TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, nullptr, nullptr, QM3_SS, &x_ss));
     }
-    TL_TRY(engine_linear(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4,
-                         x_ss ? e->ss_x : nullptr, nullptr, nullptr, nullptr, x_ss));
+    e->want_tile_max = e->lm_tile_max_on;
+    e->tile_max_rows = 0;
+    const int head_rc = engine_linear(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4,
+                                      x_ss ? e->ss_x : nullptr, nullptr, nullptr, nullptr, x_ss);
+    e->want_tile_max = false;
+    TL_TRY(head_rc);
     StepEndArgs s{};
+    if (e->tile_max_rows == batch) s.tile_max = e->lm_tile_max, s.tiles = e->head().rows / 16;
     s.logits = e->logits;
     s.vocab = c.vocab_size;
     s.slot0 = 0;
@@ -868,6 +911,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const size_t o_act = carve(R * c.intermediate_size * 2);
     const size_t o_log = carve((size_t)std::max(c.max_batch, 8) * c.vocab_size * 2);  // decode rows, or 8 verification rows
     const size_t o_vid = carve(8 * 4);
+    const size_t o_tmax = carve((size_t)8 * (c.vocab_size / 16 + 1) * sizeof(f32x2));
     // per-row partial sums of squares: QM3_SS per row from the skinny-matmul reduction / the embedding kernels, one per 16-row
     // tile (hidden / 16) from the 1-4-row GEMVs
     const size_t ss_per_row = (size_t)std::max(QM3_SS, c.hidden_size / 16 + 1);
@@ -933,6 +977,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->logits = (uint16_t *)(A + o_log);
     e->attn_ws = (float *)(A + o_ws);
     e->verify_ids = (int32_t *)(A + o_vid);
+    e->lm_tile_max = (f32x2 *)(A + o_tmax);
     e->ss_x = (float *)(A + o_ssx);
     e->ss_h = (float *)(A + o_ssh);
     if (const char *q = getenv("TL_QMM3_FUSED_NORM")) e->fuse_norm = atoi(q) != 0;
@@ -940,6 +985,8 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (const char *q = getenv("TL_GEMV_WEIGHTED_ROWS")) e->gemv_weighted_rows = atoi(q) != 0;
     if (const char *q = getenv("TL_ATTN_QKV_PARTIALS")) e->attn_qkv_partials = atoi(q) != 0;
     if (const char *q = getenv("TL_WO_MERGES_ATTN")) e->wo_merges_attn = atoi(q) != 0;
+    if (const char *q = getenv("TL_ATTN_CONTIG")) e->attn_contig = atoi(q) != 0;
+    if (const char *q = getenv("TL_LMHEAD_TILE_MAX")) e->lm_tile_max_on = atoi(q) != 0;
     if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
@@ -1577,9 +1624,10 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
             e->stats.pages_free = (int)e->free_pages.size();
             TL_TRY(poke(e, pk));
         }
-        const SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
+        SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
+        mark_contiguous(e, batch, sp);
         if (use_graph && e->warmed) {
-            const auto key = std::make_pair(batch, sp.key());
+            const auto key = std::make_tuple(batch, sp.key(), sp.key2());
             auto it = e->graphs.find(key);
             if (it == e->graphs.end()) {
                 // The split plan (and with it the key) changes every 64 * n_splits tokens of context: a long run would keep one
@@ -1702,7 +1750,8 @@ extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *
         return rc;
     }
     rc = pk.empty() ? TL_OK : poke(e, pk);
-    const SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
+    SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
+    mark_contiguous(e, batch, sp);
     const int n_splits = sp.n_splits;
     if (rc == TL_OK) rc = enqueue_step(e, batch, sp, &pc);
     if (rc != TL_OK) {
@@ -1942,12 +1991,12 @@ extern "C" size_t tl_decode_attention_fused_workspace_bytes(int batch, int num_h
            (size_t)batch * num_heads * 256 * (head_dim + ATTN_WS_PAD) * sizeof(float);
 }
 
-extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,
-                                         void *key_pages_dev, void *value_pages_dev, const int32_t *block_table_dev,
-                                         const int32_t *context_lens_dev, void *out_dev, int batch, int num_heads,
-                                         int num_kv_heads, int head_dim, int page_size, int max_pages, float rope_theta,
-                                         float eps, int max_context, void *workspace_dev, size_t workspace_bytes,
-                                         void *stream, tl_attention_info *info) {
+static int decode_attention_fused_impl(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,
+                                       void *key_pages_dev, void *value_pages_dev, const int32_t *block_table_dev,
+                                       const int32_t *context_lens_dev, void *out_dev, int batch, int num_heads,
+                                       int num_kv_heads, int head_dim, int page_size, int max_pages, float rope_theta,
+                                       float eps, int max_context, void *workspace_dev, size_t workspace_bytes,
+                                       void *stream, tl_attention_info *info, int first_page, int pool_pages) {
     TL_REQUIRE(qkv_dev && q_norm_dev && k_norm_dev && key_pages_dev && value_pages_dev && block_table_dev && context_lens_dev &&
                    out_dev, "decode_attention_fused: null pointer");
     TL_REQUIRE(batch >= 1 && batch <= 256, "decode_attention_fused: between 1 and 256 sequences");
@@ -1975,7 +2024,12 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
     read_attention_knobs(&e);
     hipLaunchKernelGGL(rope_rows_kernel, dim3(batch), dim3(64), 0, e.stream, context_lens_dev, e.rope_cur, head_dim / 2, rope_theta);
     TL_CHECK_LAUNCH("decode_attention_fused rope");
-    const SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
+    SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
+    if (first_page >= 0) {
+        TL_REQUIRE(batch == 1 && pool_pages > first_page, "decode_attention_fused_contiguous: one sequence, first_page inside the pool");
+        sp.contig_first = first_page;
+        sp.contig_pages = pool_pages - first_page;
+    }
     const int rc = engine_attention(&e, (const uint16_t *)qkv_dev, q_norm_dev, k_norm_dev, (uint16_t *)key_pages_dev,
                                     (uint16_t *)value_pages_dev, (uint16_t *)out_dev, batch, sp, nullptr);
     e.rope_cur = nullptr;  // borrowed
@@ -1986,6 +2040,29 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
         info->launches = e.last_attn_launches;
     }
     return rc;
+}
+
+extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,
+                                         void *key_pages_dev, void *value_pages_dev, const int32_t *block_table_dev,
+                                         const int32_t *context_lens_dev, void *out_dev, int batch, int num_heads,
+                                         int num_kv_heads, int head_dim, int page_size, int max_pages, float rope_theta,
+                                         float eps, int max_context, void *workspace_dev, size_t workspace_bytes,
+                                         void *stream, tl_attention_info *info) {
+    return decode_attention_fused_impl(qkv_dev, q_norm_dev, k_norm_dev, key_pages_dev, value_pages_dev, block_table_dev, context_lens_dev,
+                                       out_dev, batch, num_heads, num_kv_heads, head_dim, page_size, max_pages, rope_theta, eps, max_context,
+                                       workspace_dev, workspace_bytes, stream, info, -1, 0);
+}
+
+extern "C" int tl_decode_attention_fused_contiguous(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,
+                                                    void *key_pages_dev, void *value_pages_dev, const int32_t *block_table_dev,
+                                                    const int32_t *context_lens_dev, void *out_dev, int num_heads, int num_kv_heads,
+                                                    int head_dim, int page_size, int max_pages, float rope_theta, float eps,
+                                                    int max_context, int first_page, int pool_pages, void *workspace_dev,
+                                                    size_t workspace_bytes, void *stream, tl_attention_info *info) {
+    TL_REQUIRE(first_page >= 0, "decode_attention_fused_contiguous: first_page must be a page id");
+    return decode_attention_fused_impl(qkv_dev, q_norm_dev, k_norm_dev, key_pages_dev, value_pages_dev, block_table_dev, context_lens_dev,
+                                       out_dev, 1, num_heads, num_kv_heads, head_dim, page_size, max_pages, rope_theta, eps, max_context,
+                                       workspace_dev, workspace_bytes, stream, info, first_page, pool_pages);
 }
 
 // ---- host-only: the plans the decode path would pick (no device, no launch): what the CPU tests and a binding's dry run read -------

@@ -77,6 +77,11 @@ struct Qmv3Args {
     // element as in the reference (there of x * inv * w, here of x * w): same error bound, not the same bits.
     const uint16_t *norm_out;  // [K]      EPI_RESIDUAL, optional
     uint16_t *out_w;           // [M, K]   EPI_RESIDUAL, optional
+    // EPI_STORE, optional (the lm_head projection of a decode step, round 4): per (activation row, 16-row tile) the largest STORED
+    // bf16 value and the lowest output index that holds it, tile_max [M][K / 16] (value, index as float: indices stay below 2^24).
+    // step_end_kernel then picks the greedy id from K / 16 pairs instead of re-reading all K logits (reference: mx.argmax over the
+    // logits row, benches/bench.py:234-243; first maximum wins).
+    f32x2 *tile_max;
 };
 
 // output stores (lab: -DQ3_STORE_MODE=1 nontemporal, 2 = system-scope atomic store, i.e. write-through)
@@ -485,7 +490,15 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
                 if (r == 0 && tile_ok && arow < MR && arow < p.M) q3_store(&p.ss_out[(size_t)arow * tiles + tile_c], sq_v);
             }
         } else {
-            if (live) q3_store(&p.out[(size_t)arow * K + orow], BF16::from_float(acc[i2]));
+            const uint16_t ov = BF16::from_float(acc[i2]);
+            if (live) q3_store(&p.out[(size_t)arow * K + orow], ov);
+            if (p.tile_max) {  // uniform
+                const float v = live ? BF16::to_float(ov) : -INFINITY;
+                const float m = group16_max(v);
+                const float cand = (v == m && live) ? (float)orow : 3.0e38f;  // lowest index among the lanes that hold the maximum
+                const float lowest = -group16_max(-cand);
+                if (r == 0 && tile_ok && arow < MR && arow < p.M) p.tile_max[(size_t)arow * tiles + tile_c] = f32x2{m, lowest};
+            }
         }
     }
     Q3_STAMP(5);  // reduced and stored
