@@ -303,17 +303,6 @@ int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm_dev, const
                               int max_pages, float rope_theta, float eps, int max_context, void *workspace_dev,
                               size_t workspace_bytes, void *stream, tl_attention_info *info);
 
-/* The same launch for ONE sequence whose block-table row holds the consecutive page ids first_page, first_page + 1, ... (what a fresh
- * pool hands out): the kernel computes its page ids from `first_page` instead of loading them, so the first K/V rows are requested
- * in its first round trip.  The engine takes this route by itself whenever its host mirror says the single live sequence is
- * contiguous (TL_ATTN_CONTIG=0 turns that off).  pool_pages = P of the page pools; block_table_dev is not read.  Same arithmetic,
- * same results as tl_decode_attention_fused (reference semantics: paged_attention.metal:108-248). */
-int tl_decode_attention_fused_contiguous(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev, void *key_pages_dev,
-                                         void *value_pages_dev, const int32_t *block_table_dev, const int32_t *context_lens_dev,
-                                         void *out_dev, int num_heads, int num_kv_heads, int head_dim, int page_size, int max_pages,
-                                         float rope_theta, float eps, int max_context, int first_page, int pool_pages,
-                                         void *workspace_dev, size_t workspace_bytes, void *stream, tl_attention_info *info);
-
 #ifdef __cplusplus
 }
 #endif

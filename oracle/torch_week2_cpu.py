@@ -29,8 +29,12 @@ class TorchWeek2KvCacheCPU:
     """dense: {"embed": [V, H] bf16, "norm": [H], "layers": [{"q","k","v","o","gate","up","down": [out, in] bf16,
     "q_norm","k_norm": [D], "input_norm","post_norm": [H]}], optional "lm_head": [V, H]} -- CPU tensors."""
 
-    def __init__(self, cfg: dict, dense: dict):
+    def __init__(self, cfg: dict, dense: dict, linear_dtype: torch.dtype = torch.bfloat16):
+        """linear_dtype: storage of the linears' operands.  bf16 is the reference's; float32 (same bf16-VALUED weights, each product
+        rounded back to bf16) is for hosts whose torch build has no fast bf16 GEMM -- the arithmetic stays that of the bf16 path up
+        to the accumulation width, which the reference's backend does not pin either."""
         self.cfg, self.w = cfg, dense
+        self.ld = linear_dtype
         self.k_cache = [None] * cfg["num_hidden_layers"]
         self.v_cache = [None] * cfg["num_hidden_layers"]
         self.offset = 0
@@ -51,6 +55,9 @@ class TorchWeek2KvCacheCPU:
         x1, x2 = x[..., :self.half].float(), x[..., self.half:].float()
         return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1).to(x.dtype)
 
+    def _linear(self, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        return (x.to(self.ld) @ w.T).to(torch.bfloat16)
+
     @torch.no_grad()
     def forward(self, tokens) -> torch.Tensor:
         """Feed `tokens` (appended to the cache); returns the LAST row's logits [V] (bf16), like --prefill-logits last."""
@@ -62,9 +69,9 @@ class TorchWeek2KvCacheCPU:
         h = self.w["embed"][ids]  # [L, hidden] bf16
         for i, lw in enumerate(self.w["layers"]):
             x = self._rms_norm(h, lw["input_norm"], eps)
-            q = (x @ lw["q"].T).reshape(L, Hq, D)
-            k = (x @ lw["k"].T).reshape(L, Hkv, D)
-            v = (x @ lw["v"].T).reshape(L, Hkv, D)
+            q = self._linear(x, lw["q"]).reshape(L, Hq, D)
+            k = self._linear(x, lw["k"]).reshape(L, Hkv, D)
+            v = self._linear(x, lw["v"]).reshape(L, Hkv, D)
             q = self._rope(self._rms_norm(q, lw["q_norm"], eps), self.offset)
             k = self._rope(self._rms_norm(k, lw["k_norm"], eps), self.offset)
             self.k_cache[i] = k if self.k_cache[i] is None else torch.cat([self.k_cache[i], k], dim=0)
@@ -79,14 +86,16 @@ class TorchWeek2KvCacheCPU:
                 scores = scores.masked_fill(~keep, float("-inf"))
             att = torch.einsum("grls,gsd->grld", torch.softmax(scores, dim=-1), vf)
             att = att.permute(2, 0, 1, 3).reshape(L, Hq * D).to(h.dtype)
-            h = h + att @ lw["o"].T
+            h = h + self._linear(att, lw["o"])
             x = self._rms_norm(h, lw["post_norm"], eps)
-            g, u = x @ lw["gate"].T, x @ lw["up"].T
-            h = h + ((g * torch.sigmoid(g.float()).to(g.dtype)) * u) @ lw["down"].T
+            g, u = self._linear(x, lw["gate"]), self._linear(x, lw["up"])
+            h = h + self._linear((g * torch.sigmoid(g.float()).to(g.dtype)) * u, lw["down"])
         self.offset += L
         last = self._rms_norm(h[-1:], self.w["norm"], eps)
         head = self.w.get("lm_head")
-        return (last @ (head if head is not None else self.w["embed"]).T)[0]
+        if head is None:
+            head = self.w.get("embed_linear", self.w["embed"])  # tied head; "embed_linear": the table in linear_dtype
+        return self._linear(last, head)[0]
 
     def timed_decode(self, first_token: int, steps: int, fed=None):
         """`steps` greedy decode steps (or teacher-forced on `fed`); returns (seconds, ids, logits of the first step)."""

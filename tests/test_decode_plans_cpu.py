@@ -101,7 +101,7 @@ def test_the_planners_variant_predicate_is_the_instantiation_table(lib):
     (8, 300, 4, 4, 128), (8, 1000, 8, 4, 128), (64, 300, 1, 4, 512),                 # 5-8: 128 at 257..512; many sequences: one window each
 ])
 def test_attention_plans_by_context_and_sequences(lib, monkeypatch, batch, ctx, windows, heads_per_wg, max_window):
-    for name in ("TL_ATTN_RQ", "TL_ATTN_RQ1_CTX", "TL_ATTN_RQ1_BATCH", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS", "TL_ATTN_WG_CAP"):
+    for name in ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS"):
         monkeypatch.delenv(name, raising=False)
     n_splits, per_split, rq = attention_plan(lib, batch, ctx)
     assert (n_splits, rq) == (windows, heads_per_wg), f"{batch} sequences, {ctx} tokens: {n_splits} windows of {per_split}, {rq} heads per workgroup"

@@ -172,8 +172,7 @@ def test_greedy_ids_from_tile_maxima_equal_the_full_argmax(model_and_weights, n_
     """Round 4: the lm_head GEMV leaves, per 16-logit tile, the largest stored bf16 logit and the lowest index holding it, and
     step_end_kernel picks the greedy id from those 9,496 pairs instead of re-reading 151,936 logits.  Same rule as mx.argmax over
     the row (first maximum wins, reference benches/bench.py:234-243): on the FLAT checkpoint, where exact ties between bf16 logits
-    do occur, the ids and the logits of 12 steps must be identical with the route on and off (TL_LMHEAD_TILE_MAX, and the attention
-    kernel's computed page ids TL_ATTN_CONTIG alongside: both are pure re-arrangements)."""
+    do occur, the ids and the logits of 12 steps must be identical with the route on and off (TL_LMHEAD_TILE_MAX)."""
     from tiny_llm_hip.engine import DecodeEngine
 
     model, _ = model_and_weights
@@ -182,7 +181,6 @@ def test_greedy_ids_from_tile_maxima_equal_the_full_argmax(model_and_weights, n_
     runs = []
     for flag in ("1", "0"):
         monkeypatch.setenv("TL_LMHEAD_TILE_MAX", flag)
-        monkeypatch.setenv("TL_ATTN_CONTIG", flag)
         eng = DecodeEngine(model, page_size=128, num_pages=n_seq + 2, max_batch=n_seq, max_prefill_rows=64)
         try:
             for i, p in enumerate(prompts):

@@ -827,7 +827,7 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
         const size_t fa_need = fa_splits > 1 ? (size_t)N * L * fa_splits * (D + 2) * sizeof(float) : 0;
         if (fa_need > 0 && (!workspace || workspace_bytes < fa_need)) fa_splits = 1;  // no workspace: one pass, still correct
         const dim3 grid(item_blocks * fa_splits, num_kv_heads, B);
-        static const int fa_xcd_remap = getenv("TL_FA_XCD_REMAP") ? atoi(getenv("TL_FA_XCD_REMAP")) : 1;  // 0: launch order (lab A/B)
+        const int fa_xcd_remap = 1;  // one KV head per XCD (round 3 A/B: +2 % at 8k prefill)
         int page_shift = -1;
         for (int sh = 0; sh < 30; ++sh)
             if ((1 << sh) == page_size) page_shift = sh;

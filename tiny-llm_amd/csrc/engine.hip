@@ -8,7 +8,6 @@
 #include <cstdlib>
 #include <map>
 #include <string>
-#include <tuple>
 #include <vector>
 
 #include "../../include/tinyllm_engine.h"
@@ -80,23 +79,24 @@ struct tl_engine {
     // merged row from the split partials while it stages it (qmv3.h, PRO_ATTN_MERGE).  Measured in round 3
     // (profiles/r03_labs/wo_merges_attn_ab_after_dpp.jsonl): 4 windows 1.023 -> 0.993 ms per token, 8 windows 1.033 -> 1.009 (the
     // merging GEMV costs +0.9 / +2.0 us per layer, the merge launch cost 0.6 us + a boundary); 64-token windows stay the best
-    // (128-token windows: 1.022).  TL_WO_MERGES_ATTN=0 keeps the merge launch.
+    // (128-token windows: 1.022).  Other split counts, more sequences or another head size keep the merge launch (wo_merge_applicable).
     bool wo_merges_attn = true;
-    // TL_GEMV_PRODUCER_SS=0: the 1-4-row GEMVs re-derive the sum of squares of their input rows instead of adding the partials the
-    // producing GEMV left (qmv3.h, ss_in / ss_out).  On by default: qkv -0.44 us, gate|up -1.1 us per layer (abl_lab, bit 8)
+    // The 1-4-row GEMVs add the partial sums of squares their producer left instead of re-deriving them (a row without partials --
+    // the first step after a MoE layer, a packed-dot fallback -- is still re-derived inside the kernel: qmv3.h, ss_given):
+    // qkv -0.44 us, gate|up -1.1 us per layer (abl_lab, bit 8)
     bool gemv_producer_ss = true;
     // The wo GEMV of 1-4 decode rows also leaves h * post_attention_layernorm (bf16) and the gate|up GEMV stages THAT row and
     // multiplies its sums by the row's 1 / rms at the end (qmv3.h, PRO_RMS_WEIGHTED): the 1,216 workgroups of gate|up no longer
     // fetch the norm weights and normalise the whole row each.  tools/lab/trace_lab, back to back: gate|up 7.82 -> 7.08 us, wo
-    // 3.91 -> 4.06; the qkv and lm_head GEMVs gain nothing from it and keep the fused RMSNorm.  TL_GEMV_WEIGHTED_ROWS=0: off.
+    // 3.91 -> 4.06; the qkv and lm_head GEMVs gain nothing from it and keep the fused RMSNorm (weighted_rows_apply decides by shape).
     bool gemv_weighted_rows = true;
-    bool fuse_norm = true;                   // TL_QMM3_FUSED_NORM=0: RMSNorm ahead of a skinny matmul always as its own launch
+    bool fuse_norm = true;                   // the skinny matmul normalises its own slice whenever its producer left sums of squares
     int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
     bool use_qmm3 = true;   // TL_NO_QMM3=1 at create: rows > 8 go through the prefill GEMM path instead
     int attn_rq = 0;             // query heads per decode-attention workgroup; 0 = by context (TL_ATTN_RQ at create: 1 or 4)
-    int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup (TL_ATTN_RQ1_CTX)
-    int attn_rq1_batch = 2;      // ... and up to this many sequences (TL_ATTN_RQ1_BATCH); at 4 the re-read windows cost 261 vs 180 us
+    int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup
+    int attn_rq1_batch = 2;      // ... and up to this many sequences; at 4 the re-read windows cost 261 vs 180 us
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
     int attn_wg_cap = 0;         // most attention workgroups per launch; 0 = by sequences (pick_decode_splits)
     bool attn_min_tokens_auto = true;  // ... or more, by context and sequences (pick_decode_splits)
@@ -121,10 +121,7 @@ struct tl_engine {
     tl_engine_stats stats{};
 
     bool warmed = false;
-    std::map<std::tuple<int, long, long>, hipGraphExec_t> graphs;  // (batch, split plan, first page of a contiguous single sequence or -1)
-    // One sequence on consecutive page ids: the decode-attention kernel computes page ids instead of loading them (engine_kernels.h, CG).
-    // TL_ATTN_CONTIG=0: always through the block table.
-    bool attn_contig = true;
+    std::map<std::pair<int, long>, hipGraphExec_t> graphs;  // (batch, n_splits << 32 | tokens_per_split)
     // Qwen3-MoE layers (tl_engine_set_moe_layer): router + stacked experts instead of the dense gate|up / w_down of that layer
     std::vector<tl_moe_weights> moe;  // per layer; num_experts == 0: dense
     int moe_k_max = 0, moe_e_max = 0, moe_i_max = 0;
@@ -423,12 +420,7 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
 struct SplitPlan {
     int n_splits, tokens_per_split;
     int rq;  // query heads per workgroup
-    // One sequence whose pages are the consecutive ids contig_first, contig_first + 1, ... (contig_pages of them; -1: use the block
-    // table): the attention kernel then takes its page ids from this kernel argument (engine_kernels.h, CG).  Part of a captured
-    // graph's identity, like the split plan.
-    int contig_first = -1, contig_pages = 0;
     long key() const { return ((long)rq << 40) | ((long)n_splits << 24) | (long)tokens_per_split; }
-    long key2() const { return contig_first < 0 ? -1L : (((long)contig_first << 24) | (long)contig_pages); }
 };
 // Measured on MI355X (profiles/README.md, profiles/r02_labs): a decode-attention workgroup is bound by its dependent latency
 // chain and by how many L2 misses ONE CU keeps in flight (~32 KiB), not by chip bandwidth.  Few sequences and short
@@ -440,11 +432,8 @@ struct SplitPlan {
 // the attention plan's lab knobs (environment, read when an engine -- or the standalone operator's stand-in for one -- is set up)
 static void read_attention_knobs(tl_engine *e) {
     if (const char *q = getenv("TL_ATTN_RQ")) e->attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
-    if (const char *q = getenv("TL_ATTN_RQ1_CTX")) e->attn_rq1_ctx = atoi(q);
-    if (const char *q = getenv("TL_ATTN_RQ1_BATCH")) e->attn_rq1_batch = atoi(q);
     if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = e->attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q)), e->attn_min_tokens_auto = false;
-    if (const char *q = getenv("TL_ATTN_WG_CAP")) e->attn_wg_cap = std::max(0, atoi(q));
 }
 static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
     const int rep = e->cfg.num_heads / e->cfg.num_kv_heads;
@@ -472,7 +461,7 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     }
     // few sequences: split for latency (up to 2048 short-lived workgroups); many sequences: the chip is already full, longer
     // windows amortise the per-workgroup prologue and skip the merge launch (measured at 16 and 64 sequences)
-    const int wg_cap = e->attn_wg_cap > 0 ? e->attn_wg_cap : (batch <= 4 ? 2048 : 512);  // TL_ATTN_WG_CAP pins it (lab)
+    const int wg_cap = e->attn_wg_cap > 0 ? e->attn_wg_cap : (batch <= 4 ? 2048 : 512);
     // a whole GQA group per workgroup (long contexts / several sequences): at most 32 windows -- one workgroup per CU for one sequence;
     // measured at 8k 666 -> 680 tok/s against 64 windows, 32k unchanged (round 3)
     const int max_splits = rq == AD_RQ ? e->attn_max_splits_gqa : e->attn_max_splits;
@@ -485,46 +474,27 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     return SplitPlan{s, std::max(64, std::min(per_split, bucket / s)), rq};
 }
 
-// One live sequence (slot 0) whose pages are consecutive ids: the plan carries the first id and how many pages lie between it and the
-// end of the pool (the kernel clamps masked, out-of-context page indices there: finite memory of the pool, weight zero).  Checked on
-// the host mirror before EVERY step; a sequence that stops being contiguous simply takes the block-table kernel (another graph).
-static void mark_contiguous(const tl_engine *e, int batch, SplitPlan &sp) {
-    sp.contig_first = -1, sp.contig_pages = 0;
-    if (!e->attn_contig || batch != 1 || e->slot_pages.empty() || !e->slot_live[0]) return;
-    const auto &pages = e->slot_pages[0];
-    if (pages.empty()) return;
-    for (size_t j = 1; j < pages.size(); ++j)
-        if (pages[j] != pages[0] + (int)j) return;
-    sp.contig_first = pages[0];
-    sp.contig_pages = e->cfg.num_pages - pages[0];
-}
-
 // head_dim 128 with a whole GQA group per workgroup is the only shape that takes qkv slice partials (batched decode of 5+ rows)
 static bool attn_takes_qkv_partials(int head_dim, int rq) { return head_dim == 128 && rq == AD_RQ; }
-template <int VD, bool SP, bool IP = false, bool CG = false>
+template <int VD, bool SP, bool IP = false>
 static void launch_attn_decode_sp(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq) {
     const size_t lds = (size_t)16 * rq * (16 * VD + 2) * sizeof(float);
-    if constexpr (VD == 8 && !CG) {
+    if constexpr (VD == 8) {
         if (a.qkv_partial != nullptr && rq == AD_RQ) {
             const size_t staged = (size_t)(2 + AD_RQ) * 16 * VD * sizeof(uint16_t);
             hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP, true>), grid, dim3(256), lds + staged, st, a);
             return;
         }
     }
-    if (rq == 1) hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, 1, SP, IP, false, CG>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP, false, CG>), grid, dim3(256), lds, st, a);
+    if (rq == 1) hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, 1, SP, IP>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP>), grid, dim3(256), lds, st, a);
 }
 template <int VD>
 static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq) {
     const bool single_page = a.tokens_per_split <= a.page_size && a.page_size % a.tokens_per_split == 0;
     // every 64-token stage of a window inside one page: windows are multiples of 64 tokens, pages a power of two >= 64
-    static const bool stage_pages_off = getenv("TL_ATTN_STAGE_PAGES") && atoi(getenv("TL_ATTN_STAGE_PAGES")) == 0;
-    const bool stage_page = !single_page && !stage_pages_off && a.page_shift >= 6 && a.tokens_per_split % 64 == 0;
-    // one sequence on consecutive page ids (AttnDecodeArgs::contig_first): page ids by arithmetic, the first K/V rows in the first round trip
-    const bool contig = a.contig_first >= 0 && a.contig_pages > 0 && a.qkv_partial == nullptr && grid.z == 1 && (single_page || stage_page);
-    if (contig && single_page) launch_attn_decode_sp<VD, true, false, true>(a, grid, st, rq);
-    else if (contig) launch_attn_decode_sp<VD, false, true, true>(a, grid, st, rq);
-    else if (single_page) launch_attn_decode_sp<VD, true>(a, grid, st, rq);
+    const bool stage_page = !single_page && a.page_shift >= 6 && a.tokens_per_split % 64 == 0;
+    if (single_page) launch_attn_decode_sp<VD, true>(a, grid, st, rq);
     else if (stage_page) launch_attn_decode_sp<VD, false, true>(a, grid, st, rq);
     else launch_attn_decode_sp<VD, false>(a, grid, st, rq);
 }
@@ -608,8 +578,6 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
         if ((1 << sh) == c.page_size) a.page_shift = sh;
     a.rope_cur = e->rope_cur;
     a.prof = pc ? pc->buf : nullptr;
-    a.contig_first = batch == 1 ? sp.contig_first : -1;
-    a.contig_pages = sp.contig_pages;
     if (qkv_parts && qkv_parts->partial) {
         TL_REQUIRE(attn_takes_qkv_partials(D, sp.rq), "engine: this decode-attention plan does not read qkv slice partials");
         a.qkv_partial = qkv_parts->partial;
@@ -980,12 +948,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->lm_tile_max = (f32x2 *)(A + o_tmax);
     e->ss_x = (float *)(A + o_ssx);
     e->ss_h = (float *)(A + o_ssh);
-    if (const char *q = getenv("TL_QMM3_FUSED_NORM")) e->fuse_norm = atoi(q) != 0;
-    if (const char *q = getenv("TL_GEMV_PRODUCER_SS")) e->gemv_producer_ss = atoi(q) != 0;
-    if (const char *q = getenv("TL_GEMV_WEIGHTED_ROWS")) e->gemv_weighted_rows = atoi(q) != 0;
     if (const char *q = getenv("TL_ATTN_QKV_PARTIALS")) e->attn_qkv_partials = atoi(q) != 0;
-    if (const char *q = getenv("TL_WO_MERGES_ATTN")) e->wo_merges_attn = atoi(q) != 0;
-    if (const char *q = getenv("TL_ATTN_CONTIG")) e->attn_contig = atoi(q) != 0;
     if (const char *q = getenv("TL_LMHEAD_TILE_MAX")) e->lm_tile_max_on = atoi(q) != 0;
     if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
@@ -1624,10 +1587,9 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
             e->stats.pages_free = (int)e->free_pages.size();
             TL_TRY(poke(e, pk));
         }
-        SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
-        mark_contiguous(e, batch, sp);
+        const SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
         if (use_graph && e->warmed) {
-            const auto key = std::make_tuple(batch, sp.key(), sp.key2());
+            const auto key = std::make_pair(batch, sp.key());
             auto it = e->graphs.find(key);
             if (it == e->graphs.end()) {
                 // The split plan (and with it the key) changes every 64 * n_splits tokens of context: a long run would keep one
@@ -1750,8 +1712,7 @@ extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *
         return rc;
     }
     rc = pk.empty() ? TL_OK : poke(e, pk);
-    SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
-    mark_contiguous(e, batch, sp);
+    const SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
     const int n_splits = sp.n_splits;
     if (rc == TL_OK) rc = enqueue_step(e, batch, sp, &pc);
     if (rc != TL_OK) {
@@ -1778,16 +1739,6 @@ extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *
     out->n_splits = n_splits;
     const double us_per_tick = 1e3 / (double)rate_khz;
     prof_t first = ~0ull, last = 0;
-    // TL_PROFILE_DUMP=<file>: the raw (kind, first workgroup start, last wave end) stamps of this step, one line per launch, in
-    // ticks of the constant-rate device wall clock -- to be laid beside a rocprofv3 kernel trace of the same process (lab use)
-    if (const char *dump = getenv("TL_PROFILE_DUMP")) {
-        if (FILE *f = fopen(dump, "a")) {
-            fprintf(f, "step clock_khz %d launches %zu\n", rate_khz, pc.kinds.size());
-            for (size_t i = 0; i < pc.kinds.size(); ++i)
-                fprintf(f, "%d %llu %llu\n", pc.kinds[i], (unsigned long long)pairs[2 * i], (unsigned long long)pairs[2 * i + 1]);
-            fclose(f);
-        }
-    }
     for (size_t i = 0; i < pc.kinds.size(); ++i) {
         const prof_t t0 = pairs[2 * i], t1 = pairs[2 * i + 1];
         const double us = (t1 > t0 ? (double)(t1 - t0) : 0.0) * us_per_tick;
@@ -1991,12 +1942,12 @@ extern "C" size_t tl_decode_attention_fused_workspace_bytes(int batch, int num_h
            (size_t)batch * num_heads * 256 * (head_dim + ATTN_WS_PAD) * sizeof(float);
 }
 
-static int decode_attention_fused_impl(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,
-                                       void *key_pages_dev, void *value_pages_dev, const int32_t *block_table_dev,
-                                       const int32_t *context_lens_dev, void *out_dev, int batch, int num_heads,
-                                       int num_kv_heads, int head_dim, int page_size, int max_pages, float rope_theta,
-                                       float eps, int max_context, void *workspace_dev, size_t workspace_bytes,
-                                       void *stream, tl_attention_info *info, int first_page, int pool_pages) {
+extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,
+                                         void *key_pages_dev, void *value_pages_dev, const int32_t *block_table_dev,
+                                         const int32_t *context_lens_dev, void *out_dev, int batch, int num_heads,
+                                         int num_kv_heads, int head_dim, int page_size, int max_pages, float rope_theta,
+                                         float eps, int max_context, void *workspace_dev, size_t workspace_bytes,
+                                         void *stream, tl_attention_info *info) {
     TL_REQUIRE(qkv_dev && q_norm_dev && k_norm_dev && key_pages_dev && value_pages_dev && block_table_dev && context_lens_dev &&
                    out_dev, "decode_attention_fused: null pointer");
     TL_REQUIRE(batch >= 1 && batch <= 256, "decode_attention_fused: between 1 and 256 sequences");
@@ -2024,12 +1975,7 @@ static int decode_attention_fused_impl(const void *qkv_dev, const void *q_norm_d
     read_attention_knobs(&e);
     hipLaunchKernelGGL(rope_rows_kernel, dim3(batch), dim3(64), 0, e.stream, context_lens_dev, e.rope_cur, head_dim / 2, rope_theta);
     TL_CHECK_LAUNCH("decode_attention_fused rope");
-    SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
-    if (first_page >= 0) {
-        TL_REQUIRE(batch == 1 && pool_pages > first_page, "decode_attention_fused_contiguous: one sequence, first_page inside the pool");
-        sp.contig_first = first_page;
-        sp.contig_pages = pool_pages - first_page;
-    }
+    const SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
     const int rc = engine_attention(&e, (const uint16_t *)qkv_dev, q_norm_dev, k_norm_dev, (uint16_t *)key_pages_dev,
                                     (uint16_t *)value_pages_dev, (uint16_t *)out_dev, batch, sp, nullptr);
     e.rope_cur = nullptr;  // borrowed
@@ -2040,29 +1986,6 @@ static int decode_attention_fused_impl(const void *qkv_dev, const void *q_norm_d
         info->launches = e.last_attn_launches;
     }
     return rc;
-}
-
-extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,
-                                         void *key_pages_dev, void *value_pages_dev, const int32_t *block_table_dev,
-                                         const int32_t *context_lens_dev, void *out_dev, int batch, int num_heads,
-                                         int num_kv_heads, int head_dim, int page_size, int max_pages, float rope_theta,
-                                         float eps, int max_context, void *workspace_dev, size_t workspace_bytes,
-                                         void *stream, tl_attention_info *info) {
-    return decode_attention_fused_impl(qkv_dev, q_norm_dev, k_norm_dev, key_pages_dev, value_pages_dev, block_table_dev, context_lens_dev,
-                                       out_dev, batch, num_heads, num_kv_heads, head_dim, page_size, max_pages, rope_theta, eps, max_context,
-                                       workspace_dev, workspace_bytes, stream, info, -1, 0);
-}
-
-extern "C" int tl_decode_attention_fused_contiguous(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,
-                                                    void *key_pages_dev, void *value_pages_dev, const int32_t *block_table_dev,
-                                                    const int32_t *context_lens_dev, void *out_dev, int num_heads, int num_kv_heads,
-                                                    int head_dim, int page_size, int max_pages, float rope_theta, float eps,
-                                                    int max_context, int first_page, int pool_pages, void *workspace_dev,
-                                                    size_t workspace_bytes, void *stream, tl_attention_info *info) {
-    TL_REQUIRE(first_page >= 0, "decode_attention_fused_contiguous: first_page must be a page id");
-    return decode_attention_fused_impl(qkv_dev, q_norm_dev, k_norm_dev, key_pages_dev, value_pages_dev, block_table_dev, context_lens_dev,
-                                       out_dev, 1, num_heads, num_kv_heads, head_dim, page_size, max_pages, rope_theta, eps, max_context,
-                                       workspace_dev, workspace_bytes, stream, info, first_page, pool_pages);
 }
 
 // ---- host-only: the plans the decode path would pick (no device, no launch): what the CPU tests and a binding's dry run read -------

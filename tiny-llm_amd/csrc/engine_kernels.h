@@ -165,11 +165,6 @@ struct AttnDecodeArgs {
     const float *qkv_partial;
     int qkv_slices;
     long qkv_plane;
-    // attn_decode_fused_kernel<.., CG = true> (round 4): ONE sequence whose pages are consecutive ids contig_first .. contig_first +
-    // contig_pages - 1 (what a fresh pool hands out; checked on the host mirror at every step, part of the captured graph's key).
-    // Page ids are then arithmetic on a kernel argument: the K/V rows of the first stage are requested in the kernel's FIRST
-    // round trip, beside the q / k / v row -- not behind a block-table word that has to come back first.
-    int contig_first, contig_pages;
 };
 
 // Scalar (wave-uniform) 32-bit load through the scalar cache, and the wait that makes its result usable.  The address must
@@ -227,11 +222,8 @@ __device__ __forceinline__ void store_raw(uint16_t *dst, const RawRow<VD> &r) {
 // of bf16 rows: the (2 + RQ) D values a workgroup needs are 4-column chunks shared out over its threads (one global round
 // trip, all slices of a chunk in flight together), summed in slice order, rounded to bf16 and handed to every 16-lane group
 // through LDS -- the qkv projection's slice-reduction launch (a dependent phase of ~3.3 us per layer) is gone.
-// CG = the sequence's page ids are contig_first + logical page (AttnDecodeArgs::contig_first): no block-table loads at all; the context
-// length (masks, append slot) is still read from device memory, but nothing that is LOADED waits for it.
-template <int VD, int U, int RQ, bool SP, bool IP = false, bool QP = false, bool CG = false>
+template <int VD, int U, int RQ, bool SP, bool IP = false, bool QP = false>
 __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecodeArgs p) {
-    static_assert(!CG || ((SP || IP) && !QP), "CG: single-page or stage-page windows of one sequence");
     constexpr int D = 16 * VD;
     constexpr int STRIDE = D + 2;
     extern __shared__ __attribute__((aligned(16))) float psm[];  // [16][RQ][STRIDE] (+ QP: [(2 + RQ)][D] bf16 staged rows)
@@ -259,21 +251,15 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     // Wave-uniform words (context length, first page id, and with SP the window's page id) come through the scalar cache:
     // explicit s_load, because hipcc turns such loads into "vector load + wait + readfirstlane" at the top of the kernel.
     // They are waited for (lgkmcnt) only after the vector loads of this round trip have been issued.
-    int ctx, first_page = 0, pid_s = 0;
+    int ctx, first_page, pid_s = 0;
     sload_i32(p.context_lens + b, ctx);
-    auto cg_page = [&](int tok) { return p.contig_first + min(page_of(tok), p.contig_pages - 1); };  // CG: clamped to the pages the sequence owns
-    if constexpr (!CG) sload_i32(brow, first_page);
-    if constexpr (SP && !CG) sload_i32(brow + min(page_of(t_begin), p.max_pages - 1), pid_s);
+    sload_i32(brow, first_page);
+    if constexpr (SP) sload_i32(brow + min(page_of(t_begin), p.max_pages - 1), pid_s);
     int pid[U], pid_next[U];
     int pg_nxt = 0, pg_new = 0;  // IP: page id of the next stage / of the one after it (scalar)
-    if constexpr (IP && !CG) {
+    if constexpr (IP) {
         sload_i32(brow + min(page_of(t_begin), p.max_pages - 1), pid_s);
         sload_i32(brow + min(page_of(t_begin + 16 * U), p.max_pages - 1), pg_nxt);
-    }
-    if constexpr (CG) {
-        first_page = p.contig_first;
-        pid_s = cg_page(t_begin);
-        if constexpr (IP) pg_nxt = cg_page(t_begin + 16 * U);
     }
     if constexpr (!SP && !IP) {
 #pragma unroll
@@ -323,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     float cs[VD], sn[VD];
     rope_from_table<VD>(p.rope_cur + (long)b * (D / 2), t, cs, sn);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!CG) sload_wait(ctx, first_page, pid_s, pg_nxt);
+    sload_wait(ctx, first_page, pid_s, pg_nxt);
     const bool live = first_page >= 0;  // a sequence always owns its first page; idle slots have an all -1 row and produce zeros
     if constexpr (SP) {
 #pragma unroll
@@ -331,33 +317,12 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     }
 
     // ---- round trip 2: addresses that depend on the page ids (K/V rows) or on the context length (append slot) ------
-    // (CG: there is no second round trip -- the first stage's K/V rows go out here, before anything has come back; the context
-    // length is waited for right behind them and only feeds the masks)
-    RawRow<VD> kr[U], vr[U], kr_next[U], vr_next[U];
-    bool ok[U];
-    const int lane_row = g * D + t * VD;  // IP: element offset of this lane's 16 bytes inside a stage's first 16 rows
-    if constexpr (CG) {
-        const int lp0 = page_of(t_begin);  // uniform: the window (SP) or its first stage (IP) lies in one page
-        const long rowbase = (((long)pid_s * Hkv + kvh) * p.page_size + (t_begin - lp0 * p.page_size)) * D;
-        const uint16_t *kb = p.key_pages + rowbase, *vb = p.value_pages + rowbase;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            load_raw<VD>(kb + lane_row + u * 16 * D, kr[u]);
-            load_raw<VD>(vb + lane_row + u * 16 * D, vr[u]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        sload_wait(ctx);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int tok = t_begin + u * 16 + g;
-            ok[u] = tok < ctx && tok < t_begin + C;
-        }
-    }
     const int wp = page_of(ctx);
     const int wslot = ctx - wp * p.page_size;
     int wpage;
-    if constexpr (CG) wpage = p.contig_first + min(wp, p.contig_pages - 1);
-    else sload_i32(brow + min(wp, p.max_pages - 1), wpage);  // waited for at the very end of the kernel
+    sload_i32(brow + min(wp, p.max_pages - 1), wpage);  // waited for at the very end of the kernel
+    RawRow<VD> kr[U], vr[U], kr_next[U], vr_next[U];
+    bool ok[U];
     auto issue_kv = [&](int base, const int (&ids)[U], RawRow<VD> (&kk)[U], RawRow<VD> (&vv)[U], bool (&valid)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -370,6 +335,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             load_raw<VD>(p.value_pages + off, vv[u]);
         }
     };
+    const int lane_row = g * D + t * VD;  // IP: element offset of this lane's 16 bytes inside a stage's first 16 rows
     auto issue_kv_stage = [&](int base, int pg, RawRow<VD> (&kk)[U], RawRow<VD> (&vv)[U], bool (&valid)[U]) {
         const int lp = page_of(base);  // uniform
         const bool page_ok = lp < p.max_pages && pg >= 0;
@@ -383,8 +349,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
             load_raw<VD>(vb + lane_row + u * 16 * D, vv[u]);
         }
     };
-    if constexpr (CG) {
-    } else if constexpr (IP) issue_kv_stage(t_begin, pid_s, kr, vr, ok);
+    if constexpr (IP) issue_kv_stage(t_begin, pid_s, kr, vr, ok);
     else issue_kv(t_begin, pid, kr, vr, ok);
 
     if constexpr (QP) {
@@ -469,8 +434,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         if constexpr (IP) {
             if (more) {  // uniform
                 issue_kv_stage(t_begin + (it + 1) * 16 * U, pg_nxt, kn, vn, okn);
-                if constexpr (CG) pg_new = cg_page(t_begin + (it + 2) * 16 * U);
-                else sload_i32(brow + min(page_of(t_begin + (it + 2) * 16 * U), p.max_pages - 1), pg_new);  // waited for at the end of this stage
+                sload_i32(brow + min(page_of(t_begin + (it + 2) * 16 * U), p.max_pages - 1), pg_new);  // waited for at the end of this stage
             }
         } else if (more) {  // uniform
             issue_kv(t_begin + (it + 1) * 16 * U, pid_next, kn, vn, okn);
@@ -536,7 +500,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
         }
         if (more) {
             if constexpr (IP) {
-                if constexpr (!CG) sload_wait(pg_new);
+                sload_wait(pg_new);
                 pg_nxt = pg_new;
             }
         }
@@ -607,8 +571,8 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     }
     // append the new token's K (normed + roped) and V to the slot's page: last, so the page-id lookup that depends on
     // the context length never sits on the critical path
-    if constexpr (!CG) sload_wait(wpage);
-    if (live && wp < (CG ? p.contig_pages : p.max_pages) && wpage >= 0 && split == 0 && chunk == 0 && g == 0) {
+    sload_wait(wpage);
+    if (live && wp < p.max_pages && wpage >= 0 && split == 0 && chunk == 0 && g == 0) {
         const long off = (((long)wpage * Hkv + kvh) * p.page_size + wslot) * D + t * VD;
         store_row<VD>(p.key_pages + off, k_new);
         store_raw<VD>(p.value_pages + off, vraw_new);

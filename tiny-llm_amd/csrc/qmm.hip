@@ -305,21 +305,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const uint16_t *
     }
 }
 
-// TL_QMM_XCD_REMAP=0: tiles in launch order (lab A/B of the XCD-aware order, qmm_mfma_kernel)
-static int qmm_xcd_remap() {
-    static const int v = getenv("TL_QMM_XCD_REMAP") ? atoi(getenv("TL_QMM_XCD_REMAP")) : 1;
-    return v;
-}
+// XCD-aware tile order of qmm_mfma_kernel (round 3 A/B: 731 -> 752 TFLOP/s on a 2,048-row layer; the launch-order switch is gone)
+static int qmm_xcd_remap() { return 1; }
 static int mfma_mt(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
 // 8 waves (a 128 x 256 tile) for the widest projection at full chunks only -- r02 lab at 2,048 rows: gate|up 710 -> 781
 // TFLOP/s, but qkv 767 -> 660 and the split-K projections (o, down) 531 / 596 -> 470 / 517, and everything slower at 512 rows
 // (profiles/r02_labs/gemm_lab_r02_waves_per_workgroup.log): halving the activation re-reads is not the whole story, the
-// 8-wave barrier per 64-wide reduction step costs about as much.  TL_QMM_NW = 4 / 8 pins it (lab).
-static int mfma_nw(int M, int K) {
-    static const int forced = getenv("TL_QMM_NW") ? atoi(getenv("TL_QMM_NW")) : 0;
-    if (forced == 4 || forced == 8) return (forced == 8 && M > 64) ? 8 : 4;
-    return (M >= 1024 && K >= 8192) ? 8 : 4;
-}
+// 8-wave barrier per 64-wide reduction step costs about as much.
+static int mfma_nw(int M, int K) { return (M >= 1024 && K >= 8192) ? 8 : 4; }
 
 // Split-K policy.  Reference (quantized_matmul.cpp:138-151) targets 320
 // threadgroups of 32x32 on an M4 Pro; here a tile is (32*MT)x128 and the
@@ -330,7 +323,7 @@ static int split_k_policy(int M, int N, int K) {
     // three workgroups fit a CU (136 registers per lane): split until about 768 are in flight.  320 tiles (a 2048-row chunk
     // against the 2560-row o / down projections) measured 471 / 482 TFLOP/s unsplit against 750 for the wide projections.
     // (two of the 8-wave workgroups fit: 512)
-    const int target = getenv("TL_QMM_SPLIT_TARGET") ? atoi(getenv("TL_QMM_SPLIT_TARGET")) : (mfma_nw(M, K) == 8 ? 512 : 768);
+    const int target = mfma_nw(M, K) == 8 ? 512 : 768;
     constexpr int max_split = 16;
     // at least two quantisation groups per slice: a one-group slice is a K loop of 4 MFMA steps behind a full prologue and a
     // reduction pass (the reference's own fallback case -- 128 x 2560 over N = 256 -- must stay unsplit and bit-identical,

@@ -507,8 +507,8 @@ struct Qmm3Plan {
     bool ok;
 };
 int qmm3_num_cus();       // qmm3.hip: CUs of the current device (256 when no device is visible)
-int qmm3_default_mode();  // qmm3.hip: TL_QMM3_PERSISTENT = 0 / 1 pins the grid, unset (-1) = by shape (below)
-int qmm3_forced_lm();     // qmm3.hip: TL_QMM3P_LM (lab: pin the persistent grid's slice width; 0 = planner's choice)
+int qmm3_default_mode();  // qmm3.hip: -1 = by shape (below); tl_decode_linear's kernel 3 / 4 pin a grid through `mode`
+int qmm3_forced_lm();     // qmm3.hip: 0 = the planner's slice width
 
 // mode 0: the one-shot grid, LM the largest of {10, 8, 5, 4} whose slice fits the LDS and that still yields about one
 // workgroup per CU.  mode 1: the persistent grid.  mode -1: by shape, from the r02 lab (profiles/r02_labs/qmm3_lab_r02*.log,

@@ -109,21 +109,8 @@ int qmm3_num_cus() {
     }();
     return n;
 }
-int qmm3_default_mode() {
-    static const int m = [] {
-        const char *v = getenv("TL_QMM3_PERSISTENT");
-        return v ? (atoi(v) != 0 ? 1 : 0) : -1;
-    }();
-    return m;
-}
-
-int qmm3_forced_lm() {
-    static const int m = [] {
-        const char *v = getenv("TL_QMM3P_LM");
-        return v ? atoi(v) : 0;
-    }();
-    return m;
-}
+int qmm3_default_mode() { return -1; }  // the grid is chosen by shape (qmm3_prefers_persistent); callers that need one pass `mode`
+int qmm3_forced_lm() { return 0; }
 
 int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
     const Qmm3Plan pl = qmm3_plan(args.M, args.N, args.K, mode);

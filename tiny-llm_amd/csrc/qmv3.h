@@ -55,7 +55,7 @@ struct Qmv3Args {
 #ifdef QMV3_TRACE
     unsigned long long *trace;  // lab only
 #endif
-    // PRO_ATTN_MERGE (the wo projection of a single decode row, TL_WO_MERGES_ATTN=1): `a` is not read; the activation row is
+    // PRO_ATTN_MERGE (the wo projection of a single decode row with 2 / 4 / 8 attention windows): `a` is not read; the activation row is
     // the merge of the decode-attention kernel's split partials merge_ws [head][NS][128 + 4] (value sums, running max, running
     // sum; head dimension 128, N = heads * 128), formed while the row is staged -- attn_merge_kernel's arithmetic, term for
     // term, so the staged bf16 row has the bits that kernel would have written; its launch is dropped.

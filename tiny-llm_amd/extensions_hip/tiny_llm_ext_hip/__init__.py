@@ -134,8 +134,6 @@ _SIGNATURES.update({
     "tl_decode_attention_fused_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "tl_decode_attention_fused": (_c_int, [_c_void_p] * 8 + [_c_int] * 6 + [_c_float, _c_float, _c_int, _c_void_p, _c_size_t,
                                                              _c_void_p, _P(TlAttentionInfo)]),
-    "tl_decode_attention_fused_contiguous": (_c_int, [_c_void_p] * 8 + [_c_int] * 5 + [_c_float, _c_float, _c_int, _c_int, _c_int, _c_void_p,
-                                                      _c_size_t, _c_void_p, _P(TlAttentionInfo)]),
     "tl_engine_profile_step": (_c_int, [_c_void_p, _c_int, _P(TlStepProfile)]),
     "tl_engine_create": (_c_int, [_P(TlEngineConfig), _P(TlLayerWeights), _P(TlW4), _c_void_p, _P(TlW4), _c_void_p,
                                   _P(_c_void_p)]),
@@ -675,7 +673,7 @@ def decode_linear(w: TiledW4, a: torch.Tensor | None, *, prologue: int = PRO_NON
 def decode_attention_fused(qkv: torch.Tensor, q_norm: torch.Tensor, k_norm: torch.Tensor, key_pages: torch.Tensor,
                            value_pages: torch.Tensor, block_table: torch.Tensor, context_lens: torch.Tensor, *,
                            num_heads: int, num_kv_heads: int, rope_theta: float, eps: float,
-                           max_context: int, contiguous_first_page: int | None = None) -> tuple[torch.Tensor, dict]:
+                           max_context: int) -> tuple[torch.Tensor, dict]:
     """The attention launch of one decode layer (tl_decode_attention_fused): q/k-norm + RoPE + in-place KV append +
     paged GQA attention over ``context_lens + 1`` tokens.  qkv [B, (Hq + 2 Hkv) D]; pages [P, Hkv, page, D] (modified)."""
     _require_gpu("decode_attention_fused", qkv, q_norm, k_norm, key_pages, value_pages, block_table, context_lens)
@@ -696,15 +694,6 @@ def decode_attention_fused(qkv: torch.Tensor, q_norm: torch.Tensor, k_norm: torc
     ws_bytes = _lib.tl_decode_attention_fused_workspace_bytes(B, num_heads, D)
     ws = _workspace(ws_bytes, qkv.device)
     info = TlAttentionInfo()
-    if contiguous_first_page is not None:  # one sequence on consecutive page ids: page ids computed, not loaded (the engine's own route)
-        if B != 1:
-            raise RuntimeError("decode_attention_fused: the contiguous route takes one sequence")
-        _check(_lib.tl_decode_attention_fused_contiguous(_ptr(qkv), _ptr(q_norm), _ptr(k_norm), _ptr(key_pages), _ptr(value_pages),
-                                                         _ptr(block_table.contiguous()), _ptr(context_lens), _ptr(out), num_heads,
-                                                         num_kv_heads, D, page, int(block_table.shape[1]), float(rope_theta), float(eps),
-                                                         int(max_context), int(contiguous_first_page), P, _ptr(ws), ws.numel(), _stream(),
-                                                         ctypes.byref(info)))
-        return out, {name: getattr(info, name) for name, _ in info._fields_}
     _check(_lib.tl_decode_attention_fused(_ptr(qkv), _ptr(q_norm), _ptr(k_norm), _ptr(key_pages), _ptr(value_pages),
                                           _ptr(block_table.contiguous()), _ptr(context_lens), _ptr(out), B, num_heads,
                                           num_kv_heads, D, page, int(block_table.shape[1]), float(rope_theta), float(eps),

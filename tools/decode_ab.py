@@ -18,8 +18,8 @@ ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT, ROOT / "tiny-llm_amd", ROOT / "tiny-llm_amd" / "extensions_hip"):
     sys.path.insert(0, str(p))
 
-KNOBS = ("TL_ATTN_WG_CAP", "TL_GEMV_PRODUCER_SS", "TL_GEMV_WEIGHTED_ROWS", "TL_ATTN_WIDE_MAX", "TL_ATTN_NW", "TL_ATTN_VECTOR_IDS", "TL_ATTN_RQ", "TL_ATTN_RQ1_CTX", "TL_ATTN_MAX_SPLITS",
-         "TL_ATTN_MIN_TOKENS", "TL_QMM3_MIN_M", "TL_ATTN_RQ1_BATCH", "TL_NO_QMM3", "TL_QMM3_FUSED_NORM", "TL_ATTN_QKV_PARTIALS", "TL_WO_MERGES_ATTN", "TL_QMM3_PERSISTENT")
+KNOBS = ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS", "TL_QMM3_MIN_M", "TL_NO_QMM3", "TL_GEMM_FUSED_EPILOGUE", "TL_ATTN_QKV_PARTIALS",
+         "TL_LMHEAD_TILE_MAX")  # every knob the library still reads
 
 
 def main():
