@@ -47,6 +47,45 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); measur
 HBM_COPY_GBPS = 6290.0
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg: str) -> None:
+    """Timestamped progress on stderr (stdout carries exactly one JSON line): where a slow host spends the command's time."""
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+class time_box:
+    """`with time_box(seconds):` raises TimeoutError inside the block once the wall clock is spent (SIGALRM; main thread only --
+    elsewhere it does nothing).  Every CPU leg of this file runs in one: a reported baseline must never take the measurement
+    with it (round 4: a leg that overran on one GPU box cost the whole line twice)."""
+
+    def __init__(self, seconds: float):
+        self.seconds = max(1, int(seconds))
+        self.armed = False
+
+    def _fire(self, signum, frame):
+        raise TimeoutError(f"time box of {self.seconds} s exceeded")
+
+    def __enter__(self):
+        import signal
+        import threading
+
+        if threading.current_thread() is threading.main_thread() and hasattr(signal, "SIGALRM"):
+            self.prev = signal.signal(signal.SIGALRM, self._fire)
+            signal.alarm(self.seconds)
+            self.armed = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.armed:
+            import signal
+
+            signal.alarm(0)
+            signal.signal(signal.SIGALRM, self.prev)
+        return False
+
+
 def build_prompt(rng: random.Random, length: int, vocab: int) -> list[int]:
     """Synthetic prompt ids in [256, vocab) like the reference harness (benches/bench.py:201-225)."""
     return [rng.randrange(256, vocab) for _ in range(length)]
@@ -153,7 +192,7 @@ def rocprof_live(args) -> Path | None:
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     try:
-        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
     except (OSError, subprocess.SubprocessError):
         return None
     found = sorted(glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True))
@@ -324,17 +363,17 @@ def torch_week2_leg(mlx_model, cfg: dict, prompt: list[int], fed: list[int], gpu
             "max_abs_logit_vs_gpu_first_decode_step": None if diff is None else round(diff, 4)}
 
 
-def walk_prompt_bounded(model, prompt: list[int], budget_s: float, floor: int = 8):
-    """Feed `prompt` token by token until it ends or `budget_s` of wall clock are spent (never fewer than `floor` tokens);
-    returns (tokens fed, last greedy id, last logits)."""
+def walk_prompt_bounded(models, prompt: list[int], budget_s: float, floor: int = 8):
+    """Feed `prompt` token by token to every model of `models` IN LOCK STEP until it ends or `budget_s` of wall clock are spent
+    (never fewer than `floor` tokens): all of them end on the same prefix.  Returns (tokens fed, [(last id, last logits) per model])."""
     t0 = time.perf_counter()
-    fed, tid, logits = 0, 0, None
+    fed, last = 0, [(0, None)] * len(models)
     for t in prompt:
-        tid, logits = model.step(t)
+        last = [m.step(t) for m in models]
         fed += 1
         if fed >= floor and time.perf_counter() - t0 > budget_s:
             break
-    return fed, tid, logits
+    return fed, last
 
 
 def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_steps: int, prefill_chunk: int = 8) -> dict:
@@ -353,14 +392,20 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
     # OpenMP fork/join per matvec (7 x 36 per token) stops scaling long before a 2-socket host runs out of cores
     cores = min(os.cpu_count() or 1, 32)
     model = c_oracle.COracleQwen3(cfg, weights, max_ctx=sample_prompt + sample_steps + 1, threads=cores)
+    # ground truth beside it: oracle/qwen3_truth.c, float64 with no intermediate rounding.  The bf16 port and the HIP engine both
+    # round at every reference op boundary; their distances from THIS are what can be compared.
+    truth_steps = min(sample_steps, 8)
+    truth = c_oracle.CTruthQwen3(cfg, weights, max_ctx=sample_prompt + truth_steps + 1, threads=cores)
     prompt = build_prompt(random.Random(1234), sample_prompt, cfg["vocab_size"])
-    tid, logits = 0, None
-    # token-by-token prefill: untimed warm-up of the CPU path.  BOUNDED: the C checkers walk the prompt one token at a time (~0.3 s
-    # each on 32 threads), and this line must come out within minutes on any host -- after PROMPT_BUDGET_S the prompt is cut where it
-    # stands (never below 8 tokens; a prefix of the same seeded prompt), and the line says which length was checked.
-    fed_prompt, tid, logits = walk_prompt_bounded(model, prompt, PROMPT_BUDGET_S)
+    # Token-by-token prefill of both C checkers in lock step: untimed warm-up of the CPU path.  BOUNDED: they walk the prompt one
+    # token at a time (~0.3-0.5 s each on 32 threads, each), and this line must come out within minutes on any host -- after
+    # PROMPT_BUDGET_S the prompt is cut where it stands (never below 8 tokens; a prefix of the same seeded prompt), and the line
+    # says which length was checked.
+    progress(f"cpu_baseline: C port + C truth walk the {sample_prompt}-token prompt on {cores} threads (budget {PROMPT_BUDGET_S:.0f} s)")
+    fed_prompt, ((tid, logits), (_, tl)) = walk_prompt_bounded([model, truth], prompt, PROMPT_BUDGET_S)
     prompt = prompt[:fed_prompt]
     sample_prompt = fed_prompt
+    progress(f"cpu_baseline: {fed_prompt} prompt tokens walked; timing {sample_steps} decode steps of the port")
     cpu_ids, cpu_logits = [tid], [logits]
     t0 = time.perf_counter()
     for _ in range(sample_steps):
@@ -369,18 +414,12 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
         cpu_logits.append(logits)
     dt = time.perf_counter() - t0
     model.close()
-    # ground truth (untimed): the same tokens through oracle/qwen3_truth.c, float64 with no intermediate rounding.  The bf16
-    # port and the HIP engine both round at every reference op boundary; their distances from THIS are what can be compared.
-    truth_steps = min(sample_steps, 8)
-    truth = c_oracle.CTruthQwen3(cfg, weights, max_ctx=sample_prompt + truth_steps + 1, threads=cores)
-    truth_logits = []
-    for t in prompt:
-        _, tl = truth.step(t)
-    truth_logits.append(tl)
+    truth_logits = [tl]
     for s in range(truth_steps):
         _, tl = truth.step(cpu_ids[s])
         truth_logits.append(tl)
     truth.close()
+    progress("cpu_baseline: C legs done; engine checked against them")
 
     # checker: the engine on the same prompt, teacher-forced on the CPU ids, must give the same logits (log-softmax
     # within the band one bf16 ulp of a logit can move it) and the same greedy id wherever the top-2 margin is clear
@@ -425,7 +464,7 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
                                        f"2 x the engine's measured error of it"}
 
 
-PROMPT_BUDGET_S = 40.0   # wall-clock bound of the C port's walk over the prompt (cpu_baseline_leg)
+PROMPT_BUDGET_S = 75.0   # wall-clock bound of the C port's + C truth's walk over the prompt (cpu_baseline_leg)
 TORCH_BUDGET_S = 45.0    # ... and of the torch-CPU restatement's prefill (torch_week2_leg)
 PEAKED_RECIPE = dict(embed_sigma=0.25, residual_gain=0.2, head_permutation=(48271, 11))
 
@@ -584,6 +623,7 @@ def main() -> None:
     engine.decode(max(args.warmup, 2), batch=1, use_graph=use_graph)  # >= 2: eager warm step + graph capture
     sync()
     bytes_first = engine.step_bytes(1)
+    progress("timed region")
     elapsed, local_elapsed = timed_steps(lambda k: engine.decode(k, batch=1, use_graph=use_graph), sync, args.steps, dist, device)
     bytes_last = engine.step_bytes(1)
     per_rank = None
@@ -649,6 +689,7 @@ def main() -> None:
         })
         if kv_bytes > g_bytes:  # long contexts: the K/V stream, not the weights, is the dominant traffic
             roofline["dominant"] = "decode attention (K/V pages): see attention_kv; achieved/frac stay the GEMV stream's"
+        progress("roofline: rocprofv3 child")
         # rocprofv3-derived rate: measured now (a child of this process under rocprofv3), else the newest committed summary
         stats_csv, live = None, False
         if args.rocprof_stats == "none" or args.rocprof == "off":
@@ -703,7 +744,11 @@ def main() -> None:
         # at the bench's own prompt length (bounded at 128 tokens: the C checkers walk the prompt token by token), through the
         # bench's own prefill chunking, so that the checked decode steps run the attention plan of the timed ones
         sample_prompt = min(args.prompt_len, 128)
-        cpu = cpu_baseline_leg(mlx_model, cfg, engine, sample_prompt=sample_prompt, sample_steps=16, prefill_chunk=args.prefill_step)
+        try:
+            with time_box(200):
+                cpu = cpu_baseline_leg(mlx_model, cfg, engine, sample_prompt=sample_prompt, sample_steps=16, prefill_chunk=args.prefill_step)
+        except Exception as exc:
+            cpu = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"}
         cpu["n_splits_timed"] = prof.get("n_splits") if prof else None
         c_prompt, c_fed, c_first = cpu.pop("_prompt", None), cpu.pop("_fed", None), cpu.pop("_gpu_first_decode_logits", None)
         if c_prompt is None:  # the C checkers are not built: same sample, greedy on its own ids
@@ -713,13 +758,21 @@ def main() -> None:
             cpu["torch_week2_kv_cache"] = {"value": None, "why": "skipped: the command had already run for 5 minutes"}
         else:
             try:
-                cpu["torch_week2_kv_cache"] = torch_week2_leg(mlx_model, cfg, c_prompt, c_fed[:8] if c_fed else [0] * 8, c_first)
+                progress("torch_week2_kv_cache leg")
+                with time_box(120):
+                    cpu["torch_week2_kv_cache"] = torch_week2_leg(mlx_model, cfg, c_prompt, c_fed[:8] if c_fed else [0] * 8, c_first)
             except Exception as exc:  # a reported baseline must not take the measurement with it (e.g. a host without 9 GB to spare)
                 cpu["torch_week2_kv_cache"] = {"value": None, "why": f"{type(exc).__name__}: {exc}"}
         if time.perf_counter() - t_start > 420:
             cpu["peaked_checkpoint"] = {"checked": False, "why": "skipped: the command had already run for 7 minutes"}
         else:
-            cpu["peaked_checkpoint"] = peaked_checkpoint_leg(cfg, device, args.seed)
+            try:
+                progress("peaked_checkpoint leg")
+                with time_box(90):
+                    cpu["peaked_checkpoint"] = peaked_checkpoint_leg(cfg, device, args.seed)
+            except Exception as exc:
+                cpu["peaked_checkpoint"] = {"checked": False, "why": f"{type(exc).__name__}: {exc}"}
+        progress("CPU legs done")
         cpu["seconds_since_start"] = round(time.perf_counter() - t_start, 1)
 
     out = {

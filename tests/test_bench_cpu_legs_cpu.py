@@ -30,7 +30,7 @@ def test_torch_leg_reports_a_rate_and_respects_its_budget(monkeypatch):
     assert "8-token prompt (cut from 40" in out["sample"] and out["max_abs_logit_vs_gpu_first_decode_step"] is None
 
 
-def test_c_port_prompt_walk_is_bounded():
+def test_prompt_walk_is_bounded_and_in_lock_step():
     import bench
 
     class Slow:
@@ -41,9 +41,23 @@ def test_c_port_prompt_walk_is_bounded():
             self.fed.append(t)
             return t + 1, np.zeros(4)
 
-    m = Slow()
-    fed, tid, _ = bench.walk_prompt_bounded(m, list(range(100)), budget_s=0.0)
-    assert fed == 8 and m.fed == list(range(8)) and tid == 8, "an exhausted budget stops at the 8-token floor"
-    m = Slow()
-    fed, tid, _ = bench.walk_prompt_bounded(m, list(range(20)), budget_s=60.0)
-    assert fed == 20 and tid == 20
+    a, b = Slow(), Slow()
+    fed, last = bench.walk_prompt_bounded([a, b], list(range(100)), budget_s=0.0)
+    assert fed == 8 and a.fed == b.fed == list(range(8)) and last[0][0] == last[1][0] == 8, "an exhausted budget stops both at the 8-token floor"
+    a = Slow()
+    fed, last = bench.walk_prompt_bounded([a], list(range(20)), budget_s=60.0)
+    assert fed == 20 and last[0][0] == 20
+
+
+def test_time_box_interrupts_a_slow_leg():
+    import time
+
+    import bench
+
+    with pytest.raises(TimeoutError):
+        with bench.time_box(1):
+            for _ in range(100):
+                time.sleep(0.1)
+    with bench.time_box(5):
+        pass  # leaving the box disarms it
+    time.sleep(0.01)

@@ -801,8 +801,6 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
     TL_REQUIRE(dtype == TL_F32 || dtype == TL_BF16,
                "paged_attention: q, key_pages, and value_pages must have the same float32 or bfloat16 dtype");
     TL_REQUIRE(q && key_pages && value_pages && block_table && context_lens && out, "paged_attention: null pointer");
-    // the FlashAttention tiles take the maximum of the RAW scores and scale afterwards: only valid for a positive scale
-    TL_REQUIRE(scale > 0.f, "paged_attention: scale must be positive");
     TL_REQUIRE(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
                "paged_attention: num_heads must be divisible by num_kv_heads");
     TL_REQUIRE(N % num_heads == 0, "paged_attention: q.shape[0] must be divisible by num_heads");
@@ -816,6 +814,9 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
 
     if (L > 8 && dtype == TL_BF16) {
         if (D != 128) return fail(TL_ERR_UNSUPPORTED, "paged_attention: bfloat16 prefill requires head dimension 128");
+        // the FlashAttention tiles take the maximum of the RAW scores and scale afterwards: only valid for a positive scale.  The
+        // decode and float32 kernels scale before they compare and take any float, like the reference's paged_attention.
+        TL_REQUIRE(scale > 0.f, "paged_attention: the bfloat16 FlashAttention path needs a positive scale");
         // (the kernel is templated on QR, 32-row query blocks per wave; two of them -- every K / V fragment read feeds two MFMAs, half
         // the K/V staging per flop -- were measured in round 3 and lose at one wave per SIMD: 392 -> 573 us at 2,048 x 8,192,
         // profiles/r03_labs/prefill_fa_two_row_blocks.log; only QR = 1 is instantiated)

@@ -1104,6 +1104,14 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t *__restri
         if (tid == 0) {
             for (int w = 1; w < 4; ++w)
                 if (red[w] > best || (red[w] == best && red_i[w] < best_i)) best = red[w], best_i = red_i[w];
+            if (best_i < 0 || best_i >= E) {  // NaN / Inf router logits leave no candidate: take the lowest expert still in the pool
+                best_i = 0;               // (a finite, in-range id: the grouped GEMVs index expert weights with it inside a captured graph)
+                for (int i = 0; i < E; ++i)
+                    if (probs[i] != 0xffffu) {
+                        best_i = i;
+                        break;
+                    }
+            }
             ids[(long)row * top_k + j] = best_i;
             picked[j] = probs[best_i];
             probs[best_i] = 0xffffu;  // a NaN pattern no probability takes: out of the pool

@@ -100,6 +100,8 @@ class KvPrefixGenerator:
         """The prefix positions used by the latest continuation."""
         return self._reuse
 
+    DECODE_BLOCK = 16  # decode steps per device round trip in __call__ (ids are read back and checked for EOS after each block)
+
     def save_checkpoint(self, messages: list) -> ModelCheckpoint:
         """Render and prefill one checkpoint prefix exactly once (into the frozen slot)."""
         if self._prefix.checkpoint is not None:
@@ -108,9 +110,13 @@ class KvPrefixGenerator:
         if not token_ids:
             raise AgentError("checkpoint prompt must contain at least one token")
         self._engine.begin(self.PREFIX_SLOT)
-        self._engine.prefill(self.PREFIX_SLOT, token_ids, chunk=self._prefill_step, want_logits=False)
-        if self._engine.context_len(self.PREFIX_SLOT) != len(token_ids):
-            raise AgentError("model did not populate every dense cache layer")
+        try:
+            self._engine.prefill(self.PREFIX_SLOT, token_ids, chunk=self._prefill_step, want_logits=False)
+            if self._engine.context_len(self.PREFIX_SLOT) != len(token_ids):
+                raise AgentError("model did not populate every dense cache layer")
+        except BaseException:  # a failed prefill must not leave the frozen slot live: a retry would find "slot is live"
+            self._engine.release(self.PREFIX_SLOT)
+            raise
         offsets = (len(token_ids),) * self._layer_count  # one sequence across all layers: every layer holds the whole prefix
         checkpoint = ModelCheckpoint(len(messages), self._response_index, token_ids, offsets)
         self._prefix.tokens = token_ids
@@ -150,19 +156,26 @@ class KvPrefixGenerator:
             raise AgentError("steered prompt must add tokens after the saved prefix")
         eng = self._engine
         eng.fork(self.PREFIX_SLOT, self.WORK_SLOT)  # shared full pages, own tail page: the prefix is NOT prefilled again
-        try:
-            eng.prefill(self.WORK_SLOT, suffix, chunk=self._prefill_step)  # its last row yields the first generated token
-            if self._max_tokens > 1:
-                eng.decode(self._max_tokens - 1, batch=1)
-            produced = eng.read_tokens(self.WORK_SLOT, self._max_tokens)
-        finally:
-            eng.release(self.WORK_SLOT)
         eos = self._tokenizer.eos_token_id
         output: list[int] = []
-        for token in produced:  # greedy ids; the reference stops BEFORE emitting the end-of-sequence id
-            if token == eos:
-                break
-            output.append(int(token))
+        try:
+            eng.prefill(self.WORK_SLOT, suffix, chunk=self._prefill_step)  # its last row yields the first generated token
+            # Decode in blocks and stop at the end-of-sequence id, as the reference's loop does (agent/branching.py:139-150): a
+            # continuation that ends early neither pays for max_tokens steps nor runs into the page / context limit behind it.
+            produced = eng.read_tokens(self.WORK_SLOT, 1)
+            done = produced[0] == eos
+            if not done:
+                output.append(int(produced[0]))
+            while not done and len(output) < self._max_tokens:
+                block = min(self.DECODE_BLOCK, self._max_tokens - len(output))
+                eng.decode(block, batch=1)
+                for token in eng.read_tokens(self.WORK_SLOT, block):  # greedy ids; the reference stops BEFORE emitting the end-of-sequence id
+                    if token == eos:
+                        done = True
+                        break
+                    output.append(int(token))
+        finally:
+            eng.release(self.WORK_SLOT)
         self._response_index += 1
         self._reuse = PrefixReuse(prefix_size, cp.layer_offsets, prefix_size)
         return self._tokenizer.decode(output)
