@@ -1,5 +1,6 @@
 // Launchers of the skinny batched-decode matmul (qmm3.h) and its slice-reduction / epilogue kernel.
 #include "qmm3.h"
+#include "qmm5.h"
 
 namespace tl {
 
@@ -144,6 +145,34 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
 #undef QM3_LM
 #undef QM3_CASE
     return -2;
+}
+
+// The full-row persistent kernel for 5 .. 16 rows (qmm5.h).
+template <int G>
+static int launch_qmm5_g(const Qmm5Args &args, int pro, int epi, const Qmm5Plan &pl, hipStream_t st) {
+    const dim3 grid(pl.grid), block(QM3_WAVES * 64);
+#define QM5_CASE(PROv, EPIv)                                                                                          \
+    if (pro == PROv && epi == EPIv) {                                                                                 \
+        auto kern = qmm5_kernel<G, PROv, EPIv>;                                                                       \
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);       \
+        hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                                      \
+        return hipGetLastError() == hipSuccess ? 0 : -1;                                                              \
+    }
+    QM5_CASE(PRO_RMSNORM, EPI_SWIGLU) QM5_CASE(PRO_NONE, EPI_SWIGLU) QM5_CASE(PRO_RMSNORM, EPI_STORE) QM5_CASE(PRO_NONE, EPI_STORE)
+    QM5_CASE(PRO_NONE, EPI_RESIDUAL)
+#undef QM5_CASE
+    return -2;
+}
+int launch_qmm5_bf16(const Qmm5Args &args, int pro, int epi, hipStream_t st) {
+    Qmm5Plan pl = qmm5_plan(args.M, args.N, args.K);
+    if (!pl.ok) return -1;
+    if (pro == PRO_RMSNORM && (!args.ss || !args.norm_w || !qmm3_takes_ss(args.ss_n))) return -1;
+    if (epi == EPI_RESIDUAL && !args.residual) return -1;
+    Qmm5Args a = args;
+    a.tiles_per_wg = pl.tiles_per_wg;
+    if (pl.G == 8) return launch_qmm5_g<8>(a, pro, epi, pl, st);
+    if (pl.G == 16) return launch_qmm5_g<16>(a, pro, epi, pl, st);
+    return launch_qmm5_g<20>(a, pro, epi, pl, st);
 }
 
 }  // namespace tl
