@@ -240,7 +240,7 @@ def test_skinny_matmul_at_qwen3_4b_shapes(ext, projection, M):
         assert info["kernel"] == (5 if p.name == "gate_up" and M <= 16 else 2), f"routing at M={M}: {info}"
 
 
-FULL_ROW = ("qkv", "gate_up", "lm_head")  # the projections with 2,560 columns: 16 rows of them fit one CU's LDS
+FULL_ROW = ("qkv", "gate_up")  # 2,560 columns (16 rows of them fit one CU's LDS) and at most 8 tiles per CU (lm_head has 37)
 
 
 @pytest.mark.parametrize("M", [5, 8, 9, 16])
@@ -276,12 +276,14 @@ def test_full_row_matmul_at_qwen3_4b_shapes(ext, projection, M):
 
 
 def test_full_row_matmul_refuses_what_does_not_fit(ext):
-    """wo (4,096 columns) and w_down (9,728): 16 rows of them do not fit a CU's LDS; more than 16 rows never do."""
-    for name in ("wo", "gate_up"):
+    """wo (4,096 columns) and w_down (9,728): 16 rows of them do not fit a CU's LDS; more than 16 rows never do; the head has 37 tiles per CU."""
+    for name in ("wo", "gate_up", "lm_head"):
         if name not in _cache:
             _cache[name] = _Projection(ext, name)
     with pytest.raises(RuntimeError, match="full-row matmul"):
         _cache["wo"].run(ext, 8, (PRO_NONE, EPI_STORE), kernel=5)
+    with pytest.raises(RuntimeError, match="full-row matmul"):
+        _cache["lm_head"].run(ext, 8, (PRO_NONE, EPI_STORE), kernel=5)
     with pytest.raises(RuntimeError, match="full-row matmul"):
         _cache["gate_up"].run(ext, 17, (PRO_NONE, EPI_STORE), kernel=5)
 

@@ -1900,7 +1900,7 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
     e.qmm3_mode = kernel == 3 ? 0 : (kernel == 4 ? 1 : -1);
     if (const char *q = getenv("TL_QMM5")) e.qmm5_mode = std::min(2, std::max(0, atoi(q)));  // kernel 0: the engine's routing
     if (kernel == 5) {
-        TL_REQUIRE(qmm5_plan(M, w->w.cols, w->w.rows).ok, "decode_linear: the full-row matmul takes at most 16 rows of 1,024 / 2,048 / 2,560 columns");
+        TL_REQUIRE(qmm5_plan(M, w->w.cols, w->w.rows).ok, "decode_linear: the full-row matmul takes at most 16 rows of 1,024 / 2,048 / 2,560 columns and at most 8 tiles per CU");
         e.qmm5_mode = 3;
     } else if (kernel >= 2) {
         e.qmm5_mode = 0;
