@@ -102,29 +102,42 @@ __device__ __forceinline__ void qmm3_row_ss_finish(const Qmm3Args &p, int tid, c
 // QM3_WAVES*64 threads of the workgroup.  chunk = 8 consecutive elements; a row of the slice has LM*16 chunks; 16 consecutive
 // lanes cover one group of one row.  The loads of SB chunks per thread are issued together (one dependent round trip per
 // chunk cost ~1 us each).  PRO_RMSNORM: the rows are normalised on the way in (bf16(x * inv * w), the reference's rounding point).
-template <int MB, int LM, int PRO, int SBMAX = 5>
-__device__ __forceinline__ void qmm3_stage_slice(const Qmm3Args &p, int g0, int gn, uint16_t *xs, float *xsum, int tid, const float *s_inv) {
-    constexpr int T = QM3_WAVES * 64;
-    constexpr int ROWS = MB * 16;
-    constexpr int XS = LM * 128 + QM3_PAD;
-    const int N = p.N;
-    constexpr int CPR = LM * 16;
-    constexpr int CHUNKS = ROWS * CPR;
-    constexpr int ITER = (CHUNKS + T - 1) / T;
-    constexpr int SB = ITER < SBMAX ? ITER : SBMAX;
-    for (int it0 = 0; it0 < ITER; it0 += SB) {
-        u32x4 v[SB], gw[SB];
-        bool ok[SB];
+template <int MB, int LM, int SBMAX>
+struct Qmm3Stage {
+    static constexpr int T = QM3_WAVES * 64, ROWS = MB * 16, CPR = LM * 16, CHUNKS = ROWS * CPR;
+    static constexpr int ITER = (CHUNKS + T - 1) / T;
+    static constexpr int SB = ITER < SBMAX ? ITER : SBMAX;
+    u32x4 v[SB], gw[SB];  // one batch of a thread's chunks (and their norm weights) in flight
+    bool ok[SB];
+};
+// the loads of the batch of chunks that starts at iteration it0 (unconditional, from clamped addresses)
+template <int MB, int LM, int PRO, int SBMAX>
+__device__ __forceinline__ void qmm3_stage_issue(const Qmm3Args &p, int g0, int gn, int tid, int it0, Qmm3Stage<MB, LM, SBMAX> &st) {
+    using S = Qmm3Stage<MB, LM, SBMAX>;
 #pragma unroll
-        for (int j = 0; j < SB; ++j) {
-            const int ch = min(tid + (it0 + j) * T, CHUNKS - 1);
-            const int row = ch / CPR;
-            const int cc = ch - row * CPR;
-            ok[j] = tid + (it0 + j) * T < CHUNKS && row < p.M && (cc >> 4) < gn && !(QMM3_ABL & 2);
-            v[j] = *reinterpret_cast<const u32x4 *>(p.a + (ok[j] ? ((size_t)row * N + (size_t)g0 * 128 + (size_t)cc * 8) : 0));
-            if constexpr (PRO == PRO_RMSNORM)
-                gw[j] = *reinterpret_cast<const u32x4 *>(p.norm_w + (ok[j] ? ((size_t)g0 * 128 + (size_t)cc * 8) : 0));
-        }
+    for (int j = 0; j < S::SB; ++j) {
+        const int ch = min(tid + (it0 + j) * S::T, S::CHUNKS - 1);
+        const int row = ch / S::CPR;
+        const int cc = ch - row * S::CPR;
+        st.ok[j] = tid + (it0 + j) * S::T < S::CHUNKS && row < p.M && (cc >> 4) < gn && !(QMM3_ABL & 2);
+        st.v[j] = *reinterpret_cast<const u32x4 *>(p.a + (st.ok[j] ? ((size_t)row * p.N + (size_t)g0 * 128 + (size_t)cc * 8) : 0));
+        if constexpr (PRO == PRO_RMSNORM)
+            st.gw[j] = *reinterpret_cast<const u32x4 *>(p.norm_w + (st.ok[j] ? ((size_t)g0 * 128 + (size_t)cc * 8) : 0));
+    }
+}
+// FIRST_OUT: the first batch's loads were issued by the caller (qmm3_stage_issue at it0 = 0) ahead of the weight stream -- vector
+// loads return in issue order and the rows are needed first (round 4: staged rows used to arrive together with 64 KiB of weights)
+template <int MB, int LM, int PRO, int SBMAX = 5, bool FIRST_OUT = false>
+__device__ __forceinline__ void qmm3_stage_slice(const Qmm3Args &p, int g0, int gn, uint16_t *xs, float *xsum, int tid, const float *s_inv,
+                                                 Qmm3Stage<MB, LM, SBMAX> &st) {
+    using S = Qmm3Stage<MB, LM, SBMAX>;
+    constexpr int T = S::T, ROWS = S::ROWS, CPR = S::CPR, CHUNKS = S::CHUNKS, ITER = S::ITER, SB = S::SB;
+    constexpr int XS = LM * 128 + QM3_PAD;
+    for (int it0 = 0; it0 < ITER; it0 += SB) {
+        if (!(FIRST_OUT && it0 == 0)) qmm3_stage_issue<MB, LM, PRO, SBMAX>(p, g0, gn, tid, it0, st);
+        u32x4(&v)[SB] = st.v;
+        u32x4(&gw)[SB] = st.gw;
+        bool(&ok)[SB] = st.ok;
         if constexpr (PRO == PRO_RMSNORM) {
             if (it0 == 0) __syncthreads();  // s_inv (qmm3_row_ss_finish) is complete; this batch's loads are already out
         }
@@ -167,7 +180,8 @@ __device__ __forceinline__ void qmm3_stage_slice(const Qmm3Args &p, int g0, int 
     }
 }
 
-template <int MB, int TW, int LM, int PRO = PRO_NONE>
+// SF = the first batch of the staging's row loads goes out BEFORE the weights (lab A/B of round 4)
+template <int MB, int TW, int LM, int PRO = PRO_NONE, bool SF = false>
 __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = MB * 16;
@@ -187,6 +201,11 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
     float *s_inv = xsum + LM * ROWS;                                         // [ROWS]
     Qmm3RowSS<MB> rss;
     if constexpr (PRO == PRO_RMSNORM) qmm3_row_ss_issue<MB>(p, tid, rss);  // first: they gate the staging, and loads return in order
+    Qmm3Stage<MB, LM, 5> stage;
+    if constexpr (SF) {
+        qmm3_stage_issue<MB, LM, PRO, 5>(p, g0, gn, tid, 0, stage);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     // ---- 1. weights of this wave's tiles: everything in flight before the staging ----------------------------------
     u32x4 wq[TW][LM];
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
 
     // ---- 2. activation slice -> LDS, per-(group,row) sums ------------------------------------------------------------
     if constexpr (PRO == PRO_RMSNORM) qmm3_row_ss_finish<MB>(p, tid, rss, s_inv);
-    qmm3_stage_slice<MB, LM, PRO>(p, g0, gn, xs, xsum, tid, s_inv);
+    qmm3_stage_slice<MB, LM, PRO, 5, SF>(p, g0, gn, xs, xsum, tid, s_inv, stage);
     __syncthreads();
 
     // ---- 3. MFMA over the slice --------------------------------------------------------------------------------------
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
 #ifndef QMM3P_SB
 #define QMM3P_SB 8  // staging chunks in flight per thread
 #endif
-template <int MB, int NU, int PRO>
+template <int MB, int NU, int PRO, bool SF>
 __device__ __forceinline__ void qmm3p_body(const Qmm3Args &p, char *smem, const int slice, const int g0, const int gn, const int wg,
                                            const int tiles_per_wg) {
     constexpr int LM = 4 * NU;
@@ -308,6 +327,11 @@ __device__ __forceinline__ void qmm3p_body(const Qmm3Args &p, char *smem, const 
     float *s_inv = xsum + LM * ROWS;                                         // [ROWS]
     Qmm3RowSS<MB> rss;
     if constexpr (PRO == PRO_RMSNORM) qmm3_row_ss_issue<MB>(p, tid, rss);  // first: they gate the staging, and loads return in order
+    Qmm3Stage<MB, LM, QMM3P_SB> stage;
+    if constexpr (SF) {
+        qmm3_stage_issue<MB, LM, PRO, QMM3P_SB>(p, g0, gn, tid, 0, stage);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     const int first = wg * tiles_per_wg + wave;
     const int last = min(tiles, (wg + 1) * tiles_per_wg);
     const int n_tiles = first < last ? (last - first + QM3_WAVES - 1) / QM3_WAVES : 0;  // wave-uniform
@@ -351,7 +375,7 @@ __device__ __forceinline__ void qmm3p_body(const Qmm3Args &p, char *smem, const 
 
     // ---- 2. activation slice -> LDS, once per workgroup ----------------------------------------------------------------
     if constexpr (PRO == PRO_RMSNORM) qmm3_row_ss_finish<MB>(p, tid, rss, s_inv);
-    qmm3_stage_slice<MB, LM, PRO, QMM3P_SB>(p, g0, gn, xs, xsum, tid, s_inv);
+    qmm3_stage_slice<MB, LM, PRO, QMM3P_SB, SF>(p, g0, gn, xs, xsum, tid, s_inv, stage);
     QM3_STAMP();
     __syncthreads();
     QM3_STAMP();
@@ -473,7 +497,7 @@ struct Qmm3pGrid {
     int full_slices, wgs_full, tpw_full;  // slices of 4*NU groups: workgroups and tiles per workgroup of each
     int last_groups, wgs_last, tpw_last;  // the short last slice (0 groups = none)
 };
-template <int MB, int NU, int PRO = PRO_NONE>
+template <int MB, int NU, int PRO = PRO_NONE, bool SF = false>
 __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3p_kernel(const Qmm3Args p, const Qmm3pGrid gr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #if QMM3_ABL & 64
@@ -485,11 +509,11 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3p_kernel(const Qmm3Args p,
     const int nfull = gr.full_slices * gr.wgs_full;
     if (bid < nfull) {
         const int slice = bid / gr.wgs_full;
-        qmm3p_body<MB, NU, PRO>(p, smem, slice, slice * 4 * NU, 4 * NU, bid - slice * gr.wgs_full, gr.tpw_full);
+        qmm3p_body<MB, NU, PRO, SF>(p, smem, slice, slice * 4 * NU, 4 * NU, bid - slice * gr.wgs_full, gr.tpw_full);
     } else if (NU == 2 && gr.last_groups <= 4) {
-        qmm3p_body<MB, 1, PRO>(p, smem, gr.full_slices, gr.full_slices * 4 * NU, gr.last_groups, bid - nfull, gr.tpw_last);
+        qmm3p_body<MB, 1, PRO, SF>(p, smem, gr.full_slices, gr.full_slices * 4 * NU, gr.last_groups, bid - nfull, gr.tpw_last);
     } else {
-        qmm3p_body<MB, NU, PRO>(p, smem, gr.full_slices, gr.full_slices * 4 * NU, gr.last_groups, bid - nfull, gr.tpw_last);
+        qmm3p_body<MB, NU, PRO, SF>(p, smem, gr.full_slices, gr.full_slices * 4 * NU, gr.last_groups, bid - nfull, gr.tpw_last);
     }
 #if !(QMM3_ABL & 64)
     prof_end(p.prof, prof_t0);

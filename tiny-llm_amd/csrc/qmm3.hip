@@ -118,11 +118,13 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
     if (!pl.ok) return -1;
     if (pro == PRO_RMSNORM && (!args.ss || !args.norm_w || !qmm3_takes_ss(args.ss_n))) return -1;
     const dim3 grid(pl.grid_x, pl.slices), block(QM3_WAVES * 64);
+    static const bool sf = getenv("TL_QMM3_STAGE_FIRST") ? atoi(getenv("TL_QMM3_STAGE_FIRST")) != 0 : false;  // lab A/B (round 4)
     if (pl.persistent) {
         const dim3 pgrid(pl.grid_x);
 #define QM3P_CASE(MBv, NUv)                                                                                          \
     if (pl.MB == MBv && pl.NU == NUv) {                                                                              \
-        auto kern = pro == PRO_RMSNORM ? qmm3p_kernel<MBv, NUv, PRO_RMSNORM> : qmm3p_kernel<MBv, NUv, PRO_NONE>;     \
+        auto kern = sf ? (pro == PRO_RMSNORM ? qmm3p_kernel<MBv, NUv, PRO_RMSNORM, true> : qmm3p_kernel<MBv, NUv, PRO_NONE, true>) \
+                       : (pro == PRO_RMSNORM ? qmm3p_kernel<MBv, NUv, PRO_RMSNORM> : qmm3p_kernel<MBv, NUv, PRO_NONE>);      \
         if (pl.lds > 64 * 1024)                                                                                      \
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);  \
         hipLaunchKernelGGL(kern, pgrid, block, pl.lds, st, args, pl.pgrid);                                          \
@@ -134,7 +136,8 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
     }
 #define QM3_CASE(MBv, TWv, LMv)                                                                                     \
     if (pl.MB == MBv && pl.TW == TWv && pl.LM == LMv) {                                                             \
-        auto kern = pro == PRO_RMSNORM ? qmm3_kernel<MBv, TWv, LMv, PRO_RMSNORM> : qmm3_kernel<MBv, TWv, LMv, PRO_NONE>; \
+        auto kern = sf ? (pro == PRO_RMSNORM ? qmm3_kernel<MBv, TWv, LMv, PRO_RMSNORM, true> : qmm3_kernel<MBv, TWv, LMv, PRO_NONE, true>) \
+                       : (pro == PRO_RMSNORM ? qmm3_kernel<MBv, TWv, LMv, PRO_RMSNORM> : qmm3_kernel<MBv, TWv, LMv, PRO_NONE>);     \
         if (pl.lds > 64 * 1024)                                                                                     \
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
         hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                                    \
