@@ -118,7 +118,8 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
     if (!pl.ok) return -1;
     if (pro == PRO_RMSNORM && (!args.ss || !args.norm_w || !qmm3_takes_ss(args.ss_n))) return -1;
     const dim3 grid(pl.grid_x, pl.slices), block(QM3_WAVES * 64);
-    static const bool sf = getenv("TL_QMM3_STAGE_FIRST") ? atoi(getenv("TL_QMM3_STAGE_FIRST")) != 0 : false;  // lab A/B (round 4)
+    const char *sfv = getenv("TL_QMM3_STAGE_FIRST");  // lab A/B (round 4); read per launch: one process runs both variants
+    const bool sf = sfv && atoi(sfv) != 0;
     if (pl.persistent) {
         const dim3 pgrid(pl.grid_x);
 #define QM3P_CASE(MBv, NUv)                                                                                          \

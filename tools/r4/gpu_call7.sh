@@ -3,8 +3,7 @@
 OUT=gpurun_out/r4c7
 mkdir -p $OUT
 export TMPDIR=/tmp
-TL_QMM3_STAGE_FIRST=1 timeout 900 python -m pytest tests/test_decode_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "skinny or routing" 2>&1 | tail -6 | tee $OUT/tests_stage_first.log
-for b in 8 16 32 64; do
+for b in 8 16 64; do
   timeout 300 python tools/decode_ab.py --batch $b --prompt-len 256 --steps 64 TL_QMM5=0 TL_QMM5=0,TL_QMM3_STAGE_FIRST=1 TL_QMM5=0 TL_QMM5=0,TL_QMM3_STAGE_FIRST=1 2>&1 | grep -v Warning | tee -a $OUT/stage_first_ab.jsonl
 done
 echo done
