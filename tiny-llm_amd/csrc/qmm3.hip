@@ -118,8 +118,12 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
     if (!pl.ok) return -1;
     if (pro == PRO_RMSNORM && (!args.ss || !args.norm_w || !qmm3_takes_ss(args.ss_n))) return -1;
     const dim3 grid(pl.grid_x, pl.slices), block(QM3_WAVES * 64);
-    const char *sfv = getenv("TL_QMM3_STAGE_FIRST");  // lab A/B (round 4); read per launch: one process runs both variants
-    const bool sf = sfv && atoi(sfv) != 0;
+    // The staging's row loads ahead of the weight stream (qmm3.h, SF): up to 16 rows the staged slice is small and the kernel is a
+    // latency chain -- rows first take 1.0-1.5 us off every projection (8 sequences 1.879 -> 1.763 ms per step, 16: 2.052 -> 1.972,
+    // same box); at 64 rows the slice is 64-128 KiB per CU and delays the weight stream instead (4.675 -> 4.775): weights first there.
+    // TL_QMM3_STAGE_FIRST = 0 / 1 pins it for every row count (lab A/B; read per launch: one process runs both variants).
+    const char *sfv = getenv("TL_QMM3_STAGE_FIRST");
+    const bool sf = sfv ? atoi(sfv) != 0 : pl.MB == 1;
     if (pl.persistent) {
         const dim3 pgrid(pl.grid_x);
 #define QM3P_CASE(MBv, NUv)                                                                                          \
