@@ -230,8 +230,7 @@ int tl_tiled_w4_create(const tl_w4 *w, void *stream, tl_tiled_w4 **out);
 void tl_tiled_w4_destroy(tl_tiled_w4 *t);
 
 /* Which kernel a projection ran: 1 = fused MFMA GEMV (qmv3: p = MR, KS, CW, LM, workgroups), 2 = skinny MFMA matmul +
- * slice reduction (qmm3: p = MB, TW, LM, slices, tile groups), 3 = packed-dot GEMV fallback, 4 = prefill GEMM path,
- * 5 = full-row persistent matmul (qmm5: p = groups, tiles per workgroup, units per tile, 1, workgroups). */
+ * slice reduction (qmm3: p = MB, TW, LM, slices, tile groups), 3 = packed-dot GEMV fallback, 4 = prefill GEMM path. */
 typedef struct tl_linear_info {
     int kernel;
     int launches;
@@ -244,8 +243,7 @@ typedef struct tl_linear_info {
  *   prologue 0 none | 1 RMSNorm(a, norm_w, eps) rounded to bf16;  epilogue 0 store | 1 residual + bf16(acc) |
  *   2 SwiGLU over interleaved (gate_i, up_i) rows -> out [M, rows/2].
  *   kernel 0 = the engine's routing by M and matrix size, 1 = force the fused GEMV (M <= 8), 2 = force the skinny matmul
- *   (grid chosen by shape as the engine does), 3 / 4 = the skinny matmul on its one-shot / persistent grid, 5 = the full-row
- *   persistent matmul (M <= 16, cols 1,024 / 2,048 / 2,560: whole rows staged once per CU, no slice reduction launch).
+ *   (grid chosen by shape as the engine does), 3 / 4 = the skinny matmul on its one-shot / persistent grid.
  * The engine uses the pairs (1,0) qkv / lm_head, (0,1) wo / w_down, (1,2) gate|up, (0,0). */
 size_t tl_decode_linear_workspace_bytes(int M, int rows, int cols);
 int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,

@@ -235,57 +235,9 @@ def test_skinny_matmul_at_qwen3_4b_shapes(ext, projection, M):
     _, info = p.run(ext, M, (p.pro, p.epi), kernel=2)
     want_persistent = PERSISTENT_FROM_MB[p.name] is not None and MB >= PERSISTENT_FROM_MB[p.name] and not (p.name == "lm_head" and MB == 1)
     assert info["kernel"] == 2 and (info["p"][1] == 0) == want_persistent, f"planner's grid for {p.name} at M={M}: {info}"
-    if M > 8:  # the engine's own routing sends more than 8 rows here as well (gate|up up to 16 rows: the full-row kernel, below)
+    if M > 8:  # the engine's own routing sends more than 8 rows here as well
         _, info = p.run(ext, M, (p.pro, p.epi), kernel=0)
-        assert info["kernel"] == (5 if p.name == "gate_up" and M <= 16 else 2), f"routing at M={M}: {info}"
-
-
-FULL_ROW = ("qkv", "gate_up")  # 2,560 columns (16 rows of them fit one CU's LDS) and at most 8 tiles per CU (lm_head has 37)
-
-
-@pytest.mark.parametrize("M", [5, 8, 9, 16])
-@pytest.mark.parametrize("projection", list(FULL_ROW), indirect=True)
-def test_full_row_matmul_at_qwen3_4b_shapes(ext, projection, M):
-    """qmm5_kernel (round 4): 5-16 rows against WHOLE staged rows, one workgroup per CU walking its own tiles, units of 4 groups dealt
-    to the 8 waves, a tile's unit sums added in unit order by one wave, epilogue in the launch -- no slice planes, no reduction launch.
-    Plain and with the projection's fused prologue / epilogue against the oracle; the engine routes gate|up here at 5-16 rows."""
-    p = projection
-    tiles = p.K // 16
-    for variant in _variants(p):
-        got, info = p.run(ext, M, variant, kernel=5)
-        what = f"qmm5 {p.name} M={M} variant={variant} {info}"
-        assert info["kernel"] == 5 and info["p"][0] == 20 and info["p"][2] == 5, what
-        assert info["p"][4] <= 256 and info["p"][1] * info["p"][4] >= tiles > info["p"][1] * (info["p"][4] - 1), f"{what}: tiles per workgroup x workgroups"
-        assert info["launches"] == (2 if variant[0] == PRO_RMSNORM else 1), f"{what}: RMSNorm as its own launch when no producer partials are given"
-        _check(p, got, M, variant, what)
-    for partials in (8, 160):  # the fused RMSNorm from the producer's sums of squares: ONE launch
-        x = p.a[:M].double()
-        if partials == 8:
-            ss = torch.zeros((M, 8), dtype=torch.float32, device=DEV)
-            ss[:, 0] = (x * x).sum(dim=1).float()
-        else:
-            ss = (x * x).reshape(M, p.N // 16, 16).sum(dim=2).float().contiguous()
-        got, info = ext.decode_linear(p.tiled, p.a[:M].contiguous(), prologue=PRO_RMSNORM, epilogue=p.epi, norm_weight=p.norm_w, eps=EPS,
-                                      kernel=5, ss_in=ss)
-        what = f"qmm5 fused RMSNorm from {partials} partials {p.name} M={M} {info}"
-        assert info["kernel"] == 5 and info["launches"] == 1, what
-        _check_with_flips(p, got, M, (PRO_RMSNORM, p.epi), what)
-    if p.name == "gate_up":
-        got, info = p.run(ext, M, (p.pro, p.epi), kernel=0)
-        assert info["kernel"] == 5, f"the engine's routing at {M} rows: {info}"
-
-
-def test_full_row_matmul_refuses_what_does_not_fit(ext):
-    """wo (4,096 columns) and w_down (9,728): 16 rows of them do not fit a CU's LDS; more than 16 rows never do; the head has 37 tiles per CU."""
-    for name in ("wo", "gate_up", "lm_head"):
-        if name not in _cache:
-            _cache[name] = _Projection(ext, name)
-    with pytest.raises(RuntimeError, match="full-row matmul"):
-        _cache["wo"].run(ext, 8, (PRO_NONE, EPI_STORE), kernel=5)
-    with pytest.raises(RuntimeError, match="full-row matmul"):
-        _cache["lm_head"].run(ext, 8, (PRO_NONE, EPI_STORE), kernel=5)
-    with pytest.raises(RuntimeError, match="full-row matmul"):
-        _cache["gate_up"].run(ext, 17, (PRO_NONE, EPI_STORE), kernel=5)
+        assert info["kernel"] == 2, f"routing at M={M}: {info}"
 
 
 @pytest.mark.parametrize("M", [5, 16, 33, 64])
@@ -322,7 +274,7 @@ def test_engine_routing_between_gemv_and_skinny_matmul(ext, projection):
         assert info["kernel"] == 1, f"{p.name} M={M}: {info}"
     for M in (5, 8):
         got, info = p.run(ext, M, variant, kernel=0)
-        assert info["kernel"] == (5 if p.name == "gate_up" else 2), f"{p.name} M={M}: {info}"
+        assert info["kernel"] == 2, f"{p.name} M={M}: {info}"
         _check(p, got, M, variant, f"routing {p.name} M={M}")
 
 

@@ -16,7 +16,6 @@
 #include "qmv.h"
 #include "qmv3.h"
 #include "qmm3.h"
-#include "qmm5.h"
 
 namespace tl {
 
@@ -106,10 +105,6 @@ struct tl_engine {
     tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
     int force_linear = 0;               // kernel-level entry points: 1 = fused GEMV, 2 = skinny matmul
     int qmm3_mode = -1;                 // skinny matmul grid: -1 by shape (qmm3_plan), 0 one-shot, 1 persistent
-    // 5-16 rows: the full-row persistent kernel (qmm5.h: whole rows staged once per CU, no slice reduction launch).  0 = off
-    // (TL_QMM5=0), 1 = by shape (the projection with 4-16 tiles per CU: gate|up), 2 = every projection it takes (lab), 3 = forced
-    // (tl_decode_linear kernel 5)
-    int qmm5_mode = 1;
     bool gemm_fused_epilogue = true;    // TL_GEMM_FUSED_EPILOGUE=0: residual / SwiGLU of the prefill GEMM as separate launches
     size_t attn_ws_bytes = 0;
     int rows_cap = 0;
@@ -362,50 +357,6 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
     // qmm3_min_rows .. 64 rows (batched decode): K-sliced skinny MFMA matmul over the tiled weights, then the slice
     // reduction with the epilogue.  RMSNorm runs as its own launch (a slice does not see the whole row).
     const auto tiled = e->tiled.find(w.weight_dev);
-    {
-        // 5 .. 16 rows of up to 2,560 columns: whole rows fit one CU's LDS -- no K slices, no reduction launch, epilogue in the kernel
-        const Qmm5Plan p5 = qmm5_plan(M, w.cols, w.rows);
-        const int tiles = w.rows / 16;
-        const bool by_shape = tiles >= 4 * qmm3_num_cus() && tiles < 16 * qmm3_num_cus();  // 4-16 tiles per CU: gate|up (4.75)
-        const bool take5 = e->use_qmm3 && M <= 16 && tiled != e->tiled.end() && p5.ok &&
-                           (e->qmm5_mode == 3 || (e->force_linear != 2 && M >= e->qmm3_min_rows && (e->qmm5_mode == 2 || (e->qmm5_mode == 1 && by_shape))));
-        if (take5) {
-            const bool fused_norm = pro == PRO_RMSNORM && ss_in != nullptr && e->fuse_norm;
-            if (pro == PRO_RMSNORM && !fused_norm) {
-                TL_TRY(tl_rms_norm(a, norm_w, e->xn, M, w.cols, c.rms_norm_eps, TL_BF16, e->stream));
-                in = e->xn;
-            }
-            Qmm5Args q{};
-            q.wt = tiled->second.wt;
-            q.sbt = tiled->second.sbt;
-            q.a = in;
-            q.out = out;
-            q.M = M;
-            q.N = w.cols;
-            q.K = w.rows;
-            q.prof = pc ? pc->buf : nullptr;
-            q.norm_w = (const uint16_t *)norm_w;
-            q.ss = ss_in;
-            q.ss_n = ss_in_n;
-            q.eps = c.rms_norm_eps;
-            q.residual = residual;
-            q.ss_out = (epi == EPI_RESIDUAL && ss_out && e->fuse_norm && qmm3_takes_ss(w.rows / 16)) ? ss_out : nullptr;
-            if (launch_qmm5_bf16(q, fused_norm ? PRO_RMSNORM : PRO_NONE, epi, e->stream) != 0)
-                return fail(TL_ERR_UNSUPPORTED, "engine: full-row matmul launch failed");
-            if (pc) prof_after(e, pc, kind, p5.grid);
-            if (ss_emitted) *ss_emitted = q.ss_out != nullptr;
-            if (ss_out_n) *ss_out_n = q.ss_out != nullptr ? w.rows / 16 : 0;
-            TL_CHECK_LAUNCH("engine full-row matmul");
-            if (e->linfo) {
-                tl_linear_info &li = *e->linfo;
-                li.kernel = 5;
-                li.launches += 1 + (pro == PRO_RMSNORM && !fused_norm ? 1 : 0);
-                li.rows_per_pass = M;
-                li.p[0] = p5.G, li.p[1] = p5.tiles_per_wg, li.p[2] = p5.G / 4, li.p[3] = 1, li.p[4] = p5.grid;
-            }
-            return TL_OK;
-        }
-    }
     const Qmm3Plan p3 = qmm3_plan(M, w.cols, w.rows, e->qmm3_mode);
     if (e->use_qmm3 && M <= 64 && tiled != e->tiled.end() && p3.ok) {
         const bool fused_norm = pro == PRO_RMSNORM && ss_in != nullptr && e->fuse_norm;
@@ -999,7 +950,6 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->ss_h = (float *)(A + o_ssh);
     if (const char *q = getenv("TL_ATTN_QKV_PARTIALS")) e->attn_qkv_partials = atoi(q) != 0;
     if (const char *q = getenv("TL_LMHEAD_TILE_MAX")) e->lm_tile_max_on = atoi(q) != 0;
-    if (const char *q = getenv("TL_QMM5")) e->qmm5_mode = std::min(2, std::max(0, atoi(q)));
     if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
@@ -1877,9 +1827,8 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
     TL_REQUIRE(prologue == PRO_ATTN_MERGE || a_dev, "decode_linear: null activation rows");
     TL_REQUIRE(prologue != PRO_RMSNORM || norm_w_dev, "decode_linear: the RMSNorm prologue needs its weight");
     TL_REQUIRE(epilogue != EPI_RESIDUAL || residual_dev, "decode_linear: the residual epilogue needs the residual rows");
-    TL_REQUIRE(kernel >= 0 && kernel <= 5,
-               "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV), 2 (skinny matmul), 3 / 4 (its one-shot / persistent grid), "
-               "5 (full-row persistent matmul, at most 16 rows)");
+    TL_REQUIRE(kernel >= 0 && kernel <= 4,
+               "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV), 2 (skinny matmul), 3 / 4 (its one-shot / persistent grid)");
     TL_REQUIRE(epilogue != EPI_SWIGLU || w->w.rows % 2 == 0, "decode_linear: SwiGLU needs an even number of weight rows");
     // the engine's own fused variants: RMSNorm+store (qkv, lm_head), residual (wo, w_down), RMSNorm+SwiGLU (gate|up), plain;
     // through tl_decode_linear_ex also: merged attention partials + residual (wo of one row), weighted rows + SwiGLU (gate|up)
@@ -1898,13 +1847,6 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
     e.splitk_ws_bytes = workspace_bytes - xn_bytes;
     e.force_linear = kernel >= 2 ? 2 : kernel;
     e.qmm3_mode = kernel == 3 ? 0 : (kernel == 4 ? 1 : -1);
-    if (const char *q = getenv("TL_QMM5")) e.qmm5_mode = std::min(2, std::max(0, atoi(q)));  // kernel 0: the engine's routing
-    if (kernel == 5) {
-        TL_REQUIRE(qmm5_plan(M, w->w.cols, w->w.rows).ok, "decode_linear: the full-row matmul takes at most 16 rows of 1,024 / 2,048 / 2,560 columns and at most 8 tiles per CU");
-        e.qmm5_mode = 3;
-    } else if (kernel >= 2) {
-        e.qmm5_mode = 0;
-    }
     tl_linear_info li{};
     e.linfo = &li;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e.qmm3_min_rows = std::max(1, atoi(q));

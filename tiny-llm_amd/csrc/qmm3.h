@@ -180,7 +180,7 @@ __device__ __forceinline__ void qmm3_stage_slice(const Qmm3Args &p, int g0, int 
     }
 }
 
-// SF = the first batch of the staging's row loads goes out BEFORE the weights (lab A/B of round 4)
+// SF = the first batch of the staging's row loads goes out BEFORE the weights (the launcher sets it for MB == 1: qmm3.hip)
 template <int MB, int TW, int LM, int PRO = PRO_NONE, bool SF = false>
 __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -1,6 +1,5 @@
 // Launchers of the skinny batched-decode matmul (qmm3.h) and its slice-reduction / epilogue kernel.
 #include "qmm3.h"
-#include "qmm5.h"
 
 namespace tl {
 
@@ -118,18 +117,15 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
     if (!pl.ok) return -1;
     if (pro == PRO_RMSNORM && (!args.ss || !args.norm_w || !qmm3_takes_ss(args.ss_n))) return -1;
     const dim3 grid(pl.grid_x, pl.slices), block(QM3_WAVES * 64);
-    // The staging's row loads ahead of the weight stream (qmm3.h, SF): up to 16 rows the staged slice is small and the kernel is a
-    // latency chain -- rows first take 1.0-1.5 us off every projection (8 sequences 1.879 -> 1.763 ms per step, 16: 2.052 -> 1.972,
-    // same box); at 64 rows the slice is 64-128 KiB per CU and delays the weight stream instead (4.675 -> 4.775): weights first there.
-    // TL_QMM3_STAGE_FIRST = 0 / 1 pins it for every row count (lab A/B; read per launch: one process runs both variants).
-    const char *sfv = getenv("TL_QMM3_STAGE_FIRST");
-    const bool sf = sfv ? atoi(sfv) != 0 : pl.MB == 1;
+    // The staging's row loads go out ahead of the weight stream up to 16 rows (qmm3.h, SF = MB == 1): the staged slice is small there
+    // and the kernel is a latency chain -- rows first take 1.0-1.5 us off every projection (8 sequences 1.898 -> 1.767 ms per step,
+    // 16: 2.067 -> 1.979, same-box A/B, profiles/r04_labs/skinny_matmul_rows_before_weights_ab*.jsonl); at 32 / 64 rows the slice is
+    // 64-128 KiB per CU and delays the weight stream instead (2.87 -> 3.02, 4.675 -> 4.775 ms): weights first there.
     if (pl.persistent) {
         const dim3 pgrid(pl.grid_x);
 #define QM3P_CASE(MBv, NUv)                                                                                          \
     if (pl.MB == MBv && pl.NU == NUv) {                                                                              \
-        auto kern = sf ? (pro == PRO_RMSNORM ? qmm3p_kernel<MBv, NUv, PRO_RMSNORM, true> : qmm3p_kernel<MBv, NUv, PRO_NONE, true>) \
-                       : (pro == PRO_RMSNORM ? qmm3p_kernel<MBv, NUv, PRO_RMSNORM> : qmm3p_kernel<MBv, NUv, PRO_NONE>);      \
+        auto kern = pro == PRO_RMSNORM ? qmm3p_kernel<MBv, NUv, PRO_RMSNORM, MBv == 1> : qmm3p_kernel<MBv, NUv, PRO_NONE, MBv == 1>; \
         if (pl.lds > 64 * 1024)                                                                                      \
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);  \
         hipLaunchKernelGGL(kern, pgrid, block, pl.lds, st, args, pl.pgrid);                                          \
@@ -141,8 +137,7 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
     }
 #define QM3_CASE(MBv, TWv, LMv)                                                                                     \
     if (pl.MB == MBv && pl.TW == TWv && pl.LM == LMv) {                                                             \
-        auto kern = sf ? (pro == PRO_RMSNORM ? qmm3_kernel<MBv, TWv, LMv, PRO_RMSNORM, true> : qmm3_kernel<MBv, TWv, LMv, PRO_NONE, true>) \
-                       : (pro == PRO_RMSNORM ? qmm3_kernel<MBv, TWv, LMv, PRO_RMSNORM> : qmm3_kernel<MBv, TWv, LMv, PRO_NONE>);     \
+        auto kern = pro == PRO_RMSNORM ? qmm3_kernel<MBv, TWv, LMv, PRO_RMSNORM, MBv == 1> : qmm3_kernel<MBv, TWv, LMv, PRO_NONE, MBv == 1>; \
         if (pl.lds > 64 * 1024)                                                                                     \
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
         hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                                    \
@@ -153,34 +148,6 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
 #undef QM3_LM
 #undef QM3_CASE
     return -2;
-}
-
-// The full-row persistent kernel for 5 .. 16 rows (qmm5.h).
-template <int G>
-static int launch_qmm5_g(const Qmm5Args &args, int pro, int epi, const Qmm5Plan &pl, hipStream_t st) {
-    const dim3 grid(pl.grid), block(QM3_WAVES * 64);
-#define QM5_CASE(PROv, EPIv)                                                                                          \
-    if (pro == PROv && epi == EPIv) {                                                                                 \
-        auto kern = qmm5_kernel<G, PROv, EPIv>;                                                                       \
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);       \
-        hipLaunchKernelGGL(kern, grid, block, pl.lds, st, args);                                                      \
-        return hipGetLastError() == hipSuccess ? 0 : -1;                                                              \
-    }
-    QM5_CASE(PRO_RMSNORM, EPI_SWIGLU) QM5_CASE(PRO_NONE, EPI_SWIGLU) QM5_CASE(PRO_RMSNORM, EPI_STORE) QM5_CASE(PRO_NONE, EPI_STORE)
-    QM5_CASE(PRO_NONE, EPI_RESIDUAL)
-#undef QM5_CASE
-    return -2;
-}
-int launch_qmm5_bf16(const Qmm5Args &args, int pro, int epi, hipStream_t st) {
-    Qmm5Plan pl = qmm5_plan(args.M, args.N, args.K);
-    if (!pl.ok) return -1;
-    if (pro == PRO_RMSNORM && (!args.ss || !args.norm_w || !qmm3_takes_ss(args.ss_n))) return -1;
-    if (epi == EPI_RESIDUAL && !args.residual) return -1;
-    Qmm5Args a = args;
-    a.tiles_per_wg = pl.tiles_per_wg;
-    if (pl.G == 8) return launch_qmm5_g<8>(a, pro, epi, pl, st);
-    if (pl.G == 16) return launch_qmm5_g<16>(a, pro, epi, pl, st);
-    return launch_qmm5_g<20>(a, pro, epi, pl, st);
 }
 
 }  // namespace tl

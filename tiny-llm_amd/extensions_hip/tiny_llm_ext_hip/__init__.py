@@ -572,7 +572,7 @@ ATTN_PARTIAL_ROW = 128 + 4  # floats per (head, split) row of decode-attention s
 # values of tl_linear_info.kernel (what RAN); the `kernel` argument of decode_linear selects: 0 engine routing, 1 GEMV,
 # 2 skinny matmul (grid by shape), 3 / 4 skinny matmul on its one-shot / persistent grid
 LINEAR_KERNELS = {1: "qmv3 (fused MFMA GEMV)", 2: "qmm3 (skinny MFMA matmul + slice reduction)",
-                  3: "qmv (packed-dot GEMV fallback)", 4: "prefill GEMM path", 5: "qmm5 (full-row persistent MFMA matmul)"}
+                  3: "qmv (packed-dot GEMV fallback)", 4: "prefill GEMM path"}
 
 
 class TiledW4:
