@@ -25,6 +25,8 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
         float acc[IN_PER];
 #pragma unroll
         for (int e = 0; e < IN_PER; ++e) acc[e] = 0.f;
+        uint2 rv = uint2{0u, 0u};  // the residual values go out with the first slices, not behind the last (one round trip, not two)
+        if constexpr (EPI == EPI_RESIDUAL) rv = *reinterpret_cast<const uint2 *>(residual + in0);
         for (int s0 = 0; s0 < slices; s0 += 8) {
             f32x4 x[8][IN_PER / 4];
 #pragma unroll
@@ -54,7 +56,6 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
             }
             *reinterpret_cast<uint2 *>(out + (size_t)m * (K / 2) + (size_t)q * 4) = *reinterpret_cast<const uint2 *>(o);
         } else if constexpr (EPI == EPI_RESIDUAL) {
-            const uint2 rv = *reinterpret_cast<const uint2 *>(residual + in0);
             const uint16_t *rr = reinterpret_cast<const uint16_t *>(&rv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = BF16::from_float(BF16::to_float(rr[e]) + bf16_round(acc[e]));
