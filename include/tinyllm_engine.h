@@ -230,7 +230,8 @@ int tl_tiled_w4_create(const tl_w4 *w, void *stream, tl_tiled_w4 **out);
 void tl_tiled_w4_destroy(tl_tiled_w4 *t);
 
 /* Which kernel a projection ran: 1 = fused MFMA GEMV (qmv3: p = MR, KS, CW, LM, workgroups), 2 = skinny MFMA matmul +
- * slice reduction (qmm3: p = MB, TW, LM, slices, tile groups), 3 = packed-dot GEMV fallback, 4 = prefill GEMM path. */
+ * slice reduction (qmm3: p = MB, TW, LM, slices, tile groups), 3 = packed-dot GEMV fallback, 4 = prefill GEMM path,
+ * 5 = register-resident batched matmul (qmm6: p = MB, groups per wave, weight sets, row blocks, workgroups). */
 typedef struct tl_linear_info {
     int kernel;
     int launches;
@@ -242,9 +243,11 @@ typedef struct tl_linear_info {
 /* out = epilogue(prologue(a) @ W^T) over M (1..64) bf16 rows, exactly as one projection of a decode step:
  *   prologue 0 none | 1 RMSNorm(a, norm_w, eps) rounded to bf16;  epilogue 0 store | 1 residual + bf16(acc) |
  *   2 SwiGLU over interleaved (gate_i, up_i) rows -> out [M, rows/2].
- *   kernel 0 = the engine's routing by M and matrix size, 1 = force the fused GEMV (M <= 8), 2 = force the skinny matmul
- *   (grid chosen by shape as the engine does), 3 / 4 = the skinny matmul on its one-shot / persistent grid.
- * The engine uses the pairs (1,0) qkv / lm_head, (0,1) wo / w_down, (1,2) gate|up, (0,0). */
+ *   kernel 0 = the routing of a single projection by M and matrix size, 1 = force the fused GEMV (M <= 8), 2 = force the skinny matmul
+ *   (grid chosen by shape as the engine does), 3 / 4 = the skinny matmul on its one-shot / persistent grid, 5 = the register-resident
+ *   matmul of a batched decode step (csrc/qmm6.h; prologue 0, or 3 through tl_decode_linear_ex).
+ * The engine uses the pairs (1,0) qkv / lm_head, (0,1) wo / w_down, (1,2) gate|up, (0,0) -- and at 5..64 rows, through kernel 5,
+ * (3,0) qkv / lm_head, (0,1) + ss_out + out_w for wo / w_down, (3,2) gate|up: rows travel weighted between the projections. */
 size_t tl_decode_linear_workspace_bytes(int M, int rows, int cols);
 int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
                      const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,
@@ -263,7 +266,9 @@ int tl_decode_linear(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int
  *   ss_in_dev [M][ss_in_n] (prologues 1 and 3): partial sums of squares of each row, added instead of re-derived (the GEMV: any
  *     multiple of 4 up to 256 partials, and so does the skinny matmul).
  *   epilogue 1 through the GEMV: ss_out_dev [M][rows / 16] receives the sum of squares of every 16 stored bf16 outputs;
- *     norm_out_dev [rows] + out_w_dev [M][rows]: also store bf16(out * norm_out). */
+ *     norm_out_dev [rows] + out_w_dev [M][rows]: also store bf16(out * norm_out).
+ *   kernel 5 (M <= 64): prologue 3 with epilogue 0 or 2 (ss_in_dev required), prologue 0 with epilogue 0 or 1; epilogue 1 takes
+ *     ss_out_dev / norm_out_dev + out_w_dev as above. */
 typedef struct tl_linear_ex {
     const float *merge_ws_dev;
     int n_splits;
@@ -290,6 +295,11 @@ int tl_decode_gemv_plan(int M, int rows, int cols, int *out5);
 /* 1 when the library holds a fused-GEMV kernel for (rows per workgroup, reduction split, waves, groups per wave): a plan is only
  * ever "taken" (tl_decode_gemv_plan returns 1) for such a combination; anything else decodes through the packed-dot GEMV. */
 int tl_decode_gemv_variant_compiled(int MR, int KS, int CW, int LM);
+/* The register-resident matmul of a batched decode step (csrc/qmm6.h): M rows against [rows, cols] -> out6 = {16-row blocks per
+ * workgroup, quantisation groups per wave, weight sets, row blocks, workgroups per row block, tiles per workgroup}; returns 1 when
+ * the kernel takes the shape.  tl_decode_batched_variant_compiled: 1 when the library holds a kernel for (row blocks, groups per wave). */
+int tl_decode_batched_plan(int M, int rows, int cols, int *out6);
+int tl_decode_batched_variant_compiled(int MB, int GPW);
 int tl_decode_attention_plan(int batch, int max_context, int num_heads, int num_kv_heads, int *out3);
 
 typedef struct tl_attention_info {

@@ -117,3 +117,44 @@ def test_attention_plan_knobs_are_read(lib, monkeypatch):
     monkeypatch.delenv("TL_ATTN_MAX_SPLITS")
     monkeypatch.setenv("TL_ATTN_RQ", "4")
     assert attention_plan(lib, 1, 300)[2] == 4
+
+
+def batched_plan(lib, M, rows, cols):
+    out = (ctypes.c_int * 6)()
+    ok = lib.tl_decode_batched_plan(M, rows, cols, out)
+    return ok, tuple(out)
+
+
+def test_register_resident_matmul_plans_at_qwen3_4b_shapes(lib):
+    """csrc/qmm6.h: (16-row blocks per workgroup, groups per wave) such that MB x GPW x 16 fragment registers fit one wave per SIMD
+    (<= 320); rows beyond a workgroup's block go to further workgroups over the same tiles; one workgroup per CU and row block."""
+    for M, blocks in ((5, 1), (16, 1), (17, 2), (32, 2), (33, 3), (64, 4)):
+        for name, (rows, cols) in QWEN3_4B.items():
+            ok, (MB, GPW, sets, row_blocks, wgs, tpw) = batched_plan(lib, M, rows, cols)
+            assert ok == 1, f"{name} at {M} rows"
+            assert GPW * 4 >= cols // 128 and MB * GPW * 16 <= 320 and MB * row_blocks >= blocks, f"{name} at {M} rows: {(MB, GPW, row_blocks)}"
+            assert wgs * tpw >= rows // 16 and (wgs - 1) * tpw < rows // 16, f"{name} at {M} rows: tiles {rows // 16} over {wgs} x {tpw}"
+            assert wgs * row_blocks <= 256 or tpw == 1, f"{name} at {M} rows: more than one workgroup per CU while a workgroup walks several tiles"
+            assert sets == 1 if tpw == 1 else sets >= 2 or GPW > 8, f"{name} at {M} rows: a workgroup that walks tiles keeps a tile in flight"
+    assert batched_plan(lib, 64, 19456, 2560)[1][:4] == (4, 5, 2, 1)
+    assert batched_plan(lib, 64, 2560, 4096)[1][:4] == (2, 8, 2, 2) or batched_plan(lib, 64, 2560, 4096)[1][:4] == (2, 8, 1, 2)
+    assert batched_plan(lib, 64, 2560, 9728)[1][:2] == (1, 19) and batched_plan(lib, 64, 2560, 9728)[1][3] == 4
+    assert batched_plan(lib, 65, 2560, 2560)[0] == 0 and batched_plan(lib, 8, 100, 2560)[0] == 0 and batched_plan(lib, 8, 2560, 100)[0] == 0
+
+
+@pytest.mark.parametrize("model", list(MODEL_SHAPES))
+def test_every_taken_batched_plan_has_a_compiled_kernel(lib, model):
+    hidden, q_dim, qkv_dim, inter, vocab = MODEL_SHAPES[model]
+    projections = {"qkv": (qkv_dim, hidden), "wo": (hidden, q_dim), "gate_up": (2 * inter, hidden), "down": (hidden, inter),
+                   "lm_head": (vocab, hidden)}
+    for name, (rows, cols) in projections.items():
+        for M in (5, 8, 16, 17, 32, 33, 64):
+            ok, (MB, GPW, sets, row_blocks, wgs, tpw) = batched_plan(lib, M, rows, cols)
+            if ok:
+                assert lib.tl_decode_batched_variant_compiled(MB, GPW) == 1, f"{model} {name} at {M} rows: {(MB, GPW)} is taken but not compiled"
+                assert GPW * 4 >= (cols + 127) // 128, f"{model} {name} at {M} rows: the waves do not cover the reduction"
+
+
+def test_the_batched_planners_variant_predicate_is_the_instantiation_table(lib):
+    table = {(mb, gpw) for mb in range(1, 9) for gpw in range(1, 33) if lib.tl_decode_batched_variant_compiled(mb, gpw)}
+    assert table == {(1, 2), (1, 4), (1, 5), (1, 8), (1, 19), (2, 2), (2, 4), (2, 5), (2, 8), (4, 2), (4, 4), (4, 5)}

@@ -1,0 +1,131 @@
+"""GPU parity of the register-resident batched-decode matmul (csrc/qmm6.h, round 4): the kernel that takes every projection of a
+5..64-row decode step -- rows in registers as MFMA A operands, the reduction dimension split across the four waves of a workgroup,
+the epilogue (store / residual + sums of squares + weighted rows / SwiGLU) inside the launch, RMSNorm as `weighted rows in, 1 / rms on
+the sums`.  Called through the kernel-level C entry (tl_decode_linear / tl_decode_linear_ex, kernel 5) at the real Qwen3-4B shapes and
+held against the numpy oracle on the seeded matrices of tests/test_decode_kernels_gpu.py, the way the reference tests its matvec per
+shape (tests_refsol/test_week_2_day_3.py:89-118; kernel semantics: src/extensions_ref/src/quantized_matmul.metal:441-538).
+
+Tolerances: the plain allowance of test_decode_kernels_gpu.py (one bf16 step of the accumulated value, two for a residual); for
+weighted rows additionally the 6-sigma term of the moved rounding point (x * w rounded instead of x * inv * w), exactly as the
+weighted-row GEMV test there derives it.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tiny_oracle as O
+from helpers import assert_within, bf16_ulp, log_parity
+from test_decode_kernels_gpu import (DEV, EPS, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, PRO_NONE, PRO_RMS_WEIGHTED, PROJECTIONS, _Projection,
+                                     _bf16_host, _cache, _weighted_rows_case, ext)  # noqa: F401  (ext is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+ROWS = [5, 8, 16, 17, 32, 33, 48, 64]
+# (16-row blocks per workgroup, groups per wave) the planner picks: the fragments of MB x GPW x 4 k-steps must fit the register file
+PLAN = {"qkv": {1: (1, 5), 2: (2, 5), 3: (4, 5), 4: (4, 5)}, "gate_up": {1: (1, 5), 2: (2, 5), 3: (4, 5), 4: (4, 5)},
+        "lm_head": {1: (1, 5), 2: (2, 5), 3: (4, 5), 4: (4, 5)}, "wo": {1: (1, 8), 2: (2, 8), 3: (2, 8), 4: (2, 8)},
+        "down": {1: (1, 19), 2: (1, 19), 3: (1, 19), 4: (1, 19)}}
+
+
+def _proj(ext, name):
+    if name not in _cache:
+        _cache[name] = _Projection(ext, name)
+    return _cache[name]
+
+
+def _assert_plan(name, M, info, what):
+    blocks = (M + 15) // 16
+    mb, gpw = PLAN[name][blocks]
+    assert info["kernel"] == 5 and info["launches"] == 1, f"{what}: {info}"
+    assert (info["p"][0], info["p"][1]) == (mb, gpw), f"{what}: planned (MB, GPW) {info['p'][:2]}, expected {(mb, gpw)}"
+    assert info["p"][3] == (blocks + mb - 1) // mb, f"{what}: row blocks {info['p']}"
+
+
+@pytest.mark.parametrize("M", ROWS)
+@pytest.mark.parametrize("name", ["qkv", "wo", "down", "lm_head"])
+def test_plain_rows_store_and_residual(ext, name, M):
+    """Plain bf16 rows: store (qkv / lm_head matrices) and residual add (wo / w_down) with the producer's hand-over -- per (row, 16-row
+    tile) sums of squares of the stored values and the rows weighted by the consumer's RMSNorm weight."""
+    p = _proj(ext, name)
+    if p.epi == EPI_RESIDUAL:
+        norm_out = (1.0 + 0.05 * torch.randn((p.K,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))).to(torch.bfloat16)
+        got, info = ext.decode_linear(p.tiled, p.a[:M].contiguous(), prologue=PRO_NONE, epilogue=EPI_RESIDUAL, residual=p.residual[:M].contiguous(),
+                                      eps=EPS, kernel=5, want_ss_out=True, norm_out=norm_out)
+        what = f"qmm6 residual {name} M={M} {info['p']}"
+        _assert_plan(name, M, info, what)
+        assert_within(_bf16_host(got), p.want[(PRO_NONE, EPI_RESIDUAL)][:M], p.allowed[(PRO_NONE, EPI_RESIDUAL)][:M], what=what)
+        g64 = got.double()
+        assert torch.allclose(info["ss_out"].double(), (g64 * g64).reshape(M, p.K // 16, 16).sum(dim=2), rtol=1e-5, atol=1e-9), f"{what}: sums of squares"
+        assert torch.equal(info["out_w"], (got.float() * norm_out.float()).to(torch.bfloat16)), f"{what}: weighted rows"
+    else:
+        got, info = ext.decode_linear(p.tiled, p.a[:M].contiguous(), prologue=PRO_NONE, epilogue=EPI_STORE, eps=EPS, kernel=5)
+        what = f"qmm6 store {name} M={M} {info['p']}"
+        _assert_plan(name, M, info, what)
+        assert_within(_bf16_host(got), p.want[(PRO_NONE, EPI_STORE)][:M], p.allowed[(PRO_NONE, EPI_STORE)][:M], what=what)
+
+
+@pytest.mark.parametrize("M", ROWS)
+@pytest.mark.parametrize("name", ["qkv", "gate_up", "lm_head"])
+def test_weighted_rows_against_the_reference_order(ext, name, M):
+    """Rows weighted by their producer + its 160 partial sums of squares per row: bf16(inv * (bf16(x w) @ W^T)) against the reference's
+    bf16(bf16(x inv w) @ W^T) (FastRMSNorm then the matvec).  One rounding per staged element on both sides, of different products:
+    sigma^2 = 2 (u^2 / 12) sum_n (a_n W_kn)^2, u <= 2^-7; 6 sigma on top of the plain allowance."""
+    p = _proj(ext, name)
+    a_w, ss = _weighted_rows_case(p, M)
+    got, info = ext.decode_linear(p.tiled, a_w, prologue=PRO_RMS_WEIGHTED, epilogue=p.epi, eps=EPS, kernel=5, ss_in=ss)
+    what = f"qmm6 weighted rows {name} M={M} {info['p']}"
+    _assert_plan(name, M, info, what)
+    normed = O.rms_norm_fast(_bf16_host(p.a[:M]), _bf16_host(p.norm_w), EPS)
+    pre = p.want[(p.pro, p.epi)][:M] if p.epi == EPI_STORE else O.quantized_matmul(p.scales_host, p.biases_host, normed, p.packed_host, "bf16")
+    sigma = np.sqrt(2.0 / 12.0) * 2.0 ** -7 * np.sqrt(p.squared_dot(normed))
+    floor = 2e-4 * max(1.0, p.scale)
+    if p.epi == EPI_SWIGLU:
+        g, u = pre[:, 0::2].astype(np.float64), pre[:, 1::2].astype(np.float64)
+        dg, du = 6.0 * sigma[:, 0::2], 6.0 * sigma[:, 1::2]
+        want = O.swiglu(pre[:, 0::2], pre[:, 1::2])
+        allowed = 1.1 * (bf16_ulp(g) + floor + dg) * np.abs(u) + (bf16_ulp(u) + floor + du) * np.abs(g / (1 + np.exp(-g))) + bf16_ulp(want)
+    else:
+        want = pre
+        allowed = bf16_ulp(pre) + floor + 6.0 * sigma
+    assert_within(_bf16_host(got), want, allowed, what=what)
+    err = np.abs(_bf16_host(got).astype(np.float64) - want)
+    log_parity({"what": "qmm6_weighted_rows", "name": name, "M": M, "max_abs_err": float(err.max()),
+                "share_of_allowance_max": float((err / allowed).max()), "p": info["p"]})
+
+
+def test_partial_sums_of_squares_in_any_supported_count(ext):
+    """8 partials per row (what the embedding kernels leave ahead of layer 0) give the same values as 160."""
+    p = _proj(ext, "qkv")
+    M = 24
+    a_w, ss160 = _weighted_rows_case(p, M)
+    ss8 = torch.zeros((M, 8), dtype=torch.float32, device=DEV)
+    ss8[:, 0] = ss160.double().sum(dim=1).float()
+    a, ia = ext.decode_linear(p.tiled, a_w, prologue=PRO_RMS_WEIGHTED, epilogue=EPI_STORE, eps=EPS, kernel=5, ss_in=ss160)
+    b, ib = ext.decode_linear(p.tiled, a_w, prologue=PRO_RMS_WEIGHTED, epilogue=EPI_STORE, eps=EPS, kernel=5, ss_in=ss8)
+    assert ia["kernel"] == ib["kernel"] == 5
+    diff = (a.float() - b.float()).abs()
+    assert float((diff > 0).float().mean()) < 0.01 and float(diff.max()) <= float(bf16_ulp(np.abs(_bf16_host(a)).max())), \
+        "the two partial counts may differ by the last bit of 1 / rms only"
+
+
+def test_refusals_name_the_cause(ext):
+    p = _proj(ext, "qkv")
+    with pytest.raises(RuntimeError, match="plain rows|weighted rows"):
+        ext.decode_linear(p.tiled, p.a[:8].contiguous(), prologue=1, epilogue=EPI_STORE, norm_weight=p.norm_w, eps=EPS, kernel=5)
+    with pytest.raises(RuntimeError, match="ss_in"):
+        ext.decode_linear(p.tiled, p.a[:8].contiguous(), prologue=PRO_RMS_WEIGHTED, epilogue=EPI_STORE, eps=EPS, kernel=5)
+
+
+@pytest.mark.parametrize("M", [5, 16, 33, 64])
+def test_slice_reduction_of_w_down_leaves_the_weighted_rows(ext, M):
+    """w_down stays on the K-sliced matmul at 5..64 rows (76 groups against 160 tiles: csrc/engine.hip); its slice reduction hands the
+    next projection the rows weighted by that projection's RMSNorm weight, bf16(out * norm_out), next to out itself."""
+    p = _proj(ext, "down")
+    norm_out = (1.0 + 0.05 * torch.randn((p.K,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))).to(torch.bfloat16)
+    got, info = ext.decode_linear(p.tiled, p.a[:M].contiguous(), prologue=PRO_NONE, epilogue=EPI_RESIDUAL, residual=p.residual[:M].contiguous(),
+                                  eps=EPS, kernel=2, norm_out=norm_out)
+    what = f"skinny matmul + reduction with weighted rows, w_down M={M} {info['p']}"
+    assert info["kernel"] == 2 and info["launches"] == 2, what
+    assert_within(_bf16_host(got), p.want[(PRO_NONE, EPI_RESIDUAL)][:M], p.allowed[(PRO_NONE, EPI_RESIDUAL)][:M], what=what)
+    assert torch.equal(info["out_w"], (got.float() * norm_out.float()).to(torch.bfloat16)), f"{what}: weighted rows"

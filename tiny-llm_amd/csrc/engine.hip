@@ -16,6 +16,7 @@
 #include "qmv.h"
 #include "qmv3.h"
 #include "qmm3.h"
+#include "qmm6.h"
 
 namespace tl {
 
@@ -94,6 +95,9 @@ struct tl_engine {
     int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
     bool use_qmm3 = true;   // TL_NO_QMM3=1 at create: rows > 8 go through the prefill GEMM path instead
+    // 5 .. 64 rows: the register-resident matmul (qmm6.h) takes every projection whose plan fits; rows travel WEIGHTED between the
+    // projections (qkv <- w_down / the embedding, gate|up <- wo).  TL_NO_QMM6=1 at create: the K-sliced skinny matmul as before.
+    bool use_qmm6 = true;
     int attn_rq = 0;             // query heads per decode-attention workgroup; 0 = by context (TL_ATTN_RQ at create: 1 or 4)
     int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup
     int attn_rq1_batch = 2;      // ... and up to this many sequences; at 4 the re-read windows cost 261 vs 180 us
@@ -312,6 +316,51 @@ static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
     return TL_OK;
 }
 
+// Does the register-resident matmul (qmm6.h) take this projection at M rows?
+static bool qmm6_takes(const tl_engine *e, const tl_w4 &w, int M) {
+    return e->use_qmm6 && e->force_linear == 0 && M >= e->qmm3_min_rows && M <= 64 && e->tiled.count(w.weight_dev) != 0 && qmm6_plan(M, w.cols, w.rows).ok;
+}
+// One projection through qmm6: `a` plain rows, or (ss_in given) WEIGHTED rows whose 1 / rms scales the result.  EPI_RESIDUAL: ss_out
+// receives rows / 16 partial sums of squares per row, out_w the rows weighted for the next RMSNorm (norm_out).
+static int engine_qmm6(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int epi, const uint16_t *residual,
+                       ProfCtx *pc, int kind, const float *ss_in, int ss_in_n, float *ss_out, int *ss_out_n, const void *norm_out,
+                       uint16_t *out_w) {
+    if (ss_out_n) *ss_out_n = 0;
+    const auto tiled = e->tiled.find(w.weight_dev);
+    TL_REQUIRE(tiled != e->tiled.end(), "engine: the register-resident matmul needs the tiled weights");
+    const Qmm6Plan pl = qmm6_plan(M, w.cols, w.rows);
+    TL_REQUIRE(pl.ok, "engine: the register-resident matmul does not cover this shape");
+    Qmm6Args q{};
+    q.wt = tiled->second.wt;
+    q.sbt = tiled->second.sbt;
+    q.a = a;
+    q.out = out;
+    q.residual = residual;
+    q.norm_out = (const uint16_t *)norm_out;
+    q.out_w = out_w;
+    q.ss = ss_in;
+    q.ss_n = ss_in ? ss_in_n : 0;
+    q.ss_out = epi == EPI_RESIDUAL ? ss_out : nullptr;
+    q.eps = e->cfg.rms_norm_eps;
+    q.M = M;
+    q.N = w.cols;
+    q.K = w.rows;
+    q.prof = pc ? pc->buf : nullptr;
+    int n_wg = 0;
+    if (launch_qmm6_bf16(q, epi, e->stream, &n_wg) != 0) return fail(TL_ERR_UNSUPPORTED, "engine: register-resident matmul launch failed");
+    if (pc) prof_after(e, pc, kind, n_wg);
+    if (ss_out_n && q.ss_out) *ss_out_n = w.rows / 16;
+    if (e->linfo) {
+        tl_linear_info &li = *e->linfo;
+        li.kernel = 5;
+        li.launches += 1;
+        li.rows_per_pass = pl.MB * 16;
+        li.p[0] = pl.MB, li.p[1] = pl.GPW, li.p[2] = pl.NSETS, li.p[3] = pl.row_blocks, li.p[4] = n_wg;
+    }
+    TL_CHECK_LAUNCH("engine register-resident matmul");
+    return TL_OK;
+}
+
 // One projection of the decode step over `M` activation rows.  Up to 4 rows: the fused MFMA GEMV (weights streamed once,
 // RMSNorm / residual / SwiGLU inside).  5 .. 64 rows: the skinny matmul (qmm3.h) for every projection -- at 8 rows the GEMV
 // re-stages all rows in every workgroup (qkv 10.3 us against 4.8 + reduction; profiles/r02_labs/batched_rows_routing.log).  More rows, or TL_NO_QMM3: the
@@ -351,7 +400,8 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
     const float *ss_in = qmm3_takes_ss(ss_in_n) ? ss_in_any : nullptr;
     if (gemv_takes_rows(e, M))
         return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind, ss_in_any, ss_in_n, ss_out, ss_out_n, norm_out, out_w);
-    TL_REQUIRE(out_w == nullptr && pro != PRO_RMS_WEIGHTED, "engine: weighted rows are a route of the GEMV only");
+    TL_REQUIRE(pro != PRO_RMS_WEIGHTED && (out_w == nullptr || (epi == EPI_RESIDUAL && norm_out != nullptr)),
+               "engine: the skinny matmul leaves weighted rows behind a residual epilogue only, and takes none");
     const tl_engine_config &c = e->cfg;
     const uint16_t *in = a;
     // qmm3_min_rows .. 64 rows (batched decode): K-sliced skinny MFMA matmul over the tiled weights, then the slice
@@ -389,7 +439,8 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
             keep->plane = (long)M * w.rows;
         } else {
             int reduce_wg = 0;
-            if (launch_qmm3_reduce_bf16(q.partial, p3.slices, M, w.rows, epi, residual, out, q.prof, e->stream, ss_dst, &reduce_wg) != 0)
+            if (launch_qmm3_reduce_bf16(q.partial, p3.slices, M, w.rows, epi, residual, out, q.prof, e->stream, ss_dst, &reduce_wg,
+                                        out_w ? (const uint16_t *)norm_out : nullptr, out_w) != 0)
                 return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul reduction launch failed");
             if (pc) prof_after(e, pc, kind, reduce_wg);
         }
@@ -407,6 +458,7 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
         return TL_OK;
     }
     if (e->force_linear == 2) return fail(TL_ERR_UNSUPPORTED, "engine: the skinny matmul does not cover this shape");
+    TL_REQUIRE(out_w == nullptr, "engine: no kernel leaves weighted rows for this shape");
     if (M <= 8) return engine_qmv(e, w, a, out, M, pro, epi, norm_w, residual, pc, kind, ss_in_any, ss_in_n, ss_out, ss_out_n);
     if (pro == PRO_RMSNORM) {
         TL_TRY(tl_rms_norm(a, norm_w, e->xn, M, w.cols, c.rms_norm_eps, TL_BF16, e->stream));
@@ -645,8 +697,45 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     // x enters the step from the embedding gather (embed_slots_kernel / the previous step's step_end_kernel), which leaves the
     // per-row partial sums of squares in ss_x; every slice reduction that rewrites x or h refreshes them (or says it did not)
     int x_ss = QM3_SS;  // partials per row in ss_x (0 = none): QM3_SS from the embedding kernels, then whatever the last writer of x left
+    // 5 .. 64 rows on the register-resident matmul: xn holds x weighted by the NEXT RMSNorm's weight whenever xw is set (written by
+    // the w_down epilogue of the previous layer, or by one pointwise launch ahead of layer 0)
+    bool xw = false;
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
+        if (!e->is_moe(l) && w.wgu.weight_dev != nullptr && qmm6_takes(e, w.wqkv, batch) && qmm6_takes(e, w.wo, batch) &&
+            qmm6_takes(e, w.wgu, batch) && x_ss > 0 && qmm3_takes_ss(x_ss) && qmm3_takes_ss(w.wo.rows / 16)) {
+            if (!xw) {
+                const long n8 = (long)batch * c.hidden_size / 8;
+                hipLaunchKernelGGL(weight_rows_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, e->x, (const uint16_t *)w.input_norm_dev,
+                                   e->xn, n8, c.hidden_size / 8);
+            }
+            TL_TRY(engine_qmm6(e, w.wqkv, e->xn, e->qkv, batch, EPI_STORE, nullptr, pc, 0, e->ss_x, x_ss, nullptr, nullptr, nullptr, nullptr));
+            bool merged = false;
+            TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, nullptr, &w.wo, &merged));
+            TL_REQUIRE(!merged, "engine: a batched step left its attention windows unmerged");
+            int h_ss = 0;
+            TL_TRY(engine_qmm6(e, w.wo, e->attn, e->h, batch, EPI_RESIDUAL, e->x, pc, 1, nullptr, 0, e->ss_h, &h_ss, w.post_norm_dev, e->xn));
+            TL_TRY(engine_qmm6(e, w.wgu, e->xn, e->act, batch, EPI_SWIGLU, nullptr, pc, 2, e->ss_h, h_ss, nullptr, nullptr, nullptr, nullptr));
+            // the rows w_down leaves are weighted for their next reader: the next layer's input norm, or the final norm ahead of lm_head
+            const void *next_norm = l + 1 < c.num_layers ? e->layers[l + 1].input_norm_dev : e->final_norm;
+            // w_down: 76 groups against 160 tiles -- every workgroup of the register-resident kernel would pull 311 KB of rows for ONE tile
+            // (measured 9.0 us at 8 rows, 18.9 at 64, against 6.5 / 13.0 for the K-sliced matmul + reduction): the sliced kernel keeps
+            // it wherever its plan exists, and its reduction leaves the weighted rows
+            const Qmm3Plan pd = qmm3_plan(batch, w.wdown.cols, w.wdown.rows, e->qmm3_mode);
+            if (e->use_qmm3 && pd.ok && qmm3_reduce_can_emit_ss(EPI_RESIDUAL, w.wdown.rows) && e->fuse_norm) {
+                TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, nullptr, nullptr,
+                                     QM3_SS, &x_ss, next_norm, e->xn));
+                xw = x_ss > 0;
+            } else if (qmm6_takes(e, w.wdown, batch) && qmm3_takes_ss(w.wdown.rows / 16)) {
+                TL_TRY(engine_qmm6(e, w.wdown, e->act, e->x, batch, EPI_RESIDUAL, e->h, pc, 3, nullptr, 0, e->ss_x, &x_ss, next_norm, e->xn));
+                xw = true;
+            } else {
+                TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, nullptr, nullptr, QM3_SS, &x_ss));
+                xw = false;
+            }
+            continue;
+        }
+        xw = false;
         KeptPartials qkv_parts;
         const bool keep_qkv = e->attn_qkv_partials && attn_takes_qkv_partials(c.head_dim, sp.rq);
         TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0,
@@ -680,8 +769,10 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     }
     e->want_tile_max = e->lm_tile_max_on;
     e->tile_max_rows = 0;
-    const int head_rc = engine_linear(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4,
-                                      x_ss ? e->ss_x : nullptr, nullptr, nullptr, nullptr, x_ss);
+    const int head_rc = xw && qmm6_takes(e, e->head(), batch) && qmm3_takes_ss(x_ss)
+                            ? engine_qmm6(e, e->head(), e->xn, e->logits, batch, EPI_STORE, nullptr, pc, 4, e->ss_x, x_ss, nullptr, nullptr, nullptr, nullptr)
+                            : engine_linear(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4,
+                                            x_ss ? e->ss_x : nullptr, nullptr, nullptr, nullptr, x_ss);
     e->want_tile_max = false;
     TL_TRY(head_rc);
     StepEndArgs s{};
@@ -952,6 +1043,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (const char *q = getenv("TL_LMHEAD_TILE_MAX")) e->lm_tile_max_on = atoi(q) != 0;
     if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
+    e->use_qmm6 = getenv("TL_NO_QMM6") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
     read_attention_knobs(e);
 
@@ -1827,13 +1919,14 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
     TL_REQUIRE(prologue == PRO_ATTN_MERGE || a_dev, "decode_linear: null activation rows");
     TL_REQUIRE(prologue != PRO_RMSNORM || norm_w_dev, "decode_linear: the RMSNorm prologue needs its weight");
     TL_REQUIRE(epilogue != EPI_RESIDUAL || residual_dev, "decode_linear: the residual epilogue needs the residual rows");
-    TL_REQUIRE(kernel >= 0 && kernel <= 4,
-               "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV), 2 (skinny matmul), 3 / 4 (its one-shot / persistent grid)");
+    TL_REQUIRE(kernel >= 0 && kernel <= 5,
+               "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV), 2 (skinny matmul), 3 / 4 (its one-shot / persistent grid), 5 (register-resident matmul)");
     TL_REQUIRE(epilogue != EPI_SWIGLU || w->w.rows % 2 == 0, "decode_linear: SwiGLU needs an even number of weight rows");
     // the engine's own fused variants: RMSNorm+store (qkv, lm_head), residual (wo, w_down), RMSNorm+SwiGLU (gate|up), plain;
     // through tl_decode_linear_ex also: merged attention partials + residual (wo of one row), weighted rows + SwiGLU (gate|up)
     TL_REQUIRE((prologue == PRO_NONE && epilogue != EPI_SWIGLU) || (prologue == PRO_RMSNORM && epilogue != EPI_RESIDUAL) ||
-                   (prologue == PRO_ATTN_MERGE && epilogue == EPI_RESIDUAL) || (prologue == PRO_RMS_WEIGHTED && epilogue == EPI_SWIGLU),
+                   (prologue == PRO_ATTN_MERGE && epilogue == EPI_RESIDUAL) || (prologue == PRO_RMS_WEIGHTED && epilogue == EPI_SWIGLU) ||
+                   (kernel == 5 && prologue == PRO_RMS_WEIGHTED && epilogue == EPI_STORE),
                "decode_linear: no fused variant for this prologue / epilogue pair");
     const size_t need = tl_decode_linear_workspace_bytes(M, w->w.rows, w->w.cols);
     TL_REQUIRE(workspace_dev && workspace_bytes >= need, "decode_linear: workspace is missing or too small");
@@ -1845,7 +1938,7 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
     const size_t xn_bytes = align_up((size_t)M * w->w.cols * 2, 256);
     e.splitk_ws = (char *)workspace_dev + xn_bytes;
     e.splitk_ws_bytes = workspace_bytes - xn_bytes;
-    e.force_linear = kernel >= 2 ? 2 : kernel;
+    e.force_linear = kernel >= 2 && kernel <= 4 ? 2 : (kernel == 5 ? 0 : kernel);
     e.qmm3_mode = kernel == 3 ? 0 : (kernel == 4 ? 1 : -1);
     tl_linear_info li{};
     e.linfo = &li;
@@ -1857,13 +1950,30 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
         if (info) *info = li;
         return code;
     };
+    if (kernel == 5) {  // qmm6.h: plain rows, or weighted rows with their partial sums of squares
+        const bool weighted = prologue == PRO_RMS_WEIGHTED;
+        if (prologue == PRO_RMSNORM || prologue == PRO_ATTN_MERGE)
+            return done(fail(TL_ERR_INVALID, "decode_linear: the register-resident matmul takes plain rows (prologue 0) or weighted rows with ss_in (prologue 3)"));
+        if (weighted && (!ex || !ex->ss_in_dev || !qmm3_takes_ss(ex->ss_in_n)))
+            return done(fail(TL_ERR_INVALID, "decode_linear_ex: weighted rows need ss_in (a multiple of 4, at most 256 partials per row)"));
+        if (ex && ((ex->out_w_dev != nullptr) != (ex->norm_out_dev != nullptr) || ((ex->out_w_dev || ex->ss_out_dev) && epilogue != EPI_RESIDUAL)))
+            return done(fail(TL_ERR_INVALID, "decode_linear_ex: ss_out / (norm_out, out_w) belong to the residual epilogue; norm_out and out_w come together"));
+        if (!qmm6_plan(M, w->w.cols, w->w.rows).ok)
+            return done(fail(TL_ERR_UNSUPPORTED, "decode_linear: the register-resident matmul does not cover this shape"));
+        int ss_n6 = 0;
+        rc = engine_qmm6(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, epilogue, (const uint16_t *)residual_dev, nullptr, 0,
+                         weighted ? ex->ss_in_dev : nullptr, weighted ? ex->ss_in_n : 0, ex ? ex->ss_out_dev : nullptr, &ss_n6,
+                         ex ? ex->norm_out_dev : nullptr, ex ? (uint16_t *)ex->out_w_dev : nullptr);
+        return done(rc);
+    }
     if (!ex) {
         rc = engine_linear(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, prologue, epilogue, norm_w_dev,
                            (const uint16_t *)residual_dev, nullptr, 0);
         return done(rc);
     }
     // ---- the routes only the engine could reach before round 4 (qmv3.h: PRO_ATTN_MERGE, PRO_RMS_WEIGHTED, ss_in / ss_out, out_w)
-    const bool gemv_only = prologue == PRO_ATTN_MERGE || prologue == PRO_RMS_WEIGHTED || ex->ss_out_dev || ex->out_w_dev;
+    const bool skinny_forced = kernel >= 2 && kernel <= 4;  // its slice reduction also leaves weighted rows (not the GEMV's 16-row sums of squares)
+    const bool gemv_only = prologue == PRO_ATTN_MERGE || prologue == PRO_RMS_WEIGHTED || ex->ss_out_dev || (ex->out_w_dev && !skinny_forced);
     if (gemv_only && !(kernel == 1 || (kernel == 0 && M < e.qmm3_min_rows)))
         return done(fail(TL_ERR_INVALID, "decode_linear_ex: merged partials, weighted rows, ss_out and out_w are routes of the fused GEMV (kernel 1, or 0 with fewer than 5 rows)"));
     if ((ex->out_w_dev != nullptr) != (ex->norm_out_dev != nullptr) || (ex->out_w_dev && epilogue != EPI_RESIDUAL) ||
@@ -1903,7 +2013,8 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
     if (ex->ss_in_dev && !qmm3_takes_ss(ex->ss_in_n))
         return done(fail(TL_ERR_INVALID, "decode_linear_ex: the skinny matmul reads a multiple of 4, at most 256, partial sums of squares per row"));
     rc = engine_linear(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, prologue, epilogue, norm_w_dev,
-                       (const uint16_t *)residual_dev, nullptr, 0, ex->ss_in_dev, nullptr, nullptr, nullptr, ex->ss_in_dev ? ex->ss_in_n : 0);
+                       (const uint16_t *)residual_dev, nullptr, 0, ex->ss_in_dev, nullptr, nullptr, nullptr, ex->ss_in_dev ? ex->ss_in_n : 0,
+                       nullptr, ex->norm_out_dev, (uint16_t *)ex->out_w_dev);
     return done(rc);
 }
 
@@ -1996,6 +2107,13 @@ extern "C" int tl_decode_gemv_plan(int M, int rows, int cols, int *out5) {
     return pl.ok ? 1 : 0;
 }
 extern "C" int tl_decode_gemv_variant_compiled(int MR, int KS, int CW, int LM) { return qmv3_variant_in_table(MR, KS, CW, LM) ? 1 : 0; }
+extern "C" int tl_decode_batched_plan(int M, int rows, int cols, int *out6) {
+    if (!out6 || M < 1 || rows <= 0 || cols <= 0) return 0;
+    const Qmm6Plan pl = qmm6_plan(M, cols, rows);
+    out6[0] = pl.MB, out6[1] = pl.GPW, out6[2] = pl.NSETS, out6[3] = pl.row_blocks, out6[4] = pl.wgs, out6[5] = pl.tiles_per_wg;
+    return pl.ok ? 1 : 0;
+}
+extern "C" int tl_decode_batched_variant_compiled(int MB, int GPW) { return qmm6_variant_in_table(MB, GPW) ? 1 : 0; }
 extern "C" int tl_decode_attention_plan(int batch, int max_context, int num_heads, int num_kv_heads, int *out3) {
     if (!out3 || batch < 1 || max_context < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0) return 0;
     tl_engine e;

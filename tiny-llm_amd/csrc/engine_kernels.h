@@ -983,6 +983,20 @@ __global__ __launch_bounds__(256) void residual_add_kernel(const uint16_t *__res
     reinterpret_cast<uint4 *>(out)[idx] = *reinterpret_cast<const uint4 *>(o);
 }
 
+// out[row, :] = bf16(x[row, :] * w): rows weighted by an RMSNorm weight for a consumer that applies 1 / rms to its sums (qmm6.h);
+// one launch per batched step, ahead of layer 0 (every later layer gets its rows weighted by the w_down epilogue).  chunks of 8.
+__global__ __launch_bounds__(256) void weight_rows_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
+                                                          uint16_t *__restrict__ out, long n8, int chunks_per_row) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n8) return;
+    uint16_t a[8], g[8], o[8];
+    *reinterpret_cast<uint4 *>(a) = reinterpret_cast<const uint4 *>(x)[idx];
+    *reinterpret_cast<uint4 *>(g) = reinterpret_cast<const uint4 *>(w)[idx % chunks_per_row];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = BF16::from_float(BF16::to_float(a[e]) * BF16::to_float(g[e]));
+    reinterpret_cast<uint4 *>(out)[idx] = *reinterpret_cast<const uint4 *>(o);
+}
+
 // gu [T, 2I] with (gate_i, up_i) interleaved -> act [T, I] = bf16(silu(gate) * up)   (I % 4 == 0)
 __global__ __launch_bounds__(256) void swiglu_interleaved_kernel(const uint16_t *__restrict__ gu,
                                                                  uint16_t *__restrict__ act, long n4) {

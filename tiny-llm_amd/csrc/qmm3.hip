@@ -11,7 +11,8 @@ namespace tl {
 template <int EPI, bool SS>
 __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restrict__ partial, int slices, int M, int K,
                                                           const uint16_t *__restrict__ residual,
-                                                          uint16_t *__restrict__ out, float *__restrict__ ss_out, prof_t *prof) {
+                                                          uint16_t *__restrict__ out, float *__restrict__ ss_out, prof_t *prof,
+                                                          const uint16_t *__restrict__ norm_out, uint16_t *__restrict__ out_w) {
     __shared__ float wave_ss[4];
     const prof_t prof_t0 = prof_begin(prof);
     constexpr int IN_PER = EPI == EPI_SWIGLU ? 8 : 4;
@@ -25,8 +26,11 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
         float acc[IN_PER];
 #pragma unroll
         for (int e = 0; e < IN_PER; ++e) acc[e] = 0.f;
-        uint2 rv = uint2{0u, 0u};  // the residual values go out with the first slices, not behind the last (one round trip, not two)
-        if constexpr (EPI == EPI_RESIDUAL) rv = *reinterpret_cast<const uint2 *>(residual + in0);
+        uint2 rv = uint2{0u, 0u}, nv = uint2{0u, 0u};  // the residual values go out with the first slices, not behind the last (one round trip, not two)
+        if constexpr (EPI == EPI_RESIDUAL) {
+            rv = *reinterpret_cast<const uint2 *>(residual + in0);
+            if (out_w) nv = *reinterpret_cast<const uint2 *>(norm_out + (size_t)q * 4);  // uniform
+        }
         for (int s0 = 0; s0 < slices; s0 += 8) {
             f32x4 x[8][IN_PER / 4];
 #pragma unroll
@@ -60,6 +64,13 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = BF16::from_float(BF16::to_float(rr[e]) + bf16_round(acc[e]));
             *reinterpret_cast<uint2 *>(out + in0) = *reinterpret_cast<const uint2 *>(o);
+            if (out_w) {  // uniform: the rows weighted for the next RMSNorm's consumer (qmm6.h), bf16(out * norm_out)
+                const uint16_t *nn = reinterpret_cast<const uint16_t *>(&nv);
+                uint16_t ow[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ow[e] = BF16::from_float(BF16::to_float(o[e]) * BF16::to_float(nn[e]));
+                *reinterpret_cast<uint2 *>(out_w + in0) = *reinterpret_cast<const uint2 *>(ow);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = BF16::from_float(acc[e]);
@@ -87,17 +98,18 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
 }
 
 int launch_qmm3_reduce_bf16(const float *partial, int slices, int M, int K, int epi, const uint16_t *residual, uint16_t *out,
-                            prof_t *prof, hipStream_t st, float *ss_out, int *n_wg) {
+                            prof_t *prof, hipStream_t st, float *ss_out, int *n_wg, const uint16_t *norm_out, uint16_t *out_w) {
+    if ((out_w != nullptr) != (norm_out != nullptr) || (out_w && epi != EPI_RESIDUAL)) return -1;
     if (K % 8 != 0 || M < 1 || M > 65535) return -1;
     const int per_row = K / (epi == EPI_SWIGLU ? 8 : 4);
     const dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)M), block(256);
     if (ss_out && !qmm3_reduce_can_emit_ss(epi, K)) return -1;
     if (n_wg) *n_wg = (int)(grid.x * grid.y);
-    if (epi == EPI_SWIGLU) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_SWIGLU, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof);
-    else if (epi == EPI_RESIDUAL && ss_out) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_RESIDUAL, true>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof);
-    else if (epi == EPI_RESIDUAL) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_RESIDUAL, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof);
-    else if (ss_out) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_STORE, true>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof);
-    else hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_STORE, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof);
+    if (epi == EPI_SWIGLU) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_SWIGLU, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w);
+    else if (epi == EPI_RESIDUAL && ss_out) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_RESIDUAL, true>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w);
+    else if (epi == EPI_RESIDUAL) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_RESIDUAL, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w);
+    else if (ss_out) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_STORE, true>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w);
+    else hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_STORE, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

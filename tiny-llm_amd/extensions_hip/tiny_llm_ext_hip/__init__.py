@@ -139,6 +139,8 @@ _SIGNATURES.update({
                                   _P(_c_void_p)]),
     "tl_engine_set_moe_layer": (_c_int, [_c_void_p, _c_int, _P(TlMoeWeights)]),
     "tl_decode_gemv_plan": (_c_int, [_c_int, _c_int, _c_int, _P(_c_int)]),
+    "tl_decode_batched_plan": (_c_int, [_c_int, _c_int, _c_int, _P(_c_int)]),
+    "tl_decode_batched_variant_compiled": (_c_int, [_c_int, _c_int]),
     "tl_decode_attention_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _P(_c_int)]),
     "tl_engine_destroy": (None, [_c_void_p]),
     "tl_engine_synchronize": (_c_int, [_c_void_p]),
@@ -570,9 +572,9 @@ PRO_NONE, PRO_RMSNORM, PRO_ATTN_MERGE, PRO_RMS_WEIGHTED = 0, 1, 2, 3
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2
 ATTN_PARTIAL_ROW = 128 + 4  # floats per (head, split) row of decode-attention split partials: 128 value sums, max, sum, 2 pad
 # values of tl_linear_info.kernel (what RAN); the `kernel` argument of decode_linear selects: 0 engine routing, 1 GEMV,
-# 2 skinny matmul (grid by shape), 3 / 4 skinny matmul on its one-shot / persistent grid
+# 2 skinny matmul (grid by shape), 3 / 4 skinny matmul on its one-shot / persistent grid, 5 register-resident batched matmul
 LINEAR_KERNELS = {1: "qmv3 (fused MFMA GEMV)", 2: "qmm3 (skinny MFMA matmul + slice reduction)",
-                  3: "qmv (packed-dot GEMV fallback)", 4: "prefill GEMM path"}
+                  3: "qmv (packed-dot GEMV fallback)", 4: "prefill GEMM path", 5: "qmm6 (register-resident batched matmul)"}
 
 
 class TiledW4:
