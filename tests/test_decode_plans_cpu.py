@@ -133,9 +133,13 @@ def test_register_resident_matmul_plans_at_qwen3_4b_shapes(lib):
             ok, (MB, GPW, sets, row_blocks, wgs, tpw) = batched_plan(lib, M, rows, cols)
             assert ok == 1, f"{name} at {M} rows"
             assert GPW * 4 >= cols // 128 and MB * GPW * 16 <= 320 and MB * row_blocks >= blocks, f"{name} at {M} rows: {(MB, GPW, row_blocks)}"
-            assert wgs * tpw >= rows // 16 and (wgs - 1) * tpw < rows // 16, f"{name} at {M} rows: tiles {rows // 16} over {wgs} x {tpw}"
-            assert wgs * row_blocks <= 256 or tpw == 1, f"{name} at {M} rows: more than one workgroup per CU while a workgroup walks several tiles"
+            # several row blocks: the workgroups of one tile range sit a multiple of 8 apart (one XCD); the surplus ones find no tile and leave
+            spare = 7 if row_blocks > 1 else 0
+            assert wgs * tpw >= rows // 16 and (wgs - 1 - spare) * tpw < rows // 16, f"{name} at {M} rows: tiles {rows // 16} over {wgs} x {tpw}"
+            assert row_blocks == 1 or wgs % 8 == 0, f"{name} at {M} rows: {wgs} workgroups per row block"
+            assert wgs * row_blocks <= 256 + 8 * row_blocks or tpw == 1, f"{name} at {M} rows: more than one workgroup per CU while a workgroup walks several tiles"
             assert sets == 1 if tpw == 1 else sets >= 2 or GPW > 8, f"{name} at {M} rows: a workgroup that walks tiles keeps a tile in flight"
+            assert 4 * 7 + (sets - 1) * 2 * GPW <= 63, f"{name} at {M} rows: the counted waits of the transposer hold 6 bits"
     assert batched_plan(lib, 64, 19456, 2560)[1][:4] == (4, 5, 2, 1)
     assert batched_plan(lib, 64, 2560, 4096)[1][:4] == (2, 8, 2, 2) or batched_plan(lib, 64, 2560, 4096)[1][:4] == (2, 8, 1, 2)
     assert batched_plan(lib, 64, 2560, 9728)[1][:2] == (1, 19) and batched_plan(lib, 64, 2560, 9728)[1][3] == 4

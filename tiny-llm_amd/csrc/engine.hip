@@ -702,27 +702,48 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     bool xw = false;
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
-        if (!e->is_moe(l) && w.wgu.weight_dev != nullptr && qmm6_takes(e, w.wqkv, batch) && qmm6_takes(e, w.wo, batch) &&
-            qmm6_takes(e, w.wgu, batch) && x_ss > 0 && qmm3_takes_ss(x_ss) && qmm3_takes_ss(w.wo.rows / 16)) {
-            if (!xw) {
-                const long n8 = (long)batch * c.hidden_size / 8;
-                hipLaunchKernelGGL(weight_rows_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, e->x, (const uint16_t *)w.input_norm_dev,
-                                   e->xn, n8, c.hidden_size / 8);
+        // the sliced matmul as the producer of weighted rows (its reduction writes them): wo here, w_down below
+        auto sliced_leaves_weighted = [&](const tl_w4 &m) {
+            return e->use_qmm3 && e->fuse_norm && e->tiled.count(m.weight_dev) != 0 && qmm3_plan(batch, m.cols, m.rows, e->qmm3_mode).ok &&
+                   qmm3_reduce_can_emit_ss(EPI_RESIDUAL, m.rows);
+        };
+        const bool wo6_ok = !e->is_moe(l) && qmm6_takes(e, w.wo, batch) && qmm3_takes_ss(w.wo.rows / 16);
+        if (!e->is_moe(l) && w.wgu.weight_dev != nullptr && qmm6_takes(e, w.wgu, batch) && x_ss > 0 && qmm3_takes_ss(x_ss) &&
+            (wo6_ok || sliced_leaves_weighted(w.wo))) {
+            // gate|up and lm_head are the register-resident kernel's at every row count; qkv and wo where it measured ahead on a fast AND
+            // on a slow box (profiles/r04_labs/README.md: its per-workgroup copy of the rows rides the L2 -> CU path, the part of the chip
+            // that differs most between boxes): qkv up to 16 rows (beyond, the sliced matmul has no reduction launch to lose -- the
+            // attention kernel adds its slices), wo up to 16 and from 33 rows.  Both kinds of producer leave x / h weighted AND plain.
+            const bool qkv6 = batch <= 16 && qmm6_takes(e, w.wqkv, batch);
+            const bool wo6 = wo6_ok && (batch <= 16 || batch > 32 || !sliced_leaves_weighted(w.wo));
+            KeptPartials parts;
+            if (qkv6) {
+                if (!xw) {
+                    const long n8 = (long)batch * c.hidden_size / 8;
+                    hipLaunchKernelGGL(weight_rows_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, e->x, (const uint16_t *)w.input_norm_dev,
+                                       e->xn, n8, c.hidden_size / 8);
+                }
+                TL_TRY(engine_qmm6(e, w.wqkv, e->xn, e->qkv, batch, EPI_STORE, nullptr, pc, 0, e->ss_x, x_ss, nullptr, nullptr, nullptr, nullptr));
+            } else {
+                const bool keep_qkv = e->attn_qkv_partials && attn_takes_qkv_partials(c.head_dim, sp.rq);
+                TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0, e->ss_x, nullptr, nullptr,
+                                     keep_qkv ? &parts : nullptr, x_ss));
             }
-            TL_TRY(engine_qmm6(e, w.wqkv, e->xn, e->qkv, batch, EPI_STORE, nullptr, pc, 0, e->ss_x, x_ss, nullptr, nullptr, nullptr, nullptr));
             bool merged = false;
-            TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, nullptr, &w.wo, &merged));
+            TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, &parts, &w.wo, &merged));
             TL_REQUIRE(!merged, "engine: a batched step left its attention windows unmerged");
             int h_ss = 0;
-            TL_TRY(engine_qmm6(e, w.wo, e->attn, e->h, batch, EPI_RESIDUAL, e->x, pc, 1, nullptr, 0, e->ss_h, &h_ss, w.post_norm_dev, e->xn));
+            if (wo6) TL_TRY(engine_qmm6(e, w.wo, e->attn, e->h, batch, EPI_RESIDUAL, e->x, pc, 1, nullptr, 0, e->ss_h, &h_ss, w.post_norm_dev, e->xn));
+            else TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, nullptr, nullptr, QM3_SS, &h_ss,
+                                      w.post_norm_dev, e->xn));
+            TL_REQUIRE(h_ss > 0 && qmm3_takes_ss(h_ss), "engine: the wo projection left no sums of squares for its weighted rows");
             TL_TRY(engine_qmm6(e, w.wgu, e->xn, e->act, batch, EPI_SWIGLU, nullptr, pc, 2, e->ss_h, h_ss, nullptr, nullptr, nullptr, nullptr));
             // the rows w_down leaves are weighted for their next reader: the next layer's input norm, or the final norm ahead of lm_head
             const void *next_norm = l + 1 < c.num_layers ? e->layers[l + 1].input_norm_dev : e->final_norm;
             // w_down: 76 groups against 160 tiles -- every workgroup of the register-resident kernel would pull 311 KB of rows for ONE tile
             // (measured 9.0 us at 8 rows, 18.9 at 64, against 6.5 / 13.0 for the K-sliced matmul + reduction): the sliced kernel keeps
             // it wherever its plan exists, and its reduction leaves the weighted rows
-            const Qmm3Plan pd = qmm3_plan(batch, w.wdown.cols, w.wdown.rows, e->qmm3_mode);
-            if (e->use_qmm3 && pd.ok && qmm3_reduce_can_emit_ss(EPI_RESIDUAL, w.wdown.rows) && e->fuse_norm) {
+            if (sliced_leaves_weighted(w.wdown)) {
                 TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, nullptr, nullptr,
                                      QM3_SS, &x_ss, next_norm, e->xn));
                 xw = x_ss > 0;

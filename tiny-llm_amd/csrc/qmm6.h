@@ -37,7 +37,11 @@
 namespace tl {
 
 constexpr int QM6_WAVES = 4;
-constexpr int QM6_RING = 6;      // 4-KiB units (16 rows x one group) of a wave's transposer ring
+// 4-KiB units (16 rows x one group) of a wave's transposer ring, and how many units back a slot is re-used: 8 slots, 5 units (20 KiB per
+// wave, 80 per CU) in flight.  (Two workgroups per CU with half the ring and half the register file were measured and lost at every
+// row count but lm_head at 8-16 rows: profiles/r04_labs/README.md.)
+constexpr int QM6_RING = 8;
+constexpr int QM6_LAG = 2;
 constexpr int QM6_SS_MAX = 256;  // partial sums of squares per row the prologue can fetch (16 lanes x 4 x 16 bytes)
 
 struct Qmm6Args {
@@ -66,10 +70,11 @@ struct Qmm6Args {
 #define QM6_STAMP() do { } while (0)
 #endif
 
-// LDS: the four waves' transposer rings, the per-(row, group) sums, a tile's partial sums x 2, 1 / rms per row
+// LDS: the four waves' transposer rings -- re-used, once every wave holds its fragments, for a tile's partial sums x 2 --, the
+// per-(row, group) sums, 1 / rms per row
 __host__ __device__ inline size_t qmm6_lds_ring_bytes() { return (size_t)QM6_WAVES * QM6_RING * 4096; }
 __host__ __device__ inline size_t qmm6_lds_bytes(int MB, int GPW) {
-    return qmm6_lds_ring_bytes() + (size_t)QM6_WAVES * GPW * MB * 64 + (size_t)2 * QM6_WAVES * MB * 1024 + (size_t)MB * 16 * 4;
+    return qmm6_lds_ring_bytes() + (size_t)QM6_WAVES * GPW * MB * 64 + (size_t)MB * 16 * 4;
 }
 
 template <int I, int E, typename F>
@@ -82,7 +87,8 @@ __device__ __forceinline__ void qmm6_static_for(F &&f) {
 
 template <int MB, int GPW, int EPI, int NSETS>
 __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args p) {
-    static_assert(NSETS >= 1 && NSETS <= 5, "one to five weight sets");
+    static_assert(2 * QM6_WAVES * MB * 1024 <= QM6_WAVES * QM6_RING * 4096, "a tile's partial sums re-use the rings");
+    static_assert(NSETS >= 1 && NSETS <= 4, "one to four weight sets");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int ROWS = MB * 16;
     constexpr int U = MB * GPW;                            // transposer units of a wave: (row block, group)
@@ -108,10 +114,11 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
     const int g0 = wave * GPW;
     char *ring = smem + (size_t)wave * QM6_RING * 4096;                          // this wave's units
     float *xg = reinterpret_cast<float *>(smem + qmm6_lds_ring_bytes());         // [wave][GPW][MB][16]: sum_k a of (row 4c+j, group)
-    f32x4 *red = reinterpret_cast<f32x4 *>(xg + QM6_WAVES * GPW * MB * 16);      // [2][wave][MB][64 lanes]
-    float *s_inv = reinterpret_cast<float *>(red + 2 * QM6_WAVES * MB * 64);     // [ROWS]
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem);                                // [2][wave][MB][64 lanes], over the rings (after the barrier below)
+    float *s_inv = xg + QM6_WAVES * GPW * MB * 16;                               // [ROWS]
     const int first = blockIdx.x * p.tiles_per_wg;
-    const int n_tiles = min(p.tiles_per_wg, tiles - first);  // >= 1 by the launcher's grid
+    const int n_tiles = min(p.tiles_per_wg, tiles - first);
+    if (n_tiles <= 0) return;  // the grid is padded to a multiple of 8 workgroups per row block (uniform: before any barrier)
 
     // ---- 1. the rows' partial sums of squares: 16 lanes per row, 16 rows per pass.  Requested first and turned into 1 / rms (LDS) while
     // nothing else is live: 16 MB registers here, none later.
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
     };
     // Unit u is read once its four pieces have landed; the slot of unit u - 2 is re-used (and its fragments pinned) once at most the
     // eight reads of units u - 1 and u pend -- LDS returns in order, so nothing here waits for a read it has just issued.
-    constexpr int LAG = 2;
+    constexpr int LAG = QM6_LAG;
     qmm6_static_for<0, U>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value;
         constexpr int mb = u / GPW, gl = u % GPW;
@@ -253,6 +260,7 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
         if ((tid & 15) == 0) s_inv[ps * 16 + (tid >> 4)] = normed ? rsqrtf(tot / (float)N + p.eps) : 1.0f;
     }
 
+    __syncthreads();  // every wave holds its fragments: the rings become the tiles' partial-sum buffers (and 1 / rms is published)
     QM6_STAMP();  // 2: fragments in registers, group sums in LDS
     uint32_t nib_mask = 0x000f000fu;
     uint32_t magic = 0x43004300u;
@@ -399,11 +407,12 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
             }
         }
     };
-    for (int u0 = 0; u0 < n_tiles; u0 += NSETS) {
+    int u0 = 0;
+    for (; u0 + NSETS <= n_tiles; u0 += NSETS) {  // whole rounds
         qmm6_static_for<0, NSETS>([&](auto sc) __attribute__((always_inline)) {
             constexpr int st = decltype(sc)::value;
             const int u = u0 + st;
-            const int tile = min(first + u, last_tile);
+            const int tile = first + u;
             uint16_t resv[MB] = {}, nwo = 0;
             residual_loads(tile, resv, nwo);
             __builtin_amdgcn_sched_barrier(0);
@@ -413,6 +422,20 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
             run_tile(wq[st], sq[st], tile, u, resv, nwo);
             __builtin_amdgcn_sched_barrier(0);
             QM6_STAMP();  // tile: epilogue issued
+        });
+    }
+    // the last, partial round: its tiles' sets are in flight already (nothing is requested any more, so hipcc's conservative waits
+    // behind these branches cost nothing)
+    if constexpr (NSETS > 1) {
+        qmm6_static_for<0, NSETS - 1>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int st = decltype(sc)::value;
+            const int u = u0 + st;
+            if (u < n_tiles) {  // uniform
+                uint16_t resv[MB] = {}, nwo = 0;
+                residual_loads(first + u, resv, nwo);
+                run_tile(wq[st], sq[st], first + u, u, resv, nwo);
+                QM6_STAMP();
+            }
         });
     }
 #ifdef QMM6_TRACE
@@ -443,17 +466,11 @@ inline bool qmm6_has_variant(int MB, int GPW) {
     return MB * GPW * 16 <= 320;
 }
 // weight sets of a workgroup that walks several tiles: tiles in flight ahead of the one computed = sets - 1, as many as the registers
-// next to the fragments hold (a tile of few rows computes in a fraction of the memory latency)
-constexpr int qmm6_sets(int MB, int GPW) { return GPW > 8 ? 1 : (MB * GPW <= 5 ? 5 : (MB * GPW <= 10 ? 3 : 2)); }
-// sets for a workgroup of `tpw` tiles: all of them when they fit; else the most sets whose last, partly empty round wastes at most a
-// tenth of the tiles (the tile loop runs whole rounds: qmm6_kernel), at least two
-inline int qmm6_pick_sets(int MB, int GPW, int tpw) {
-    const int most = qmm6_sets(MB, GPW);
-    if (tpw <= most) return tpw;
-    for (int n = most; n > 2; --n)
-        if (((tpw + n - 1) / n * n - tpw) * 10 <= tpw) return n;
-    return most >= 2 ? 2 : 1;
-}
+// next to the fragments hold (a tile of few rows computes in a fraction of the memory latency) and the 6-bit vmcnt counts behind the
+// first ring of units (4 (RING - 1) + (sets - 1) 2 GPW <= 63)
+constexpr int qmm6_sets(int MB, int GPW) { return GPW > 8 ? 1 : (MB * GPW <= 5 ? 4 : (MB * GPW <= 10 ? 3 : 2)); }
+// sets for a workgroup of `tpw` tiles: whole rounds of `sets` tiles run in the branch-free loop, the rest behind it (qmm6_kernel)
+inline int qmm6_pick_sets(int MB, int GPW, int tpw) { return std::min(tpw, qmm6_sets(MB, GPW)); }
 inline int qmm6_round_gpw(int gpw) { return gpw <= 2 ? 2 : (gpw <= 4 ? 4 : (gpw <= 5 ? 5 : (gpw <= 8 ? 8 : 19))); }
 inline Qmm6Plan qmm6_plan(int M, int N, int K) {
     Qmm6Plan pl{};
@@ -471,6 +488,8 @@ inline Qmm6Plan qmm6_plan(int M, int N, int K) {
     const int wgs = std::min(tiles, std::max(1, ncu / pl.row_blocks));
     pl.tiles_per_wg = (tiles + wgs - 1) / wgs;
     pl.wgs = (tiles + pl.tiles_per_wg - 1) / pl.tiles_per_wg;
+    // the workgroups of one tile range sit a multiple of 8 apart in the launch order: one XCD, one L2 for the weights they share
+    if (pl.row_blocks > 1) pl.wgs = (pl.wgs + 7) / 8 * 8;
     pl.NSETS = qmm6_pick_sets(pl.MB, pl.GPW, pl.tiles_per_wg);
     pl.lds = qmm6_lds_bytes(pl.MB, pl.GPW);
     pl.ok = pl.lds <= 150 * 1024;

@@ -1,7 +1,7 @@
 // Kernel laboratory (not part of the product): the register-resident batched-decode matmul (csrc/qmm6.h) at the Qwen3-4B projection
 // shapes, HIP events, next to the K-sliced skinny matmul + slice reduction (csrc/qmm3.h) on the same inputs.  With -DQMM6_TRACE the
 // kernel leaves per-wave wall-clock stamps at its phase boundaries; the lab prints their mean distance from the wave's start.
-// usage: qmm6_lab <rows> [epilogue 0|1|2]     build + run: tools/lab/run_qmm6_lab.sh
+// usage: qmm6_lab <rows>     build + run: tools/lab/run_qmm6_lab.sh
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -48,7 +48,7 @@ int main(int argc, char **argv) {
         const Qmm3Plan p3 = qmm3_plan(M, N, K, -1);
         CK(hipMalloc(&partial, std::max<size_t>(p3.partial_bytes, 16)));
         if (!pl.ok) { printf("%-8s rows %d: no plan\n", sh.name, M); continue; }
-        const int epi = argc > 2 ? atoi(argv[2]) : sh.epi;
+        const int epi = sh.epi;
         unsigned long long *pb = nullptr;
         const size_t nwaves = (size_t)pl.wgs * pl.row_blocks * QM6_WAVES;
         CK(hipMalloc(&pb, nwaves * 16 * 8)); CK(hipMemset(pb, 0, nwaves * 16 * 8));
