@@ -277,6 +277,11 @@ typedef struct tl_linear_ex {
     float *ss_out_dev;
     const void *norm_out_dev;
     void *out_w_dev;
+    int fragment_order; /* kernels 2-5: the weighted rows on either side -- a_dev with prologue 3 (kernel 5), out_w_dev -- lie in the
+                           batched step's FRAGMENT ORDER instead of row-major: [16-row block][128-column group][k-step t 0..3]
+                           [lane = r + 16 c][8 elements] = row 16 block + r, columns 128 g + 32 c + 8 t .. + 7 (rows padded to 16: out_w_dev
+                           holds ceil16(M) x rows elements).  The engine hands its rows over that way (every load of the consumer is one
+                           contiguous 1 KiB). */
 } tl_linear_ex;
 int tl_decode_linear_ex(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, int M, int prologue, int epilogue,
                         const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,

@@ -129,3 +129,25 @@ def test_slice_reduction_of_w_down_leaves_the_weighted_rows(ext, M):
     assert info["kernel"] == 2 and info["launches"] == 2, what
     assert_within(_bf16_host(got), p.want[(PRO_NONE, EPI_RESIDUAL)][:M], p.allowed[(PRO_NONE, EPI_RESIDUAL)][:M], what=what)
     assert torch.equal(info["out_w"], (got.float() * norm_out.float()).to(torch.bfloat16)), f"{what}: weighted rows"
+
+
+@pytest.mark.parametrize("M", [5, 16, 40, 64])
+def test_weighted_rows_travel_in_fragment_order(ext, M):
+    """The engine hands weighted rows from producer to consumer in FRAGMENT ORDER (csrc/qmm6.h: every load of the consumer is one
+    contiguous 1 KiB, no LDS pass).  Producers: the register-resident kernel's residual epilogue (wo shape) and the slice reduction of
+    the K-sliced matmul (w_down shape) must write exactly the row-major weighted rows, re-ordered; the consumer must give the same
+    bits whether the entry point re-orders row-major rows itself or takes them in fragment order."""
+    wo, down, qkv = _proj(ext, "wo"), _proj(ext, "down"), _proj(ext, "qkv")
+    for p, kernel in ((wo, 5), (down, 2)):
+        norm_out = (1.0 + 0.05 * torch.randn((p.K,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(11))).to(torch.bfloat16)
+        kw = dict(prologue=PRO_NONE, epilogue=EPI_RESIDUAL, residual=p.residual[:M].contiguous(), eps=EPS, kernel=kernel, norm_out=norm_out)
+        got_r, info_r = ext.decode_linear(p.tiled, p.a[:M].contiguous(), **kw)
+        got_f, info_f = ext.decode_linear(p.tiled, p.a[:M].contiguous(), fragment_order=True, **kw)
+        assert torch.equal(got_r, got_f), f"{p.name} M={M}: the output rows must not depend on the layout of the weighted copy"
+        assert info_f["out_w"].shape[0] == (M + 15) // 16 * 16
+        assert torch.equal(ext.rows_from_fragment_order(info_f["out_w"], M), info_r["out_w"]), f"{p.name} M={M} kernel {kernel}: fragment order of out_w"
+    a_w, ss = _weighted_rows_case(qkv, M)
+    a, ia = ext.decode_linear(qkv.tiled, a_w, prologue=PRO_RMS_WEIGHTED, epilogue=EPI_STORE, eps=EPS, kernel=5, ss_in=ss)
+    b, ib = ext.decode_linear(qkv.tiled, ext.fragment_order_of(a_w), prologue=PRO_RMS_WEIGHTED, epilogue=EPI_STORE, eps=EPS, kernel=5, ss_in=ss,
+                              fragment_order=True, fragment_rows=M)
+    assert ia["kernel"] == ib["kernel"] == 5 and torch.equal(a, b), f"qkv M={M}: rows in fragment order"

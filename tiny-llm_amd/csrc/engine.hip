@@ -324,11 +324,13 @@ static bool qmm6_takes(const tl_engine *e, const tl_w4 &w, int M) {
 // receives rows / 16 partial sums of squares per row, out_w the rows weighted for the next RMSNorm (norm_out).
 static int engine_qmm6(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int epi, const uint16_t *residual,
                        ProfCtx *pc, int kind, const float *ss_in, int ss_in_n, float *ss_out, int *ss_out_n, const void *norm_out,
-                       uint16_t *out_w) {
+                       uint16_t *out_w, bool frag = false, int out_w_frag = -1) {
+    // frag: the weighted rows on either side (`a` with ss_in, `out_w`) lie in fragment order (qmm6.h) -- the engine's own hand-over;
+    // out_w_frag >= 0 decides for out_w alone (the kernel-level entry point)
     if (ss_out_n) *ss_out_n = 0;
     const auto tiled = e->tiled.find(w.weight_dev);
     TL_REQUIRE(tiled != e->tiled.end(), "engine: the register-resident matmul needs the tiled weights");
-    const Qmm6Plan pl = qmm6_plan(M, w.cols, w.rows);
+    const Qmm6Plan pl = qmm6_plan(M, w.cols, w.rows, frag && ss_in != nullptr && epi != EPI_RESIDUAL);
     TL_REQUIRE(pl.ok, "engine: the register-resident matmul does not cover this shape");
     Qmm6Args q{};
     q.wt = tiled->second.wt;
@@ -346,6 +348,8 @@ static int engine_qmm6(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
     q.N = w.cols;
     q.K = w.rows;
     q.prof = pc ? pc->buf : nullptr;
+    q.a_frag = frag && ss_in != nullptr && epi != EPI_RESIDUAL;
+    q.out_w_frag = (out_w_frag >= 0 ? out_w_frag != 0 : frag) && out_w != nullptr;
     int n_wg = 0;
     if (launch_qmm6_bf16(q, epi, e->stream, &n_wg) != 0) return fail(TL_ERR_UNSUPPORTED, "engine: register-resident matmul launch failed");
     if (pc) prof_after(e, pc, kind, n_wg);
@@ -391,7 +395,7 @@ struct KeptPartials {
 static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int pro, int epi,
                          const void *norm_w, const uint16_t *residual, ProfCtx *pc, int kind, const float *ss_in_any = nullptr,
                          float *ss_out = nullptr, bool *ss_emitted = nullptr, KeptPartials *keep = nullptr, int ss_in_n = QM3_SS,
-                         int *ss_out_n = nullptr, const void *norm_out = nullptr, uint16_t *out_w = nullptr) {
+                         int *ss_out_n = nullptr, const void *norm_out = nullptr, uint16_t *out_w = nullptr, bool out_w_frag = false) {
     // ss_in_any holds ss_in_n partials per row; the skinny matmul reads exactly QM3_SS of them, the GEMV any number.
     // *ss_out_n (when asked for) = partials per row left in ss_out: QM3_SS by the slice reduction, rows / 16 by a GEMV, 0 = none
     if (ss_emitted) *ss_emitted = false;
@@ -440,7 +444,7 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
         } else {
             int reduce_wg = 0;
             if (launch_qmm3_reduce_bf16(q.partial, p3.slices, M, w.rows, epi, residual, out, q.prof, e->stream, ss_dst, &reduce_wg,
-                                        out_w ? (const uint16_t *)norm_out : nullptr, out_w) != 0)
+                                        out_w ? (const uint16_t *)norm_out : nullptr, out_w, out_w_frag ? 1 : 0) != 0)
                 return fail(TL_ERR_UNSUPPORTED, "engine: skinny matmul reduction launch failed");
             if (pc) prof_after(e, pc, kind, reduce_wg);
         }
@@ -516,7 +520,12 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     const int wg_cap = e->attn_wg_cap > 0 ? e->attn_wg_cap : (batch <= 4 ? 2048 : 512);
     // a whole GQA group per workgroup (long contexts / several sequences): at most 32 windows -- one workgroup per CU for one sequence;
     // measured at 8k 666 -> 680 tok/s against 64 windows, 32k unchanged (round 3)
-    const int max_splits = rq == AD_RQ ? e->attn_max_splits_gqa : e->attn_max_splits;
+    int max_splits = rq == AD_RQ ? e->attn_max_splits_gqa : e->attn_max_splits;
+    // Many sequences at short contexts: one window per sequence and NO merge launch (round 4, same-box A/B at ~190 / ~660 tokens,
+    // profiles/r04_labs/README.md): 12 / 16 sequences 1.623 -> 1.603 / 1.661 -> 1.634 ms per step at ~190 tokens (at ~660 the split stays:
+    // 16 sequences 1.885 against 2.000), 24 / 32 sequences 2.15 -> 2.03 / 2.215 -> 2.07 at ~190 and 32 sequences 2.56 -> 2.495 at ~660.
+    // The merge launch and its boundary cost ~2.5 us per layer; the unsplit walk of a few stages costs less once every CU has a workgroup.
+    if (e->attn_min_tokens_auto && ((batch >= 24 && bucket <= 1024) || (batch >= 12 && bucket <= 256))) max_splits = 1;
     while (s * 2 <= bucket / min_tokens && s * 2 * base <= wg_cap && s * 2 <= max_splits) s *= 2;  // >= min_tokens per workgroup
     // Windows sized to the context, not to its power-of-two bucket: a workgroup walks its whole window in 64-token stages
     // whether or not the tokens exist, so a 33k context on a 64k bucket spent half of every window on masked loads (r02:
@@ -714,6 +723,9 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             // on a slow box (profiles/r04_labs/README.md: its per-workgroup copy of the rows rides the L2 -> CU path, the part of the chip
             // that differs most between boxes): qkv up to 16 rows (beyond, the sliced matmul has no reduction launch to lose -- the
             // attention kernel adds its slices), wo up to 16 and from 33 rows.  Both kinds of producer leave x / h weighted AND plain.
+            // the weighted rows travel in fragment order from 9 rows (same-box A/B, profiles/r04_labs/README.md: 16 / 32 / 64 sequences
+            // -1.5 / -4 / -1.3 % per step; at 8 sequences +2 %: row-major there)
+            const bool frag = batch > 8;
             const bool qkv6 = batch <= 16 && qmm6_takes(e, w.wqkv, batch);
             const bool wo6 = wo6_ok && (batch <= 16 || batch > 32 || !sliced_leaves_weighted(w.wo));
             KeptPartials parts;
@@ -721,9 +733,9 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
                 if (!xw) {
                     const long n8 = (long)batch * c.hidden_size / 8;
                     hipLaunchKernelGGL(weight_rows_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, e->x, (const uint16_t *)w.input_norm_dev,
-                                       e->xn, n8, c.hidden_size / 8);
+                                       e->xn, n8, c.hidden_size / 8, frag ? 1 : 0);
                 }
-                TL_TRY(engine_qmm6(e, w.wqkv, e->xn, e->qkv, batch, EPI_STORE, nullptr, pc, 0, e->ss_x, x_ss, nullptr, nullptr, nullptr, nullptr));
+                TL_TRY(engine_qmm6(e, w.wqkv, e->xn, e->qkv, batch, EPI_STORE, nullptr, pc, 0, e->ss_x, x_ss, nullptr, nullptr, nullptr, nullptr, frag));
             } else {
                 const bool keep_qkv = e->attn_qkv_partials && attn_takes_qkv_partials(c.head_dim, sp.rq);
                 TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0, e->ss_x, nullptr, nullptr,
@@ -733,11 +745,11 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, &parts, &w.wo, &merged));
             TL_REQUIRE(!merged, "engine: a batched step left its attention windows unmerged");
             int h_ss = 0;
-            if (wo6) TL_TRY(engine_qmm6(e, w.wo, e->attn, e->h, batch, EPI_RESIDUAL, e->x, pc, 1, nullptr, 0, e->ss_h, &h_ss, w.post_norm_dev, e->xn));
+            if (wo6) TL_TRY(engine_qmm6(e, w.wo, e->attn, e->h, batch, EPI_RESIDUAL, e->x, pc, 1, nullptr, 0, e->ss_h, &h_ss, w.post_norm_dev, e->xn, frag));
             else TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, nullptr, nullptr, QM3_SS, &h_ss,
-                                      w.post_norm_dev, e->xn));
+                                      w.post_norm_dev, e->xn, frag));
             TL_REQUIRE(h_ss > 0 && qmm3_takes_ss(h_ss), "engine: the wo projection left no sums of squares for its weighted rows");
-            TL_TRY(engine_qmm6(e, w.wgu, e->xn, e->act, batch, EPI_SWIGLU, nullptr, pc, 2, e->ss_h, h_ss, nullptr, nullptr, nullptr, nullptr));
+            TL_TRY(engine_qmm6(e, w.wgu, e->xn, e->act, batch, EPI_SWIGLU, nullptr, pc, 2, e->ss_h, h_ss, nullptr, nullptr, nullptr, nullptr, frag));
             // the rows w_down leaves are weighted for their next reader: the next layer's input norm, or the final norm ahead of lm_head
             const void *next_norm = l + 1 < c.num_layers ? e->layers[l + 1].input_norm_dev : e->final_norm;
             // w_down: 76 groups against 160 tiles -- every workgroup of the register-resident kernel would pull 311 KB of rows for ONE tile
@@ -745,10 +757,10 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             // it wherever its plan exists, and its reduction leaves the weighted rows
             if (sliced_leaves_weighted(w.wdown)) {
                 TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, nullptr, nullptr,
-                                     QM3_SS, &x_ss, next_norm, e->xn));
+                                     QM3_SS, &x_ss, next_norm, e->xn, frag));
                 xw = x_ss > 0;
             } else if (qmm6_takes(e, w.wdown, batch) && qmm3_takes_ss(w.wdown.rows / 16)) {
-                TL_TRY(engine_qmm6(e, w.wdown, e->act, e->x, batch, EPI_RESIDUAL, e->h, pc, 3, nullptr, 0, e->ss_x, &x_ss, next_norm, e->xn));
+                TL_TRY(engine_qmm6(e, w.wdown, e->act, e->x, batch, EPI_RESIDUAL, e->h, pc, 3, nullptr, 0, e->ss_x, &x_ss, next_norm, e->xn, frag));
                 xw = true;
             } else {
                 TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, nullptr, nullptr, QM3_SS, &x_ss));
@@ -791,7 +803,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     e->want_tile_max = e->lm_tile_max_on;
     e->tile_max_rows = 0;
     const int head_rc = xw && qmm6_takes(e, e->head(), batch) && qmm3_takes_ss(x_ss)
-                            ? engine_qmm6(e, e->head(), e->xn, e->logits, batch, EPI_STORE, nullptr, pc, 4, e->ss_x, x_ss, nullptr, nullptr, nullptr, nullptr)
+                            ? engine_qmm6(e, e->head(), e->xn, e->logits, batch, EPI_STORE, nullptr, pc, 4, e->ss_x, x_ss, nullptr, nullptr, nullptr, nullptr, batch > 8)
                             : engine_linear(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4,
                                             x_ss ? e->ss_x : nullptr, nullptr, nullptr, nullptr, x_ss);
     e->want_tile_max = false;
@@ -981,7 +993,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const size_t o_ptok = carve(R * 4);
     const size_t o_x = carve(R * c.hidden_size * 2);
     const size_t o_h = carve(R * c.hidden_size * 2);
-    const size_t o_xn = carve(R * c.hidden_size * 2);
+    const size_t o_xn = carve((R + 15) / 16 * 16 * c.hidden_size * 2);  // weighted rows of a batched step lie in 16-row fragment blocks (qmm6.h)
     const size_t o_tmp = carve(R * c.hidden_size * 2);
     const size_t o_qkv = carve(R * qkv_dim * 2);
     const size_t o_qt = carve(R * q_dim * 2);
@@ -1919,7 +1931,7 @@ extern "C" void tl_tiled_w4_destroy(tl_tiled_w4 *t) {
 
 extern "C" size_t tl_decode_linear_workspace_bytes(int M, int rows, int cols) {
     if (M <= 0 || rows <= 0 || cols <= 0) return 0;
-    size_t need = align_up((size_t)M * cols * 2, 256);  // RMSNorm output ahead of the skinny matmul
+    size_t need = align_up((size_t)((M + 15) / 16 * 16) * cols * 2, 256);  // RMSNorm output ahead of the skinny matmul / rows in fragment order (kernel 5)
     size_t partial = 0;
     for (int mode = 0; mode < 2; ++mode) {  // either grid of the skinny matmul (kernel 3 / 4 pin one)
         const Qmm3Plan p3 = qmm3_plan(std::min(M, 64), cols, rows, mode);
@@ -1956,7 +1968,7 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
     e.stream = (hipStream_t)stream;
     e.tiled[w->w.weight_dev] = w->t;
     e.xn = (uint16_t *)workspace_dev;
-    const size_t xn_bytes = align_up((size_t)M * w->w.cols * 2, 256);
+    const size_t xn_bytes = align_up((size_t)((M + 15) / 16 * 16) * w->w.cols * 2, 256);
     e.splitk_ws = (char *)workspace_dev + xn_bytes;
     e.splitk_ws_bytes = workspace_bytes - xn_bytes;
     e.force_linear = kernel >= 2 && kernel <= 4 ? 2 : (kernel == 5 ? 0 : kernel);
@@ -1981,10 +1993,17 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
             return done(fail(TL_ERR_INVALID, "decode_linear_ex: ss_out / (norm_out, out_w) belong to the residual epilogue; norm_out and out_w come together"));
         if (!qmm6_plan(M, w->w.cols, w->w.rows).ok)
             return done(fail(TL_ERR_UNSUPPORTED, "decode_linear: the register-resident matmul does not cover this shape"));
+        // weighted rows enter the kernel in fragment order (qmm6.h): as the caller left them (ex->fragment_order), or re-ordered here
+        const uint16_t *a6 = (const uint16_t *)a_dev;
+        if (weighted && !ex->fragment_order) {
+            const long n8 = (long)M * w->w.cols / 8;
+            hipLaunchKernelGGL(weight_rows_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e.stream, a6, (const uint16_t *)nullptr, e.xn, n8, w->w.cols / 8, 1);
+            a6 = e.xn;
+        }
         int ss_n6 = 0;
-        rc = engine_qmm6(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, epilogue, (const uint16_t *)residual_dev, nullptr, 0,
+        rc = engine_qmm6(&e, w->w, a6, (uint16_t *)out_dev, M, epilogue, (const uint16_t *)residual_dev, nullptr, 0,
                          weighted ? ex->ss_in_dev : nullptr, weighted ? ex->ss_in_n : 0, ex ? ex->ss_out_dev : nullptr, &ss_n6,
-                         ex ? ex->norm_out_dev : nullptr, ex ? (uint16_t *)ex->out_w_dev : nullptr);
+                         ex ? ex->norm_out_dev : nullptr, ex ? (uint16_t *)ex->out_w_dev : nullptr, weighted, ex ? (ex->fragment_order ? 1 : 0) : 0);
         return done(rc);
     }
     if (!ex) {
@@ -2035,7 +2054,7 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
         return done(fail(TL_ERR_INVALID, "decode_linear_ex: the skinny matmul reads a multiple of 4, at most 256, partial sums of squares per row"));
     rc = engine_linear(&e, w->w, (const uint16_t *)a_dev, (uint16_t *)out_dev, M, prologue, epilogue, norm_w_dev,
                        (const uint16_t *)residual_dev, nullptr, 0, ex->ss_in_dev, nullptr, nullptr, nullptr, ex->ss_in_dev ? ex->ss_in_n : 0,
-                       nullptr, ex->norm_out_dev, (uint16_t *)ex->out_w_dev);
+                       nullptr, ex->norm_out_dev, (uint16_t *)ex->out_w_dev, ex->fragment_order != 0);
     return done(rc);
 }
 

@@ -983,18 +983,30 @@ __global__ __launch_bounds__(256) void residual_add_kernel(const uint16_t *__res
     reinterpret_cast<uint4 *>(out)[idx] = *reinterpret_cast<const uint4 *>(o);
 }
 
-// out[row, :] = bf16(x[row, :] * w): rows weighted by an RMSNorm weight for a consumer that applies 1 / rms to its sums (qmm6.h);
-// one launch per batched step, ahead of layer 0 (every later layer gets its rows weighted by the w_down epilogue).  chunks of 8.
+// out[row, :] = bf16(x[row, :] * w) (w == nullptr: a copy): rows weighted by an RMSNorm weight for a consumer that applies 1 / rms to
+// its sums (qmm6.h); one launch per batched step, ahead of layer 0 (every later layer gets its rows weighted by the w_down epilogue).
+// Chunks of 8 columns; frag != 0: written in qmm6.h's fragment order (a chunk is one 16-byte run there too).
 __global__ __launch_bounds__(256) void weight_rows_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
-                                                          uint16_t *__restrict__ out, long n8, int chunks_per_row) {
+                                                          uint16_t *__restrict__ out, long n8, int chunks_per_row, int frag) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n8) return;
     uint16_t a[8], g[8], o[8];
     *reinterpret_cast<uint4 *>(a) = reinterpret_cast<const uint4 *>(x)[idx];
-    *reinterpret_cast<uint4 *>(g) = reinterpret_cast<const uint4 *>(w)[idx % chunks_per_row];
+    const int row = (int)(idx / chunks_per_row), ch = (int)(idx - (long)row * chunks_per_row);
+    if (w) {
+        *reinterpret_cast<uint4 *>(g) = reinterpret_cast<const uint4 *>(w)[ch];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = BF16::from_float(BF16::to_float(a[e]) * BF16::to_float(g[e]));
-    reinterpret_cast<uint4 *>(out)[idx] = *reinterpret_cast<const uint4 *>(o);
+        for (int e = 0; e < 8; ++e) o[e] = BF16::from_float(BF16::to_float(a[e]) * BF16::to_float(g[e]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = a[e];
+    }
+    uint16_t *dst = out + idx * 8;
+    if (frag) {  // qmm6_frag_offset(row, 8 ch, 8 chunks_per_row), spelled out (this header does not see qmm6.h)
+        const int G = chunks_per_row >> 4, gcol = ch >> 4, k8 = ch & 15;  // k8: 8-column run inside the group; c = k8 >> 2, t = k8 & 3
+        dst = out + ((((size_t)(row >> 4) * G + gcol) * 4 + (k8 & 3)) * 64 + (size_t)(16 * (k8 >> 2) + (row & 15))) * 8;
+    }
+    *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(o);
 }
 
 // gu [T, 2I] with (gate_i, up_i) interleaved -> act [T, I] = bf16(silu(gate) * up)   (I % 4 == 0)

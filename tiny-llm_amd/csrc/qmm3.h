@@ -603,7 +603,8 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro = PRO_NONE, i
 // for the next projection's fused RMSNorm; returns the number of workgroups launched through *n_wg.
 int launch_qmm3_reduce_bf16(const float *partial, int slices, int M, int K, int epi, const uint16_t *residual, uint16_t *out,
                             prof_t *prof, hipStream_t st, float *ss_out = nullptr, int *n_wg = nullptr, const uint16_t *norm_out = nullptr,
-                            uint16_t *out_w = nullptr);  // norm_out + out_w (EPI_RESIDUAL): also bf16(out * norm_out), the next consumer's weighted rows
+                            uint16_t *out_w = nullptr, int out_w_frag = 0);  // norm_out + out_w (EPI_RESIDUAL): also bf16(out * norm_out), the next
+                                                                             // consumer's weighted rows (out_w_frag: in qmm6.h's fragment order)
 inline bool qmm3_reduce_can_emit_ss(int epi, int K) { return epi != EPI_SWIGLU && K % 4 == 0 && (K / 4 + 255) / 256 <= QM3_SS; }
 // the fused RMSNorm of the skinny matmul takes any ss_n the staging prologue can fetch in four 16-byte loads per lane
 inline bool qmm3_takes_ss(int ss_n) { return ss_n > 0 && ss_n <= QM3_SS_MAX && ss_n % 4 == 0; }

@@ -1,5 +1,6 @@
 // Launchers of the skinny batched-decode matmul (qmm3.h) and its slice-reduction / epilogue kernel.
 #include "qmm3.h"
+#include "qmm6.h"
 
 namespace tl {
 
@@ -12,7 +13,7 @@ template <int EPI, bool SS>
 __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restrict__ partial, int slices, int M, int K,
                                                           const uint16_t *__restrict__ residual,
                                                           uint16_t *__restrict__ out, float *__restrict__ ss_out, prof_t *prof,
-                                                          const uint16_t *__restrict__ norm_out, uint16_t *__restrict__ out_w) {
+                                                          const uint16_t *__restrict__ norm_out, uint16_t *__restrict__ out_w, int out_w_frag) {
     __shared__ float wave_ss[4];
     const prof_t prof_t0 = prof_begin(prof);
     constexpr int IN_PER = EPI == EPI_SWIGLU ? 8 : 4;
@@ -69,7 +70,9 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
                 uint16_t ow[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ow[e] = BF16::from_float(BF16::to_float(o[e]) * BF16::to_float(nn[e]));
-                *reinterpret_cast<uint2 *>(out_w + in0) = *reinterpret_cast<const uint2 *>(ow);
+                // fragment order (qmm6.h): the four columns of a thread stay together inside an 8-column run
+                const size_t wo = out_w_frag ? qmm6_frag_offset(m, q * 4, K) : in0;
+                *reinterpret_cast<uint2 *>(out_w + wo) = *reinterpret_cast<const uint2 *>(ow);
             }
         } else {
 #pragma unroll
@@ -98,18 +101,18 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
 }
 
 int launch_qmm3_reduce_bf16(const float *partial, int slices, int M, int K, int epi, const uint16_t *residual, uint16_t *out,
-                            prof_t *prof, hipStream_t st, float *ss_out, int *n_wg, const uint16_t *norm_out, uint16_t *out_w) {
-    if ((out_w != nullptr) != (norm_out != nullptr) || (out_w && epi != EPI_RESIDUAL)) return -1;
+                            prof_t *prof, hipStream_t st, float *ss_out, int *n_wg, const uint16_t *norm_out, uint16_t *out_w, int out_w_frag) {
+    if ((out_w != nullptr) != (norm_out != nullptr) || (out_w && epi != EPI_RESIDUAL) || (out_w_frag && K % 128 != 0)) return -1;
     if (K % 8 != 0 || M < 1 || M > 65535) return -1;
     const int per_row = K / (epi == EPI_SWIGLU ? 8 : 4);
     const dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)M), block(256);
     if (ss_out && !qmm3_reduce_can_emit_ss(epi, K)) return -1;
     if (n_wg) *n_wg = (int)(grid.x * grid.y);
-    if (epi == EPI_SWIGLU) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_SWIGLU, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w);
-    else if (epi == EPI_RESIDUAL && ss_out) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_RESIDUAL, true>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w);
-    else if (epi == EPI_RESIDUAL) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_RESIDUAL, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w);
-    else if (ss_out) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_STORE, true>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w);
-    else hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_STORE, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w);
+    if (epi == EPI_SWIGLU) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_SWIGLU, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w, out_w_frag);
+    else if (epi == EPI_RESIDUAL && ss_out) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_RESIDUAL, true>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w, out_w_frag);
+    else if (epi == EPI_RESIDUAL) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_RESIDUAL, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w, out_w_frag);
+    else if (ss_out) hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_STORE, true>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w, out_w_frag);
+    else hipLaunchKernelGGL((qmm3_reduce_kernel<EPI_STORE, false>), grid, block, 0, st, partial, slices, M, K, residual, out, ss_out, prof, norm_out, out_w, out_w_frag);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

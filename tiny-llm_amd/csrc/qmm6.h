@@ -47,19 +47,30 @@ constexpr int QM6_SS_MAX = 256;  // partial sums of squares per row the prologue
 struct Qmm6Args {
     const uint32_t *wt;        // tiled packed weights [K/16][G][64][4]
     const uint32_t *sbt;       // tiled scale|bias<<16 [K/16][G][16]
-    const uint16_t *a;         // [M, N] bf16 rows; with `ss` they are WEIGHTED rows (x * norm weight) and out is scaled by 1 / rms
+    const uint16_t *a;         // [M, N] bf16 rows; with `ss` they are WEIGHTED rows (x * norm weight) and out is scaled by 1 / rms.
+                               // a_frag: the rows are stored in FRAGMENT ORDER (qmm6_frag_offset): every load of the kernel is one
+                               // contiguous 1 KiB straight into the registers -- no LDS pass (the engine's weighted rows arrive so)
     uint16_t *out;             // [M, K]  (EPI_SWIGLU: [M, K/2])
     const uint16_t *residual;  // EPI_RESIDUAL [M, K]
     const uint16_t *norm_out;  // EPI_RESIDUAL, optional [K]: the consumer's RMSNorm weight
-    uint16_t *out_w;           // EPI_RESIDUAL, optional [M, K]: out * norm_out (bf16), the consumer's weighted rows
+    uint16_t *out_w;           // EPI_RESIDUAL, optional [M, K]: out * norm_out (bf16), the consumer's weighted rows (out_w_frag: in fragment order)
     const float *ss;           // optional [M][ss_n]: partial sums of squares of the UNWEIGHTED rows (multiple of 4, <= 256)
     float *ss_out;             // EPI_RESIDUAL, optional [M][K/16]: per 16-row tile, the squares of the bf16 values stored
     float eps;
     int ss_n;
     int M, N, K;
     int tiles_per_wg;
+    int a_frag, out_w_frag;
     prof_t *prof;
 };
+
+// Fragment order of a [rows, cols] bf16 matrix (cols % 128 == 0, rows padded to 16): [16-row block][group of 128 columns][k-step t]
+// [lane = r + 16 c][8 elements] -- lane (r, c) of k-step t holds row 16 block + r, columns 128 g + 32 c + 8 t .. + 7, i.e. exactly the
+// MFMA A fragment the tiled weight layout pairs with word t of its lane.  Element offset of (row, col):
+__host__ __device__ inline size_t qmm6_frag_offset(int row, int col, int cols) {
+    const int G = cols >> 7, k = col & 127;
+    return (((((size_t)(row >> 4) * G + (col >> 7)) * 4 + ((k & 31) >> 3)) * 64) + (size_t)(16 * (k >> 5) + (row & 15))) * 8 + (k & 7);
+}
 
 #ifndef QMM6_ABL
 #define QMM6_ABL 0  // tools/lab/qmm6_lab only: 1 no MFMA in the tile loop, 2 no nibble unpack, 4 no per-group scaling, 8 no bias pre-pass
@@ -72,9 +83,10 @@ struct Qmm6Args {
 
 // LDS: the four waves' transposer rings -- re-used, once every wave holds its fragments, for a tile's partial sums x 2 --, the
 // per-(row, group) sums, 1 / rms per row
-__host__ __device__ inline size_t qmm6_lds_ring_bytes() { return (size_t)QM6_WAVES * QM6_RING * 4096; }
-__host__ __device__ inline size_t qmm6_lds_bytes(int MB, int GPW) {
-    return qmm6_lds_ring_bytes() + (size_t)QM6_WAVES * GPW * MB * 64 + (size_t)MB * 16 * 4;
+// (rows in fragment order need no rings: only the tiles' partial sums live there)
+__host__ __device__ inline size_t qmm6_lds_ring_bytes(int MB, bool frag) { return frag ? (size_t)2 * QM6_WAVES * MB * 1024 : (size_t)QM6_WAVES * QM6_RING * 4096; }
+__host__ __device__ inline size_t qmm6_lds_bytes(int MB, int GPW, bool frag = false) {
+    return qmm6_lds_ring_bytes(MB, frag) + (size_t)QM6_WAVES * GPW * MB * 64 + (size_t)MB * 16 * 4;
 }
 
 template <int I, int E, typename F>
@@ -85,7 +97,7 @@ __device__ __forceinline__ void qmm6_static_for(F &&f) {
     }
 }
 
-template <int MB, int GPW, int EPI, int NSETS>
+template <int MB, int GPW, int EPI, int NSETS, bool FRAG = false>
 __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args p) {
     static_assert(2 * QM6_WAVES * MB * 1024 <= QM6_WAVES * QM6_RING * 4096, "a tile's partial sums re-use the rings");
     static_assert(NSETS >= 1 && NSETS <= 4, "one to four weight sets");
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
     constexpr int U = MB * GPW;                            // transposer units of a wave: (row block, group)
     constexpr int P = U < QM6_RING ? U : QM6_RING;         // units in flight before the first is read
     constexpr int W = (NSETS - 1) * 2 * GPW;               // weight-set loads issued behind the first P units
-    static_assert(4 * (QM6_RING - 1) + W <= 63, "vmcnt holds 6 bits");  // the most that is ever counted behind a unit
+    static_assert(FRAG || 4 * (QM6_RING - 1) + W <= 63, "vmcnt holds 6 bits");  // the most that is ever counted behind a unit
 #ifdef QMM6_TRACE
     unsigned long long stamps[16];
     int n_stamps = 0;
@@ -113,7 +125,7 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
     const int row0 = blockIdx.y * ROWS;
     const int g0 = wave * GPW;
     char *ring = smem + (size_t)wave * QM6_RING * 4096;                          // this wave's units
-    float *xg = reinterpret_cast<float *>(smem + qmm6_lds_ring_bytes());         // [wave][GPW][MB][16]: sum_k a of (row 4c+j, group)
+    float *xg = reinterpret_cast<float *>(smem + qmm6_lds_ring_bytes(MB, FRAG)); // [wave][GPW][MB][16]: sum_k a of (row 4c+j, group)
     f32x4 *red = reinterpret_cast<f32x4 *>(smem);                                // [2][wave][MB][64 lanes], over the rings (after the barrier below)
     float *s_inv = xg + QM6_WAVES * GPW * MB * 16;                               // [ROWS]
     const int first = blockIdx.x * p.tiles_per_wg;
@@ -162,7 +174,24 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
         for (int rq = 0; rq < 4; ++rq)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void *)(slot + rq * 1024), 16, voff[rq] + mb * block_bytes, soff, 0, 0);
     };
-    qmm6_static_for<0, P>([&](auto uc) __attribute__((always_inline)) { issue_unit(decltype(uc)::value); });
+    // The fragments are MFMA A operands and nothing else: the first 64 of them (256 registers) are pinned in the accumulation half of
+    // the register file (ds_read_b128 / global_load write it, v_mfma reads it directly); left to itself hipcc parks them there as SPILLS
+    // and copies every fragment back with four v_accvgpr_read before each MFMA (644 copies per two tiles at 64 rows).
+    u32x4 av[MB][GPW][4];
+    if constexpr (FRAG) {
+        // rows stored in fragment order by their producer: MB x GPW x 4 contiguous 1-KiB loads per wave, straight into the registers
+        const char *abase = reinterpret_cast<const char *>(p.a) + (size_t)(row0 >> 4) * G * 4096 + (size_t)lane * 16;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int gl = 0; gl < GPW; ++gl) {
+                const char *gb = abase + ((size_t)mb * G + min(g0 + gl, G - 1)) * 4096;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) av[mb][gl][t] = *reinterpret_cast<const u32x4 *>(gb + t * 1024);
+            }
+    } else {
+        qmm6_static_for<0, P>([&](auto uc) __attribute__((always_inline)) { issue_unit(decltype(uc)::value); });
+    }
     __builtin_amdgcn_sched_barrier(0);
     // the weights of the first NSETS - 1 tiles go out behind the first units (vector loads return in issue order; the rows come first)
     u32x4 wq[NSETS][GPW];
@@ -189,10 +218,6 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
     __builtin_amdgcn_sched_barrier(0);
     QM6_STAMP();  // 1: first units and weight sets requested
 
-    // The fragments are MFMA A operands and nothing else: the first 64 of them (256 registers) are pinned in the accumulation half of
-    // the register file (ds_read_b128 writes it, v_mfma reads it directly); left to itself hipcc parks them there as SPILLS and copies
-    // every fragment back with four v_accvgpr_read before each MFMA (644 copies per two tiles at 64 rows).
-    u32x4 av[MB][GPW][4];
 #define QM6_PIN_UNIT(uu)                                                              \
     if constexpr ((uu) * 4 + 3 < 64) {                                                \
         u32x4(&fr)[4] = av[(uu) / GPW][(uu) % GPW];                                   \
@@ -216,6 +241,12 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
     // Unit u is read once its four pieces have landed; the slot of unit u - 2 is re-used (and its fragments pinned) once at most the
     // eight reads of units u - 1 and u pend -- LDS returns in order, so nothing here waits for a read it has just issued.
     constexpr int LAG = QM6_LAG;
+    if constexpr (FRAG) {
+        qmm6_static_for<0, U>([&](auto uc) __attribute__((always_inline)) {
+            QM6_PIN_UNIT(decltype(uc)::value)
+            group_sum(uc);
+        });
+    } else {
     qmm6_static_for<0, U>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value;
         constexpr int mb = u / GPW, gl = u % GPW;
@@ -245,6 +276,7 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
         QM6_PIN_UNIT(decltype(uc)::value)
         group_sum(uc);
     });
+    }
 #undef QM6_PIN_UNIT
     // 1 / rms of the rows from the partial sums requested first (long landed): fixed-order sums, published by the first tile's barrier
 #pragma unroll
@@ -275,8 +307,8 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
     // store nothing, and every store is a buffer store whose offset lies outside the resource when the element is not live.
     const int out_cols = EPI == EPI_SWIGLU ? (K >> 1) : K;
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((uint32_t)p.M * (uint32_t)out_cols * 2u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs =
-        __builtin_amdgcn_make_buffer_rsrc(p.out_w ? p.out_w : p.out, 0, p.out_w ? (int)((uint32_t)p.M * (uint32_t)K * 2u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(  // (fragment order pads the rows to 16)
+        p.out_w ? p.out_w : p.out, 0, p.out_w ? (int)((uint32_t)(p.out_w_frag ? (p.M + 15) / 16 * 16 : p.M) * (uint32_t)K * 2u) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t srs =
         __builtin_amdgcn_make_buffer_rsrc(p.ss_out ? p.ss_out : reinterpret_cast<float *>(p.out), 0, p.ss_out ? (int)((uint32_t)p.M * (uint32_t)tiles * 4u) : 0, 0x00020000);
     constexpr uint32_t DEAD = 0x7fffffffu;  // an offset no resource here reaches
@@ -305,7 +337,7 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
         // on a wave that has no second wave to hide it).  With fewer than 4 row blocks a group's four k-steps run as CH independent
         // MFMA chains: one chain alone waits out every MFMA's latency.
         constexpr int CH = GPW > 8 ? 1 : 4 / MB;
-        constexpr int XD = MB == 4 ? 1 : 2;  // groups the LDS reads run ahead (a group of 16 MFMAs covers an LDS round trip; one of 4 does not)
+        constexpr int XD = (MB == 4 || GPW > 8) ? 1 : 2;  // groups the LDS reads run ahead (a group of 16 MFMAs covers an LDS round trip; one of 4 does not; 19 groups: registers)
         f32x4 acc[MB], d[2][MB][CH], xs[XD][MB];
         const uint32_t xg_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(reinterpret_cast<char *>(xg + (wave * GPW * MB) * 16 + 4 * c));
         // (macros, not generic lambdas: clang rejects inline-asm operands that name a variable of an enclosing lambda from inside a
@@ -398,7 +430,8 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
                 const uint32_t o = (uint32_t)row * (uint32_t)K + (uint32_t)ocol;
                 const uint16_t ov = BF16::from_float(BF16::to_float(resv[i]) + bf16_round(v));
                 __builtin_amdgcn_raw_buffer_store_b16((short)ov, ors, live ? o * 2u : DEAD, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b16((short)BF16::from_float(BF16::to_float(ov) * BF16::to_float(nwo)), wrs, live ? o * 2u : DEAD, 0, 0);
+                const uint32_t ow = p.out_w_frag ? (uint32_t)qmm6_frag_offset(row, ocol, K) : o;
+                __builtin_amdgcn_raw_buffer_store_b16((short)BF16::from_float(BF16::to_float(ov) * BF16::to_float(nwo)), wrs, live ? ow * 2u : DEAD, 0, 0);
                 // one partial per (activation row, 16-row tile): the squares of the stored bf16 values (an empty resource when not asked for)
                 const float sq_v = group16_sum(live ? BF16::to_float(ov) * BF16::to_float(ov) : 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sq_v), srs, (live && r == 0) ? ((uint32_t)row * (uint32_t)tiles + (uint32_t)tile) * 4u : DEAD, 0, 0);
@@ -472,7 +505,7 @@ constexpr int qmm6_sets(int MB, int GPW) { return GPW > 8 ? 1 : (MB * GPW <= 5 ?
 // sets for a workgroup of `tpw` tiles: whole rounds of `sets` tiles run in the branch-free loop, the rest behind it (qmm6_kernel)
 inline int qmm6_pick_sets(int MB, int GPW, int tpw) { return std::min(tpw, qmm6_sets(MB, GPW)); }
 inline int qmm6_round_gpw(int gpw) { return gpw <= 2 ? 2 : (gpw <= 4 ? 4 : (gpw <= 5 ? 5 : (gpw <= 8 ? 8 : 19))); }
-inline Qmm6Plan qmm6_plan(int M, int N, int K) {
+inline Qmm6Plan qmm6_plan(int M, int N, int K, bool frag = false) {
     Qmm6Plan pl{};
     if (M < 1 || M > 64 || N <= 0 || N % 128 != 0 || K <= 0 || K % 16 != 0) return pl;
     const int G = N / 128, tiles = K / 16;
@@ -491,7 +524,7 @@ inline Qmm6Plan qmm6_plan(int M, int N, int K) {
     // the workgroups of one tile range sit a multiple of 8 apart in the launch order: one XCD, one L2 for the weights they share
     if (pl.row_blocks > 1) pl.wgs = (pl.wgs + 7) / 8 * 8;
     pl.NSETS = qmm6_pick_sets(pl.MB, pl.GPW, pl.tiles_per_wg);
-    pl.lds = qmm6_lds_bytes(pl.MB, pl.GPW);
+    pl.lds = qmm6_lds_bytes(pl.MB, pl.GPW, frag);
     pl.ok = pl.lds <= 150 * 1024;
     return pl;
 }

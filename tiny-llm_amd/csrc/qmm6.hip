@@ -18,7 +18,11 @@ template <int MB, int GPW, int EPI, int NS>
 static int launch_sets6(const Qmm6Args &a, const Qmm6Plan &pl, hipStream_t st) {
     if (pl.NSETS == NS) {
         const dim3 grid(pl.wgs, pl.row_blocks), block(QM6_WAVES * 64);
-        auto kern = qmm6_kernel<MB, GPW, EPI, NS>;
+        // rows in fragment order: the consumers of weighted rows only (store / SwiGLU); a residual projection reads plain rows
+        auto kern = qmm6_kernel<MB, GPW, EPI, NS, false>;
+        if constexpr (EPI != EPI_RESIDUAL) {
+            if (a.a_frag) kern = qmm6_kernel<MB, GPW, EPI, NS, true>;
+        }
         if (pl.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
         hipLaunchKernelGGL(kern, grid, block, pl.lds, st, a);
         return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -36,7 +40,8 @@ static int launch_variant6(const Qmm6Args &a, const Qmm6Plan &pl, hipStream_t st
 }
 
 int launch_qmm6_bf16(const Qmm6Args &args, int epi, hipStream_t st, int *n_wg) {
-    const Qmm6Plan pl = qmm6_plan(args.M, args.N, args.K);
+    if (args.a_frag && (epi == EPI_RESIDUAL || !args.ss)) return -1;  // fragment order is the layout of WEIGHTED rows
+    const Qmm6Plan pl = qmm6_plan(args.M, args.N, args.K, args.a_frag != 0);
     if (!pl.ok) return -1;
     if (args.ss && (args.ss_n <= 0 || args.ss_n > QM6_SS_MAX || args.ss_n % 4 != 0)) return -1;
     if (epi == EPI_RESIDUAL && !args.residual) return -1;

@@ -113,7 +113,7 @@ class TlLinearInfo(ctypes.Structure):
 
 class TlLinearEx(ctypes.Structure):
     _fields_ = [("merge_ws_dev", _c_void_p), ("n_splits", _c_int), ("ss_in_dev", _c_void_p), ("ss_in_n", _c_int),
-                ("ss_out_dev", _c_void_p), ("norm_out_dev", _c_void_p), ("out_w_dev", _c_void_p)]
+                ("ss_out_dev", _c_void_p), ("norm_out_dev", _c_void_p), ("out_w_dev", _c_void_p), ("fragment_order", _c_int)]
 
 
 class TlAttentionInfo(ctypes.Structure):
@@ -611,15 +611,18 @@ class TiledW4:
 def decode_linear(w: TiledW4, a: torch.Tensor | None, *, prologue: int = PRO_NONE, epilogue: int = EPI_STORE,
                   norm_weight: torch.Tensor | None = None, residual: torch.Tensor | None = None, eps: float = 1e-6,
                   kernel: int = 0, merge_partials: torch.Tensor | None = None, ss_in: torch.Tensor | None = None,
-                  want_ss_out: bool = False, norm_out: torch.Tensor | None = None):
+                  want_ss_out: bool = False, norm_out: torch.Tensor | None = None, fragment_order: bool = False,
+                  fragment_rows: int | None = None):
     """One projection of a decode step over ``a`` [M <= 64, cols] bf16 (tl_decode_linear).  Returns (out, info) where info
     names the kernel that ran and its launch parameters.
 
     The keyword arguments after ``kernel`` reach the routes of tl_decode_linear_ex (include/tinyllm_engine.h):
     ``merge_partials`` [cols / 128, n_splits, 132] fp32 with prologue PRO_ATTN_MERGE (``a`` is None, one row);
     ``ss_in`` [M, n] fp32 partial sums of squares for prologue PRO_RMSNORM / PRO_RMS_WEIGHTED; ``want_ss_out`` /
-    ``norm_out`` [rows] with the residual epilogue -- info then carries "ss_out" [M, rows / 16] and "out_w" [M, rows]."""
-    extended = merge_partials is not None or ss_in is not None or want_ss_out or norm_out is not None \
+    ``norm_out`` [rows] with the residual epilogue -- info then carries "ss_out" [M, rows / 16] and "out_w" [M, rows].
+    ``fragment_order``: the weighted rows on either side (``a`` with PRO_RMS_WEIGHTED through kernel 5: [ceil16(M), cols] in fragment
+    order; "out_w": [ceil16(M), rows]) lie in the batched step's fragment order (fragment_order_of / rows_from_fragment_order)."""
+    extended = merge_partials is not None or ss_in is not None or want_ss_out or norm_out is not None or fragment_order \
         or prologue in (PRO_ATTN_MERGE, PRO_RMS_WEIGHTED)
     if prologue == PRO_ATTN_MERGE:
         if merge_partials is None or a is not None:
@@ -634,6 +637,10 @@ def decode_linear(w: TiledW4, a: torch.Tensor | None, *, prologue: int = PRO_NON
         if a.dtype != torch.bfloat16 or a.dim() != 2 or a.shape[1] != w.cols or not a.is_contiguous():
             raise RuntimeError("decode_linear: a must be a contiguous bfloat16 [M, cols] tensor")
         M, device = int(a.shape[0]), a.device
+        if fragment_order and prologue == PRO_RMS_WEIGHTED:  # rows padded to 16: the caller says how many are real
+            if M % 16 != 0 or fragment_rows is None or not (M - 16 < fragment_rows <= M):
+                raise RuntimeError("decode_linear: rows in fragment order come as [ceil16(M), cols] with fragment_rows = M")
+            M = int(fragment_rows)
     out_cols = w.rows // 2 if epilogue == EPI_SWIGLU else w.rows
     out = torch.empty((M, out_cols), dtype=torch.bfloat16, device=device)
     if residual is not None and (residual.dtype != torch.bfloat16 or tuple(residual.shape) != (M, w.rows)
@@ -665,11 +672,30 @@ def decode_linear(w: TiledW4, a: torch.Tensor | None, *, prologue: int = PRO_NON
         if norm_out is not None:
             if norm_out.dtype != torch.bfloat16 or tuple(norm_out.shape) != (w.rows,):
                 raise RuntimeError("decode_linear: norm_out must be bfloat16 [rows]")
-            extra["out_w"] = torch.empty((M, w.rows), dtype=torch.bfloat16, device=device)
+            extra["out_w"] = torch.zeros(((M + 15) // 16 * 16 if fragment_order else M, w.rows), dtype=torch.bfloat16, device=device)
             ex.norm_out_dev, ex.out_w_dev = _ptr(norm_out), _ptr(extra["out_w"])
+        ex.fragment_order = 1 if fragment_order else 0
         _check(_lib.tl_decode_linear_ex(*common, ctypes.byref(ex), ctypes.byref(info)))
     return out, {"kernel": info.kernel, "kernel_name": LINEAR_KERNELS.get(info.kernel, "?"), "launches": info.launches,
                  "rows_per_pass": info.rows_per_pass, "p": list(info.p), **extra}
+
+
+def fragment_order_of(rows: torch.Tensor) -> torch.Tensor:
+    """[M, cols] -> the batched step's fragment order, [ceil16(M), cols] (zero rows appended): [16-row block][128-column group]
+    [k-step t][lane = r + 16 c][8 elements] = row 16 block + r, columns 128 g + 32 c + 8 t .. + 7 (csrc/qmm6.h, qmm6_frag_offset)."""
+    M, cols = rows.shape
+    pad = (M + 15) // 16 * 16
+    x = torch.zeros((pad, cols), dtype=rows.dtype, device=rows.device)
+    x[:M] = rows
+    x = x.reshape(pad // 16, 16, cols // 128, 4, 4, 8)      # [block, r, g, c, t, e]
+    return x.permute(0, 2, 4, 3, 1, 5).contiguous().reshape(pad, cols)  # [block, g, t, c, r, e]
+
+
+def rows_from_fragment_order(frag: torch.Tensor, M: int) -> torch.Tensor:
+    """Inverse of fragment_order_of: [ceil16(M), cols] in fragment order -> [M, cols] row-major."""
+    pad, cols = frag.shape
+    x = frag.reshape(pad // 16, cols // 128, 4, 4, 16, 8)   # [block, g, t, c, r, e]
+    return x.permute(0, 4, 1, 3, 2, 5).contiguous().reshape(pad, cols)[:M]
 
 
 def decode_attention_fused(qkv: torch.Tensor, q_norm: torch.Tensor, k_norm: torch.Tensor, key_pages: torch.Tensor,
