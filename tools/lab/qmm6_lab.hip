@@ -1,7 +1,7 @@
 // Kernel laboratory (not part of the product): the register-resident batched-decode matmul (csrc/qmm6.h) at the Qwen3-4B projection
 // shapes, HIP events, next to the K-sliced skinny matmul + slice reduction (csrc/qmm3.h) on the same inputs.  With -DQMM6_TRACE the
 // kernel leaves per-wave wall-clock stamps at its phase boundaries; the lab prints their mean distance from the wave's start.
-// usage: qmm6_lab <rows>     build + run: tools/lab/run_qmm6_lab.sh
+// usage: qmm6_lab <rows> [1 = the weighted rows of qkv / gate|up / lm_head in fragment order]     build + run: tools/lab/run_qmm6_lab.sh
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -29,7 +29,7 @@ int main(int argc, char **argv) {
         const size_t wwords = (size_t)K * N / 8, swords = (size_t)K * G;
         const int copies = (size_t)wwords * 4 > (64u << 20) ? 3 : 8;
         uint32_t *w, *sb; uint16_t *a, *out, *res, *nw_dev, *outw; float *partial, *ss, *ssout;
-        CK(hipMalloc(&w, wwords * 4 * copies)); CK(hipMalloc(&sb, swords * 4 * copies)); CK(hipMalloc(&a, (size_t)M * N * 2));
+        CK(hipMalloc(&w, wwords * 4 * copies)); CK(hipMalloc(&sb, swords * 4 * copies)); CK(hipMalloc(&a, (size_t)(M + 15) / 16 * 16 * N * 2)); CK(hipMemset(a, 0, (size_t)(M + 15) / 16 * 16 * N * 2));
         CK(hipMalloc(&out, (size_t)M * K * 2)); CK(hipMalloc(&res, (size_t)M * K * 2)); CK(hipMalloc(&outw, (size_t)M * K * 2));
         CK(hipMalloc(&nw_dev, (size_t)K * 2)); CK(hipMalloc(&ss, (size_t)M * 160 * 4)); CK(hipMalloc(&ssout, (size_t)M * (K / 16) * 4));
         {
@@ -44,7 +44,8 @@ int main(int argc, char **argv) {
             CK(hipMemcpy(nw_dev, hn.data(), hn.size() * 2, hipMemcpyHostToDevice));
             std::vector<float> hss((size_t)M * 160, 10.f); CK(hipMemcpy(ss, hss.data(), hss.size() * 4, hipMemcpyHostToDevice));
         }
-        const Qmm6Plan pl = qmm6_plan(M, N, K);
+        const int frag = (argc > 2 ? atoi(argv[2]) : 0) && sh.epi != EPI_RESIDUAL;
+        const Qmm6Plan pl = qmm6_plan(M, N, K, frag != 0);
         const Qmm3Plan p3 = qmm3_plan(M, N, K, -1);
         CK(hipMalloc(&partial, std::max<size_t>(p3.partial_bytes, 16)));
         if (!pl.ok) { printf("%-8s rows %d: no plan\n", sh.name, M); continue; }
@@ -54,7 +55,7 @@ int main(int argc, char **argv) {
         CK(hipMalloc(&pb, nwaves * 16 * 8)); CK(hipMemset(pb, 0, nwaves * 16 * 8));
         auto mm6 = [&](int i, unsigned long long *prof) {
             Qmm6Args q{}; q.wt = w + (size_t)(i % copies) * wwords; q.sbt = sb + (size_t)(i % copies) * swords; q.a = a; q.out = out; q.M = M; q.N = N; q.K = K; q.eps = 1e-6f;
-            if (epi == EPI_RESIDUAL) { q.residual = res; q.norm_out = nw_dev; q.out_w = outw; q.ss_out = ssout; } else { q.ss = ss; q.ss_n = 160; }
+            if (epi == EPI_RESIDUAL) { q.residual = res; q.norm_out = nw_dev; q.out_w = outw; q.ss_out = ssout; } else { q.ss = ss; q.ss_n = 160; q.a_frag = frag; }
             q.prof = prof;
             if (launch_qmm6_bf16(q, epi, 0) != 0) { printf("qmm6 launch failed\n"); exit(1); } };
         auto mm3 = [&](int i) {
@@ -71,7 +72,7 @@ int main(int argc, char **argv) {
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0, 0)); for (int i = 0; i < iters; ++i) mm3(i); CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
         CK(hipEventElapsedTime(&ms3, e0, e1));
-        printf("%-8s rows %2d  qmm6 <MB %d GPW %2d sets %d> %3d x %d wg, %2d tiles each: %6.2f us   |   qmm3 + reduction (%d slices): %6.2f us\n", sh.name, M, pl.MB, pl.GPW,
+        printf("%-8s rows %2d  qmm6%s <MB %d GPW %2d sets %d> %3d x %d wg, %2d tiles each: %6.2f us   |   qmm3 + reduction (%d slices): %6.2f us\n", sh.name, M, frag ? " (fragment order)" : "", pl.MB, pl.GPW,
                pl.NSETS, pl.wgs, pl.row_blocks, pl.tiles_per_wg, ms6 * 1000.f / iters, p3.slices, ms3 * 1000.f / iters);
 #ifdef QMM6_TRACE
         mm6(0, pb); CK(hipDeviceSynchronize());

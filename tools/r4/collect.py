@@ -25,6 +25,7 @@ def main() -> None:
         "bench_c5.json": prof / "r04_bench_config5.json", "bench_driver_shape.json": prof / "r04_bench_driver_shape.json",
         "bench.err": labs / "bench_config2_progress.txt",
         "ab_batched.jsonl": labs / "batched_decode_final.jsonl",
+        "ab_qmm6.jsonl": labs / "batched_decode_final_ab_without_qmm6.jsonl", "qmm6_lab.txt": labs / "batched_matmul_qmm6_lab_final.txt",
         "replicas_n1.json": labs / "serve_replicas_n1_b64.json", "replicas_n1.log": labs / "serve_replicas_n1_b64.txt",
         "operators.json": labs / "operators_decode_projections.json", "operators.log": labs / "operators_decode_projections.txt",
         "attention.json": labs / "attention_decode_contexts.json", "attention.log": labs / "attention_decode_contexts.txt",

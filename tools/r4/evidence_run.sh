@@ -35,6 +35,16 @@ import json
 for l in open("gpurun_out/evidence_r4/ab_batched.jsonl"):
     r=json.loads(l); print("batch",r["batch"],"ms/step",r["ms_per_step"],"tok/s",r["tokens_per_s"],"launches",r.get("launches"))
 PY
+rm -f $OUT/ab_qmm6.jsonl
+for B in 8 16 32 64; do
+  timeout 300 python tools/decode_ab.py --batch $B --prompt-len 128 --steps 64 - TL_NO_QMM6=1 - TL_NO_QMM6=1 >> $OUT/ab_qmm6.jsonl 2>> $OUT/ab_qmm6.err
+done
+python - <<'PY'
+import json
+for l in open("gpurun_out/evidence_r4/ab_qmm6.jsonl"):
+    r=json.loads(l); print("batch",r["batch"],r["variant"],"ms/step",r["ms_per_step"],"launches",r.get("launches"))
+PY
+if [ -x tools/lab/qmm6_lab_abl0 ]; then for m in 64 32 16 8; do tools/lab/qmm6_lab_abl0 $m 1; tools/lab/qmm6_lab_abl0 $m 0; done > $OUT/qmm6_lab.txt 2>&1; fi
 timeout 900 python benches/serve_replicas.py --num-seqs 128 --batch-size 64 --json-output $OUT/replicas_n1.json > $OUT/replicas_n1.log 2>&1
 echo "replicas rc=$?"; grep -E "^Time|^Total|^Prefill|^Decode throughput|Decode step p50" $OUT/replicas_n1.log; tail -1 $OUT/replicas_n1.log | cut -c1-400
 timeout 600 python benches/bench_week2_operators.py --json-output $OUT/operators.json > $OUT/operators.log 2>&1; tail -12 $OUT/operators.log
