@@ -726,6 +726,8 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             // the weighted rows travel in fragment order from 9 rows (same-box A/B, profiles/r04_labs/README.md: 16 / 32 / 64 sequences
             // -1.5 / -4 / -1.3 % per step; at 8 sequences +2 %: row-major there)
             const bool frag = batch > 8;
+            // (qkv on this kernel beyond 16 rows, rows in fragment order, fast box: 24 / 32 / 64 sequences -1 / -1.1 / -2.9 % per step; without
+            // fragment order on a slow box it cost +4.7 us per layer at 32 rows: not taken)
             const bool qkv6 = batch <= 16 && qmm6_takes(e, w.wqkv, batch);
             const bool wo6 = wo6_ok && (batch <= 16 || batch > 32 || !sliced_leaves_weighted(w.wo));
             KeptPartials parts;
