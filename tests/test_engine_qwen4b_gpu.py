@@ -86,9 +86,14 @@ def test_single_stream_decode_matches_truth_as_closely_as_the_bf16_oracle(model_
         assert gap <= 2.0 * rec["max_abs_hip_vs_truth"] + rec["bf16_ulp_at_max"], f"step {s}: id {tok} is {gap:.4f} below the truth's best"
 
 
-@pytest.mark.parametrize("n_seq", [4, 8, 12])
+@pytest.mark.parametrize("n_seq", [4, 8, 12, 16, 24, 40, 64])
 def test_batched_decode_rows_match_truth(model_and_weights, n_seq):
-    """4 rows: the fused GEMV with MR = 4.  8 and 12 rows: the skinny matmul (MB = 1) for every projection.  First, middle and last sequence of the batch against their own truth."""
+    """4 rows: the fused GEMV with MR = 4.  From 5 rows the batched route of round 4 (csrc/engine.hip enqueue_step), every combination
+    of it: 8 rows -- qkv / wo / gate|up / lm_head on the register-resident matmul, weighted rows row-major; 12 and 16 -- the same with the
+    weighted rows in fragment order and ONE attention window per sequence; 24 -- qkv and wo back on the K-sliced matmul (the attention
+    kernel adds the qkv slices, the slice reduction writes the fragment-ordered rows), gate|up and lm_head register-resident on two row
+    blocks; 40 and 64 -- wo register-resident again on two workgroups per tile range, three / four row blocks.  First, middle and last
+    sequence of the batch against their own truth."""
     from tiny_llm_hip.engine import DecodeEngine
 
     model, weights = model_and_weights
