@@ -1,6 +1,7 @@
 // Device kernels private to the decode engine (engine.hip).  See include/tinyllm_engine.h for the step
 // structure; every kernel here keeps the reference's op boundaries as bf16 rounding points.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace tl {
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     const int b = __builtin_amdgcn_readfirstlane(blockIdx.z);
     const int Hq = p.num_heads, Hkv = p.num_kv_heads;
     const int rep = p.rep;
-    auto page_of = [&](int tok) { return p.page_shift >= 0 ? (tok >> p.page_shift) : tok / p.page_size; };
+    // (IP implies a power-of-two page: no division branch, which would be a control-flow join inside the stage loop)
+    auto page_of = [&](int tok) { return (IP || p.page_shift >= 0) ? (tok >> p.page_shift) : tok / p.page_size; };
     const int g = threadIdx.x >> 4;
     const int t = threadIdx.x & 15;
     const int32_t *brow = p.block_table + (long)b * p.max_pages;
@@ -428,16 +430,19 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
     // Two register sets for the K/V rows, used alternately (the loop is unrolled by two through this lambda): handing the
     // prefetched rows over by copying them cost 96 v_mov per stage.
     bool ok_next[U];
+    // The next stage's K/V rows are requested first -- UNCONDITIONALLY (the last stage requests itself again: rows that have just been
+    // read).  A branch around those loads is a control-flow join, and at a join hipcc's wait bookkeeping loses the issue order of pending
+    // loads: the first use of THIS stage's rows then waited for the rows just requested for the next one (round 4, found in the ISA:
+    // vmcnt(7) .. vmcnt(0) behind the prefetch) -- a stage cost one memory round trip whatever was prefetched.
     auto walk_stage = [&](int it, RawRow<VD>(&kc)[U], RawRow<VD>(&vc)[U], bool(&okc)[U], RawRow<VD>(&kn)[U], RawRow<VD>(&vn)[U],
                           bool(&okn)[U]) {
         const bool more = it + 1 < n_it;
+        const int nx = min(it + 1, n_it - 1);
         if constexpr (IP) {
-            if (more) {  // uniform
-                issue_kv_stage(t_begin + (it + 1) * 16 * U, pg_nxt, kn, vn, okn);
-                sload_i32(brow + min(page_of(t_begin + (it + 2) * 16 * U), p.max_pages - 1), pg_new);  // waited for at the end of this stage
-            }
-        } else if (more) {  // uniform
-            issue_kv(t_begin + (it + 1) * 16 * U, pid_next, kn, vn, okn);
+            issue_kv_stage(t_begin + nx * 16 * U, pg_nxt, kn, vn, okn);  // (last stage: any valid rows; the result is not used)
+            if (more) sload_i32(brow + min(page_of(t_begin + (it + 2) * 16 * U), p.max_pages - 1), pg_new);  // scalar: waited for at the end of this stage
+        } else {
+            issue_kv(t_begin + nx * 16 * U, pid_next, kn, vn, okn);
             if constexpr (!SP) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -498,8 +503,8 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
                 for (int i = 0; i < VD; ++i) acc[r][i] += pw * BF16::to_float(vc[u].v[i]);
             }
         }
-        if (more) {
-            if constexpr (IP) {
+        if constexpr (IP) {
+            if (more) {  // scalar loads only inside: both sides of this join carry the same pending vector loads
                 sload_wait(pg_new);
                 pg_nxt = pg_new;
             }
