@@ -295,7 +295,8 @@ int tl_decode_linear_ex(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, 
 /* Host-only (no device, no launch): the plans the decode path picks.  tl_decode_gemv_plan: MFMA GEMV of M rows against a
  * [rows, cols] W4 matrix -> out5 = {activation rows per workgroup, reduction split, waves, groups per wave, workgroups}; returns 1
  * when the MFMA GEMV takes the shape (0: the packed-dot GEMV would).  tl_decode_attention_plan: `batch` sequences whose longest
- * holds max_context tokens before this step -> out3 = {windows per sequence, tokens per window, query heads per workgroup}. */
+ * holds max_context tokens before this step -> out3 = {windows per sequence, tokens per window, query heads per workgroup}, at head size
+ * 128 on 128-token pages. */
 int tl_decode_gemv_plan(int M, int rows, int cols, int *out5);
 /* 1 when the library holds a fused-GEMV kernel for (rows per workgroup, reduction split, waves, groups per wave): a plan is only
  * ever "taken" (tl_decode_gemv_plan returns 1) for such a combination; anything else decodes through the packed-dot GEMV. */

@@ -17,6 +17,7 @@
 #include "qmv3.h"
 #include "qmm3.h"
 #include "qmm6.h"
+#include "attn_mfma.h"
 
 namespace tl {
 
@@ -104,7 +105,9 @@ struct tl_engine {
     int attn_min_tokens = 64;    // tokens per attention workgroup before the context is split (TL_ATTN_MIN_TOKENS)
     int attn_wg_cap = 0;         // most attention workgroups per launch; 0 = by sequences (pick_decode_splits)
     bool attn_min_tokens_auto = true;  // ... or more, by context and sequences (pick_decode_splits)
+    bool attn_mfma = true;       // TL_ATTN_MFMA=0: the GQA-group walk on the VALU (attn_decode_fused_kernel), the A/B twin of attn_mfma.h
     int attn_max_splits = 64;    // most context splits per sequence (TL_ATTN_MAX_SPLITS, a power of two <= 256)
+    bool attn_max_splits_auto = true;  // false once TL_ATTN_MAX_SPLITS pins the count
     int attn_max_splits_gqa = 32;  // ... when a workgroup takes a whole GQA group (TL_ATTN_MAX_SPLITS sets both)
     tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
     int force_linear = 0;               // kernel-level entry points: 1 = fused GEMV, 2 = skinny matmul
@@ -487,8 +490,12 @@ struct SplitPlan {
 // removed in round 3 together with the last-arriver in-kernel merge, which measured neutral.)
 // the attention plan's lab knobs (environment, read when an engine -- or the standalone operator's stand-in for one -- is set up)
 static void read_attention_knobs(tl_engine *e) {
+    if (const char *q = getenv("TL_ATTN_MFMA")) e->attn_mfma = atoi(q) != 0;
     if (const char *q = getenv("TL_ATTN_RQ")) e->attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
-    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = e->attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
+    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) {
+        e->attn_max_splits = e->attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
+        e->attn_max_splits_auto = false;
+    }
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q)), e->attn_min_tokens_auto = false;
 }
 static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
@@ -521,6 +528,10 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // a whole GQA group per workgroup (long contexts / several sequences): at most 32 windows -- one workgroup per CU for one sequence;
     // measured at 8k 666 -> 680 tok/s against 64 windows, 32k unchanged (round 3)
     int max_splits = rq == AD_RQ ? e->attn_max_splits_gqa : e->attn_max_splits;
+    // ... and 64 from 24k tokens when the walk runs on the matrix cores (two workgroups per CU = two stages in flight; round 4, same box:
+    // 1.931 / 1.896 -> 1.898 / 1.866 ms per step at 32k; at 8k 64 windows of 128 tokens lose, 1.256 -> 1.332)
+    const bool mfma_walk = e->attn_mfma && e->cfg.head_dim == 128 && e->cfg.page_size >= 32 && (e->cfg.page_size & (e->cfg.page_size - 1)) == 0;
+    if (rq == AD_RQ && mfma_walk && e->attn_max_splits_auto && max_ctx >= 24576) max_splits = 64;  // (windows of 384+ tokens)
     // Many sequences at short contexts: one window per sequence and NO merge launch (round 4, same-box A/B at ~190 / ~660 tokens,
     // profiles/r04_labs/README.md): 12 / 16 sequences 1.623 -> 1.603 / 1.661 -> 1.634 ms per step at ~190 tokens (at ~660 the split stays:
     // 16 sequences 1.885 against 2.000), 24 / 32 sequences 2.15 -> 2.03 / 2.215 -> 2.07 at ~190 and 32 sequences 2.56 -> 2.495 at ~660.
@@ -551,7 +562,17 @@ static void launch_attn_decode_sp(const AttnDecodeArgs &a, dim3 grid, hipStream_
     else hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP>), grid, dim3(256), lds, st, a);
 }
 template <int VD>
-static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq) {
+static void launch_attn_decode(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq, bool mfma) {
+    if constexpr (VD == 8) {
+        // a whole GQA group per workgroup: the walk on the matrix cores (attn_mfma.h) from 128-token windows -- a stage is 4 waves x 32
+        // tokens, and on 64-token windows half of the waves idle (round 4, same-box A/B: 4 / 8 sequences at ~230 tokens 1.445 / 1.539
+        // against 1.416 / 1.527 ms per step for the VALU walk; 4 sequences at 2k 1.691 against 1.729, one at 8k / 32k 1.256 / 1.90
+        // against 1.35 / 2.13)
+        if (mfma && a.tokens_per_split >= 128 && attn_decode_mfma_applicable(a, 16 * VD, rq)) {
+            launch_attn_decode_mfma(a, grid, st);
+            return;
+        }
+    }
     const bool single_page = a.tokens_per_split <= a.page_size && a.page_size % a.tokens_per_split == 0;
     // every 64-token stage of a window inside one page: windows are multiples of 64 tokens, pages a power of two >= 64
     const bool stage_page = !single_page && a.page_shift >= 6 && a.tokens_per_split % 64 == 0;
@@ -649,9 +670,9 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
                "engine: attention workspace too small for this split plan");
     const dim3 grid(n_splits * chunks, c.num_kv_heads, batch);
     switch (D) {
-        case 128: launch_attn_decode<8>(a, grid, e->stream, sp.rq); break;
-        case 64: launch_attn_decode<4>(a, grid, e->stream, sp.rq); break;
-        case 32: launch_attn_decode<2>(a, grid, e->stream, sp.rq); break;
+        case 128: launch_attn_decode<8>(a, grid, e->stream, sp.rq, e->attn_mfma); break;
+        case 64: launch_attn_decode<4>(a, grid, e->stream, sp.rq, false); break;
+        case 32: launch_attn_decode<2>(a, grid, e->stream, sp.rq, false); break;
         default: return fail(TL_ERR_UNSUPPORTED, "engine: head_dim must be 32, 64 or 128");
     }
     if (pc) prof_after(e, pc, 5, (int)(grid.x * grid.y * grid.z));
@@ -2161,6 +2182,8 @@ extern "C" int tl_decode_attention_plan(int batch, int max_context, int num_head
     tl_engine e;
     e.cfg.num_heads = num_heads;
     e.cfg.num_kv_heads = num_kv_heads;
+    e.cfg.head_dim = 128;  // the plan of the Qwen3 head size on 128-token pages
+    e.cfg.page_size = 128;
     read_attention_knobs(&e);
     const SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
     out3[0] = sp.n_splits, out3[1] = sp.tokens_per_split, out3[2] = sp.rq;

@@ -88,7 +88,7 @@ __device__ __forceinline__ void head_norm_rope(const uint16_t *src, const uint16
 // device with the SAME expression as rope_kernel (pointwise.hip) / the reference fast kernel
 // (week2_kernels.metal:86-104), so table and on-the-fly values are bit-identical.  Decode then does no trig at all.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rope_table_kernel(float2 *__restrict__ table, int max_pos, int half, float base) {
+static __global__ __launch_bounds__(256) void rope_table_kernel(float2 *__restrict__ table, int max_pos, int half, float base) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)max_pos * half) return;
     const int pos = (int)(idx / half);
@@ -224,7 +224,7 @@ __device__ __forceinline__ void store_raw(uint16_t *dst, const RawRow<VD> &r) {
 // trip, all slices of a chunk in flight together), summed in slice order, rounded to bf16 and handed to every 16-lane group
 // through LDS -- the qkv projection's slice-reduction launch (a dependent phase of ~3.3 us per layer) is gone.
 template <int VD, int U, int RQ, bool SP, bool IP = false, bool QP = false>
-__global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecodeArgs p) {
+static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecodeArgs p) {
     constexpr int D = 16 * VD;
     constexpr int STRIDE = D + 2;
     extern __shared__ __attribute__((aligned(16))) float psm[];  // [16][RQ][STRIDE] (+ QP: [(2 + RQ)][D] bf16 staged rows)
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecode
 
 // partials [rows, NS, D+2] -> out [rows, D]; all loads of a thread are independent and issued together
 template <int NS>
-__global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out,
+static __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out,
                                                          int D, prof_t *prof) {
     const prof_t prof_t0 = prof_begin(prof);
     const long orow = blockIdx.x;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__restrict
 // Here a row's partials are read by 4 workgroups x 8 split groups, 8 loads in flight per thread; every group folds its
 // splits (s = sg, sg + 8, ...) with the online-softmax update in index order, and the 8 groups meet in LDS in group order:
 // deterministic.
-__global__ __launch_bounds__(256) void attn_merge_cols_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out, int D,
+static __global__ __launch_bounds__(256) void attn_merge_cols_kernel(const float *__restrict__ ws, uint16_t *__restrict__ out, int D,
                                                               int n_splits, prof_t *prof) {
     __shared__ float s_m[8][32], s_l[8][32], s_a[8][32];
     const prof_t prof_t0 = prof_begin(prof);
@@ -707,7 +707,7 @@ struct StepEndArgs {
     int tiles;
 };
 
-__global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
+static __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
     __shared__ float s_val[16];
     __shared__ int s_idx[16];
     __shared__ int s_token, s_ctx;
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs p) {
 
 // Greedy id of every logits row (speculative verification): same tie rule as step_end_kernel (first maximum wins).
 //   grid = rows, block = 1024
-__global__ __launch_bounds__(1024) void argmax_rows_kernel(const uint16_t *__restrict__ logits, int vocab,
+static __global__ __launch_bounds__(1024) void argmax_rows_kernel(const uint16_t *__restrict__ logits, int vocab,
                                                            int32_t *__restrict__ ids) {
     __shared__ float s_val[16];
     __shared__ int s_idx[16];
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const uint16_t *__res
 }
 
 // (start, end) of one instrumented launch: min over workgroup starts, max over ends; clears the buffer.
-__global__ __launch_bounds__(1024) void prof_reduce_kernel(prof_t *buf, int n_wg, prof_t *out_pair) {
+static __global__ __launch_bounds__(1024) void prof_reduce_kernel(prof_t *buf, int n_wg, prof_t *out_pair) {
     __shared__ prof_t s_min[16], s_max[16];
     prof_t lo = ~0ull, hi = 0ull;
     for (int i = threadIdx.x; i < n_wg; i += 1024) {
@@ -930,7 +930,7 @@ struct QkvPostArgs {
 };
 
 template <int VD>
-__global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs p) {
+static __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs p) {
     constexpr int D = 16 * VD;
     const int r = blockIdx.x;
     const int g = threadIdx.x >> 4;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs p) {
 }
 
 // [H, T, D] -> [T, H*D], 16 B per thread (D % 8 == 0)
-__global__ __launch_bounds__(256) void heads_to_rows_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out,
+static __global__ __launch_bounds__(256) void heads_to_rows_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out,
                                                             int H, int T, int D) {
     const int vpr = D / 8;
     const long total = (long)H * T * vpr;
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(256) void heads_to_rows_kernel(const uint16_t *__re
 }
 
 // out = bf16(a + b), n % 8 == 0
-__global__ __launch_bounds__(256) void residual_add_kernel(const uint16_t *__restrict__ a, const uint16_t *__restrict__ b,
+static __global__ __launch_bounds__(256) void residual_add_kernel(const uint16_t *__restrict__ a, const uint16_t *__restrict__ b,
                                                            uint16_t *__restrict__ out, long n8) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n8) return;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void residual_add_kernel(const uint16_t *__res
 // out[row, :] = bf16(x[row, :] * w) (w == nullptr: a copy): rows weighted by an RMSNorm weight for a consumer that applies 1 / rms to
 // its sums (qmm6.h); one launch per batched step, ahead of layer 0 (every later layer gets its rows weighted by the w_down epilogue).
 // Chunks of 8 columns; frag != 0: written in qmm6.h's fragment order (a chunk is one 16-byte run there too).
-__global__ __launch_bounds__(256) void weight_rows_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
+static __global__ __launch_bounds__(256) void weight_rows_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w,
                                                           uint16_t *__restrict__ out, long n8, int chunks_per_row, int frag) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n8) return;
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(256) void weight_rows_kernel(const uint16_t *__rest
 }
 
 // gu [T, 2I] with (gate_i, up_i) interleaved -> act [T, I] = bf16(silu(gate) * up)   (I % 4 == 0)
-__global__ __launch_bounds__(256) void swiglu_interleaved_kernel(const uint16_t *__restrict__ gu,
+static __global__ __launch_bounds__(256) void swiglu_interleaved_kernel(const uint16_t *__restrict__ gu,
                                                                  uint16_t *__restrict__ act, long n4) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n4) return;
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(256) void swiglu_interleaved_kernel(const uint16_t 
 }
 
 // tokens[max_batch] -> x[slot, hidden] for slots [0, batch): one block per slot
-__global__ __launch_bounds__(256) void embed_slots_kernel(const int32_t *__restrict__ tokens,
+static __global__ __launch_bounds__(256) void embed_slots_kernel(const int32_t *__restrict__ tokens,
                                                           const uint32_t *__restrict__ emb_w,
                                                           const uint16_t *__restrict__ emb_s,
                                                           const uint16_t *__restrict__ emb_b, uint16_t *__restrict__ x,
@@ -1081,10 +1081,10 @@ struct PokeArgs {
     int32_t value[8];
     int n;
 };
-__global__ void poke_kernel(const PokeArgs p) {
+static __global__ void poke_kernel(const PokeArgs p) {
     if ((int)threadIdx.x < p.n) *p.addr[threadIdx.x] = p.value[threadIdx.x];
 }
-__global__ void fill_i32_kernel(int32_t *dst, int32_t value, int n) {
+static __global__ void fill_i32_kernel(int32_t *dst, int32_t value, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = value;
 }
@@ -1094,7 +1094,7 @@ __global__ void fill_i32_kernel(int32_t *dst, int32_t value, int n) {
 // largest probabilities in descending order (equal probabilities: the lower expert index first) and their scores, renormalised over
 // the selection when `norm` (bf16 arithmetic as the reference's arrays: the sum rounded once, the quotient rounded once).
 // One workgroup per activation row; E <= 1024, top_k <= 16.
-__global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t *__restrict__ logits, int E, int top_k, int norm,
+static __global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t *__restrict__ logits, int E, int top_k, int norm,
                                                         int32_t *__restrict__ ids, uint16_t *__restrict__ scores) {
     __shared__ float red[4];
     __shared__ int red_i[4];
@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t *__restri
 }
 
 // act = bf16(bf16(silu(gate)) * up), 8 elements per thread (moe.py:83-84: silu(gate) * up on bf16 arrays, two roundings)
-__global__ __launch_bounds__(256) void moe_silu_mul_kernel(const uint16_t *__restrict__ gate, const uint16_t *__restrict__ up,
+static __global__ __launch_bounds__(256) void moe_silu_mul_kernel(const uint16_t *__restrict__ gate, const uint16_t *__restrict__ up,
                                                            uint16_t *__restrict__ act, long n8) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n8) return;
@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(256) void moe_silu_mul_kernel(const uint16_t *__res
 
 // out[m] = bf16(h[m] + bf16(sum_j bf16(y[m, j] * score[m, j])))   (moe.py:89 then the layer's residual add, qwen3_week3.py:204-205);
 // the sum over the top_k expert rows accumulates in fp32 in expert order.  grid = rows, D % 8 == 0.
-__global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t *__restrict__ y, const uint16_t *__restrict__ scores,
+static __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t *__restrict__ y, const uint16_t *__restrict__ scores,
                                                           const uint16_t *__restrict__ h, uint16_t *__restrict__ out, int D,
                                                           int top_k) {
     const int m = blockIdx.x;
