@@ -529,17 +529,21 @@ def test_decode_attention_contexts_up_to_4k(ext, ctx, monkeypatch):
 
 
 @pytest.mark.parametrize("ctxs", [[8191], [8192, 5000, 129, -1], [32767], [32768, 1, 700, 20000]])
-@pytest.mark.parametrize("mode", ["default", "splits256", "legacy_rq1"])
+@pytest.mark.parametrize("mode", ["default", "splits256", "legacy_rq1", "valu_walk"])
 def test_decode_attention_long_contexts(ext, ctxs, mode, monkeypatch):
     """BASELINE configs 3 and 5 (8k and 32k cached tokens, page 128), 1 and 4 sequences (ragged, one idle slot written as
-    -1): the default plan (one workgroup per GQA group walking 64-token stages, split + merge), 256 context splits
-    (attn_merge_cols_kernel over many groups), and the one-head split kernel."""
-    for name in ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS"):
+    -1): the default plan (one workgroup per GQA group walking its window on the matrix cores, csrc/attn_mfma.h, split + merge), 256
+    context splits (128-token windows; attn_merge_cols_kernel over many groups), the one-head split kernel, and the GQA-group walk on
+    the VALU (TL_ATTN_MFMA=0: attn_decode_fused_kernel in 64-token stages, the route of rounds 2-3 and still the one for 64-token
+    windows)."""
+    for name in ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MFMA"):
         monkeypatch.delenv(name, raising=False)
     if mode == "splits256":
         monkeypatch.setenv("TL_ATTN_MAX_SPLITS", "256")
     elif mode == "legacy_rq1":
         monkeypatch.setenv("TL_ATTN_RQ", "1")
+    elif mode == "valu_walk":
+        monkeypatch.setenv("TL_ATTN_MFMA", "0")
     idle = [c < 0 for c in ctxs]
     rng = np.random.default_rng(abs(sum(ctxs)) + len(mode))
     case = _attention_case(rng, ctxs)

@@ -95,9 +95,8 @@ def test_the_planners_variant_predicate_is_the_instantiation_table(lib):
     (1, 40, 1, 1, 64), (1, 100, 2, 1, 64), (1, 150, 4, 1, 64), (1, 255, 4, 1, 64),   # up to 256 tokens: 64-token windows
     (1, 300, 4, 1, 128), (1, 511, 4, 1, 128),                                        # 257..512: 128 (4 partials for the wo GEMV, not 8)
     (1, 700, 4, 1, 256), (1, 1500, 8, 1, 256), (1, 3000, 16, 1, 256),                # beyond: 256-token windows
-    (1, 5000, 32, 4, 256), (1, 20000, 32, 4, 1024),                                  # above 4,096 tokens a GQA group per workgroup, 32 windows
-    (1, 32700, 64, 4, 512), (1, 40000, 64, 4, 1024),                                 # ... 64 from 32k (matrix-core walk, two workgroups per CU)
-    (2, 300, 8, 1, 64), (2, 700, 4, 1, 256), (2, 1500, 8, 1, 256), (2, 3000, 16, 4, 256),  # two sequences switch at 2,048 tokens
+    (1, 5000, 32, 4, 256), (1, 20000, 32, 4, 1024), (1, 32768, 32, 4, 2048),         # above 4,096 tokens a GQA group per workgroup, 32 windows
+    (2, 300, 8, 1, 64), (2, 700, 4, 1, 256), (2, 1500, 8, 4, 256), (2, 3000, 16, 4, 256),  # two sequences switch at 1,024 tokens
     (4, 256, 8, 4, 64), (4, 1000, 4, 4, 256),                                        # 3+ sequences: always the GQA-group walk
     (8, 300, 4, 4, 128), (8, 1000, 8, 4, 128), (64, 300, 1, 4, 512),                 # 5-8: 128 at 257..512; many sequences: one window each
     (12, 200, 1, 4, 256), (16, 200, 1, 4, 256), (16, 600, 4, 4, 256), (11, 200, 4, 4, 64),   # round 4: from 12 sequences no split up to 256 tokens ...
@@ -120,9 +119,6 @@ def test_attention_plan_knobs_are_read(lib, monkeypatch):
     monkeypatch.delenv("TL_ATTN_MAX_SPLITS")
     monkeypatch.setenv("TL_ATTN_RQ", "4")
     assert attention_plan(lib, 1, 300)[2] == 4
-    monkeypatch.delenv("TL_ATTN_RQ")
-    monkeypatch.setenv("TL_ATTN_MFMA", "0")
-    assert attention_plan(lib, 1, 32700)[0] == 32  # the VALU walk keeps one workgroup per CU
 
 
 def batched_plan(lib, M, rows, cols):

@@ -22,11 +22,11 @@ from oracle import tiny_oracle as O
 pytestmark = [pytest.mark.gpu]
 
 
-def run(model, cfg, n_seq, steps, page_size, partials, profile=False):
+def run(model, cfg, n_seq, steps, page_size, partials, profile=False, prompt_base=3, prompt_spread=19):
     from tiny_llm_hip.engine import DecodeEngine
 
     rng = np.random.default_rng(500 + n_seq)
-    prompts = [[int(t) for t in rng.integers(1, cfg["vocab_size"], size=3 + (7 * i) % 19)] for i in range(n_seq)]
+    prompts = [[int(t) for t in rng.integers(1, cfg["vocab_size"], size=prompt_base + (7 * i) % prompt_spread)] for i in range(n_seq)]
     old = os.environ.pop("TL_ATTN_QKV_PARTIALS", None)
     os.environ["TL_ATTN_QKV_PARTIALS"] = "1" if partials else "0"  # read when the engine is created (default since round 3: 1)
     try:
@@ -78,3 +78,17 @@ def test_qwen3_4b_shapes_same_bits_and_one_launch_fewer_per_layer(n_seq):
     assert torch.equal(a[2].view(torch.int16), b[2].view(torch.int16)), "final logits differ in their bits"
     launches = [sum(v["launches"] for v in r[3]["kinds"].values()) for r in (a, b)]
     assert launches[1] == launches[0] - cfg["num_hidden_layers"], f"launches per step {launches}: expected one fewer per layer"
+
+
+@pytest.mark.parametrize("n_seq", [17, 40])
+def test_qwen3_4b_shapes_same_bits_on_the_matrix_core_walk(n_seq):
+    """The same comparison where the window walk runs on the matrix cores (csrc/attn_mfma.h, QP: windows of 128 tokens and more --
+    prompts of 130..319 tokens; the short prompts above stay on the 64-token windows of the VALU walk)."""
+    from tiny_llm_hip.synthetic import synthetic_qwen3
+
+    cfg = dict(QWEN4B_CFG, num_hidden_layers=3)
+    model = synthetic_qwen3(cfg, seed=4, sigma=0.02, device="cuda")
+    a = run(model, cfg, n_seq, steps=4, page_size=128, partials=False, prompt_base=130, prompt_spread=190)
+    b = run(model, cfg, n_seq, steps=4, page_size=128, partials=True, prompt_base=130, prompt_spread=190)
+    assert a[0] == b[0] and a[1] == b[1], "greedy tokens differ"
+    assert torch.equal(a[2].view(torch.int16), b[2].view(torch.int16)), "final logits differ in their bits"

@@ -42,10 +42,16 @@ def checkpoint():
     return G.CFG, to_mlx_shaped(G.CFG, weights), vec
 
 
-@pytest.mark.parametrize("prompt_len", list(PLANS))
-def test_engine_logits_behind_long_prompts_against_the_truth(checkpoint, prompt_len):
+@pytest.mark.parametrize("prompt_len,walk", [(n, "default") for n in PLANS] + [(300, "gqa_group"), (1200, "gqa_group"), (2500, "gqa_group")])
+def test_engine_logits_behind_long_prompts_against_the_truth(checkpoint, prompt_len, walk, monkeypatch):
+    """walk = "gqa_group": TL_ATTN_RQ=4, the plan of 3+ sequences and of contexts beyond 4k -- a whole GQA group per workgroup, whose
+    windows of 128 / 256 tokens are walked on the matrix cores (csrc/attn_mfma.h); same windows, same merge, same truth."""
     from tiny_llm_hip.engine import DecodeEngine
 
+    for name in ("TL_ATTN_RQ", "TL_ATTN_MFMA", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS"):
+        monkeypatch.delenv(name, raising=False)
+    if walk == "gqa_group":
+        monkeypatch.setenv("TL_ATTN_RQ", "4")
     cfg, model, vec = checkpoint
     windows, merged_by_wo = PLANS[prompt_len]
     prompt = [int(t) for t in vec[f"prompt_{prompt_len}"]]
@@ -67,7 +73,7 @@ def test_engine_logits_behind_long_prompts_against_the_truth(checkpoint, prompt_
     finally:
         eng.close()
     merges = prof["kinds"]["attention_merge"]["launches"]
-    what = f"Qwen3-4B layer shapes x {cfg['num_hidden_layers']}, prompt {prompt_len}: {prof['n_splits']} windows, {merges} merge launches per step"
+    what = f"Qwen3-4B layer shapes x {cfg['num_hidden_layers']}, prompt {prompt_len}, walk {walk}: {prof['n_splits']} windows, {merges} merge launches per step"
     assert prof["n_splits"] == windows, what
     assert merges == (0 if merged_by_wo else cfg["num_hidden_layers"]), what
     assert st["graph_replays"] >= len(fed) - 1, "the decode steps must run through the captured graph"
@@ -75,4 +81,4 @@ def test_engine_logits_behind_long_prompts_against_the_truth(checkpoint, prompt_
     # row 0 comes out of the prefill path (GEMM + FlashAttention), rows 1.. out of the fused decode step
     check_against_truth(got[:1], oracle[:1], truth[:1], what=what + " [prefill row]")
     rec = check_against_truth(got[1:], oracle[1:], truth[1:], what=what + " [decode rows]")
-    log_parity({"what": "engine_windows_vs_truth", "prompt": prompt_len, "windows": windows, "wo_merges": merged_by_wo, **rec})
+    log_parity({"what": "engine_windows_vs_truth", "prompt": prompt_len, "walk": walk, "windows": windows, "wo_merges": merged_by_wo, **rec})

@@ -117,12 +117,16 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
     sload_i32(brow + min(wp, p.max_pages - 1), wpage);
     // lane (c, g) reads dims 8 c .. 8 c + 7 of rows 4 g + e (e < 4) and 16 + 4 g + e - 4 of the wave's 32: the order of the second
     // product's reduction index
-    const int lane_off = (4 * g) * D + c * VD;
+    // Buffer loads: the stage's row base is a scalar resource, a lane's offset never changes -- no 64-bit address arithmetic on the
+    // VALU, and no address registers for the allocator to recycle as load destinations (which made the next stage's requests wait for
+    // this stage's V rows: a write-after-write on the recycled register).
+    const int lane_bytes = ((4 * g) * D + c * VD) * 2;
     auto issue_rows = [&](const uint16_t *pool, int tb, int pg, u32x4(&rows)[8]) {
         const long rowbase = (((long)max(pg, 0) * Hkv + kvh) * p.page_size + (tb & (p.page_size - 1))) * D;  // uniform
-        const uint16_t *src = pool + rowbase + lane_off;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(pool + rowbase), 0, WT * D * 2, 0x00020000);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rows[e] = *reinterpret_cast<const u32x4 *>(src + ((e < 4) ? e : 12 + e) * D);
+        for (int e = 0; e < 8; ++e)
+            rows[e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes + ((e < 4) ? e : 12 + e) * D * 2, 0, 0));
     };
     u32x4 kr[8], va[8], vb[8];
     issue_rows(p.key_pages, wave_base(0), pg_cur, kr);

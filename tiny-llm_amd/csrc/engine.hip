@@ -107,7 +107,6 @@ struct tl_engine {
     bool attn_min_tokens_auto = true;  // ... or more, by context and sequences (pick_decode_splits)
     bool attn_mfma = true;       // TL_ATTN_MFMA=0: the GQA-group walk on the VALU (attn_decode_fused_kernel), the A/B twin of attn_mfma.h
     int attn_max_splits = 64;    // most context splits per sequence (TL_ATTN_MAX_SPLITS, a power of two <= 256)
-    bool attn_max_splits_auto = true;  // false once TL_ATTN_MAX_SPLITS pins the count
     int attn_max_splits_gqa = 32;  // ... when a workgroup takes a whole GQA group (TL_ATTN_MAX_SPLITS sets both)
     tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
     int force_linear = 0;               // kernel-level entry points: 1 = fused GEMV, 2 = skinny matmul
@@ -492,18 +491,17 @@ struct SplitPlan {
 static void read_attention_knobs(tl_engine *e) {
     if (const char *q = getenv("TL_ATTN_MFMA")) e->attn_mfma = atoi(q) != 0;
     if (const char *q = getenv("TL_ATTN_RQ")) e->attn_rq = atoi(q) <= 0 ? 0 : (atoi(q) == 1 ? 1 : AD_RQ);
-    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) {
-        e->attn_max_splits = e->attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
-        e->attn_max_splits_auto = false;
-    }
+    if (const char *q = getenv("TL_ATTN_MAX_SPLITS")) e->attn_max_splits = e->attn_max_splits_gqa = std::min(256, std::max(1, atoi(q)));
     if (const char *q = getenv("TL_ATTN_MIN_TOKENS")) e->attn_min_tokens = std::max(64, atoi(q)), e->attn_min_tokens_auto = false;
 }
 static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) {
     const int rep = e->cfg.num_heads / e->cfg.num_kv_heads;
     int rq = e->attn_rq;
-    // two sequences re-read twice the windows: the GQA-group walk takes over at half the context (round 3, 2 sequences at 1,500 tokens
+    // two sequences re-read twice the windows: the GQA-group walk takes over at a quarter of the context (round 3, 2 sequences at 1,500 tokens
     // one head per workgroup 1.326 against 1.383 ms per step, at 3,000 tokens 1.527 against 1.465)
-    if (rq <= 0) rq = (max_ctx <= (batch <= 1 ? e->attn_rq1_ctx : e->attn_rq1_ctx / 2) && batch <= e->attn_rq1_batch) ? 1 : AD_RQ;
+    // (round 4, with the group walk on the matrix cores: 2 sequences at 1,500 tokens 1.46 -> 1.38 ms per step, at 700 a tie; one sequence
+    // at 700 / 1,500 / 3,000 tokens 1.05 / 1.11 / 1.24 for one head per workgroup against 1.13 / 1.21 / 1.24)
+    if (rq <= 0) rq = (max_ctx <= (batch <= 1 ? e->attn_rq1_ctx : e->attn_rq1_ctx / 4) && batch <= e->attn_rq1_batch) ? 1 : AD_RQ;
     if (rq != 1) rq = AD_RQ;
     int bucket = 64;
     while (bucket < max_ctx) bucket *= 2;
@@ -528,10 +526,8 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // a whole GQA group per workgroup (long contexts / several sequences): at most 32 windows -- one workgroup per CU for one sequence;
     // measured at 8k 666 -> 680 tok/s against 64 windows, 32k unchanged (round 3)
     int max_splits = rq == AD_RQ ? e->attn_max_splits_gqa : e->attn_max_splits;
-    // ... and 64 from 24k tokens when the walk runs on the matrix cores (two workgroups per CU = two stages in flight; round 4, same box:
-    // 1.931 / 1.896 -> 1.898 / 1.866 ms per step at 32k; at 8k 64 windows of 128 tokens lose, 1.256 -> 1.332)
-    const bool mfma_walk = e->attn_mfma && e->cfg.head_dim == 128 && e->cfg.page_size >= 32 && (e->cfg.page_size & (e->cfg.page_size - 1)) == 0;
-    if (rq == AD_RQ && mfma_walk && e->attn_max_splits_auto && max_ctx >= 24576) max_splits = 64;  // (windows of 384+ tokens)
+    // (64 windows = two workgroups per CU for the matrix-core walk at 32k: 1.931 / 1.896 -> 1.898 / 1.866 ms per step in one same-box
+    // A/B, 1.874 -> 1.891 in the next: within the noise, not taken)
     // Many sequences at short contexts: one window per sequence and NO merge launch (round 4, same-box A/B at ~190 / ~660 tokens,
     // profiles/r04_labs/README.md): 12 / 16 sequences 1.623 -> 1.603 / 1.661 -> 1.634 ms per step at ~190 tokens (at ~660 the split stays:
     // 16 sequences 1.885 against 2.000), 24 / 32 sequences 2.15 -> 2.03 / 2.215 -> 2.07 at ~190 and 32 sequences 2.56 -> 2.495 at ~660.
