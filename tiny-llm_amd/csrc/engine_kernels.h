@@ -1,5 +1,7 @@
 // Device kernels private to the decode engine (engine.hip).  See include/tinyllm_engine.h for the step
 // structure; every kernel here keeps the reference's op boundaries as bf16 rounding points.
+// (Kernels are `static`: attn_mfma.hip includes this header for the argument block and the prologue helpers of the decode attention
+// and is compiled with its own MFMA flag; internal linkage keeps the two objects from defining the same symbols.)
 #pragma once
 #include <type_traits>
 #include "common.h"
