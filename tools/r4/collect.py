@@ -26,6 +26,7 @@ def main() -> None:
         "bench.err": labs / "bench_config2_progress.txt",
         "ab_batched.jsonl": labs / "batched_decode_final.jsonl",
         "ab_qmm6.jsonl": labs / "batched_decode_final_ab_without_qmm6.jsonl", "qmm6_lab.txt": labs / "batched_matmul_qmm6_lab_final.txt",
+        "ab_attn_mfma.jsonl": labs / "attention_mfma_walk_final_ab.jsonl",
         "replicas_n1.json": labs / "serve_replicas_n1_b64.json", "replicas_n1.log": labs / "serve_replicas_n1_b64.txt",
         "operators.json": labs / "operators_decode_projections.json", "operators.log": labs / "operators_decode_projections.txt",
         "attention.json": labs / "attention_decode_contexts.json", "attention.log": labs / "attention_decode_contexts.txt",
@@ -45,6 +46,33 @@ def main() -> None:
             shutil.copyfile(found[-1], traces / dst)
         else:
             print("missing", tag)
+    # PMC passes (tools/lab/pmc_gemv.sh): per-kernel medians under profiles/r04_pmc/, profiles/traffic.json by tools/make_traffic_json.py
+    pmc = ROOT / "gpurun_out" / "pmc_gemv"
+    if pmc.exists():
+        import collections
+        import csv
+        import subprocess
+        (prof / "r04_pmc").mkdir(exist_ok=True)
+        ok = True
+        for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            found = sorted((pmc / kind).rglob("lab_counter_collection.csv"))
+            if not found:
+                print("missing pmc", kind)
+                ok = False
+                continue
+            if found[-1] != pmc / kind / "lab_counter_collection.csv":
+                shutil.copyfile(found[-1], pmc / kind / "lab_counter_collection.csv")
+            rows = collections.defaultdict(list)
+            for r in csv.DictReader(open(found[-1])):
+                rows[(r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+            with open(prof / "r04_pmc" / f"gemv_lab_{kind}_size.csv", "w") as f:
+                f.write("kernel,grid_size,counter,dispatches,median_KiB,min_KiB,max_KiB,sum_KiB\n")
+                for (k, g), v in sorted(rows.items()):
+                    v = sorted(v)
+                    f.write(f'"{k}",{g},{counter},{len(v)},{v[len(v) // 2]},{v[0]},{v[-1]},{round(sum(v), 1)}\n')
+        if ok:
+            subprocess.run(["python3", str(ROOT / "tools" / "make_traffic_json.py")], check=False, stdout=subprocess.DEVNULL)
+            print("traffic.json rewritten from this round's PMC passes")
     if (src / "pytest.log").exists():
         tail = (src / "pytest.log").read_text().strip().splitlines()[-14:]
         (prof / "r04_gpu_pytest_summary.txt").write_text("\n".join(tail) + "\n")

@@ -44,6 +44,16 @@ import json
 for l in open("gpurun_out/evidence_r4/ab_qmm6.jsonl"):
     r=json.loads(l); print("batch",r["batch"],r["variant"],"ms/step",r["ms_per_step"],"launches",r.get("launches"))
 PY
+rm -f $OUT/ab_attn_mfma.jsonl
+timeout 400 python tools/decode_ab.py --batch 1 --prompt-len 32000 --steps 64 - TL_ATTN_MFMA=0 - TL_ATTN_MFMA=0 >> $OUT/ab_attn_mfma.jsonl 2>> $OUT/ab_attn_mfma.err
+timeout 300 python tools/decode_ab.py --batch 1 --prompt-len 8000 --steps 64 - TL_ATTN_MFMA=0 - TL_ATTN_MFMA=0 >> $OUT/ab_attn_mfma.jsonl 2>> $OUT/ab_attn_mfma.err
+timeout 300 python tools/decode_ab.py --batch 16 --prompt-len 2000 --steps 64 - TL_ATTN_MFMA=0 - TL_ATTN_MFMA=0 >> $OUT/ab_attn_mfma.jsonl 2>> $OUT/ab_attn_mfma.err
+timeout 400 python tools/decode_ab.py --batch 64 --prompt-len 1000 --steps 64 - TL_ATTN_MFMA=0 - TL_ATTN_MFMA=0 >> $OUT/ab_attn_mfma.jsonl 2>> $OUT/ab_attn_mfma.err
+python - <<'PY'
+import json
+for l in open("gpurun_out/evidence_r4/ab_attn_mfma.jsonl"):
+    r=json.loads(l); print("batch",r["batch"],"prompt",r["prompt"],r["variant"],"ms/step",r["ms_per_step"],"attention",r["us_per_step"]["attention"],"merge",r["us_per_step"]["attention_merge"])
+PY
 if [ -x tools/lab/qmm6_lab_abl0 ]; then for m in 64 32 16 8; do tools/lab/qmm6_lab_abl0 $m 1; tools/lab/qmm6_lab_abl0 $m 0; done > $OUT/qmm6_lab.txt 2>&1; fi
 timeout 900 python benches/serve_replicas.py --num-seqs 128 --batch-size 64 --json-output $OUT/replicas_n1.json > $OUT/replicas_n1.log 2>&1
 echo "replicas rc=$?"; grep -E "^Time|^Total|^Prefill|^Decode throughput|Decode step p50" $OUT/replicas_n1.log; tail -1 $OUT/replicas_n1.log | cut -c1-400
@@ -54,6 +64,12 @@ rocprofv3 --kernel-trace --stats -d $OUT/trace_b64 -o b64 --output-format csv --
 echo "trace b64 rc=$?"
 rocprofv3 --kernel-trace --stats -d $OUT/trace_b8 -o b8 --output-format csv -- python $R/tools/decode_ab.py --batch 8 --prompt-len 256 --steps 32 --profile-steps 0 - > $OUT/trace_b8.log 2>&1
 echo "trace b8 rc=$?"
+# HBM bytes per GEMV launch: PMC passes of their own (counters only, no trace domain), tools/make_traffic_json.py reads them
+rm -rf $R/gpurun_out/pmc_gemv
+if [ -x $R/tools/lab/gemv_lab ]; then timeout 600 bash $R/tools/lab/pmc_gemv.sh > $OUT/pmc_gemv.log 2>&1; echo "pmc rc=$?"; fi
+find $R/gpurun_out/pmc_gemv -type f ! -name "lab_counter_collection.csv" ! -name "*.log" -delete 2>/dev/null
+du -sh $R/gpurun_out/pmc_gemv 2>/dev/null
+cd $R
 cp $R/gpurun_out/parity_numbers.jsonl $OUT/ 2>/dev/null
 cp -r $R/gpurun_out/bench_rocprof $OUT/ 2>/dev/null
 find $OUT -name "*.csv" | grep -v kernel_stats | xargs rm -f 2>/dev/null
