@@ -741,9 +741,10 @@ def main() -> None:
         traffic_file = ROOT / "profiles" / "traffic.json"
         if traffic_file.exists():
             try:
-                roofline["traffic"] = json.loads(traffic_file.read_text()).get("qmv_hbm_bytes_per_launch")
+                traffic = json.loads(traffic_file.read_text())
+                roofline["traffic"] = traffic.get("qmv_hbm_bytes_per_launch")
                 roofline["traffic_note"] = ("HBM bytes per GEMV launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; NOT measured in "
-                                            "this run: replayed from the committed profiles/traffic.json")
+                                            "this run: replayed from the committed profiles/traffic.json (" + str(traffic.get("collected", "round 3")) + ")")
             except Exception:
                 roofline["traffic"] = None
     roofline["step_achieved"] = round(step_gbps, 1)

@@ -33,7 +33,10 @@ for r in csv.DictReader(open(src / "fetch" / "lab_counter_collection.csv")):
     if "stream_kernel" in r["Kernel_Name"]:
         seen += float(r["Counter_Value"]) * 1024
 factor = known / seen
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/lab/gemv_lab pmc (separate passes)", "fetch_size_correction": round(factor, 4), "fetch_size_calibration": "stream_kernel<4, true>, %.3f GB of known reads" % (known / 1e9),
+import datetime
+stamp = datetime.datetime.utcfromtimestamp((src / "fetch" / "lab_counter_collection.csv").stat().st_mtime).strftime("%Y-%m-%d")
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/lab/gemv_lab pmc (separate passes)",
+       "collected": "passes merged " + stamp + " (UTC), lab linked against that day's csrc/build/qmv3.o", "fetch_size_correction": round(factor, 4), "fetch_size_calibration": "stream_kernel<4, true>, %.3f GB of known reads" % (known / 1e9),
        "per_kind": {}}
 tot_bytes, tot_alg, launches = 0.0, 0.0, 0
 for name, (K, N, kern, grid) in shapes.items():
