@@ -40,7 +40,7 @@ def kernel_metadata():
                 if not name:
                     continue
                 field = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", block).group(1))
-                out.append({"name": name.group(1), "scratch": field("private_segment_fixed_size"), "vgpr_spills": field("vgpr_spill_count"),
+                out.append({"name": name.group(1), "agprs": int(block.split()[0]), "scratch": field("private_segment_fixed_size"), "vgpr_spills": field("vgpr_spill_count"),
                             "sgpr_spills": field("sgpr_spill_count"), "vgprs": field("vgpr_count"), "lds": field("group_segment_fixed_size")})
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -71,3 +71,9 @@ def test_the_hot_kernels_are_in_the_library_with_the_expected_footprint():
         assert found, f"no kernel matching {tag}"
         for k in found:
             assert k["vgprs"] <= 512 and k["lds"] <= 160 * 1024, k
+    # the matrix-core attention walk (csrc/attn_mfma.h) is planned at TWO workgroups per CU: 256 registers per lane at most, MFMA
+    # results in VGPRs (the softmax rescales every accumulator; its object is compiled with -amdgpu-mfma-vgpr-form)
+    walk = [k for n, k in kernels.items() if "attn_decode_mfma_kernel" in n]
+    assert len(walk) == 2, [k["name"] for k in walk]
+    for k in walk:
+        assert k["vgprs"] <= 256 and k["agprs"] == 0, k  # (.vgpr_count is the unified count: architectural + accumulation)
