@@ -95,7 +95,8 @@ __device__ __forceinline__ u32x4 dequant_word(uint32_t w, float s, float beta) {
 }
 
 #ifndef QMM_ABL
-#define QMM_ABL 0  // tools/lab/gemm_lab only: 1 = no dequant arithmetic, 2 = no MFMA, 4 = no activation re-staging
+#define QMM_ABL 0  // tools/lab/gemm_lab only: 1 = no dequant arithmetic, 2 = no MFMA, 4 = no activation re-staging, 8 = the next
+                   // step's requests outside the branch (clamped step index: the last step requests itself again)
 #endif
 #ifndef QMM_OCC
 #define QMM_OCC 3  // waves per SIMD the register allocation aims for (136 registers fit 3; 4 costs 5 spilled VGPRs)
@@ -210,12 +211,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
     for (int j = j0; j < j1; ++j) {
         if (!(QMM_ABL & 4) || j == j0) store_a(buf);
         __syncthreads();
-        if (j + 1 < j1) {
-            if (!(QMM_ABL & 4)) load_a(j + 1);
+        if ((QMM_ABL & 8) || j + 1 < j1) {
+            const int jn = (QMM_ABL & 8) ? min(j + 1, j1 - 1) : j + 1;
+            if (!(QMM_ABL & 4)) load_a(jn);
             // (columns past K read weight row 0 -- wsrc / ssrc / bsrc are clamped -- and are never stored)
-            wnext = *reinterpret_cast<const u32x4 *>(wsrc + (j + 1) * 8 + h * 4);
-            sc_next = ssrc[(j + 1) >> 1];
-            be_next = bsrc[(j + 1) >> 1];
+            wnext = *reinterpret_cast<const u32x4 *>(wsrc + jn * 8 + h * 4);
+            sc_next = ssrc[jn >> 1];
+            be_next = bsrc[jn >> 1];
         }
         u32x4 bf[4];
 #pragma unroll
