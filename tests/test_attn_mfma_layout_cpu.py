@@ -146,3 +146,24 @@ def test_the_k_image_reads_are_free_of_bank_conflicts():
                     byte = c * stride + 64 * g + 16 * j
                     banks.update(((byte // 4) + k) % 64 for k in range(4))
                 assert len(banks) == distinct
+
+
+def _bf16_round(x):
+    """Round-to-nearest-even to bf16, returned as float32 (the v_cvt_pk_bf16_f32 the kernel packs its weights with)."""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def test_weights_as_bf16_hi_plus_lo_keep_sixteen_mantissa_bits():
+    """P goes through the second product as two bf16 operands: hi = bf16(p), lo = bf16(p - hi).  hi + lo is within 2^-16 of p
+    (relative), where one bf16 operand alone is within 2^-8: the weighted sum of V then differs from the fp32 walk by less than the
+    output's own bf16 rounding, which is why the 1-ulp bar of the long-context parity cases held."""
+    rng = np.random.default_rng(11)
+    p = np.exp2(-rng.uniform(0.0, 24.0, size=100_000)).astype(np.float32)
+    hi = _bf16_round(p)
+    lo = _bf16_round(p - hi)
+    rel_hi = np.abs(hi.astype(np.float64) - p) / p
+    rel_both = np.abs(hi.astype(np.float64) + lo.astype(np.float64) - p) / p
+    assert rel_hi.max() <= 2.0 ** -8 and rel_hi.max() > 2.0 ** -10
+    assert rel_both.max() <= 2.0 ** -16
