@@ -1,0 +1,585 @@
+// Kernel laboratory (not part of the product), round 5: can the decode step's dependent launches OVERLAP?
+//
+// Rounds 3-4 priced every form of in-launch hand-off (tools/lab/xcd_lab, mega_lab) and found that an all-to-all edge costs what a
+// kernel boundary costs.  What none of them removed is the serialisation a boundary imposes on things that do NOT depend on the
+// predecessor: the successor's launch ramp, its kernel-argument fetch and -- the large one -- the round trip of its weight loads
+// (weights never depend on activations).  An AQL dispatch packet whose BARRIER bit is clear starts as soon as the packet in front
+// of it has been DISPATCHED (all of its workgroups placed), not completed: packets of one queue are still consumed in order, so
+// every workgroup a successor waits for is already resident or finished -- no deadlock, and no persistent kernel.  The successor
+// puts its weights in flight and polls its input vector, which the predecessor publishes as 8-byte {value, tag} granules with
+// device-scope (sc1) stores; nothing else orders the two.
+//
+// This lab measures R dependent rounds of a GEMV-shaped phase (256 workgroups x 256 threads, 40 KiB of fresh weights per workgroup
+// and round, an n-value activation vector all-gathered between rounds) under
+//   A  hipGraph of plain launches, plain loads / stores            (the product's structure; the baseline)
+//   B  hipGraph of plain launches, tagged granules                 (what the tags cost by themselves)
+//   C  eager hipExtLaunchKernel(hipExtAnyOrderLaunch), tagged      (HIP's own way to clear the barrier bit, if the runtime honours it)
+//   D  raw AQL packets on an own HSA queue, barrier bit SET, fence scopes none, tagged   (a boundary without HIP's cache maintenance)
+//   E  raw AQL packets, barrier bit CLEAR, tagged                   (overlapped dispatch)
+// and prints us per round, the measured overlap (start of round r+1 minus end of round r, from in-kernel wall-clock stamps), give-ups
+// and wrong sums.  Every spin is bounded by the wall clock.
+//
+// build (tools/lab/run_overlap_lab.sh):
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/lab/overlap_lab.hip -o tools/lab/overlap_lab -lhsa-runtime64
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output tools/lab/overlap_lab.hip -o tools/lab/overlap_lab.hsaco
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include <chrono>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+struct LinkArgs {
+    const u64 *in_g;        // tagged input  [n] {value | tag << 32}
+    u64 *out_g;             // tagged output [n]
+    const uint32_t *in_p;   // plain input  [n]
+    uint32_t *out_p;        // plain output [n]
+    const u32x4 *w;         // this round's weights: grid * 2560 u32x4
+    u64 *stamp;             // [grid][2] wall clock of thread 0 at start / end
+    int *err;               // [0] give-ups, [1] wrong sums
+    int n, r, tagged, weights, grid, poll;  // poll: 0 granule sweep, sleep 2 | 1 granule sweep after the weights have landed, sleep 32 | 2 arrival counter, then one sweep
+    unsigned *count_in, *count_out;  // poll 2: arrivals of the producing / this round
+    uint32_t tag_in, tag_out;
+    u64 give_up_ticks;
+};
+
+constexpr int T = 256;
+constexpr int NG = 16;  // most granules per thread (n <= 4096)
+
+extern "C" __global__ __launch_bounds__(T) void link_kernel(const LinkArgs p) {
+    __shared__ uint32_t s_part[T / 64];
+    __shared__ int s_gave_up;
+    const int tid = threadIdx.x;
+    const u64 t0 = wall_clock64();
+    if (tid == 0) p.stamp[2 * blockIdx.x] = t0, s_gave_up = 0;
+    const int per_thread = (p.n + T - 1) / T;
+    u64 g[NG];
+    uint32_t s = 0;
+    // first attempt at the input goes out BEFORE the weights (vmcnt retires in order and the input is needed first)
+    if (p.tagged == 1) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int i = tid + k * T;
+            g[k] = __hip_atomic_load(p.in_g + (k < per_thread && i < p.n ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (p.tagged == 3) {  // untagged values through L2-bypassing (device-scope) loads
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int i = tid + k * T;
+            g[k] = __hip_atomic_load(p.in_p + ((k < per_thread && i < p.n) ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int i = tid + k * T;
+            g[k] = p.in_p[(k < per_thread && i < p.n) ? i : 0];  // unconditional, like the tagged path (masked in the sum below)
+        }
+    }
+    u32x4 wv[10];
+    if (p.weights) {
+        const u32x4 *wp = p.w + (size_t)blockIdx.x * (T * 10) + tid;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) wv[i] = __builtin_nontemporal_load(wp + (size_t)i * T);
+    }
+    __syncthreads();  // s_gave_up initialised
+    uint32_t x = 0;
+    if (p.weights && p.poll >= 1) {  // the weights first: a successor that started early has nothing to poll for yet
+#pragma unroll
+        for (int i = 0; i < 10; ++i) x ^= wv[i][0] ^ wv[i][1] ^ wv[i][2] ^ wv[i][3];
+        asm volatile("" : "+v"(x));
+    }
+    if (p.tagged == 1 && p.poll == 2) {
+        // arrival counter: one lane polls one word; when every producer has arrived, one sweep of the vector
+        __shared__ int s_ready;
+        if (tid == 0) {
+            int ok = 0;
+            while (true) {
+                if (__hip_atomic_load(p.count_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.grid) { ok = 1; break; }
+                if (wall_clock64() - t0 > p.give_up_ticks) { if (atomicExch(&s_gave_up, 1) == 0) atomicAdd(&p.err[0], 1); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            s_ready = ok;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int i = tid + k * T;
+            g[k] = __hip_atomic_load(p.in_g + (k < per_thread && i < p.n ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (p.tagged == 1) {
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                const int i = tid + k * T;
+                if (k < per_thread && i < p.n) ok = ok && (uint32_t)(g[k] >> 32) == p.tag_in;
+            }
+            if (ok) break;
+            if (s_gave_up) break;
+            if (wall_clock64() - t0 > p.give_up_ticks) {
+                if (atomicExch(&s_gave_up, 1) == 0) atomicAdd(&p.err[0], 1);
+                break;
+            }
+            if (p.poll >= 1) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                const int i = tid + k * T;
+                if (k < per_thread && i < p.n && (uint32_t)(g[k] >> 32) != p.tag_in)
+                    g[k] = __hip_atomic_load(p.in_g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int i = tid + k * T;
+        if (k < per_thread && i < p.n) s += (uint32_t)g[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((tid & 63) == 0) s_part[tid >> 6] = s;
+    __syncthreads();
+    s = 0;
+    for (int w2 = 0; w2 < T / 64; ++w2) s += s_part[w2];
+    if (p.weights && p.poll == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) x ^= wv[i][0] ^ wv[i][1] ^ wv[i][2] ^ wv[i][3];
+    }
+    const bool right = s == (uint32_t)p.n * (uint32_t)p.r;
+    if (tid == 0 && !right && !s_gave_up) atomicAdd(&p.err[1], 1);
+    const uint32_t v = (uint32_t)p.r + 1u + (right ? 0u : 1u) + (x == 0x9e3779b9u ? 1u : 0u);
+    const int per = p.n / p.grid;  // n is a multiple of the grid (gridDim would pull in hidden kernel arguments: the raw AQL path passes none)
+    if (tid < per) {
+        const int j = blockIdx.x * per + tid;
+        if (p.tagged == 1) __hip_atomic_store(p.out_g + j, (u64)v | ((u64)p.tag_out << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (p.tagged >= 2) __hip_atomic_store(p.out_p + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+        else p.out_p[j] = v;
+    }
+    if (p.tagged == 1 && p.poll == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's granules have been written through
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.count_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) p.stamp[2 * blockIdx.x + 1] = wall_clock64();
+}
+
+// two trivial kernels for the mechanism probe: spin for `ticks` of the wall clock, stamp start and end
+extern "C" __global__ void spin_kernel(u64 *stamp, u64 ticks) {
+    const u64 t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+    if (threadIdx.x == 0) stamp[2 * blockIdx.x] = t0, stamp[2 * blockIdx.x + 1] = wall_clock64();
+}
+
+#ifndef __HIP_DEVICE_COMPILE__
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+#define HK(x) do { hsa_status_t s_ = (x); if (s_ != HSA_STATUS_SUCCESS && s_ != HSA_STATUS_INFO_BREAK) { const char *m_ = nullptr; hsa_status_string(s_, &m_); printf("HSA error %s at line %d\n", m_ ? m_ : "?", __LINE__); return false; } } while (0)
+
+struct Aql {
+    hsa_agent_t agent{};
+    hsa_queue_t *q = nullptr, *q2 = nullptr;
+    hsa_signal_t done{}, done2{};
+    hsa_executable_t exe{};
+    uint64_t link_obj = 0, spin_obj = 0;
+    uint32_t link_lds = 0, spin_lds = 0, link_args = 0, spin_args = 0;
+    char *kernarg = nullptr;  // DEVICE memory (run 1 kept them in pinned host memory: every CU's first s_load of a kernel crossed PCIe, +1.8 us per kernel)
+    std::vector<char> kernarg_host;
+    bool ok = false;
+};
+
+static hsa_status_t find_gpu(hsa_agent_t a, void *data) {
+    hsa_device_type_t t;
+    hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t);
+    if (t == HSA_DEVICE_TYPE_GPU) { *(hsa_agent_t *)data = a; return HSA_STATUS_INFO_BREAK; }
+    return HSA_STATUS_SUCCESS;
+}
+
+static bool aql_symbol(Aql &a, const char *name, uint64_t *obj, uint32_t *lds, uint32_t *args) {
+    hsa_executable_symbol_t sym;
+    HK(hsa_executable_get_symbol_by_name(a.exe, name, &a.agent, &sym));
+    HK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, obj));
+    HK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, lds));
+    HK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, args));
+    uint32_t priv = 0;
+    HK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &priv));
+    printf("aql: %s object %llx lds %u kernarg %u private %u\n", name, (unsigned long long)*obj, *lds, *args, priv);
+    return priv == 0;
+}
+
+static bool aql_init(Aql &a, const std::string &hsaco_path) {
+    HK(hsa_init());
+    HK(hsa_iterate_agents(find_gpu, &a.agent));
+    HK(hsa_queue_create(a.agent, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &a.q));
+    HK(hsa_signal_create(1, 0, nullptr, &a.done));
+    HK(hsa_queue_create(a.agent, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &a.q2));
+    HK(hsa_signal_create(1, 0, nullptr, &a.done2));
+    FILE *f = fopen(hsaco_path.c_str(), "rb");
+    if (!f) { printf("aql: cannot open %s\n", hsaco_path.c_str()); return false; }
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    static std::vector<char> blob;
+    blob.resize(sz);
+    if (fread(blob.data(), 1, sz, f) != (size_t)sz) { fclose(f); return false; }
+    fclose(f);
+    hsa_code_object_reader_t reader;
+    HK(hsa_code_object_reader_create_from_memory(blob.data(), blob.size(), &reader));
+    HK(hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &a.exe));
+    HK(hsa_executable_load_agent_code_object(a.exe, a.agent, reader, nullptr, nullptr));
+    HK(hsa_executable_freeze(a.exe, nullptr));
+    if (!aql_symbol(a, "link_kernel.kd", &a.link_obj, &a.link_lds, &a.link_args)) return false;
+    if (!aql_symbol(a, "spin_kernel.kd", &a.spin_obj, &a.spin_lds, &a.spin_args)) return false;
+    CK(hipMalloc((void **)&a.kernarg, 2 * 4096 * 512));
+    a.kernarg_host.resize(4096 * 512);
+    a.ok = true;
+    return true;
+}
+
+struct Pkt {
+    uint64_t obj;
+    uint32_t lds, grid, block;
+    const void *args;
+    size_t args_bytes;
+    bool barrier;
+    int acquire, release;  // hsa_fence_scope_t
+};
+
+// n packets, kernargs copied into slots of a.kernarg; the last packet signals a.done.  Returns host seconds spent enqueuing.
+static double aql_submit(Aql &a, const std::vector<Pkt> &pk, int which = 0, bool copy_args = true, bool ring = true) {
+    hsa_queue_t *q = which ? a.q2 : a.q;
+    hsa_signal_t done = which ? a.done2 : a.done;
+    char *kbase = a.kernarg + (size_t)which * 4096 * 512;
+    // kernel arguments first, in one copy (a product would build them once per plan)
+    if (copy_args) {
+        const uint64_t idx0 = hsa_queue_load_write_index_relaxed(q);
+        for (size_t i = 0; i < pk.size(); ++i) memcpy(a.kernarg_host.data() + ((idx0 + i) & 4095) * 512, pk[i].args, pk[i].args_bytes);
+        CK(hipMemcpy(kbase, a.kernarg_host.data(), a.kernarg_host.size(), hipMemcpyHostToDevice));
+    }
+    const auto h0 = std::chrono::steady_clock::now();
+    hsa_signal_store_relaxed(done, 1);
+    const uint32_t mask = q->size - 1;
+    const uint64_t idx = hsa_queue_add_write_index_relaxed(q, pk.size());
+    auto *base = (hsa_kernel_dispatch_packet_t *)q->base_address;
+    for (size_t i = 0; i < pk.size(); ++i) {
+        while (idx + i - hsa_queue_load_read_index_scacquire(q) >= q->size) { }
+        char *ka = kbase + ((idx + i) & 4095) * 512;
+        hsa_kernel_dispatch_packet_t *slot = base + ((idx + i) & mask);
+        hsa_kernel_dispatch_packet_t d{};
+        d.workgroup_size_x = (uint16_t)pk[i].block; d.workgroup_size_y = 1; d.workgroup_size_z = 1;
+        d.grid_size_x = pk[i].grid * pk[i].block; d.grid_size_y = 1; d.grid_size_z = 1;
+        d.private_segment_size = 0;
+        d.group_segment_size = pk[i].lds;
+        d.kernel_object = pk[i].obj;
+        d.kernarg_address = ka;
+        d.completion_signal.handle = i + 1 == pk.size() ? done.handle : 0;
+        memcpy((char *)slot + 4, (char *)&d + 4, sizeof(d) - 4);
+        const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((pk[i].barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
+                                           (pk[i].acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (pk[i].release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+        const uint16_t setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+        __atomic_store_n((uint32_t *)slot, (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
+        if (ring && ((i & 63) == 63 || i + 1 == pk.size())) hsa_signal_store_screlease(q->doorbell_signal, idx + i);
+    }
+    const double host_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
+    return host_s;
+}
+static bool aql_wait(Aql &a, double seconds, int which = 0) {
+    hsa_signal_t done_sig = which ? a.done2 : a.done;
+    const auto h0 = std::chrono::steady_clock::now();
+    while (hsa_signal_wait_scacquire(done_sig, HSA_SIGNAL_CONDITION_LT, 1, 1000000, HSA_WAIT_STATE_ACTIVE) >= 1) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count() > seconds) return false;
+    }
+    return true;
+}
+
+int main(int argc, char **argv) {
+    int khz; CK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0));
+    const double us = 1e3 / khz;
+    const int WG = 256, R = 200;
+    std::string self = argv[0];
+    Aql aql;
+    if (!aql_init(aql, self + ".hsaco")) printf("aql: NOT available, modes D / E skipped\n");
+    const size_t w_units = (size_t)WG * T * 10;            // u32x4 per round (10 MiB)
+    const int W_ROUNDS = 64;                                // 640 MiB ring of weights: nothing is re-read within ~3 ms
+    u32x4 *w; CK(hipMalloc(&w, w_units * 16 * W_ROUNDS)); CK(hipMemset(w, 1, w_units * 16 * W_ROUNDS));
+    u64 *gbuf[2]; uint32_t *pbuf[2];
+    for (int i = 0; i < 2; ++i) { CK(hipMalloc(&gbuf[i], 4096 * 8)); CK(hipMemset(gbuf[i], 0, 4096 * 8)); CK(hipMalloc(&pbuf[i], 4096 * 4)); }
+    u64 *stamp; CK(hipMalloc(&stamp, (size_t)(R + 2) * WG * 2 * 8));
+    int *err; CK(hipMalloc(&err, 16));
+    unsigned *counts; CK(hipMalloc(&counts, (size_t)(R + 2) * 64));
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<u64> hs((size_t)(R + 2) * WG * 2);
+
+    // ---- 1. mechanism: does a second dispatch start before the first has ended? ----------------------------------------------
+    {
+        const u64 ticks = (u64)khz * 40 / 1000;  // 40 us
+        auto report = [&](const char *what) {
+            CK(hipMemcpy(hs.data(), stamp, (size_t)2 * WG * 2 * 8, hipMemcpyDeviceToHost));
+            u64 a_end = 0, b_start = ~0ull;
+            for (int b = 0; b < 64; ++b) { a_end = std::max(a_end, hs[2 * b + 1]); b_start = std::min(b_start, hs[(size_t)WG * 2 + 2 * b]); }
+            printf("mechanism %-44s: second kernel starts %+8.2f us relative to the END of the first (negative = overlapped)\n", what,
+                   ((double)b_start - (double)a_end) * us);
+        };
+        for (int flag = 0; flag < 2; ++flag) {
+            CK(hipMemset(stamp, 0, (size_t)2 * WG * 2 * 8));
+            hipExtLaunchKernelGGL(spin_kernel, dim3(64), dim3(64), 0, st, nullptr, nullptr, 0, stamp, ticks);
+            hipExtLaunchKernelGGL(spin_kernel, dim3(64), dim3(64), 0, st, nullptr, nullptr, flag ? hipExtAnyOrderLaunch : 0, stamp + (size_t)WG * 2, ticks);
+            CK(hipStreamSynchronize(st));
+            report(flag ? "HIP eager, hipExtAnyOrderLaunch" : "HIP eager, ordered");
+        }
+        if (aql.ok) for (int barrier = 1; barrier >= 0; --barrier) {
+            CK(hipMemset(stamp, 0, (size_t)2 * WG * 2 * 8));
+            CK(hipDeviceSynchronize());
+            struct { u64 *s; u64 t; } a0{stamp, ticks}, a1{stamp + (size_t)WG * 2, ticks};
+            std::vector<Pkt> pk;
+            pk.push_back(Pkt{aql.spin_obj, aql.spin_lds, 64, 64, &a0, sizeof(a0), true, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_AGENT});
+            pk.push_back(Pkt{aql.spin_obj, aql.spin_lds, 64, 64, &a1, sizeof(a1), barrier != 0, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM});
+            aql_submit(aql, pk);
+            if (!aql_wait(aql, 5.0)) { printf("aql: TIMEOUT in the mechanism probe\n"); aql.ok = false; break; }
+            report(barrier ? "raw AQL, barrier bit set" : "raw AQL, barrier bit clear");
+        }
+        fflush(stdout);
+    }
+
+    // ---- 1b. mechanism in detail: three spin kernels A (barrier) B C (barrier clear) on one queue, per kernel first / last start and end
+    if (aql.ok) {
+        for (int grid : {64, 256, 1024})
+        for (int block : {64, 256})
+        for (int tus : {10, 40}) {
+            const u64 ticks = (u64)khz * tus / 1000;
+            CK(hipMemset(stamp, 0, (size_t)3 * 1024 * 2 * 8));
+            CK(hipDeviceSynchronize());
+            struct SA { u64 *s; u64 t; } sa[3];
+            std::vector<Pkt> pk;
+            for (int k = 0; k < 3; ++k) {
+                sa[k] = SA{stamp + (size_t)k * 1024 * 2, ticks};
+                pk.push_back(Pkt{aql.spin_obj, aql.spin_lds, (uint32_t)grid, (uint32_t)block, &sa[k], sizeof(SA), k == 0, k == 0 ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE,
+                                 k == 2 ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE});
+            }
+            aql_submit(aql, pk);
+            if (!aql_wait(aql, 5.0)) { printf("aql: TIMEOUT in the detailed mechanism probe\n"); aql.ok = false; break; }
+            CK(hipMemcpy(hs.data(), stamp, (size_t)3 * 1024 * 2 * 8, hipMemcpyDeviceToHost));
+            u64 t00 = ~0ull;
+            for (int b = 0; b < grid; ++b) t00 = std::min(t00, hs[2 * b]);
+            printf("detail grid %4d x %3d threads, %2d us spin:", grid, block, tus);
+            for (int k = 0; k < 3; ++k) {
+                u64 s0 = ~0ull, s1 = 0, e0v = ~0ull, e1v = 0;
+                for (int b = 0; b < grid; ++b) {
+                    const u64 st0 = hs[((size_t)k * 1024 + b) * 2], en = hs[((size_t)k * 1024 + b) * 2 + 1];
+                    s0 = std::min(s0, st0); s1 = std::max(s1, st0); e0v = std::min(e0v, en); e1v = std::max(e1v, en);
+                }
+                printf("  %c start %6.2f..%6.2f end %6.2f..%6.2f", 'A' + k, (double)(s0 - t00) * us, (double)(s1 - t00) * us, (double)(e0v - t00) * us, (double)(e1v - t00) * us);
+            }
+            printf("\n");
+        }
+        // two queues: A on queue 0, B on queue 1 (both barrier set; nothing orders them)
+        {
+            const u64 ticks = (u64)khz * 40 / 1000;
+            CK(hipMemset(stamp, 0, (size_t)3 * 1024 * 2 * 8));
+            CK(hipDeviceSynchronize());
+            struct SA { u64 *s; u64 t; } sa0{stamp, ticks}, sa1{stamp + (size_t)1024 * 2, ticks};
+            std::vector<Pkt> p0{Pkt{aql.spin_obj, aql.spin_lds, 256, 256, &sa0, sizeof(SA), true, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_SYSTEM}};
+            std::vector<Pkt> p1{Pkt{aql.spin_obj, aql.spin_lds, 256, 256, &sa1, sizeof(SA), true, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_SYSTEM}};
+            aql_submit(aql, p0, 0);
+            aql_submit(aql, p1, 1);
+            if (!aql_wait(aql, 5.0, 0) || !aql_wait(aql, 5.0, 1)) { printf("aql: TIMEOUT in the two-queue probe\n"); aql.ok = false; }
+            else {
+                CK(hipMemcpy(hs.data(), stamp, (size_t)2 * 1024 * 2 * 8, hipMemcpyDeviceToHost));
+                u64 a0 = ~0ull, a1 = 0, b0 = ~0ull, b1 = 0;
+                for (int b = 0; b < 256; ++b) { a0 = std::min(a0, hs[2 * b]); a1 = std::max(a1, hs[2 * b + 1]); b0 = std::min(b0, hs[((size_t)1024 + b) * 2]); b1 = std::max(b1, hs[((size_t)1024 + b) * 2 + 1]); }
+                printf("two queues, 256 x 256, 40 us spin: A %6.2f..%6.2f  B %6.2f..%6.2f (us from A's first start)\n", 0.0, (double)(a1 - a0) * us, ((double)b0 - (double)a0) * us, ((double)b1 - (double)a0) * us);
+            }
+        }
+        fflush(stdout);
+    }
+
+    // ---- 2. the chain --------------------------------------------------------------------------------------------------------
+    uint32_t epoch = 1;
+    for (int weights = 0; weights < 2; ++weights)
+    for (int n : {1024, 2560, 4096}) {
+        auto make_args = [&](int r, int tagged, uint32_t ep, int poll = 0) {
+            LinkArgs a{};
+            a.in_g = gbuf[r & 1]; a.out_g = gbuf[(r + 1) & 1]; a.in_p = pbuf[r & 1]; a.out_p = pbuf[(r + 1) & 1];
+            a.w = w + (size_t)(r % W_ROUNDS) * w_units; a.stamp = stamp + (size_t)r * WG * 2; a.err = err;
+            a.n = n; a.r = r; a.tagged = tagged; a.weights = weights; a.grid = WG; a.poll = poll;
+            a.count_in = counts + (size_t)r * 16; a.count_out = counts + (size_t)(r + 1) * 16;
+            a.tag_in = ep * 65536u + (uint32_t)r; a.tag_out = ep * 65536u + (uint32_t)r + 1u;
+            a.give_up_ticks = (u64)khz * 20;  // 20 ms per kernel
+            return a;
+        };
+        // round 0's input: value 0 everywhere, tag epoch * 65536 + 0
+        auto seed = [&](uint32_t ep) {
+            std::vector<u64> g0(4096, (u64)(ep * 65536u) << 32);
+            CK(hipMemcpyAsync(gbuf[0], g0.data(), 4096 * 8, hipMemcpyHostToDevice, st));
+            CK(hipMemsetAsync(pbuf[0], 0, 4096 * 4, st));
+            CK(hipMemsetAsync(err, 0, 16, st));
+            CK(hipMemsetAsync(counts, 0, (size_t)(R + 2) * 64, st));
+            CK(hipMemsetAsync(counts, 1, 64, st));  // round 0's producers have all arrived (any count >= the grid)
+            CK(hipStreamSynchronize(st));
+        };
+        auto overlap_of = [&](double *med_gap, double *med_len) {
+            CK(hipMemcpy(hs.data(), stamp, (size_t)R * WG * 2 * 8, hipMemcpyDeviceToHost));
+            std::vector<double> gaps, lens;
+            u64 prev_end = 0;
+            for (int r = 0; r < R; ++r) {
+                u64 s0 = ~0ull, e9 = 0;
+                for (int b = 0; b < WG; ++b) { s0 = std::min(s0, hs[((size_t)r * WG + b) * 2]); e9 = std::max(e9, hs[((size_t)r * WG + b) * 2 + 1]); }
+                if (r > 8) gaps.push_back(((double)s0 - (double)prev_end) * us), lens.push_back((double)(e9 - s0) * us);
+                prev_end = e9;
+            }
+            std::sort(gaps.begin(), gaps.end()); std::sort(lens.begin(), lens.end());
+            *med_gap = gaps[gaps.size() / 2]; *med_len = lens[lens.size() / 2];
+        };
+        auto finish = [&](const char *mode, double us_round, double host_us) {
+            int herr[4]; CK(hipMemcpy(herr, err, 16, hipMemcpyDeviceToHost));
+            double gap, len; overlap_of(&gap, &len);
+            u64 s0 = ~0ull, e9 = 0;  // hs was refreshed by overlap_of: the last run's stamps
+            for (int b = 0; b < WG; ++b) { s0 = std::min(s0, hs[(size_t)b * 2]); e9 = std::max(e9, hs[((size_t)(R - 1) * WG + b) * 2 + 1]); }
+            printf("weights %d n %4d  %-52s: %6.2f us/round (stamps, last run %6.2f) | next first-WG start - last-WG end %+6.2f us, kernel span %5.2f us | host %5.2f us/launch | give-ups %d wrong sums %d\n",
+                   weights, n, mode, us_round, (double)(e9 - s0) * us / R, gap, len, host_us, herr[0], herr[1]);
+            fflush(stdout);
+        };
+        // A / B: hipGraph of ordered launches, plain or tagged
+        for (int tagged = 0; tagged < 2; ++tagged) {
+            const uint32_t ep = epoch++;
+            hipGraph_t graph; hipGraphExec_t exec;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+            for (int r = 0; r < R; ++r) hipLaunchKernelGGL(link_kernel, dim3(WG), dim3(T), 0, st, make_args(r, tagged, ep));
+            CK(hipStreamEndCapture(st, &graph));
+            CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                seed(ep);  // the same tags again: a replay re-publishes every granule with the tag it already has, so rep > 0 of B is not a valid tagged run ...
+                if (tagged && rep > 0) break;  // ... one timed replay for B
+                CK(hipEventRecord(e0, st)); CK(hipGraphLaunch(exec, st)); CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+            }
+            finish(tagged ? "B graph, ordered, tagged granules" : "A graph, ordered, plain (baseline)", best * 1e3 / R, 0.0);
+            CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph));
+        }
+        // C: eager, hipExtAnyOrderLaunch on every launch but the first
+        for (int pad : {0, 72 * 1024}) {
+            double best = 1e9, host_best = 1e9;
+            for (int rep = 0; rep < 3; ++rep) {
+                const uint32_t ep = epoch++;
+                seed(ep);
+                const auto h0 = std::chrono::steady_clock::now();
+                CK(hipEventRecord(e0, st));
+                for (int r = 0; r < R; ++r)
+                    hipExtLaunchKernelGGL(link_kernel, dim3(WG), dim3(T), pad, st, nullptr, nullptr, r ? hipExtAnyOrderLaunch : 0, make_args(r, 1, ep));
+                CK(hipEventRecord(e1, st));
+                const double host_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
+                CK(hipStreamSynchronize(st));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, (double)ms); host_best = std::min(host_best, host_s);
+            }
+            finish(pad ? "C eager, hipExtAnyOrderLaunch, tagged, <= 2 WG/CU" : "C eager, hipExtAnyOrderLaunch, tagged", best * 1e3 / R, host_best * 1e6 / R);
+        }
+        // D / E: raw AQL
+        // F: two queues, even rounds on queue 0, odd rounds on queue 1, barrier bits set inside each queue: rounds r and r + 1 overlap, r + 2 waits for r
+        for (int poll = 0; poll < 3 && aql.ok; ++poll) {
+            double best = 1e9;
+            for (int rep = 0; rep < 3; ++rep) {
+                const uint32_t ep = epoch++;
+                seed(ep);
+                CK(hipDeviceSynchronize());
+                std::vector<LinkArgs> args(R);
+                std::vector<Pkt> pk[2];
+                for (int r = 0; r < R; ++r) {
+                    args[r] = make_args(r, 1, ep, poll);
+                    const bool first = r < 2, last = r >= R - 2;
+                    pk[r & 1].push_back(Pkt{aql.link_obj, aql.link_lds + 72 * 1024, WG, T, &args[r], sizeof(LinkArgs), true, first ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE,
+                                            last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE});
+                }
+                const uint64_t w0 = hsa_queue_load_write_index_relaxed(aql.q), w1 = hsa_queue_load_write_index_relaxed(aql.q2);
+                aql_submit(aql, pk[0], 0, true, false);
+                aql_submit(aql, pk[1], 1, true, false);
+                hsa_signal_store_screlease(aql.q->doorbell_signal, w0 + pk[0].size() - 1);
+                hsa_signal_store_screlease(aql.q2->doorbell_signal, w1 + pk[1].size() - 1);
+                if (!aql_wait(aql, 10.0, 0) || !aql_wait(aql, 10.0, 1)) { printf("aql: TIMEOUT in the two-queue chain\n"); aql.ok = false; break; }
+                CK(hipMemcpy(hs.data(), stamp, (size_t)R * WG * 2 * 8, hipMemcpyDeviceToHost));
+                u64 s0 = ~0ull, e9 = 0;
+                for (int b = 0; b < WG; ++b) { s0 = std::min(s0, hs[(size_t)b * 2]); e9 = std::max(e9, hs[((size_t)(R - 1) * WG + b) * 2 + 1]); }
+                best = std::min(best, (double)(e9 - s0) * us / 1e3);
+            }
+            const char *fn[3] = {"F0 two AQL queues alternating, sweep / sleep 2", "F1 two AQL queues, weights first, sweep / sleep 32", "F2 two AQL queues, weights first, arrival counter"};
+            if (aql.ok) finish(fn[poll], best * 1e3 / R, 0.0);
+        }
+        // G: raw AQL, barrier SET, UNTAGGED data: which part of a boundary is cache maintenance, and can write-through stores replace the release?
+        if (aql.ok) for (int variant = 0; variant < 5; ++variant) {
+            // 0 plain/plain, acquire+release agent (what a HIP launch carries) | 1 plain loads + write-through stores, acquire agent only
+            // 2 bypassing loads + write-through stores, no fences | 3 plain/plain, acquire agent only (NOT coherent: timing + wrong sums only) | 4 plain/plain no fences (NOT coherent)
+            const int kmode[5] = {0, 2, 3, 0, 0};
+            const int acqs[5] = {HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE};
+            const int rels[5] = {HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE};
+            double best = 1e9, host_best = 1e9;
+            for (int rep = 0; rep < 3 && aql.ok; ++rep) {
+                const uint32_t ep = epoch++;
+                seed(ep);
+                CK(hipDeviceSynchronize());
+                std::vector<LinkArgs> args(R);
+                std::vector<Pkt> pk;
+                for (int r = 0; r < R; ++r) {
+                    args[r] = make_args(r, kmode[variant], ep);
+                    const bool first = r == 0, last = r == R - 1;
+                    pk.push_back(Pkt{aql.link_obj, aql.link_lds, WG, T, &args[r], sizeof(LinkArgs), true, first ? HSA_FENCE_SCOPE_SYSTEM : acqs[variant],
+                                     last ? HSA_FENCE_SCOPE_SYSTEM : rels[variant]});
+                }
+                const double host_s = aql_submit(aql, pk);
+                if (!aql_wait(aql, 10.0)) { printf("aql: TIMEOUT in chain G%d\n", variant); aql.ok = false; break; }
+                CK(hipMemcpy(hs.data(), stamp, (size_t)R * WG * 2 * 8, hipMemcpyDeviceToHost));
+                u64 s0 = ~0ull, e9 = 0;
+                for (int b = 0; b < WG; ++b) { s0 = std::min(s0, hs[(size_t)b * 2]); e9 = std::max(e9, hs[((size_t)(R - 1) * WG + b) * 2 + 1]); }
+                best = std::min(best, (double)(e9 - s0) * us / 1e3); host_best = std::min(host_best, host_s);
+            }
+            const char *gn[5] = {"G0 raw AQL barrier, plain data, acquire + release agent", "G1 raw AQL barrier, write-through stores, acquire agent", "G2 raw AQL barrier, bypassing loads + w-t stores, no fences",
+                                 "G3 raw AQL barrier, plain data, acquire only (NOT coherent)", "G4 raw AQL barrier, plain data, no fences (NOT coherent)"};
+            if (aql.ok) finish(gn[variant], best * 1e3 / R, host_best * 1e6 / R);
+        }
+        if (aql.ok) for (int variant = 0; variant < 4; ++variant) {
+            const uint32_t pad = variant == 3 ? 72 * 1024 : 0;  // 3 = barrier clear, no fences, at most 2 workgroups per CU
+            // 0: barrier set, fences none | 1: barrier clear, fences none | 2: barrier clear, acquire agent (what HIP would put)
+            double best = 1e9, host_best = 1e9;
+            bool dead = false;
+            for (int rep = 0; rep < 3 && !dead; ++rep) {
+                const uint32_t ep = epoch++;
+                seed(ep);
+                CK(hipDeviceSynchronize());
+                std::vector<LinkArgs> args(R);
+                std::vector<Pkt> pk;
+                for (int r = 0; r < R; ++r) {
+                    args[r] = make_args(r, 1, ep);
+                    const bool first = r == 0, last = r == R - 1;
+                    const int acq = first ? HSA_FENCE_SCOPE_SYSTEM : (variant == 2 ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE);
+                    (void)pad;
+                    const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : (variant == 2 ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE);
+                    pk.push_back(Pkt{aql.link_obj, aql.link_lds + pad, WG, T, &args[r], sizeof(LinkArgs), first || variant == 0, acq, rel});
+                }
+                const auto h0 = std::chrono::steady_clock::now();
+                const double host_s = aql_submit(aql, pk);
+                if (!aql_wait(aql, 10.0)) { printf("aql: TIMEOUT in the chain (variant %d)\n", variant); dead = true; aql.ok = false; break; }
+                const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
+                // device time: first start .. last end from the stamps
+                CK(hipMemcpy(hs.data(), stamp, (size_t)R * WG * 2 * 8, hipMemcpyDeviceToHost));
+                u64 s0 = ~0ull, e9 = 0;
+                for (int b = 0; b < WG; ++b) { s0 = std::min(s0, hs[(size_t)b * 2]); e9 = std::max(e9, hs[((size_t)(R - 1) * WG + b) * 2 + 1]); }
+                (void)wall;
+                best = std::min(best, (double)(e9 - s0) * us / 1e3); host_best = std::min(host_best, host_s);
+            }
+            if (dead) break;
+            const char *names[4] = {"D raw AQL, barrier SET, no fences, tagged", "E raw AQL, barrier CLEAR, no fences, tagged", "E2 raw AQL, barrier CLEAR, agent fences, tagged",
+                                    "E3 raw AQL, barrier CLEAR, no fences, tagged, <= 2 WG/CU"};
+            finish(names[variant], best * 1e3 / R, host_best * 1e6 / R);
+        }
+    }
+    return 0;
+}
+#endif
