@@ -579,3 +579,38 @@ def test_flash_attention_2048_row_chunk_over_8k_context(ext):
         want = O.paged_attention(q[:, r:r + 1], kp, vp, table, np.asarray([vis], dtype=np.int32), D ** -0.5, True, HKV, HQ,
                                  "bf16", round_p=True)
         assert_bf16_close(got[:, r], want[:, 0], ulps=1.0, abs_floor=1.5e-3, what=f"FA row {r} (sees {vis} tokens)")
+
+
+@pytest.mark.parametrize("ctxs,mode", [([100], "default"), ([700], "default"), ([8191], "default"), ([8192, 5000, 129, -1], "default"),
+                                       ([8191], "valu_walk"), ([300, 17, 2000], "valu_walk"), ([300, 17, 2000], "default")])
+def test_decode_attention_ignores_what_pages_hold_behind_the_context(ext, ctxs, mode, monkeypatch):
+    """A masked token has weight 0 -- and 0 x NaN is NaN: rows behind a sequence's context (the rest of its last page, pages it does not
+    own, a recycled page) must not reach the output whatever they hold.  Every K/V row no sequence can see is NaN here (the row the kernel
+    appends included: it is written, not read); outputs and appended rows must equal the run on clean pages bit for bit
+    (reference: paged_attention.metal:158-160 reads visible rows only)."""
+    for name in ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MFMA"):
+        monkeypatch.delenv(name, raising=False)
+    if mode == "valu_walk":
+        monkeypatch.setenv("TL_ATTN_MFMA", "0")
+    idle = [c < 0 for c in ctxs]
+    rng = np.random.default_rng(77 + abs(sum(ctxs)))
+    case = _attention_case(rng, ctxs)
+    kp, vp, table, ctx = case[0], case[1], case[2], case[3]
+    visible = np.zeros(kp.shape[:1] + kp.shape[2:3], dtype=bool)  # [P, slot]
+    for b, is_idle in enumerate(idle):
+        if not is_idle:
+            for tok in range(int(ctx[b])):
+                visible[int(table[b, tok // PAGE]), tok % PAGE] = True
+    kp_nan, vp_nan = kp.copy(), vp.copy()
+    kp_nan[~visible[:, None, :].repeat(HKV, axis=1)] = np.nan
+    vp_nan[~visible[:, None, :].repeat(HKV, axis=1)] = np.nan
+    want, kpa_w, vpa_w, info = _run_attention(ext, case, max(ctxs))
+    got, kpa, vpa, _ = _run_attention(ext, (kp_nan, vp_nan) + tuple(case[2:]), max(ctxs))
+    what = f"ctxs={ctxs} mode={mode} {info}"
+    assert np.isfinite(got).all(), f"{what}: a value behind the context reached the output"
+    np.testing.assert_array_equal(got, want, err_msg=what)
+    for b, is_idle in enumerate(idle):
+        if not is_idle:
+            pid, slot = int(table[b, ctx[b] // PAGE]), int(ctx[b] % PAGE)
+            np.testing.assert_array_equal(kpa[pid, :, slot], kpa_w[pid, :, slot], err_msg=f"{what}: appended K row")
+            np.testing.assert_array_equal(vpa[pid, :, slot], vpa_w[pid, :, slot], err_msg=f"{what}: appended V row")

@@ -151,3 +151,33 @@ def test_weighted_rows_travel_in_fragment_order(ext, M):
     b, ib = ext.decode_linear(qkv.tiled, ext.fragment_order_of(a_w), prologue=PRO_RMS_WEIGHTED, epilogue=EPI_STORE, eps=EPS, kernel=5, ss_in=ss,
                               fragment_order=True, fragment_rows=M)
     assert ia["kernel"] == ib["kernel"] == 5 and torch.equal(a, b), f"qkv M={M}: rows in fragment order"
+
+
+@pytest.mark.parametrize("M", [33, 40, 48])
+def test_fragment_order_rows_are_read_inside_ceil16_rows(ext, M):
+    """Rows in fragment order are provided as ceil16(M) rows (include/tinyllm_engine.h).  At 33..48 rows the planner's 64-row workgroup
+    (MB = 4) has a fourth 16-row block with no rows behind it: the kernel must re-read a real block there (csrc/qmm6.h, FRAG path), not
+    the 16 x N x 2 bytes past the buffer.  The rows are handed over as the head of a larger allocation whose tail is NaN: outputs must be
+    bit-identical to the call on an exact-size buffer -- and the call runs at the very end of a dedicated allocation in the last case
+    (a read past it is a memory fault on a box whose next pages are unmapped)."""
+    qkv = _proj(ext, "qkv")
+    a_w, ss = _weighted_rows_case(qkv, M)
+    frag = ext.fragment_order_of(a_w)
+    rows16 = (M + 15) // 16 * 16
+    assert frag.numel() == rows16 * qkv.N
+    want, info = ext.decode_linear(qkv.tiled, frag, prologue=PRO_RMS_WEIGHTED, epilogue=EPI_STORE, eps=EPS, kernel=5, ss_in=ss, fragment_order=True, fragment_rows=M)
+    assert info["kernel"] == 5 and info["p"][0] == 4
+    big = torch.full((rows16 * qkv.N + 64 * qkv.N,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    big[: rows16 * qkv.N] = frag.reshape(-1)
+    got, _ = ext.decode_linear(qkv.tiled, big[: rows16 * qkv.N].reshape(frag.shape), prologue=PRO_RMS_WEIGHTED, epilogue=EPI_STORE, eps=EPS, kernel=5, ss_in=ss,
+                               fragment_order=True, fragment_rows=M)
+    assert torch.equal(got, want) and torch.isfinite(got.float()).all()
+    # the same rows as the tail of a dedicated 64-MiB allocation (torch's allocator serves requests of this size with their own hipMalloc)
+    n = 32 * 1024 * 1024
+    slab = torch.zeros((n,), dtype=torch.bfloat16, device=DEV)
+    tail = slab[n - rows16 * qkv.N:]
+    tail.copy_(frag.reshape(-1))
+    got2, _ = ext.decode_linear(qkv.tiled, tail.reshape(frag.shape), prologue=PRO_RMS_WEIGHTED, epilogue=EPI_STORE, eps=EPS, kernel=5, ss_in=ss,
+                                fragment_order=True, fragment_rows=M)
+    torch.cuda.synchronize()
+    assert torch.equal(got2, want)

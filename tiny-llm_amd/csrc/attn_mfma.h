@@ -121,9 +121,14 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
     // VALU, and no address registers for the allocator to recycle as load destinations (which made the next stage's requests wait for
     // this stage's V rows: a write-after-write on the recycled register).
     const int lane_bytes = ((4 * g) * D + c * VD) * 2;
+    // The resource ends behind the last VISIBLE row of the wave's 32 (context length, window end, an unmapped page: none): rows past it
+    // come back as zeros from the range check -- a masked token's weight is 0, but 0 x NaN is NaN, and a recycled or caller-provided
+    // page may hold anything behind the context (scalar arithmetic only: nothing is added to the walk)
     auto issue_rows = [&](const uint16_t *pool, int tb, int pg, u32x4(&rows)[8]) {
         const long rowbase = (((long)max(pg, 0) * Hkv + kvh) * p.page_size + (tb & (p.page_size - 1))) * D;  // uniform
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(pool + rowbase), 0, WT * D * 2, 0x00020000);
+        const int end = (pg >= 0 && page_of(tb) < p.max_pages && live) ? min(ctx, t_begin + C) : 0;
+        const int visible = min(max(end - tb, 0), WT);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(pool + rowbase), 0, visible * D * 2, 0x00020000);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             rows[e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes + ((e < 4) ? e : 12 + e) * D * 2, 0, 0));

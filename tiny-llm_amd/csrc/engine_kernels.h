@@ -451,6 +451,13 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
                     pid_next[u] = brow[min(page_of(t_begin + (it + 2) * 16 * U + u * 16 + g), p.max_pages - 1)];
             }
         }
+        // V rows of masked tokens are ZERO, not "whatever the page holds times a zero weight": 0 x NaN is NaN, and a recycled or
+        // caller-provided page may hold anything behind the context
+        float vf[U][VD];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < VD; ++i) vf[u][i] = (okc[u] && live) ? BF16::to_float(vc[u].v[i]) : 0.f;
         float sc[RQ][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -502,7 +509,7 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
                 const float pw = (okc[u] && live) ? exp2_hw(sc[r][u] - nm) : 0.f;
                 l[r] += pw;
 #pragma unroll
-                for (int i = 0; i < VD; ++i) acc[r][i] += pw * BF16::to_float(vc[u].v[i]);
+                for (int i = 0; i < VD; ++i) acc[r][i] += pw * vf[u][i];
             }
         }
         if constexpr (IP) {

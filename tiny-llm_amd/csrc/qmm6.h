@@ -180,12 +180,15 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
     u32x4 av[MB][GPW][4];
     if constexpr (FRAG) {
         // rows stored in fragment order by their producer: MB x GPW x 4 contiguous 1-KiB loads per wave, straight into the registers
-        const char *abase = reinterpret_cast<const char *>(p.a) + (size_t)(row0 >> 4) * G * 4096 + (size_t)lane * 16;
+        // (the caller provides ceil16(M) rows: a row block past the last real one -- M = 33..48 on MB = 4, or the second workgroup row of
+        // MB = 2 -- re-reads the last real block instead of running past the buffer; its rows lie at or beyond ceil16(M) and are never stored)
+        const char *abase = reinterpret_cast<const char *>(p.a) + (size_t)lane * 16;
+        const int last_block = ((p.M + 15) >> 4) - 1;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int gl = 0; gl < GPW; ++gl) {
-                const char *gb = abase + ((size_t)mb * G + min(g0 + gl, G - 1)) * 4096;
+                const char *gb = abase + ((size_t)min((row0 >> 4) + mb, last_block) * G + min(g0 + gl, G - 1)) * 4096;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) av[mb][gl][t] = *reinterpret_cast<const u32x4 *>(gb + t * 1024);
             }

@@ -163,17 +163,27 @@ class KvPrefixGenerator:
             # Decode in blocks and stop at the end-of-sequence id, as the reference's loop does (agent/branching.py:139-150): a
             # continuation that ends early neither pays for max_tokens steps nor runs into the page / context limit behind it.
             produced = eng.read_tokens(self.WORK_SLOT, 1)
-            done = produced[0] == eos
+            done = produced[0] == eos or self._max_tokens <= 0  # the reference's `for _ in range(max_tokens)` emits nothing at max_tokens <= 0
             if not done:
                 output.append(int(produced[0]))
             while not done and len(output) < self._max_tokens:
                 block = min(self.DECODE_BLOCK, self._max_tokens - len(output))
-                eng.decode(block, batch=1)
-                for token in eng.read_tokens(self.WORK_SLOT, block):  # greedy ids; the reference stops BEFORE emitting the end-of-sequence id
+                # a block reserves pages / context step by step and stops where the slot's room ends: the steps that did run count --
+                # an end-of-sequence id among them ends the continuation cleanly, as in the reference's token-by-token loop; only a
+                # continuation that is still going when the room ends is the caller's error
+                before, refused = eng.context_len(self.WORK_SLOT), None
+                try:
+                    eng.decode(block, batch=1)
+                    ran = block
+                except RuntimeError as error:
+                    ran, refused = eng.context_len(self.WORK_SLOT) - before, error
+                for token in (eng.read_tokens(self.WORK_SLOT, ran) if ran > 0 else []):  # greedy ids; the reference stops BEFORE emitting the end-of-sequence id
                     if token == eos:
                         done = True
                         break
                     output.append(int(token))
+                if refused is not None and not done and len(output) < self._max_tokens:
+                    raise refused
         finally:
             eng.release(self.WORK_SLOT)
         self._response_index += 1

@@ -27,6 +27,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="qwen3-4b")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="also print the per-kind in-kernel stamps of one profiled step (tl_engine_profile_step)")
     args = ap.parse_args()
 
     import torch
@@ -51,7 +52,13 @@ def main() -> None:
     engine.synchronize()
     dt = time.perf_counter() - t0
     step_bytes = engine.step_bytes(args.batch)
-    print(json.dumps({"batch": args.batch, "context": args.context, "steps": args.steps,
+    prof = None
+    if args.profile:
+        p = engine.profile_step(args.batch)
+        prof = {k: {"us": round(v["us"], 1), "launches": v["launches"]} for k, v in p["kinds"].items() if v["launches"]}
+        prof["span_us"] = round(p["span_us"], 1)
+        prof["n_splits"] = p.get("n_splits")
+    print(json.dumps({"profile": prof,"batch": args.batch, "context": args.context, "steps": args.steps,
                       "ms_per_step": round(dt * 1e3 / args.steps, 4),
                       "tokens_per_s": round(args.batch * args.steps / dt, 1),
                       "step_bytes": int(step_bytes), "step_GBps": round(step_bytes / (dt / args.steps) / 1e9, 1)}))
