@@ -150,7 +150,7 @@ def test_a_continuation_that_ends_before_the_room_does_is_not_an_error():
         branch = gen.fork()
         branch.restore_checkpoint(cp)
         assert branch(MESSAGES + [STEER_A]) == tok.decode(expected)
-        tok.eos_token_id = 1023  # never produced: the continuation is still going when the room ends
+        tok.eos_token_id = -1  # never produced: the continuation is still going when the room ends
         branch2 = gen.fork()
         branch2.restore_checkpoint(cp)
         with pytest.raises(RuntimeError):

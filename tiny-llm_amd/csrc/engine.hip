@@ -389,6 +389,11 @@ static bool weighted_rows_apply(const tl_engine *e, const tl_w4 &producer, const
     if (!pp.ok || !pcn.ok || producer.rows != consumer.cols) return false;
     return qmv3_takes_weighted_rows(pcn, consumer.cols, producer.rows / 16);
 }
+// Does engine_linear send M rows of this projection to the K-sliced skinny matmul (qmm3.h)?  ONE predicate for the router below and for
+// every caller that plans around its answer (enqueue_step decides from it whether a producer will leave weighted rows).
+static bool takes_skinny_matmul(const tl_engine *e, const tl_w4 &w, int M) {
+    return !gemv_takes_rows(e, M) && e->use_qmm3 && M <= 64 && e->tiled.count(w.weight_dev) != 0 && qmm3_plan(M, w.cols, w.rows, e->qmm3_mode).ok;
+}
 struct KeptPartials {
     const float *partial = nullptr;
     int slices = 0;
@@ -414,7 +419,7 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
     // reduction with the epilogue.  RMSNorm runs as its own launch (a slice does not see the whole row).
     const auto tiled = e->tiled.find(w.weight_dev);
     const Qmm3Plan p3 = qmm3_plan(M, w.cols, w.rows, e->qmm3_mode);
-    if (e->use_qmm3 && M <= 64 && tiled != e->tiled.end() && p3.ok) {
+    if (takes_skinny_matmul(e, w, M)) {
         const bool fused_norm = pro == PRO_RMSNORM && ss_in != nullptr && e->fuse_norm;
         if (pro == PRO_RMSNORM && !fused_norm) {
             TL_TRY(tl_rms_norm(a, norm_w, e->xn, M, w.cols, c.rms_norm_eps, TL_BF16, e->stream));
@@ -729,9 +734,8 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
         // the sliced matmul as the producer of weighted rows (its reduction writes them): wo here, w_down below
-        auto sliced_leaves_weighted = [&](const tl_w4 &m) {
-            return e->use_qmm3 && e->fuse_norm && e->tiled.count(m.weight_dev) != 0 && qmm3_plan(batch, m.cols, m.rows, e->qmm3_mode).ok &&
-                   qmm3_reduce_can_emit_ss(EPI_RESIDUAL, m.rows);
+        auto sliced_leaves_weighted = [&](const tl_w4 &m) {  // (the router's own predicate + what its reduction needs to emit the hand-over)
+            return takes_skinny_matmul(e, m, batch) && e->fuse_norm && qmm3_reduce_can_emit_ss(EPI_RESIDUAL, m.rows);
         };
         const bool wo6_ok = !e->is_moe(l) && qmm6_takes(e, w.wo, batch) && qmm3_takes_ss(w.wo.rows / 16);
         if (!e->is_moe(l) && w.wgu.weight_dev != nullptr && qmm6_takes(e, w.wgu, batch) && x_ss > 0 && qmm3_takes_ss(x_ss) &&
