@@ -454,6 +454,9 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
         worst_logit = max(worst_logit, float(np.abs(np.asarray(cl, np.float64) - gl).max()))
     e_gpu = max(float(np.abs(np.asarray(g, np.float64) - t).max()) for g, t in zip(gpu_logits, truth_logits))
     e_cpu = max(float(np.abs(np.asarray(c, np.float64) - t).max()) for c, t in zip(cpu_logits, truth_logits))
+    # the same comparison on a statistic that does not hang on ONE of 151,936 x steps logits: root mean square error over all of them
+    rms_gpu = float(np.sqrt(np.mean([np.mean((np.asarray(g, np.float64) - t) ** 2) for g, t in zip(gpu_logits, truth_logits)])))
+    rms_cpu = float(np.sqrt(np.mean([np.mean((np.asarray(c, np.float64) - t) ** 2) for c, t in zip(cpu_logits, truth_logits)])))
     # greedy ids: the engine's choice must be the truth's argmax or lie within the engine's own measured error of it
     near, exact = 0, 0
     for gi, t in zip(gpu_ids, truth_logits):
@@ -470,6 +473,8 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
                            "the MMA FlashAttention restatements follow the .metal text and are pinned by PyTorch only (MLX's steel headers are not in the reference tree)",
             "max_abs_logit_gpu_vs_truth": round(e_gpu, 5), "max_abs_logit_cpu_vs_truth": round(e_cpu, 5),
             "gpu_error_over_cpu_error": round(e_gpu / e_cpu, 3) if e_cpu > 0 else None,
+            "rms_logit_gpu_vs_truth": round(rms_gpu, 5), "rms_logit_cpu_vs_truth": round(rms_cpu, 5),
+            "gpu_rms_error_over_cpu_rms_error": round(rms_gpu / rms_cpu, 3) if rms_cpu > 0 else None,
             "max_abs_logit_gpu_vs_cpu": round(worst_logit, 5), "gpu_vs_cpu_max_logprob_diff": round(worst, 4),
             "gpu_greedy_ids_vs_truth": f"{exact}/{len(truth_logits)} are the truth's argmax, {near}/{len(truth_logits)} within "
                                        f"2 x the engine's measured error of it"}

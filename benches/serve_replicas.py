@@ -78,7 +78,7 @@ def aggregate(reports: list[dict]) -> dict:
         "decode_step_p95_ms": nearest_rank(steps, 0.95),
         "peak_active_requests": [r["metrics"]["peak_active_requests"] for r in reports],
         "slowest_over_fastest_wall": wall / min(r["wall_s"] for r in reports) if reports else 0.0,
-        "per_replica": [{"rank": r["rank"], "requests": r["requests"], "wall_s": r["wall_s"],
+        "per_replica": [{"rank": r["rank"], "requests": r["requests"], "request_indices": r.get("request_indices"), "wall_s": r["wall_s"],
                          "output_tok_s": r["metrics"]["generated_tokens"] / r["wall_s"] if r["wall_s"] else 0.0,
                          "decode_tok_s": (r["metrics"]["decode_tokens"] / r["metrics"]["decode_time"]
                                           if r["metrics"]["decode_time"] else 0.0),
@@ -222,7 +222,8 @@ def main(argv=None) -> dict | None:
     t0 = clock()
     metrics = run(mine)
     wall = clock() - t0
-    report = {"rank": rank, "requests": len(mine), "prompt_tokens": sum(len(r.prompt_token_ids) for r in mine), "wall_s": wall,
+    report = {"rank": rank, "requests": len(mine), "request_indices": list(range(rank, len(trace), world)),  # deal(): request i -> replica i mod N
+              "prompt_tokens": sum(len(r.prompt_token_ids) for r in mine), "wall_s": wall,
               "decode_step_ms": metrics.decode_step_ms, "metrics": {k: v for k, v in asdict(metrics).items() if k != "decode_step_ms"}}
     reports = [report]
     if dist is not None:

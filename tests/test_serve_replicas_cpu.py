@@ -213,3 +213,40 @@ def test_serve_replicas_starts_its_own_ranks_when_no_launcher_did():
         data = json.loads(report.read_text())
     text = json.dumps(data)
     assert '"replicas": 2' in text, text[:500]
+
+
+def test_eight_ranks_rehearsal_of_both_launch_paths():
+    """The shape the driver runs on an 8-GPU node (SCALE_rNN: `python bench.py --gpus 8 ...`; config 4: `serve_replicas.py --gpus 8`),
+    rehearsed at world size 8 over gloo without a GPU: rendezvous on 127.0.0.1, barrier, MAX over ranks, one line from rank 0 --
+    `per_rank` holds eight clocks, and request i of the seeded trace is served by replica i mod 8 (requests shard,
+    nothing else does; no collective on the data path)."""
+    import os
+    import tempfile
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--engine", "sleep"],
+                          env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["parallelism"].startswith("request-parallel x8")
+    pr = out["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and len(pr["tokens_per_s"]) == 8 and 0 <= pr["slowest_rank"] < 8
+    assert out["value"] == pytest.approx(8 * 4 / (out["ms_per_step"] * 4 / 1e3), rel=1e-3), "whole-job aggregate over the eight ranks"
+
+    with tempfile.TemporaryDirectory() as tmp:
+        report = Path(tmp) / "report.json"
+        proc = subprocess.run([sys.executable, str(ROOT / "benches" / "serve_replicas.py"), "--gpus", "8", "--solution", "schedule-only",
+                               "--num-seqs", "43", "--batch-size", "4", "--json-output", str(report)], env=env, capture_output=True,
+                              text=True, timeout=600)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        data = json.loads(report.read_text())
+    agg = data["aggregate"]
+    assert agg["replicas"] == 8 and agg["requests"] == 43
+    assert [r["rank"] for r in agg["per_replica"]] == list(range(8))
+    for r in agg["per_replica"]:
+        assert r["request_indices"] == list(range(r["rank"], 43, 8)), "request i -> replica i mod 8"
+        assert r["requests"] == len(r["request_indices"])
+    line = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1 and json.loads(line[0])["n_gpus"] == 8 and len(json.loads(line[0])["per_gpu"]) == 8
