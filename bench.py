@@ -466,7 +466,7 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
     return {"value": round(sample_steps / dt, 3), "unit": "tokens/s", "cores": cores, "os_cpu_count": os.cpu_count(), "kind": "port",
             "sample": f"{sample_steps} decode steps after a {sample_prompt}-token prompt, same Qwen3-4B W4 checkpoint, "
                       f"oracle/qwen3_decode.c with OpenMP on {cores} threads",
-            "n_splits_checked": n_splits_checked, "_prompt": prompt, "_fed": cpu_ids[:sample_steps], "_gpu_first_decode_logits": gpu_logits[1],
+            "n_splits_checked": n_splits_checked, "engine_prefill_rows_per_pass_checked": prefill_chunk, "_prompt": prompt, "_fed": cpu_ids[:sample_steps], "_gpu_first_decode_logits": gpu_logits[1],
             "truth": f"oracle/qwen3_truth.c (float64, no intermediate rounding), first {len(truth_logits)} steps",
             "oracle_pins": "the numpy / C checkers are bit-identical in 16 bits to the reference's own Metal kernels compiled for the host (oracle/_ref) for the "
                            "vanilla matmul, decode matvec, embedding, split-K reduce, RMSNorm, RoPE, SwiGLU, dense and paged decode attention; the tile GEMM and "
@@ -868,7 +868,10 @@ def main() -> None:
         t_cpu0 = time.perf_counter()
         try:
             with time_box(max(90, int(1.5 * args.cpu_legs_budget))):
-                cpu = cpu_baseline_leg(mlx_model, cfg, engine, sample_prompt=sample_prompt, sample_steps=16, prefill_chunk=args.prefill_step)
+                # the checked engine is prefilled in 8-row passes: rows <= 8 take the matvec arithmetic (quantize.py:54-65), which is what the
+                # C port walks the prompt with -- a 128-row chunk takes the tile GEMM, whose weights are rounded to bf16 first
+                # (quantized_matmul.metal:96-249): reference-mandated extra rounding in the cached K/V that is not the decode kernels' error
+                cpu = cpu_baseline_leg(mlx_model, cfg, engine, sample_prompt=sample_prompt, sample_steps=16, prefill_chunk=8)
         except Exception as exc:
             cpu = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"}
         cpu["n_splits_timed"] = prof.get("n_splits") if prof else None

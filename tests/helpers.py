@@ -139,9 +139,16 @@ def log_parity(record: dict) -> None:
         pass
 
 
-def check_against_truth(got, oracle, truth, what: str, factor: float = TRUTH_FACTOR) -> dict:
+# The root-mean-square error over all logits does not hang on one of 151,936 x steps values the way the maximum does: where both sides
+# run the SAME arithmetic per row (decode rows: the matvec form on both sides) the HIP path's rms error must stay within this multiple
+# of the bf16 checker's (measured in round 5 over every decode route at the Qwen3-4B shapes: 0.955 .. 1.06).
+RMS_FACTOR_DECODE = 1.10
+
+
+def check_against_truth(got, oracle, truth, what: str, factor: float = TRUTH_FACTOR, rms_factor: float | None = None) -> dict:
     """got / oracle: bf16 logits [steps, vocab] of the HIP path and of the bf16 oracle; truth: float64 logits.
-    Asserts max|got - truth| <= factor * max|oracle - truth| + one bf16 ulp of the largest logit, logs the numbers."""
+    Asserts max|got - truth| <= factor * max|oracle - truth| + one bf16 ulp of the largest logit (and rms <= rms_factor * the oracle's
+    rms error when given: a tighter band on the stabler statistic), logs the numbers."""
     got, oracle, truth = (np.asarray(a, dtype=np.float64) for a in (got, oracle, truth))
     e_hip = float(np.abs(got - truth).max())
     e_orc = float(np.abs(oracle - truth).max())
@@ -154,6 +161,10 @@ def check_against_truth(got, oracle, truth, what: str, factor: float = TRUTH_FAC
     log_parity(rec)
     assert e_hip <= factor * e_orc + ulp, f"{what}: HIP is {e_hip:.4g} from the float64 truth, the bf16 oracle {e_orc:.4g}"
     assert rms_hip <= factor * rms_orc + 1e-6, f"{what}: rms error {rms_hip:.4g} (HIP) vs {rms_orc:.4g} (oracle)"
+    if rms_factor is not None:
+        assert rms_hip <= rms_factor * rms_orc + 1e-6, (f"{what}: rms error {rms_hip:.4g} (HIP) is {rms_hip / rms_orc:.3f} x the bf16 checker's "
+                                                        f"{rms_orc:.4g}; the band for rows on the same arithmetic is {rms_factor}")
+    rec["rms_ratio"] = rms_hip / rms_orc if rms_orc > 0 else None
     return rec
 
 

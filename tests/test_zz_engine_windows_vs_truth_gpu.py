@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import check_against_truth, log_parity, to_mlx_shaped
+from helpers import RMS_FACTOR_DECODE, check_against_truth, log_parity, to_mlx_shaped
 from oracle import tiny_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -80,5 +80,7 @@ def test_engine_logits_behind_long_prompts_against_the_truth(checkpoint, prompt_
     got = np.stack(got)
     # row 0 comes out of the prefill path (GEMM + FlashAttention), rows 1.. out of the fused decode step
     check_against_truth(got[:1], oracle[:1], truth[:1], what=what + " [prefill row]")
-    rec = check_against_truth(got[1:], oracle[1:], truth[1:], what=what + " [decode rows]")
+    # decode rows run the matvec arithmetic on both sides: the tighter band on the rms error (the prefill row went through the tile GEMM,
+    # whose weights are rounded to bf16 first -- reference-mandated extra rounding the matvec-form checker does not carry)
+    rec = check_against_truth(got[1:], oracle[1:], truth[1:], what=what + " [decode rows]", rms_factor=RMS_FACTOR_DECODE)
     log_parity({"what": "engine_windows_vs_truth", "prompt": prompt_len, "walk": walk, "windows": windows, "wo_merges": merged_by_wo, **rec})
