@@ -27,6 +27,7 @@ def moe_model(tmp_path_factory):
     words = [f"w{i}" for i in range(cfg["vocab_size"] - 2)]
     path = write_checkpoint(tmp_path_factory.mktemp("moe") / "ckpt", cfg, w, vocab_words=words)
     model, _ = load(str(path))
+    model._oracle_weights = w  # the numpy weight dict the checkpoint was written from (oracle / truth side of the tests below)
     return cfg, model
 
 
@@ -135,3 +136,34 @@ def test_two_sequences_decode_together_as_they_do_alone(moe_model):
         have = np.stack(got[slot])
         step = 2.0 ** -7 * max(1.0, float(np.abs(want).max()))
         assert float(np.abs(have - want).max()) <= 2 * step, f"sequence {slot}: batched and single-sequence logits differ"
+
+
+@pytest.mark.parametrize("n_prompt,chunk", [(5, 64), (7, 64), (23, 64)])
+def test_fused_engine_with_moe_layers_against_the_oracle_and_the_float64_truth(moe_model, n_prompt, chunk):
+    """The comparand of the first test is the HIP op-by-op model (the same expert kernels on both sides).  Here it is the CPU side: the
+    numpy oracle with Qwen3-MoE layers (oracle.OracleQwen3 + moe_block: src/tiny_llm_ref/moe.py:39-89 inside qwen3_week3.py:55-121)
+    and the float64 truth (oracle.TruthQwen3, pinned to transformers' Qwen3MoeForCausalLM by tests/test_truth_vs_transformers_cpu.py),
+    teacher-forced on the same tokens.  The top-k choice is the model's one discontinuity: the truth is evaluated on the ORACLE's
+    choice, and a position counts only where the truth's own choice is the same set of experts (a toss-up between the k-th and the
+    (k+1)-th expert is not an error of either side); at least two thirds of the positions must count.  Bar: the engine sits as close to
+    the truth as the bf16 oracle does (helpers.check_against_truth); 5 and 7 prompt tokens prefill by GEMV rows, 23 by the tile GEMM."""
+    from helpers import check_against_truth
+    from oracle import tiny_oracle as O
+
+    cfg, model = moe_model
+    w = model._oracle_weights
+    rng = np.random.default_rng(100 + n_prompt)
+    prompt = [int(t) for t in rng.integers(2, cfg["vocab_size"], size=n_prompt)]
+    forced = [int(t) for t in rng.integers(2, cfg["vocab_size"], size=6)]
+    got, stats = engine_logits(model, prompt, forced, chunk)
+    assert stats["graph_replays"] + stats["graph_captures"] >= len(forced)
+    oracle, truth = O.OracleQwen3(cfg, w), O.TruthQwen3(cfg, w)
+    want = [oracle.forward(prompt)[0, -1]] + [oracle.forward([t])[0, -1] for t in forced]
+    truth.forced_moe_ids = oracle.moe_ids
+    exact = [truth.forward(prompt)[0, -1]] + [truth.forward([t])[0, -1] for t in forced]
+    # call c of a sparse layer = position c of the teacher-forced sequence (call 0: the prompt, its last token is the row compared)
+    counted = [all(bool(calls[c]["same_choice"][-1]) for calls in truth.moe_margins.values()) for c in range(len(forced) + 1)]
+    assert sum(counted) >= 2 * len(counted) // 3 + 1, f"too many toss-up selections to compare: {counted}"
+    keep = np.asarray(counted)
+    check_against_truth(np.asarray(got)[keep], np.stack(want)[keep], np.stack(exact)[keep],
+                        what=f"fused engine with 2 MoE layers, prompt {n_prompt} (chunk {chunk}), {int(keep.sum())} of {len(keep)} positions")

@@ -135,17 +135,9 @@ def test_product_week1_model_on_the_host_against_transformers():
         np.all(np.take_along_axis(want, np.argmax(want, -1)[:, None], -1)[:, 0] - np.take_along_axis(want, np.argmax(got, -1)[:, None], -1)[:, 0] <= 2 * e_week1)
 
 
-def test_facade_moe_model_agrees_with_transformers_qwen3_moe(tmp_path):
-    from checkpoint_fixture import MOE_CFG_OVERRIDES, make_moe_weights, write_checkpoint
-
-    for extra in (ROOT / "tiny-llm_amd" / "compat", ROOT / "tiny-llm_amd", ROOT / "tiny-llm_amd" / "extensions_hip"):
-        if str(extra) not in sys.path:
-            sys.path.insert(0, str(extra))
-    from mlx_lm.models.qwen3 import Model
-    from tiny_llm_hip.loader import load_weights
-
-    cfg = dict(TINY_CFG, **MOE_CFG_OVERRIDES)
-    w = make_moe_weights(cfg, seed=5)
+def hf_moe_model(cfg: dict, w: dict):
+    """transformers' Qwen3MoeForCausalLM in float64 holding exactly the checkpoint's stored weights (dense mlp_only_layers, router +
+    stacked experts on the sparse layers)."""
     hf_cfg = transformers.Qwen3MoeConfig(**hf_common(cfg), num_experts=cfg["num_experts"], num_experts_per_tok=cfg["num_experts_per_tok"],
                                          moe_intermediate_size=cfg["moe_intermediate_size"], norm_topk_prob=cfg["norm_topk_prob"],
                                          decoder_sparse_step=cfg["decoder_sparse_step"], mlp_only_layers=cfg["mlp_only_layers"],
@@ -165,6 +157,21 @@ def test_facade_moe_model_agrees_with_transformers_qwen3_moe(tmp_path):
             for name, key in (("gate_proj", "gate"), ("up_proj", "up"), ("down_proj", "down")):
                 tensors[base + name + ".weight"] = dense64(lw[key])
     load_exactly(model, tensors)
+    return model
+
+
+def test_facade_moe_model_agrees_with_transformers_qwen3_moe(tmp_path):
+    from checkpoint_fixture import MOE_CFG_OVERRIDES, make_moe_weights, write_checkpoint
+
+    for extra in (ROOT / "tiny-llm_amd" / "compat", ROOT / "tiny-llm_amd", ROOT / "tiny-llm_amd" / "extensions_hip"):
+        if str(extra) not in sys.path:
+            sys.path.insert(0, str(extra))
+    from mlx_lm.models.qwen3 import Model
+    from tiny_llm_hip.loader import load_weights
+
+    cfg = dict(TINY_CFG, **MOE_CFG_OVERRIDES)
+    w = make_moe_weights(cfg, seed=5)
+    model = hf_moe_model(cfg, w)
 
     # the SAME checkpoint through the product's loader into the facade's mlx_lm model, parameters widened to float32
     tree = load_weights(write_checkpoint(tmp_path / "moe", cfg, w), device="cpu")
@@ -191,3 +198,34 @@ def test_facade_moe_model_agrees_with_transformers_qwen3_moe(tmp_path):
     worst = float((got.double() - want).abs().max())
     print(f"max |facade MoE model (float32) - transformers Qwen3-MoE (float64)| = {worst:.3e}")
     assert worst < 2e-4, worst  # float32 accumulation over 3 layers on O(3) logits; a routing or wiring difference is O(1)
+
+
+@pytest.mark.parametrize("seed", [5, 21])
+def test_float64_truth_with_moe_layers_agrees_with_transformers_qwen3_moe(seed):
+    """oracle.TruthQwen3 on a checkpoint with Qwen3-MoE sparse layers (round 5: the ground truth of tests/test_engine_moe_gpu.py) against
+    transformers' Qwen3MoeForCausalLM in float64 on the same stored weights, every prompt position and KV-cached decode steps: router
+    softmax over all experts, top-k, renormalised scores, SwiGLU experts, weighted sum, dense layer 0 (reference: moe.py:39-89 inside
+    qwen3_week3.py:209-214).  The bf16 oracle with the same layers sits one bf16 pipeline error from it."""
+    from checkpoint_fixture import MOE_CFG_OVERRIDES, make_moe_weights
+
+    cfg = dict(TINY_CFG, **MOE_CFG_OVERRIDES)
+    w = make_moe_weights(cfg, seed=seed)
+    model = hf_moe_model(cfg, w)
+    rng = np.random.default_rng(seed)
+    prompt = [int(t) for t in rng.integers(1, cfg["vocab_size"], size=19)]
+    steps = [int(t) for t in rng.integers(1, cfg["vocab_size"], size=4)]
+    with torch.no_grad():
+        want = model(torch.tensor([prompt + steps])).logits[0].numpy()
+    truth = O.TruthQwen3(cfg, w)
+    got = [truth.forward(prompt, logits_to_keep=None)[0]]
+    for t in steps:
+        got.append(truth.forward([t])[0])
+    got = np.concatenate(got)
+    worst = float(np.abs(got - want).max())
+    print(f"max |TruthQwen3 with MoE layers - transformers Qwen3-MoE (float64)| = {worst:.3e} on logits up to {np.abs(want).max():.2f}")
+    assert worst < 5e-6, worst  # (transformers keeps its rotary table in float32; a routing or wiring difference is O(1))
+    assert all(m["same_choice"].all() for calls in truth.moe_margins.values() for m in calls)
+    oracle = O.OracleQwen3(cfg, w)
+    rows = [oracle.forward(prompt, logits_to_keep=None)[0]] + [oracle.forward([t])[0] for t in steps]
+    err = float(np.abs(np.concatenate(rows) - want).max())
+    assert 1e-3 < err < 0.15, f"the bf16 oracle with MoE layers is {err:.4f} from transformers' float64 logits"
