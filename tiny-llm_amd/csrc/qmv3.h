@@ -510,13 +510,17 @@ struct Qmv3Plan {
     size_t lds;
     bool ok;
 };
-// The (MR, KS, CW, LM) combinations qmv3.hip instantiates (its Q3_CASE table, restated): 1 / 2 / 4 / 8 rows x {1, 2, 4 reduction
-// splits on 4 waves, 2, 4, 8 on 8 waves} x {4, 5, 8, 10} groups per wave, and 4 rows x 16 splits on 16 waves x {4, 5} groups.
+// The (MR, KS, CW, LM) combinations qmv3.hip instantiates (its Q3_TABLE, restated) = the ones the planner below can return:
+//   1 / 2 / 4 / 8 rows x {1, 2, 4 reduction splits on 4 waves} x {4, 5, 8, 10 groups per wave} (8 rows: 2 / 4 splits only beyond 10 groups,
+//   i.e. 8 or 10 per wave -- the finer cut of short reductions is a rule for 1-4 rows); 8 splits on 8 waves with 8 or 10 groups per wave
+//   (8 splits mean more than 40 groups; four rows over 65-80 groups go to 16 waves instead); 4 rows x 16 splits on 16 waves x {4, 5}.
 inline bool qmv3_has_variant(int MR, int KS, int CW, int LM) {
-    const bool lm = LM == 4 || LM == 5 || LM == 8 || LM == 10;
     const bool mr = MR == 1 || MR == 2 || MR == 4 || MR == 8;
-    const bool cut = (CW == 4 && (KS == 1 || KS == 2 || KS == 4)) || (CW == 8 && (KS == 2 || KS == 4 || KS == 8));
-    return (mr && lm && cut) || (MR == 4 && KS == 16 && CW == 16 && (LM == 4 || LM == 5));
+    const bool lm4 = LM == 4 || LM == 5 || LM == 8 || LM == 10, hi = LM == 8 || LM == 10;
+    if (CW == 4 && KS == 1) return mr && lm4;
+    if (CW == 4 && (KS == 2 || KS == 4)) return mr && (MR == 8 ? hi : lm4);
+    if (CW == 8 && KS == 8) return mr && hi && !(MR == 4 && LM == 10);
+    return MR == 4 && KS == 16 && CW == 16 && (LM == 4 || LM == 5);
 }
 inline int qmv3_round_lm(int lper) { return lper <= 4 ? 4 : (lper <= 5 ? 5 : (lper <= 8 ? 8 : Q3_LMAX)); }
 inline Qmv3Plan qmv3_plan(int M, int N, int K, int force_ks = 0, int force_cw = 0) {

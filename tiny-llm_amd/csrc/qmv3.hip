@@ -50,11 +50,18 @@ int repack_w4_tiled(const uint32_t *w, const uint16_t *scales, const uint16_t *b
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// The instantiation table, written once: Q3_TABLE(X) expands X(MR, KS, CW, LM) for every compiled combination.
-#define Q3_LM(X, MRv, KSv, CWv) X(MRv, KSv, CWv, 4) X(MRv, KSv, CWv, 5) X(MRv, KSv, CWv, 8) X(MRv, KSv, CWv, 10)
-#define Q3_MR(X, MRv) Q3_LM(X, MRv, 1, 4) Q3_LM(X, MRv, 2, 4) Q3_LM(X, MRv, 4, 4) Q3_LM(X, MRv, 8, 8) Q3_LM(X, MRv, 2, 8) Q3_LM(X, MRv, 4, 8)
-#define Q3_TABLE(X) Q3_MR(X, 1) Q3_MR(X, 2) Q3_MR(X, 4) Q3_MR(X, 8) \
-    X(4, 16, 16, 4) X(4, 16, 16, 5)  /* qmv3_plan: four rows over a long reduction (8 x <= 10 groups cut 16 x <= 5) */
+// The instantiation table, written once: Q3_TABLE(X) expands X(MR, KS, CW, LM) for every compiled combination -- exactly the
+// combinations qmv3_plan can return (round 5: the 45 of 98 that no shape reaches -- 8-wave workgroups with 2 / 4 reduction splits,
+// 8 splits with 4 / 5 groups per wave, 8 rows on the finer cut of 1-4 rows -- are gone: 231 kernels; tests/test_decode_plans_cpu.py
+// sweeps the planner and fails on an entry nothing reaches).  Laboratories instantiate what they sweep themselves (tools/lab/plan_lab.hip).
+#define Q3_LM4(X, MRv, KSv, CWv) X(MRv, KSv, CWv, 4) X(MRv, KSv, CWv, 5) X(MRv, KSv, CWv, 8) X(MRv, KSv, CWv, 10)
+#define Q3_LMHI(X, MRv, KSv, CWv) X(MRv, KSv, CWv, 8) X(MRv, KSv, CWv, 10)
+#define Q3_TABLE(X)                                                                                                     \
+    Q3_LM4(X, 1, 1, 4) Q3_LM4(X, 1, 2, 4) Q3_LM4(X, 1, 4, 4) Q3_LMHI(X, 1, 8, 8)                                        \
+    Q3_LM4(X, 2, 1, 4) Q3_LM4(X, 2, 2, 4) Q3_LM4(X, 2, 4, 4) Q3_LMHI(X, 2, 8, 8)                                        \
+    Q3_LM4(X, 4, 1, 4) Q3_LM4(X, 4, 2, 4) Q3_LM4(X, 4, 4, 4) X(4, 8, 8, 8)                                              \
+    X(4, 16, 16, 4) X(4, 16, 16, 5) /* qmv3_plan: four rows over a long reduction (8 x <= 10 groups cut 16 x <= 5) */   \
+    Q3_LM4(X, 8, 1, 4) Q3_LMHI(X, 8, 2, 4) Q3_LMHI(X, 8, 4, 4) Q3_LMHI(X, 8, 8, 8)
 
 // what the table holds, for the CPU test that keeps qmv3_has_variant (qmv3.h, used by the planner) in step with it
 bool qmv3_variant_in_table(int MR, int KS, int CW, int LM) {
@@ -98,7 +105,7 @@ static int launch_merge_variant3(const Qmv3Args &args, hipStream_t st, const Qmv
         return 0;                                                                                                    \
     }
 #define Q3_MLM(KSv, CWv) Q3_MCASE(KSv, CWv, 4) Q3_MCASE(KSv, CWv, 5) Q3_MCASE(KSv, CWv, 8) Q3_MCASE(KSv, CWv, 10)
-    Q3_MLM(2, 4) Q3_MLM(4, 4) Q3_MLM(8, 8)
+    Q3_MLM(2, 4) Q3_MLM(4, 4) Q3_MCASE(8, 8, 8) Q3_MCASE(8, 8, 10)  // (8 splits mean more than 40 groups: 8 or 10 per wave)
 #undef Q3_MLM
 #undef Q3_MCASE
     return -1;
