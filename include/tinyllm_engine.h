@@ -89,6 +89,7 @@ typedef struct tl_engine_stats {
     long decode_steps, graph_captures, graph_replays, prefill_tokens;
     size_t kv_bytes, workspace_bytes;
     long graph_cache_flushes; /* times the cache of captured decode graphs (48 plans) was emptied */
+    long aql_steps;           /* decode steps replayed as AQL packets on the engine's own HSA queue (TL_AQL=1; 0 on the hipGraph route) */
 } tl_engine_stats;
 
 /* A Qwen3-MoE layer (reference: src/tiny_llm_ref/qwen3_week3.py:209-214, 258-272 builds a Moe block for it; moe.py:39-89 is the

@@ -18,6 +18,10 @@
 #include "qmm3.h"
 #include "qmm6.h"
 #include "attn_mfma.h"
+#include "aql.h"
+
+#include <dlfcn.h>
+#include <memory>
 
 namespace tl {
 
@@ -128,6 +132,13 @@ struct tl_engine {
 
     bool warmed = false;
     std::map<std::pair<int, long>, hipGraphExec_t> graphs;  // (batch, n_splits << 32 | tokens_per_split)
+    // AQL replay (aql.h; TL_AQL=1 at create): a captured step also becomes a program of hand-written dispatch packets on the engine's own
+    // HSA queue; a plan without a program (a kernel outside the device-only code objects, a node that is not a kernel) stays on hipGraphLaunch
+    bool aql_on = false;
+    std::unique_ptr<AqlQueue> aql_queue;
+    std::map<std::pair<int, long>, std::unique_ptr<AqlProgram>> aql_programs;
+    AqlFences aql_fences;
+    std::string aql_why;  // why the last plan got no program
     // Qwen3-MoE layers (tl_engine_set_moe_layer): router + stacked experts instead of the dense gate|up / w_down of that layer
     std::vector<tl_moe_weights> moe;  // per layer; num_experts == 0: dense
     int moe_k_max = 0, moe_e_max = 0, moe_i_max = 0;
@@ -146,6 +157,9 @@ struct tl_engine {
     uint16_t *layer_k(int l) const { return kpool + (size_t)l * layer_pool_elems; }
     uint16_t *layer_v(int l) const { return vpool + (size_t)l * layer_pool_elems; }
 };
+
+static int aql_drain(tl_engine *e);
+static std::string library_dir();
 
 namespace tl {
 
@@ -1102,6 +1116,22 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->use_qmm6 = getenv("TL_NO_QMM6") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
     read_attention_knobs(e);
+    // TL_AQL=1: decode steps replay as AQL packets on the engine's own HSA queue (aql.h); asked for and not available is an error, not
+    // a silent fallback.  TL_AQL_FENCES=0 drops the agent-scope cache maintenance between the launches of a step (only with kernels
+    // that exchange their activations through device-scope loads and write-through stores).
+    if (const char *q = getenv("TL_AQL")) {
+        if (atoi(q) != 0) {
+            AqlRuntime &rt = AqlRuntime::get();
+            std::string why;
+            e->aql_queue = std::make_unique<AqlQueue>();
+            if (!rt.ensure_loaded(library_dir()) || !e->aql_queue->create(why)) {
+                const std::string msg = "engine_create: TL_AQL=1 but the AQL route is not available: " + (rt.ok() ? why : rt.why());
+                tl_engine_destroy(e);
+                return fail(TL_ERR_UNSUPPORTED, msg);
+            }
+            e->aql_on = true;
+        }
+    }
 
     // state words: zero everything up to the activations, then the block table to -1
     if (hipMemsetAsync(e->arena, 0, o_x, e->stream) != hipSuccess) return cleanup_fail("engine_create: memset failed");
@@ -1250,7 +1280,10 @@ extern "C" int tl_engine_set_moe_layer(tl_engine *e, int layer, const tl_moe_wei
 
 extern "C" void tl_engine_destroy(tl_engine *e) {
     if (!e) return;
+    (void)aql_drain(e);
     (void)hipStreamSynchronize(e->stream);
+    e->aql_programs.clear();
+    e->aql_queue.reset();
     if (e->moe_ws) (void)hipFree(e->moe_ws);
     for (auto &kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     if (e->arena) (void)hipFree(e->arena);
@@ -1716,6 +1749,24 @@ extern "C" int tl_engine_verify(tl_engine *e, int slot, const int32_t *tokens, i
     return TL_OK;
 }
 
+// directory of this shared library: the device-only code objects of the AQL route lie next to it
+static std::string library_dir() {
+    Dl_info info{};
+    if (dladdr((const void *)&library_dir, &info) == 0 || !info.dli_fname) return ".";
+    const std::string path = info.dli_fname;
+    const size_t slash = path.rfind('/');
+    return slash == std::string::npos ? std::string(".") : path.substr(0, slash);
+}
+
+// everything the AQL queue holds has run: the stream may be used again (and the host may read what the steps wrote)
+static int aql_drain(tl_engine *e) {
+    if (e->aql_queue && e->aql_queue->busy()) {
+        std::string why;
+        if (!e->aql_queue->wait(30.0, why)) return fail(TL_ERR_HIP, "engine: " + why);
+    }
+    return TL_OK;
+}
+
 extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_graph) {
     TL_REQUIRE(e, "engine_decode: null engine");
     TL_REQUIRE(batch > 0 && batch <= e->cfg.max_batch, "engine_decode: batch out of range");
@@ -1728,11 +1779,20 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
                        c.vocab_size, e->context_lens, e->rope_table, e->rope_cur, e->rope_positions, c.head_dim / 2, e->ss_x);
     TL_CHECK_LAUNCH("engine embed");
     std::vector<std::pair<int32_t *, int32_t>> pk;
+    bool on_queue = false;  // steps of this call are in flight on the AQL queue (the stream is idle and must stay so until they are drained)
     for (int s = 0; s < steps; ++s) {
         int max_ctx = 1;
-        TL_TRY(reserve_step_locked(e, batch, pk, &max_ctx));
+        const int rrc = reserve_step_locked(e, batch, pk, &max_ctx);
+        if (rrc != TL_OK) {
+            (void)aql_drain(e);
+            return rrc;
+        }
         if (!pk.empty()) {
             e->stats.pages_free = (int)e->free_pages.size();
+            if (on_queue) {  // a page id changes: the poke is a stream launch and must land between the steps
+                TL_TRY(aql_drain(e));
+                on_queue = false;
+            }
             TL_TRY(poke(e, pk));
         }
         const SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
@@ -1743,10 +1803,15 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
                 // The split plan (and with it the key) changes every 64 * n_splits tokens of context: a long run would keep one
                 // ~220-node executable graph per plan and row bucket for ever.  Plans are visited in order of growing context, so
                 // when the cache is full the old ones are dead: drop them all (a live plan is re-captured once, ~0.3 ms).
+                if (on_queue) {
+                    TL_TRY(aql_drain(e));
+                    on_queue = false;
+                }
                 if (e->graphs.size() >= 48) {
                     TL_HIP(hipStreamSynchronize(e->stream));
                     for (auto &kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
                     e->graphs.clear();
+                    e->aql_programs.clear();
                     e->stats.graph_cache_flushes++;
                 }
                 hipGraph_t graph = nullptr;
@@ -1760,14 +1825,41 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
                 if (ce != hipSuccess) return fail(TL_ERR_HIP, std::string("engine_decode: graph capture failed: ") + hipGetErrorString(ce));
                 hipGraphExec_t exec = nullptr;
                 const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                if (ie == hipSuccess && e->aql_on) {  // the same nodes as packet templates (aql.h); a plan that cannot be built keeps the graph route
+                    auto prog = std::make_unique<AqlProgram>();
+                    if (aql_program_from_graph(graph, e->stream, *prog, e->aql_why) == 0) e->aql_programs[key] = std::move(prog);
+                }
                 (void)hipGraphDestroy(graph);
                 if (ie != hipSuccess) return fail(TL_ERR_HIP, std::string("engine_decode: graph instantiate failed: ") + hipGetErrorString(ie));
                 it = e->graphs.emplace(key, exec).first;
                 e->stats.graph_captures++;
             }
-            TL_HIP(hipGraphLaunch(it->second, e->stream));
+            const auto prog = e->aql_on ? e->aql_programs.find(key) : e->aql_programs.end();
+            if (prog != e->aql_programs.end()) {
+                bool first = false;
+                if (!on_queue) {  // hand-over stream -> queue: everything enqueued so far (embedding gather, pokes, earlier steps) has run
+                    TL_HIP(hipStreamSynchronize(e->stream));
+                    on_queue = first = true;
+                }
+                std::string why;
+                if (!e->aql_queue->submit(*prog->second, e->aql_fences, first, s + 1 == steps, why)) {
+                    (void)aql_drain(e);
+                    return fail(TL_ERR_HIP, "engine_decode: " + why);
+                }
+                e->stats.aql_steps++;
+            } else {
+                if (on_queue) {
+                    TL_TRY(aql_drain(e));
+                    on_queue = false;
+                }
+                TL_HIP(hipGraphLaunch(it->second, e->stream));
+            }
             e->stats.graph_replays++;
         } else {
+            if (on_queue) {
+                TL_TRY(aql_drain(e));
+                on_queue = false;
+            }
             TL_TRY(enqueue_step(e, batch, sp));
             e->warmed = true;
         }
@@ -1778,6 +1870,8 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
         }
         e->stats.decode_steps++;
     }
+    // the queue is not the stream: what follows this call (reads, prefills, the next call's embedding gather) is stream-ordered
+    if (on_queue) TL_TRY(aql_drain(e));
     e->logits_rows = batch;
     return TL_OK;
 }

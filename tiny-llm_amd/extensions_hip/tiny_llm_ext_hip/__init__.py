@@ -99,7 +99,7 @@ class TlEngineStats(ctypes.Structure):
                 ("page_allocations", ctypes.c_long), ("reused_page_allocations", ctypes.c_long),
                 ("decode_steps", ctypes.c_long), ("graph_captures", ctypes.c_long), ("graph_replays", ctypes.c_long),
                 ("prefill_tokens", ctypes.c_long), ("kv_bytes", _c_size_t), ("workspace_bytes", _c_size_t),
-                ("graph_cache_flushes", ctypes.c_long)]
+                ("graph_cache_flushes", ctypes.c_long), ("aql_steps", ctypes.c_long)]
 
 
 class TlStepProfile(ctypes.Structure):

@@ -46,6 +46,9 @@ struct LinkArgs {
     int *err;               // [0] give-ups, [1] wrong sums
     int n, r, tagged, weights, grid, poll;  // poll: 0 granule sweep, sleep 2 | 1 granule sweep after the weights have landed, sleep 32 | 2 arrival counter, then one sweep
     unsigned *count_in, *count_out;  // poll 2: arrivals of the producing / this round
+    const u32x4 *w_next;             // section I: the NEXT round's weights: this workgroup requests block (blockIdx + next_shift) % grid of them (L2 prefetch)
+    int next_shift, pad2_;
+    unsigned *progress;              // section H: round number published by workgroup 0 at its start (a prefetching sidecar paces itself by it)
     uint32_t tag_in, tag_out;
     u64 give_up_ticks;
 };
@@ -85,9 +88,21 @@ extern "C" __global__ __launch_bounds__(T) void link_kernel(const LinkArgs p) {
     u32x4 wv[10];
     if (p.weights) {
         const u32x4 *wp = p.w + (size_t)blockIdx.x * (T * 10) + tid;
+        if (p.weights == 2) {  // section H: plain (L2-allocating) loads -- a sidecar may have brought the lines into this XCD's L2
 #pragma unroll
-        for (int i = 0; i < 10; ++i) wv[i] = __builtin_nontemporal_load(wp + (size_t)i * T);
+            for (int i = 0; i < 10; ++i) wv[i] = wp[(size_t)i * T];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) wv[i] = __builtin_nontemporal_load(wp + (size_t)i * T);
+        }
     }
+    u32x4 pv[10];
+    if (p.w_next) {  // behind the own weights: loads return in issue order, these may stay in flight until the very end of the kernel
+        const u32x4 *np = p.w_next + (size_t)((blockIdx.x + (unsigned)p.next_shift) % (unsigned)p.grid) * (T * 10) + tid;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) pv[i] = np[(size_t)i * T];
+    }
+    if (p.progress && blockIdx.x == 0 && tid == 0) __hip_atomic_store(p.progress, (unsigned)p.r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();  // s_gave_up initialised
     uint32_t x = 0;
     if (p.weights && p.poll >= 1) {  // the weights first: a successor that started early has nothing to poll for yet
@@ -170,6 +185,49 @@ extern "C" __global__ __launch_bounds__(T) void link_kernel(const LinkArgs p) {
     if (tid == 0) p.stamp[2 * blockIdx.x + 1] = wall_clock64();
 }
 
+
+// Section H: a persistent SIDECAR on a second queue that streams the weights of the round AHEAD into the L2 of the XCD that will consume
+// them.  One 64-thread workgroup per CU; workgroup j fetches block (j + shift) % grid of round r + 1 (shift 0: the block consumer
+// workgroup j -- same launch-order index, hence same XCD -- will read; shift 1: the neighbour's, i.e. the WRONG XCD, as a control) as soon
+// as round r has started (progress word).  The lines are requested by LDS-DMA into a scratch ring (no registers, nothing waits).
+struct SideArgs {
+    const u32x4 *w;      // rounds x grid x 2560 u32x4
+    size_t w_units;      // u32x4 per round
+    unsigned *progress;
+    int rounds, w_rounds, grid, shift;
+    u64 give_up_ticks;
+    int *err;
+    int mode, sleep;   // mode 0: paced by the progress word | 1: polls only, fetches nothing | 2: paced by the wall clock (period_ticks per round)
+    u64 period_ticks;
+};
+extern "C" __global__ __launch_bounds__(64) void sidecar_kernel(const SideArgs p) {
+    __shared__ __attribute__((aligned(1024))) char ring[8 * 1024];
+    const int lane = threadIdx.x;
+    const u64 t0 = wall_clock64();
+    const int blk = (int)((blockIdx.x + (unsigned)p.shift) % (unsigned)p.grid);
+    for (int r = 1; r < p.rounds; ++r) {
+        // wait until round r - 1 has started
+        if (p.mode == 2) {
+            while (wall_clock64() - t0 < (u64)(r - 1) * p.period_ticks) __builtin_amdgcn_s_sleep(2);
+        } else if (lane == 0) {
+            while (__hip_atomic_load(p.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)r) {
+                if (wall_clock64() - t0 > p.give_up_ticks) { atomicAdd(&p.err[2], 1); break; }
+                if (p.sleep >= 32) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        if (p.mode == 1) continue;
+        const u32x4 *src = p.w + (size_t)(r % p.w_rounds) * p.w_units + (size_t)blk * 2560;
+        // 40 KiB = 40 x 1 KiB LDS-DMA instructions, 8 slots of scratch re-used (the data is never read)
+#pragma unroll 8
+        for (int i = 0; i < 40; ++i) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(src), 0, 40 * 1024, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(ring + (i & 7) * 1024), 16, lane * 16, i * 1024, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // two trivial kernels for the mechanism probe: spin for `ticks` of the wall clock, stamp start and end
 extern "C" __global__ void spin_kernel(u64 *stamp, u64 ticks) {
     const u64 t0 = wall_clock64();
@@ -188,8 +246,8 @@ struct Aql {
     hsa_queue_t *q = nullptr, *q2 = nullptr;
     hsa_signal_t done{}, done2{};
     hsa_executable_t exe{};
-    uint64_t link_obj = 0, spin_obj = 0;
-    uint32_t link_lds = 0, spin_lds = 0, link_args = 0, spin_args = 0;
+    uint64_t link_obj = 0, spin_obj = 0, side_obj = 0;
+    uint32_t link_lds = 0, spin_lds = 0, link_args = 0, spin_args = 0, side_lds = 0, side_args = 0;
     char *kernarg = nullptr;  // DEVICE memory (run 1 kept them in pinned host memory: every CU's first s_load of a kernel crossed PCIe, +1.8 us per kernel)
     std::vector<char> kernarg_host;
     bool ok = false;
@@ -237,6 +295,7 @@ static bool aql_init(Aql &a, const std::string &hsaco_path) {
     HK(hsa_executable_freeze(a.exe, nullptr));
     if (!aql_symbol(a, "link_kernel.kd", &a.link_obj, &a.link_lds, &a.link_args)) return false;
     if (!aql_symbol(a, "spin_kernel.kd", &a.spin_obj, &a.spin_lds, &a.spin_args)) return false;
+    if (!aql_symbol(a, "sidecar_kernel.kd", &a.side_obj, &a.side_lds, &a.side_args)) return false;
     CK(hipMalloc((void **)&a.kernarg, 2 * 4096 * 512));
     a.kernarg_host.resize(4096 * 512);
     a.ok = true;
@@ -313,7 +372,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 2; ++i) { CK(hipMalloc(&gbuf[i], 4096 * 8)); CK(hipMemset(gbuf[i], 0, 4096 * 8)); CK(hipMalloc(&pbuf[i], 4096 * 4)); }
     u64 *stamp; CK(hipMalloc(&stamp, (size_t)(R + 2) * WG * 2 * 8));
     int *err; CK(hipMalloc(&err, 16));
-    unsigned *counts; CK(hipMalloc(&counts, (size_t)(R + 2) * 64));
+    unsigned *counts; CK(hipMalloc(&counts, (size_t)(R + 4) * 64));
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<u64> hs((size_t)(R + 2) * WG * 2);
@@ -512,6 +571,102 @@ int main(int argc, char **argv) {
             }
             const char *fn[3] = {"F0 two AQL queues alternating, sweep / sleep 2", "F1 two AQL queues, weights first, sweep / sleep 32", "F2 two AQL queues, weights first, arrival counter"};
             if (aql.ok) finish(fn[poll], best * 1e3 / R, 0.0);
+        }
+        // I: raw AQL chain without cache maintenance; every workgroup of round r also requests the weights of round r + 1 (plain loads nobody
+        // consumes): nothing invalidates L2 between the launches, so round r + 1 finds its weights in its XCD's L2 -- software pipelining of the
+        // weight stream ACROSS kernel boundaries, with no second queue, no sidecar and no hand-off
+        if (aql.ok && weights) for (int variant = 0; variant < 4; ++variant) {
+            // 0: block b prefetches block b of the next round (same launch-order index: same XCD) | 1: block b + 1 (another XCD) | 2: b + 8 (same XCD,
+            // another CU) | 3: as 0 but the consumers carry agent-scope acquire fences (what a HIP launch does: L2 invalidated)
+            const int shifts[4] = {0, 1, 8, 0};
+            double best = 1e9;
+            for (int rep = 0; rep < 3 && aql.ok; ++rep) {
+                const uint32_t ep = epoch++;
+                seed(ep);
+                CK(hipDeviceSynchronize());
+                std::vector<LinkArgs> args(R);
+                std::vector<Pkt> pk;
+                for (int r = 0; r < R; ++r) {
+                    args[r] = make_args(r, 3, ep);
+                    args[r].weights = 2;
+                    args[r].w_next = w + (size_t)((r + 1) % W_ROUNDS) * w_units;
+                    args[r].next_shift = shifts[variant];
+                    const bool first = r == 0, last = r == R - 1;
+                    const int acq = first ? HSA_FENCE_SCOPE_SYSTEM : (variant == 3 ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE);
+                    pk.push_back(Pkt{aql.link_obj, aql.link_lds, WG, T, &args[r], sizeof(LinkArgs), true, acq, last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE});
+                }
+                aql_submit(aql, pk);
+                if (!aql_wait(aql, 10.0)) { printf("aql: TIMEOUT in chain I%d\n", variant); aql.ok = false; break; }
+                CK(hipMemcpy(hs.data(), stamp, (size_t)R * WG * 2 * 8, hipMemcpyDeviceToHost));
+                u64 s0 = ~0ull, e9 = 0;
+                for (int b = 0; b < WG; ++b) { s0 = std::min(s0, hs[(size_t)b * 2]); e9 = std::max(e9, hs[((size_t)(R - 1) * WG + b) * 2 + 1]); }
+                best = std::min(best, (double)(e9 - s0) * us / 1e3);
+            }
+            const char *in[4] = {"I0 each workgroup prefetches ITS block of the next round", "I1 ... block + 1 of the next round (other XCD)", "I2 ... block + 8 (same XCD, other CU)",
+                                 "I3 as I0, consumers with acquire fences"};
+            if (aql.ok) finish(in[variant], best * 1e3 / R, 0.0);
+        }
+        // the same inside a hipGraph of ordinary launches (HIP's own fences between the kernels): does the prefetch survive a HIP boundary?
+        if (weights) {
+            const uint32_t ep = epoch++;
+            hipGraph_t graph; hipGraphExec_t exec;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+            for (int r = 0; r < R; ++r) {
+                LinkArgs a = make_args(r, 0, ep);
+                a.weights = 2; a.w_next = w + (size_t)((r + 1) % W_ROUNDS) * w_units; a.next_shift = 0;
+                hipLaunchKernelGGL(link_kernel, dim3(WG), dim3(T), 0, st, a);
+            }
+            CK(hipStreamEndCapture(st, &graph));
+            CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            float bestg = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                seed(ep);
+                CK(hipEventRecord(e0, st)); CK(hipGraphLaunch(exec, st)); CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); bestg = std::min(bestg, ms);
+            }
+            finish("I4 hipGraph, plain data, each workgroup prefetches its next block", bestg * 1e3 / R, 0.0);
+            CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph));
+        }
+        // H: raw AQL chain without cache maintenance (bypassing loads + write-through stores: G2), weights through PLAIN loads, and a
+        // persistent sidecar on the second queue that streams the next round's weights into the consuming XCD's L2 (nothing invalidates it)
+        if (aql.ok && weights) for (int variant = 0; variant < 8; ++variant) {
+            // 4: sidecar (shift 1) polling with long sleeps | 5: sidecar that only polls | 6 / 7: sidecar (shift 1 / 0) paced by the wall clock, no polling
+            // 0: no sidecar (plain weight loads alone) | 1: sidecar, right XCD | 2: sidecar, WRONG XCD | 3: sidecar right XCD, consumers with agent acquire fences
+            double best = 1e9;
+            unsigned *progress = counts + (size_t)(R + 1) * 16;
+            for (int rep = 0; rep < 3 && aql.ok; ++rep) {
+                const uint32_t ep = epoch++;
+                seed(ep);
+                CK(hipMemset(progress, 0, 4));
+                CK(hipDeviceSynchronize());
+                std::vector<LinkArgs> args(R);
+                std::vector<Pkt> pk;
+                for (int r = 0; r < R; ++r) {
+                    args[r] = make_args(r, 3, ep);
+                    args[r].weights = 2;
+                    args[r].progress = progress;
+                    const bool first = r == 0, last = r == R - 1;
+                    const int acq = first ? HSA_FENCE_SCOPE_SYSTEM : (variant == 3 ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE);
+                    pk.push_back(Pkt{aql.link_obj, aql.link_lds, WG, T, &args[r], sizeof(LinkArgs), true, acq, last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE});
+                }
+                SideArgs sa{w, w_units, progress, R, W_ROUNDS, WG, (variant == 2 || variant == 4 || variant == 5 || variant == 6) ? 1 : 0, (u64)khz * 50, err,
+                            variant == 5 ? 1 : (variant >= 6 ? 2 : 0), variant == 4 ? 32 : 4, (u64)(khz * 4.5 / 1000.0)};
+                std::vector<Pkt> sp{Pkt{aql.side_obj, aql.side_lds, WG, 64, &sa, sizeof(SideArgs), true, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_NONE}};
+                const uint64_t w0 = hsa_queue_load_write_index_relaxed(aql.q), w1 = hsa_queue_load_write_index_relaxed(aql.q2);
+                if (variant != 0) aql_submit(aql, sp, 1, true, false);
+                aql_submit(aql, pk, 0, true, false);
+                if (variant != 0) hsa_signal_store_screlease(aql.q2->doorbell_signal, w1);
+                hsa_signal_store_screlease(aql.q->doorbell_signal, w0 + pk.size() - 1);
+                if (!aql_wait(aql, 10.0, 0) || (variant != 0 && !aql_wait(aql, 10.0, 1))) { printf("aql: TIMEOUT in chain H%d\n", variant); aql.ok = false; break; }
+                CK(hipMemcpy(hs.data(), stamp, (size_t)R * WG * 2 * 8, hipMemcpyDeviceToHost));
+                u64 s0 = ~0ull, e9 = 0;
+                for (int b = 0; b < WG; ++b) { s0 = std::min(s0, hs[(size_t)b * 2]); e9 = std::max(e9, hs[((size_t)(R - 1) * WG + b) * 2 + 1]); }
+                best = std::min(best, (double)(e9 - s0) * us / 1e3);
+            }
+            const char *hn[8] = {"H0 AQL no fences, plain weight loads, no sidecar", "H1 + sidecar, block b", "H2 + sidecar, block b + 1",
+                                 "H3 sidecar block b, consumers with acquire fences", "H4 sidecar block b + 1, long poll sleeps", "H5 sidecar that only polls",
+                                 "H6 sidecar block b + 1, paced by the clock (4.5 us)", "H7 sidecar block b, paced by the clock (4.5 us)"};
+            if (aql.ok) finish(hn[variant], best * 1e3 / R, 0.0);
         }
         // G: raw AQL, barrier SET, UNTAGGED data: which part of a boundary is cache maintenance, and can write-through stores replace the release?
         if (aql.ok) for (int variant = 0; variant < 5; ++variant) {
