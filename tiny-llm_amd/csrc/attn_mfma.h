@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
     sload_i32(brow + min(page_of(wave_base(min(1, n_it - 1))), p.max_pages - 1), pg_nxt);
     RawRow<VD> kraw_new, vraw_new, qraw[RQ], qw, kw;
     if constexpr (!QP) {
-        load_raw<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
-        load_raw<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
+        load_raw_act<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
+        load_raw_act<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
     }
     load_raw<VD>(p.q_norm_w + t * VD, qw);
     load_raw<VD>(p.k_norm_w + t * VD, kw);
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
 #pragma unroll
         for (int r = 0; r < RQ; ++r) {
             const int hq = min(chunk * RQ + r, rep - 1);
-            load_raw<VD>(row + (long)(kvh * rep + hq) * D + t * VD, qraw[r]);
+            load_raw_act<VD>(row + (long)(kvh * rep + hq) * D + t * VD, qraw[r]);
         }
     }
     float cs[VD], sn[VD];
@@ -348,13 +348,13 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
         }
         const long orow = (long)b * Hq + kvh * rep + hq;
         if (p.n_splits == 1) {
-            p.out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : vs / gl);
+            act_store(&p.out[orow * D + d], BF16::from_float(gl == 0.f ? 0.f : vs / gl));
         } else {
             float *wsr = p.ws + (orow * p.n_splits + split) * (D + ATTN_WS_PAD);
-            wsr[d] = vs;
+            act_store(&wsr[d], vs);
             if (d == 0) {
-                wsr[D] = gm;
-                wsr[D + 1] = gl;
+                act_store(&wsr[D], gm);
+                act_store(&wsr[D + 1], gl);
             }
         }
     }

@@ -139,6 +139,35 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
+// ---- activations between the launches of a decode step -------------------------------------------------------------------------
+// A kernel reads what the launch before it wrote.  Behind an ordinary launch boundary the runtime writes every L2 back and invalidates
+// every L2 and L1 (agent-scope release / acquire: 0.4-0.55 us per launch on this chip, and a cold L2 for whoever comes next).  The AQL
+// replay route (aql.h) issues the launches INSIDE a step without that maintenance; what makes that correct is a pair of rules:
+//   * every store of a value another launch of the step reads is WRITTEN THROUGH to memory (a relaxed device-scope atomic store: sc1)
+//     -- in the route's device-only code objects, which are compiled with -DTL_COHERENT; relaxed atomics of 2 / 4 / 8 bytes order
+//     nothing and wait for nothing (a `volatile` store, the back end's other spelling, is followed by s_waitcnt vmcnt(0));
+//   * every such value lives at an address that is written ONCE per step and read only after it (csrc/engine.hip: the decode
+//     activations of the route are per-layer buffers): no cache -- L1, or another XCD's L2 -- can hold an older copy of the line, because
+//     the step's first packet invalidates them all and nobody touched the line since; the consumers' loads stay PLAIN (one fetch per
+//     XCD, then L2 hits for the other workgroups of that XCD -- device-scope loads were tried first: every workgroup's copy of the row
+//     crossed the fabric, 0.99 -> 1.03 ms per step).
+// The fat binary inside the library is compiled without the macro: plain stores, for the routes that keep their launch boundaries.
+template <typename T>
+__device__ __forceinline__ T act_load(const T *ptr) {
+    return *ptr;
+}
+template <typename T>
+__device__ __forceinline__ void act_store(T *ptr, T v) {
+#ifdef TL_COHERENT
+    static_assert(sizeof(T) == 2 || sizeof(T) == 4 || sizeof(T) == 8, "act_store: 2, 4 or 8 bytes");
+    if constexpr (sizeof(T) == 2) __hip_atomic_store(reinterpret_cast<uint16_t *>(ptr), __builtin_bit_cast(uint16_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if constexpr (sizeof(T) == 4) __hip_atomic_store(reinterpret_cast<uint32_t *>(ptr), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(reinterpret_cast<uint64_t *>(ptr), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *ptr = v;
+#endif
+}
+
 // ---- optional in-kernel timing (engine profile step) ---------------------------------------------
 // buf = nullptr in normal operation.  Otherwise buf[2*wg] receives the workgroup's first timestamp and
 // buf[2*wg+1] the maximum end timestamp over its waves (constant-rate wall clock, hipDeviceAttributeWallClockRate).

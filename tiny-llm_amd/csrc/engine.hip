@@ -139,6 +139,17 @@ struct tl_engine {
     std::map<std::pair<int, long>, std::unique_ptr<AqlProgram>> aql_programs;
     AqlFences aql_fences;
     std::string aql_why;  // why the last plan got no program
+    // Per-layer decode activations (common.h, "activations between the launches of a decode step"): with the AQL route every value a launch
+    // hands to a later launch of the SAME step lives at an address written once per step -- layer l's x / h / weighted h / qkv / attention
+    // rows and partials / SwiGLU rows / sums of squares have their own buffers (1-4 rows: the fused-GEMV route; 36 x ~0.3 MB at Qwen3-4B)
+    struct LayerAct {
+        uint16_t *x_out, *h, *xn, *qkv, *attn, *act;
+        float *ss_x_out, *ss_h, *attn_ws;
+    };
+    std::vector<LayerAct> layer_act;
+    char *layer_act_mem = nullptr;
+    int layer_act_rows = 0;       // rows the per-layer buffers hold (0: none)
+    size_t layer_ws_bytes = 0;    // attention partials per layer
     // Qwen3-MoE layers (tl_engine_set_moe_layer): router + stacked experts instead of the dense gate|up / w_down of that layer
     std::vector<tl_moe_weights> moe;  // per layer; num_experts == 0: dense
     int moe_k_max = 0, moe_e_max = 0, moe_i_max = 0;
@@ -745,6 +756,13 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     // 5 .. 64 rows on the register-resident matmul: xn holds x weighted by the NEXT RMSNorm's weight whenever xw is set (written by
     // the w_down epilogue of the previous layer, or by one pointwise launch ahead of layer 0)
     bool xw = false;
+    // where the residual stream and its sums of squares stand (the shared buffers, or the last layer's own in per-layer mode)
+    uint16_t *x_cur = e->x;
+    float *ssx_cur = e->ss_x;
+    // per-layer hand-over buffers: the fused-GEMV rows of a dense model whose attention partials fit the per-layer workspace
+    bool per_layer = e->layer_act_rows > 0 && batch <= e->layer_act_rows && gemv_takes_rows(e, batch) &&
+                     (sp.n_splits == 1 || (size_t)batch * c.num_heads * sp.n_splits * (c.head_dim + ATTN_WS_PAD) * sizeof(float) <= e->layer_ws_bytes);
+    for (int l = 0; per_layer && l < c.num_layers; ++l) per_layer = !e->is_moe(l);
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
         // the sliced matmul as the producer of weighted rows (its reduction writes them): wo here, w_down below
@@ -806,43 +824,61 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             continue;
         }
         xw = false;
+        // this layer's hand-over buffers: the shared ones, or -- per-layer mode -- its own (written once per step)
+        uint16_t *x_in = x_cur, *x_out = e->x, *hb = e->h, *xnb = e->xn, *qkvb = e->qkv, *attnb = e->attn, *actb = e->act;
+        float *ssx_in = ssx_cur, *ssx_out = e->ss_x, *sshb = e->ss_h;
+        float *const ws_shared = e->attn_ws;
+        if (per_layer) {
+            const tl_engine::LayerAct &la = e->layer_act[l];
+            x_out = la.x_out, hb = la.h, xnb = la.xn, qkvb = la.qkv, attnb = la.attn, actb = la.act, ssx_out = la.ss_x_out, sshb = la.ss_h;
+            e->attn_ws = la.attn_ws;  // engine_attention / engine_wo_merge read the member
+        }
+        auto restore_ws = [&]() { e->attn_ws = ws_shared; };
+        auto run_layer = [&]() -> int {
         KeptPartials qkv_parts;
         const bool keep_qkv = e->attn_qkv_partials && attn_takes_qkv_partials(c.head_dim, sp.rq);
-        TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0,
-                             x_ss ? e->ss_x : nullptr, nullptr, nullptr, keep_qkv ? &qkv_parts : nullptr, x_ss));
+        TL_TRY(engine_linear(e, w.wqkv, x_in, qkvb, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0,
+                             x_ss ? ssx_in : nullptr, nullptr, nullptr, keep_qkv ? &qkv_parts : nullptr, x_ss));
         bool merge_left = false;
-        TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, &qkv_parts,
+        TL_TRY(engine_attention(e, qkvb, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), attnb, batch, sp, pc, &qkv_parts,
                                 &w.wo, &merge_left));
         int h_ss = 0;
         if (e->is_moe(l)) {  // wo + residual, then the MoE MLP as its own launches (no producer-side sums for the next layer)
-            if (merge_left) TL_TRY(engine_wo_merge(e, w.wo, e->x, e->h, sp.n_splits, pc, nullptr, nullptr));
-            else TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1));
-            TL_TRY(tl_rms_norm(e->h, w.post_norm_dev, e->xn, batch, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
-            TL_TRY(engine_moe_mlp(e, l, e->xn, e->h, e->x, batch, pc));
+            if (merge_left) TL_TRY(engine_wo_merge(e, w.wo, x_in, hb, sp.n_splits, pc, nullptr, nullptr));
+            else TL_TRY(engine_linear(e, w.wo, attnb, hb, batch, PRO_NONE, EPI_RESIDUAL, nullptr, x_in, pc, 1));
+            TL_TRY(tl_rms_norm(hb, w.post_norm_dev, xnb, batch, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
+            TL_TRY(engine_moe_mlp(e, l, xnb, hb, x_out, batch, pc));
             x_ss = 0;
-            continue;
+            return TL_OK;
         }
         TL_REQUIRE(w.wgu.weight_dev != nullptr, "engine: a layer has neither a dense MLP nor experts (tl_engine_set_moe_layer)");
         // h leaves the wo GEMV twice when the gate|up GEMV can take it weighted: as the residual stream and, in xn, times the
         // post-attention norm weight
         const bool weighted = weighted_rows_apply(e, w.wo, w.wgu, batch);
-        uint16_t *hw = weighted ? e->xn : nullptr;
-        if (merge_left) TL_TRY(engine_wo_merge(e, w.wo, e->x, e->h, sp.n_splits, pc, e->ss_h, &h_ss, w.post_norm_dev, hw));
-        else TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, nullptr, nullptr, QM3_SS, &h_ss, w.post_norm_dev, hw));
+        uint16_t *hw = weighted ? xnb : nullptr;
+        if (merge_left) TL_TRY(engine_wo_merge(e, w.wo, x_in, hb, sp.n_splits, pc, sshb, &h_ss, w.post_norm_dev, hw));
+        else TL_TRY(engine_linear(e, w.wo, attnb, hb, batch, PRO_NONE, EPI_RESIDUAL, nullptr, x_in, pc, 1, nullptr, sshb, nullptr, nullptr, QM3_SS, &h_ss, w.post_norm_dev, hw));
         if (weighted) {
             TL_REQUIRE(h_ss > 0, "engine: the wo GEMV left no sums of squares for its weighted rows");
-            TL_TRY(engine_linear(e, w.wgu, e->xn, e->act, batch, PRO_RMS_WEIGHTED, EPI_SWIGLU, nullptr, nullptr, pc, 2, e->ss_h, nullptr, nullptr, nullptr, h_ss));
+            TL_TRY(engine_linear(e, w.wgu, xnb, actb, batch, PRO_RMS_WEIGHTED, EPI_SWIGLU, nullptr, nullptr, pc, 2, sshb, nullptr, nullptr, nullptr, h_ss));
         } else
-        TL_TRY(engine_linear(e, w.wgu, e->h, e->act, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2,
-                             h_ss ? e->ss_h : nullptr, nullptr, nullptr, nullptr, h_ss));
-        TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, nullptr, nullptr, QM3_SS, &x_ss));
+        TL_TRY(engine_linear(e, w.wgu, hb, actb, batch, PRO_RMSNORM, EPI_SWIGLU, w.post_norm_dev, nullptr, pc, 2,
+                             h_ss ? sshb : nullptr, nullptr, nullptr, nullptr, h_ss));
+        TL_TRY(engine_linear(e, w.wdown, actb, x_out, batch, PRO_NONE, EPI_RESIDUAL, nullptr, hb, pc, 3, nullptr, ssx_out, nullptr, nullptr, QM3_SS, &x_ss));
+        return TL_OK;
+        };
+        const int layer_rc = run_layer();
+        restore_ws();
+        TL_TRY(layer_rc);
+        x_cur = x_out;
+        ssx_cur = ssx_out;
     }
     e->want_tile_max = e->lm_tile_max_on;
     e->tile_max_rows = 0;
     const int head_rc = xw && qmm6_takes(e, e->head(), batch) && qmm3_takes_ss(x_ss)
                             ? engine_qmm6(e, e->head(), e->xn, e->logits, batch, EPI_STORE, nullptr, pc, 4, e->ss_x, x_ss, nullptr, nullptr, nullptr, nullptr, batch > 8)
-                            : engine_linear(e, e->head(), e->x, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4,
-                                            x_ss ? e->ss_x : nullptr, nullptr, nullptr, nullptr, x_ss);
+                            : engine_linear(e, e->head(), x_cur, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4,
+                                            x_ss ? ssx_cur : nullptr, nullptr, nullptr, nullptr, x_ss);
     e->want_tile_max = false;
     TL_TRY(head_rc);
     StepEndArgs s{};
@@ -1130,6 +1166,43 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
                 return fail(TL_ERR_UNSUPPORTED, msg);
             }
             e->aql_on = true;
+            // the route's code objects are compiled with TL_COHERENT (common.h): no cache maintenance between the launches of a step.
+            // TL_AQL_FENCES=1 puts HIP's agent-scope fences back on every packet (A/B: what the maintenance costs).
+            e->aql_fences.inner_acquire = e->aql_fences.inner_release = HSA_FENCE_SCOPE_NONE;
+            if (const char *f = getenv("TL_AQL_FENCES")) {
+                if (atoi(f) != 0) e->aql_fences.inner_acquire = e->aql_fences.inner_release = HSA_FENCE_SCOPE_AGENT;
+            }
+            // per-layer decode activations for the fused-GEMV rows (1-4): every hand-over address of a step is written once per step
+            {
+                const int rows = std::min(c.max_batch, 4);
+                const size_t ssr = (size_t)std::max(QM3_SS, c.hidden_size / 16 + 1);
+                const size_t b_x = align_up((size_t)rows * c.hidden_size * 2, 256), b_qkv = align_up((size_t)rows * qkv_dim * 2, 256),
+                             b_attn = align_up((size_t)rows * q_dim * 2, 256), b_act = align_up((size_t)rows * c.intermediate_size * 2, 256),
+                             b_ss = align_up((size_t)rows * ssr * 4, 256),
+                             b_ws = align_up((size_t)rows * c.num_heads * 64 * (c.head_dim + ATTN_WS_PAD) * 4, 256);
+                const size_t per_layer = 3 * b_x + b_qkv + b_attn + b_act + 2 * b_ss + b_ws;
+                if (hipMalloc((void **)&e->layer_act_mem, per_layer * c.num_layers) != hipSuccess ||
+                    hipMemsetAsync(e->layer_act_mem, 0, per_layer * c.num_layers, e->stream) != hipSuccess) {
+                    tl_engine_destroy(e);
+                    return fail(TL_ERR_HIP, "engine_create: hipMalloc(per-layer decode activations) failed");
+                }
+                e->layer_act.resize(c.num_layers);
+                for (int l = 0; l < c.num_layers; ++l) {
+                    char *m = e->layer_act_mem + (size_t)l * per_layer;
+                    tl_engine::LayerAct &a = e->layer_act[l];
+                    a.x_out = (uint16_t *)m, m += b_x;
+                    a.h = (uint16_t *)m, m += b_x;
+                    a.xn = (uint16_t *)m, m += b_x;
+                    a.qkv = (uint16_t *)m, m += b_qkv;
+                    a.attn = (uint16_t *)m, m += b_attn;
+                    a.act = (uint16_t *)m, m += b_act;
+                    a.ss_x_out = (float *)m, m += b_ss;
+                    a.ss_h = (float *)m, m += b_ss;
+                    a.attn_ws = (float *)m;
+                }
+                e->layer_act_rows = rows;
+                e->layer_ws_bytes = b_ws;
+            }
         }
     }
 
@@ -1284,6 +1357,7 @@ extern "C" void tl_engine_destroy(tl_engine *e) {
     (void)hipStreamSynchronize(e->stream);
     e->aql_programs.clear();
     e->aql_queue.reset();
+    if (e->layer_act_mem) (void)hipFree(e->layer_act_mem);
     if (e->moe_ws) (void)hipFree(e->moe_ws);
     for (auto &kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     if (e->arena) (void)hipFree(e->arena);

@@ -202,6 +202,18 @@ __device__ __forceinline__ void load_raw(const uint16_t *src, RawRow<VD> &r) {
     }
 }
 
+// a row another launch of this step has written (the qkv projection's output): common.h, TL_COHERENT
+template <int VD>
+__device__ __forceinline__ void load_raw_act(const uint16_t *src, RawRow<VD> &r) {
+    if constexpr (VD == 8) {
+        *reinterpret_cast<u32x4 *>(r.v) = act_load(reinterpret_cast<const u32x4 *>(src));  // (clang vector types: HIP's uint4 is a class)
+    } else if constexpr (VD == 4) {
+        *reinterpret_cast<u32x2 *>(r.v) = act_load(reinterpret_cast<const u32x2 *>(src));
+    } else {
+        *reinterpret_cast<uint32_t *>(r.v) = act_load(reinterpret_cast<const uint32_t *>(src));
+    }
+}
+
 template <int VD>
 __device__ __forceinline__ void store_raw(uint16_t *dst, const RawRow<VD> &r) {
     if constexpr (VD == 8) {
@@ -275,8 +287,8 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
     }
     RawRow<VD> kraw_new, vraw_new, qraw[RQ], qw, kw;
     if constexpr (!QP) {
-        load_raw<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
-        load_raw<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
+        load_raw_act<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
+        load_raw_act<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
     }
     load_raw<VD>(p.q_norm_w + t * VD, qw);
     load_raw<VD>(p.k_norm_w + t * VD, kw);
@@ -306,7 +318,7 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
 #pragma unroll
         for (int r = 0; r < RQ; ++r) {
             const int hq = min(chunk * RQ + r, rep - 1);
-            load_raw<VD>(row + (long)(kvh * rep + hq) * D + t * VD, qraw[r]);
+            load_raw_act<VD>(row + (long)(kvh * rep + hq) * D + t * VD, qraw[r]);
         }
     }
 
@@ -573,13 +585,13 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
         }
         const long orow = (long)b * Hq + kvh * rep + hq;
         if (p.n_splits == 1) {
-            p.out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : vs / gl);
+            act_store(&p.out[orow * D + d], BF16::from_float(gl == 0.f ? 0.f : vs / gl));
         } else {
             float *w = p.ws + (orow * p.n_splits + split) * (D + ATTN_WS_PAD);
-            w[d] = vs;
+            act_store(&w[d], vs);
             if (d == 0) {
-                w[D] = gm;
-                w[D + 1] = gl;
+                act_store(&w[D], gm);
+                act_store(&w[D + 1], gl);
             }
         }
     }
@@ -606,9 +618,9 @@ static __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__r
     float ms[NS], ls[NS], vs[NS];
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) {
-        ms[s2] = base[s2 * stride + D];
-        ls[s2] = base[s2 * stride + D + 1];
-        vs[s2] = base[s2 * stride + d];
+        ms[s2] = act_load(base + s2 * stride + D);
+        ls[s2] = act_load(base + s2 * stride + D + 1);
+        vs[s2] = act_load(base + s2 * stride + d);
     }
     float gm = -1e30f;
 #pragma unroll
@@ -620,7 +632,7 @@ static __global__ __launch_bounds__(128) void attn_merge_kernel(const float *__r
         gl += ls[s2] * f;
         acc += vs[s2] * f;
     }
-    if ((int)threadIdx.x < D) out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : acc / gl);
+    if ((int)threadIdx.x < D) act_store(&out[orow * D + d], BF16::from_float(gl == 0.f ? 0.f : acc / gl));
     prof_end(prof, prof_t0);
 }
 
@@ -645,9 +657,9 @@ static __global__ __launch_bounds__(256) void attn_merge_cols_kernel(const float
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float *row = base + (size_t)min(s0 + 8 * j, n_splits - 1) * stride;
-            ms[j] = row[D];
-            ls[j] = row[D + 1];
-            vs[j] = row[d];
+            ms[j] = act_load(row + D);
+            ls[j] = act_load(row + D + 1);
+            vs[j] = act_load(row + d);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -675,7 +687,7 @@ static __global__ __launch_bounds__(256) void attn_merge_cols_kernel(const float
             gl += s_l[j][c] * f;
             ga += s_a[j][c] * f;
         }
-        if ((int)blockIdx.y * 32 + c < D) out[orow * D + d] = BF16::from_float(gl == 0.f ? 0.f : ga / gl);
+        if ((int)blockIdx.y * 32 + c < D) act_store(&out[orow * D + d], BF16::from_float(gl == 0.f ? 0.f : ga / gl));
     }
     prof_end(prof, prof_t0);
 }
@@ -734,7 +746,7 @@ static __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs
         for (int t0 = threadIdx.x; t0 < p.tiles; t0 += 1024 * TM_NB) {
             f32x2 pr[TM_NB];
 #pragma unroll
-            for (int j = 0; j < TM_NB; ++j) pr[j] = tm[min(t0 + j * 1024, p.tiles - 1)];
+            for (int j = 0; j < TM_NB; ++j) pr[j] = act_load(tm + min(t0 + j * 1024, p.tiles - 1));  // (the lm_head launch of this step wrote them)
 #pragma unroll
             for (int j = 0; j < TM_NB; ++j) {
                 if (t0 + j * 1024 >= p.tiles) continue;
@@ -754,15 +766,15 @@ static __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs
     // two round trips.
     constexpr int SE_NB = 10;
     for (int c0 = threadIdx.x * 8; c0 < vec_end; c0 += 1024 * 8 * SE_NB) {
-        uint4 rawv[SE_NB];
+        u32x4 rawv[SE_NB];
 #pragma unroll
-        for (int j = 0; j < SE_NB; ++j) rawv[j] = *reinterpret_cast<const uint4 *>(lg + min(c0 + j * 8192, vec_end - 8));
+        for (int j = 0; j < SE_NB; ++j) rawv[j] = act_load(reinterpret_cast<const u32x4 *>(lg + min(c0 + j * 8192, vec_end - 8)));
 #pragma unroll
         for (int j = 0; j < SE_NB; ++j) {
             const int c = c0 + j * 8192;
             if (c >= vec_end) continue;
             uint16_t raw[8];
-            *reinterpret_cast<uint4 *>(raw) = rawv[j];
+            *reinterpret_cast<u32x4 *>(raw) = rawv[j];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = BF16::to_float(raw[e]);
@@ -774,7 +786,7 @@ static __global__ __launch_bounds__(1024) void step_end_kernel(const StepEndArgs
         }
     }
     for (int c = scalar_from + threadIdx.x; c < p.vocab; c += 1024) {
-        const float v = BF16::to_float(lg[c]);
+        const float v = BF16::to_float(act_load(lg + c));
         if (v > best || (v == best && c < best_i)) {
             best = v;
             best_i = c;

@@ -94,7 +94,7 @@ template <typename T> __device__ __forceinline__ void q3_store(T *ptr, T v) {
 #elif Q3_STORE_MODE == 2
     __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #else
-    *ptr = v;
+    act_store(ptr, v);  // (write-through in the AQL route's code objects: common.h TL_COHERENT)
 #endif
 }
 #ifdef QMV3_LAB
@@ -181,11 +181,11 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
             const int cc = min(tid + k * T, cpr - 1);
             const float *hb = p.merge_ws + (size_t)(cc >> 4) * NS * MWS;
 #pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) mml[k][s2] = *reinterpret_cast<const f32x2 *>(hb + s2 * MWS + 128);
+            for (int s2 = 0; s2 < NS; ++s2) mml[k][s2] = act_load(reinterpret_cast<const f32x2 *>(hb + s2 * MWS + 128));
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) mval[k][s2][e] = *reinterpret_cast<const f32x4 *>(hb + s2 * MWS + (cc & 15) * 8 + 4 * e);
+                for (int e = 0; e < 2; ++e) mval[k][s2][e] = act_load(reinterpret_cast<const f32x4 *>(hb + s2 * MWS + (cc & 15) * 8 + 4 * e));
         }
     }
     // EPI_RESIDUAL: the residual values and the consumer's norm weight of this lane's output element are fetched now, not by a
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
 #pragma unroll
         for (int i2 = 0; i2 < ROWS; ++i2) {
             const int arow = 4 * c + i2;
-            resv[i2] = p.residual[(size_t)((arow < MR && arow < p.M) ? arow : 0) * K + orow];
+            resv[i2] = act_load(p.residual + (size_t)((arow < MR && arow < p.M) ? arow : 0) * K + orow);
         }
         nwo = (p.out_w ? p.norm_out : p.residual)[orow];
     }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
         for (int m = 0; m < MR; ++m) {  // unconditional load from a clamped address (no branch around a load), masked after
             const bool ok = ss_given && m < p.M && 4 * lane < p.ss_n;
             const float *src = ss_given ? p.ss_in : reinterpret_cast<const float *>(p.norm_w);
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (ok ? (size_t)m * p.ss_n + 4 * lane : 0));
+            const f32x4 v = act_load(reinterpret_cast<const f32x4 *>(src + (ok ? (size_t)m * p.ss_n + 4 * lane : 0)));
             ssv[m] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
                 xv[k][m] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
                 continue;
             }
-            xv[k][m] = *reinterpret_cast<const u32x4 *>(p.a + (ok ? (size_t)m * N + coff : 0));
+            xv[k][m] = act_load(reinterpret_cast<const u32x4 *>(p.a + (ok ? (size_t)m * N + coff : 0)));
             if (!ok) xv[k][m] = u32x4{0u, 0u, 0u, 0u};
         }
         if constexpr (PRO == PRO_RMSNORM)
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
                     const bool ok = m < p.M;
-                    u32x4 v = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0));
+                    u32x4 v = act_load(reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0)));
                     if (!ok) v = u32x4{0u, 0u, 0u, 0u};
                     *reinterpret_cast<u32x4 *>(xs + (size_t)m * xstride + (size_t)cc * 8) = v;
                     ss[m] += chunk_sumsq(v);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
                     v = *reinterpret_cast<const u32x4 *>(xs + (size_t)m * xstride + (size_t)cc * 8);
                 } else {
                     const bool ok = m < p.M;
-                    v = *reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0));
+                    v = act_load(reinterpret_cast<const u32x4 *>(p.a + (ok ? ((size_t)m * N + (size_t)cc * 8) : 0)));
                     if (!ok) v = u32x4{0u, 0u, 0u, 0u};
                 }
                 finish_chunk(m, cc, v, g, inv[m]);
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(CW * 64) void qmv3_kernel(const Qmv3Args p) {
                 const float m = group16_max(v);
                 const float cand = (v == m && live) ? (float)orow : 3.0e38f;  // lowest index among the lanes that hold the maximum
                 const float lowest = -group16_max(-cand);
-                if (r == 0 && tile_ok && arow < MR && arow < p.M) p.tile_max[(size_t)arow * tiles + tile_c] = f32x2{m, lowest};
+                if (r == 0 && tile_ok && arow < MR && arow < p.M) act_store(&p.tile_max[(size_t)arow * tiles + tile_c], f32x2{m, lowest});
             }
         }
     }

@@ -34,7 +34,7 @@ def main() -> None:
     model = synthetic_qwen3(cfg, seed=0, sigma=0.02, device="cuda:0")
     rng = random.Random(0)
     prompt = [rng.randrange(256, cfg["vocab_size"]) for _ in range(args.prompt)]
-    env = {"graph": {}, "aql": {"TL_AQL": "1"}, "aql_nofence": {"TL_AQL": "1", "TL_AQL_FENCES": "0"},
+    env = {"graph": {}, "aql": {"TL_AQL": "1"}, "aql_fences": {"TL_AQL": "1", "TL_AQL_FENCES": "1"},
            "aql_sidecar": {"TL_AQL": "1", "TL_AQL_FENCES": "0", "TL_AQL_SIDECAR": "1"}}
     results = {}
     for rnd in range(args.rounds):
