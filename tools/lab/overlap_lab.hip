@@ -629,9 +629,9 @@ int main(int argc, char **argv) {
         }
         // H: raw AQL chain without cache maintenance (bypassing loads + write-through stores: G2), weights through PLAIN loads, and a
         // persistent sidecar on the second queue that streams the next round's weights into the consuming XCD's L2 (nothing invalidates it)
-        if (aql.ok && weights) for (int variant = 0; variant < 8; ++variant) {
-            // 4: sidecar (shift 1) polling with long sleeps | 5: sidecar that only polls | 6 / 7: sidecar (shift 1 / 0) paced by the wall clock, no polling
-            // 0: no sidecar (plain weight loads alone) | 1: sidecar, right XCD | 2: sidecar, WRONG XCD | 3: sidecar right XCD, consumers with agent acquire fences
+        if (aql.ok && weights) for (int variant = 0; variant < 12; ++variant) {
+            // 0: no sidecar | 1..11: sidecar (long poll sleeps) prefetching block b + shift for shift = 0, 1, 2, 3, 4, 7, 8, 9, 16, 64, 128
+            const int shifts[12] = {0, 0, 1, 2, 3, 4, 7, 8, 9, 16, 64, 128};
             double best = 1e9;
             unsigned *progress = counts + (size_t)(R + 1) * 16;
             for (int rep = 0; rep < 3 && aql.ok; ++rep) {
@@ -646,11 +646,10 @@ int main(int argc, char **argv) {
                     args[r].weights = 2;
                     args[r].progress = progress;
                     const bool first = r == 0, last = r == R - 1;
-                    const int acq = first ? HSA_FENCE_SCOPE_SYSTEM : (variant == 3 ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE);
-                    pk.push_back(Pkt{aql.link_obj, aql.link_lds, WG, T, &args[r], sizeof(LinkArgs), true, acq, last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE});
+                    pk.push_back(Pkt{aql.link_obj, aql.link_lds, WG, T, &args[r], sizeof(LinkArgs), true, first ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE,
+                                     last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE});
                 }
-                SideArgs sa{w, w_units, progress, R, W_ROUNDS, WG, (variant == 2 || variant == 4 || variant == 5 || variant == 6) ? 1 : 0, (u64)khz * 50, err,
-                            variant == 5 ? 1 : (variant >= 6 ? 2 : 0), variant == 4 ? 32 : 4, (u64)(khz * 4.5 / 1000.0)};
+                SideArgs sa{w, w_units, progress, R, W_ROUNDS, WG, shifts[variant], (u64)khz * 50, err, 0, 32, 0};
                 std::vector<Pkt> sp{Pkt{aql.side_obj, aql.side_lds, WG, 64, &sa, sizeof(SideArgs), true, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_NONE}};
                 const uint64_t w0 = hsa_queue_load_write_index_relaxed(aql.q), w1 = hsa_queue_load_write_index_relaxed(aql.q2);
                 if (variant != 0) aql_submit(aql, sp, 1, true, false);
@@ -663,10 +662,10 @@ int main(int argc, char **argv) {
                 for (int b = 0; b < WG; ++b) { s0 = std::min(s0, hs[(size_t)b * 2]); e9 = std::max(e9, hs[((size_t)(R - 1) * WG + b) * 2 + 1]); }
                 best = std::min(best, (double)(e9 - s0) * us / 1e3);
             }
-            const char *hn[8] = {"H0 AQL no fences, plain weight loads, no sidecar", "H1 + sidecar, block b", "H2 + sidecar, block b + 1",
-                                 "H3 sidecar block b, consumers with acquire fences", "H4 sidecar block b + 1, long poll sleeps", "H5 sidecar that only polls",
-                                 "H6 sidecar block b + 1, paced by the clock (4.5 us)", "H7 sidecar block b, paced by the clock (4.5 us)"};
-            if (aql.ok) finish(hn[variant], best * 1e3 / R, 0.0);
+            char nm[96];
+            if (variant == 0) snprintf(nm, sizeof nm, "H no sidecar");
+            else snprintf(nm, sizeof nm, "H sidecar, block b + %d", shifts[variant]);
+            if (aql.ok) finish(nm, best * 1e3 / R, 0.0);
         }
         // G: raw AQL, barrier SET, UNTAGGED data: which part of a boundary is cache maintenance, and can write-through stores replace the release?
         if (aql.ok) for (int variant = 0; variant < 5; ++variant) {
