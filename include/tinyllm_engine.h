@@ -197,6 +197,11 @@ const int32_t *tl_engine_tokens_dev(const tl_engine *e);
 
 int tl_engine_get_stats(const tl_engine *e, tl_engine_stats *out);
 
+/* How captured decode steps are replayed: "aql" -- hand-written AQL dispatch packets on the engine's own HSA queue, no cache
+ * maintenance between the launches of a step (the default; csrc/aql.h) -- or "hipgraph: <why the AQL route is not available>"
+ * (hipGraphLaunch; also TL_AQL=0).  The string lives until the calling thread's next call. */
+const char *tl_engine_replay_route(const tl_engine *e);
+
 /* Algorithmic HBM bytes of ONE decode step at the current state: all W4 weights
  * streamed once + K/V of every live context. */
 size_t tl_engine_step_bytes(const tl_engine *e, int batch);

@@ -1152,19 +1152,27 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->use_qmm6 = getenv("TL_NO_QMM6") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
     read_attention_knobs(e);
-    // TL_AQL=1: decode steps replay as AQL packets on the engine's own HSA queue (aql.h); asked for and not available is an error, not
-    // a silent fallback.  TL_AQL_FENCES=0 drops the agent-scope cache maintenance between the launches of a step (only with kernels
-    // that exchange their activations through device-scope loads and write-through stores).
-    if (const char *q = getenv("TL_AQL")) {
-        if (atoi(q) != 0) {
+    // Decode steps replay as AQL packets on the engine's own HSA queue (aql.h) unless TL_AQL=0: the same captured step, without the
+    // cache maintenance HIP puts between its launches (0.987 -> 0.929 ms per token at Qwen3-4B, logits bit-identical).  Where the route is
+    // not available (no code objects next to the library, no HSA agent for the device) the engine stays on hipGraphLaunch and says why
+    // in tl_engine_replay_route(); TL_AQL=1 makes that an error instead.
+    const char *aql_env = getenv("TL_AQL");
+    if (aql_env == nullptr || atoi(aql_env) != 0) {
+        {
             AqlRuntime &rt = AqlRuntime::get();
             std::string why;
             e->aql_queue = std::make_unique<AqlQueue>();
             if (!rt.ensure_loaded(library_dir()) || !e->aql_queue->create(why)) {
-                const std::string msg = "engine_create: TL_AQL=1 but the AQL route is not available: " + (rt.ok() ? why : rt.why());
-                tl_engine_destroy(e);
-                return fail(TL_ERR_UNSUPPORTED, msg);
+                e->aql_why = rt.ok() ? why : rt.why();
+                e->aql_queue.reset();
+                if (aql_env != nullptr) {
+                    const std::string msg = "engine_create: TL_AQL=1 but the AQL route is not available: " + e->aql_why;
+                    tl_engine_destroy(e);
+                    return fail(TL_ERR_UNSUPPORTED, msg);
+                }
             }
+        }
+        if (e->aql_queue) {
             e->aql_on = true;
             // the route's code objects are compiled with TL_COHERENT (common.h): no cache maintenance between the launches of a step.
             // TL_AQL_FENCES=1 puts HIP's agent-scope fences back on every packet (A/B: what the maintenance costs).
@@ -1372,6 +1380,13 @@ extern "C" void tl_engine_destroy(tl_engine *e) {
     }
     if (e->owns_stream) (void)hipStreamDestroy(e->stream);
     delete e;
+}
+
+extern "C" const char *tl_engine_replay_route(const tl_engine *e) {
+    static thread_local std::string text;
+    if (!e) return "";
+    text = e->aql_on ? std::string("aql") : ("hipgraph" + (e->aql_why.empty() ? std::string() : ": " + e->aql_why));
+    return text.c_str();
 }
 
 extern "C" int tl_engine_synchronize(tl_engine *e) {

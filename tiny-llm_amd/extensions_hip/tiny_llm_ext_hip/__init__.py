@@ -162,6 +162,7 @@ _SIGNATURES.update({
     "tl_engine_copy_logits": (_c_int, [_c_void_p, _c_void_p, _c_int]),
     "tl_engine_tokens_dev": (_c_void_p, [_c_void_p]),
     "tl_engine_get_stats": (_c_int, [_c_void_p, _P(TlEngineStats)]),
+    "tl_engine_replay_route": (ctypes.c_char_p, [_c_void_p]),
     "tl_engine_step_bytes": (_c_size_t, [_c_void_p, _c_int]),
 })
 

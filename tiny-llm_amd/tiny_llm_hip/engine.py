@@ -255,6 +255,10 @@ class DecodeEngine:
                                   "bytes": p.gemv_bytes[i] if i < 5 else 0.0}
         return out
 
+    def replay_route(self) -> str:
+        """"aql" (captured steps replay as AQL packets on the engine's own HSA queue) or "hipgraph: <why>" (include/tinyllm_engine.h)."""
+        return (_lib.tl_engine_replay_route(self._h) or b"").decode()
+
     def stats(self) -> dict:
         s = _ext.TlEngineStats()
         _ext.check(_lib.tl_engine_get_stats(self._h, ctypes.byref(s)))
