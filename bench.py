@@ -187,7 +187,7 @@ def rocprof_live(args) -> Path | None:
     cmd = [exe, "--kernel-trace", "--stats", "-d", tmp, "-o", "bench", "--output-format", "csv", "--", sys.executable,
            str(Path(__file__).resolve()), "--config", str(args.config), "--steps", "20", "--warmup", "5", "--seed", str(args.seed),
            "--model", args.model, "--prompt-len", str(args.prompt_len), "--prefill-step", str(args.prefill_step),
-           "--no-cpu-baseline", "--profile-steps", "0", "--rocprof", "off"]
+           "--no-cpu-baseline", "--no-extra-configs", "--profile-steps", "0", "--rocprof", "off"]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -759,6 +759,9 @@ def main() -> None:
                 prof["kinds"][k]["us"] += v["us"]
             prof["span_us"] += p["span_us"]
     stats = engine.stats()
+    # "aql": the captured step replays as hand-written AQL packets on the engine's own HSA queue, no cache maintenance between its
+    # launches (the default; csrc/aql.h); "hipgraph...": hipGraphLaunch (TL_AQL=0, or the route was not available: the text says why)
+    replay_route = engine.replay_route() if hasattr(engine, "replay_route") else "none"
     engine.release(0)
 
     if rank != 0:
@@ -922,14 +925,15 @@ def main() -> None:
         "config": {"workload": workload[0],
                    "prompt_tokens": args.prompt_len, "decode_steps": args.steps, "batch_per_gpu": 1,
                    "parallelism": f"request-parallel x{args.gpus} (no collective on the data path)",
-                   "page_size": page, "graph_replay": use_graph, "prefill_step": args.prefill_step},
+                   "page_size": page, "graph_replay": use_graph, "prefill_step": args.prefill_step, "replay_route": replay_route},
         "tokens_per_s_per_gpu": round(args.steps / elapsed, 2),
         "per_rank": per_rank,
         "prefill_tokens_per_s": round(args.prompt_len / prefill_s, 1),
         "roofline": roofline,
         "cpu_baseline": cpu,
         "extra_configs": extra,
-        "engine": {k: stats[k] for k in ("graph_captures", "graph_replays", "decode_steps", "kv_bytes")},
+        "engine": dict({k: stats[k] for k in ("graph_captures", "graph_replays", "decode_steps", "kv_bytes")}, aql_steps=stats.get("aql_steps"),
+                       replay_route=replay_route),
         "first_ids": ids,
     }
     print(json.dumps(out), flush=True)
