@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of the decode step's two replay routes on one box: hipGraphLaunch (default) against AQL packets on the engine's own HSA queue
-(TL_AQL=1, csrc/aql.h) -- same captured step, same kernels.  Prints ms per step, the greedy ids (must be identical) and the engine's counters.
+"""A/B of the decode step's two replay routes on one box: hipGraphLaunch (TL_AQL=0) against AQL packets on the engine's own HSA queue
+(the default, csrc/aql.h; aql_fences = the same packets with HIP's agent-scope fences on every one) -- same captured step, same kernels.  Prints ms per step, the greedy ids (must be identical) and the engine's counters.
 
-  python tools/aql_ab.py [--prompt 128] [--steps 64] [--rounds 3] [--modes graph,aql,aql_nofence]
+  python tools/aql_ab.py [--prompt 128] [--steps 64] [--rounds 3] [--modes graph,aql,aql_fences]
 """
 import argparse
 import json
@@ -34,12 +34,12 @@ def main() -> None:
     model = synthetic_qwen3(cfg, seed=0, sigma=0.02, device="cuda:0")
     rng = random.Random(0)
     prompt = [rng.randrange(256, cfg["vocab_size"]) for _ in range(args.prompt)]
-    env = {"graph": {}, "aql": {"TL_AQL": "1"}, "aql_fences": {"TL_AQL": "1", "TL_AQL_FENCES": "1"},
-           "aql_sidecar": {"TL_AQL": "1", "TL_AQL_FENCES": "0", "TL_AQL_SIDECAR": "1"}}
+    env = {"graph": {"TL_AQL": "0"}, "aql": {"TL_AQL": "1"}, "aql_fences": {"TL_AQL": "1", "TL_AQL_FENCES": "1"},
+           "default": {}}
     results = {}
     for rnd in range(args.rounds):
         for mode in args.modes.split(","):
-            for k in ("TL_AQL", "TL_AQL_FENCES", "TL_AQL_SIDECAR"):
+            for k in ("TL_AQL", "TL_AQL_FENCES"):
                 os.environ.pop(k, None)
             os.environ.update(env[mode])
             eng = DecodeEngine(model, page_size=128, num_pages=(args.prompt + args.steps + 80) // 128 + 3, max_batch=1, max_prefill_rows=128)
