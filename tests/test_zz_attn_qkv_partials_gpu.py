@@ -1,6 +1,6 @@
 """GPU tier (collected last): the default route wherever the qkv projection of a batched step runs on the K-sliced matmul (TL_ATTN_QKV_PARTIALS=0 turns it
-off) -- 17..64 decode rows since round 4 (up to 16 rows the register-resident matmul of csrc/qmm6.h takes qkv and there are no slices), and 5..64
-rows of any model whose shapes that kernel does not take: the qkv projection's slice-reduction launch is
+off) -- 5..64 rows of any model whose shapes the register-resident matmul of csrc/qmm6.h does not take, and of every model with that kernel switched
+off (TL_NO_QMM6=1: the Qwen3-4B-shape cases below; since round 5 qmm6 takes qkv at every row count there and leaves no slices): the qkv projection's slice-reduction launch is
 dropped and the decode-attention kernel adds the skinny matmul's fp32 slice partials itself (csrc/engine_kernels.h, QP; csrc/engine.hip
 engine_linear `keep`).  The kernel adds the slices in the reduction kernel's order and rounds once like it, so the two routes must
 agree BIT FOR BIT: same greedy tokens, same final logits, over several decode steps (the appended K/V rows feed later steps).
@@ -22,19 +22,25 @@ from oracle import tiny_oracle as O
 pytestmark = [pytest.mark.gpu]
 
 
-def run(model, cfg, n_seq, steps, page_size, partials, profile=False, prompt_base=3, prompt_spread=19):
+def run(model, cfg, n_seq, steps, page_size, partials, profile=False, prompt_base=3, prompt_spread=19, no_qmm6=False):
     from tiny_llm_hip.engine import DecodeEngine
 
     rng = np.random.default_rng(500 + n_seq)
     prompts = [[int(t) for t in rng.integers(1, cfg["vocab_size"], size=prompt_base + (7 * i) % prompt_spread)] for i in range(n_seq)]
     old = os.environ.pop("TL_ATTN_QKV_PARTIALS", None)
+    old6 = os.environ.pop("TL_NO_QMM6", None)
     os.environ["TL_ATTN_QKV_PARTIALS"] = "1" if partials else "0"  # read when the engine is created (default since round 3: 1)
+    if no_qmm6:
+        os.environ["TL_NO_QMM6"] = "1"  # the K-sliced route of rounds 2-3: qkv leaves fp32 slice planes
     try:
         eng = DecodeEngine(model, page_size=page_size, num_pages=n_seq * 3 + 2, max_batch=n_seq, max_prefill_rows=32)
     finally:
         os.environ.pop("TL_ATTN_QKV_PARTIALS", None)
+        os.environ.pop("TL_NO_QMM6", None)
         if old is not None:
             os.environ["TL_ATTN_QKV_PARTIALS"] = old
+        if old6 is not None:
+            os.environ["TL_NO_QMM6"] = old6
     try:
         for i, p in enumerate(prompts):
             eng.begin(i)
@@ -72,8 +78,8 @@ def test_qwen3_4b_shapes_same_bits_and_one_launch_fewer_per_layer(n_seq):
 
     cfg = dict(QWEN4B_CFG, num_hidden_layers=3)
     model = synthetic_qwen3(cfg, seed=4, sigma=0.02, device="cuda")
-    a = run(model, cfg, n_seq, steps=4, page_size=128, partials=False, profile=True)
-    b = run(model, cfg, n_seq, steps=4, page_size=128, partials=True, profile=True)
+    a = run(model, cfg, n_seq, steps=4, page_size=128, partials=False, profile=True, no_qmm6=True)
+    b = run(model, cfg, n_seq, steps=4, page_size=128, partials=True, profile=True, no_qmm6=True)
     assert a[0] == b[0] and a[1] == b[1], "greedy tokens differ"
     assert torch.equal(a[2].view(torch.int16), b[2].view(torch.int16)), "final logits differ in their bits"
     launches = [sum(v["launches"] for v in r[3]["kinds"].values()) for r in (a, b)]
@@ -88,7 +94,7 @@ def test_qwen3_4b_shapes_same_bits_on_the_matrix_core_walk(n_seq):
 
     cfg = dict(QWEN4B_CFG, num_hidden_layers=3)
     model = synthetic_qwen3(cfg, seed=4, sigma=0.02, device="cuda")
-    a = run(model, cfg, n_seq, steps=4, page_size=128, partials=False, prompt_base=130, prompt_spread=190)
-    b = run(model, cfg, n_seq, steps=4, page_size=128, partials=True, prompt_base=130, prompt_spread=190)
+    a = run(model, cfg, n_seq, steps=4, page_size=128, partials=False, prompt_base=130, prompt_spread=190, no_qmm6=True)
+    b = run(model, cfg, n_seq, steps=4, page_size=128, partials=True, prompt_base=130, prompt_spread=190, no_qmm6=True)
     assert a[0] == b[0] and a[1] == b[1], "greedy tokens differ"
     assert torch.equal(a[2].view(torch.int16), b[2].view(torch.int16)), "final logits differ in their bits"

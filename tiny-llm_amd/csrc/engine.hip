@@ -774,14 +774,15 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             (wo6_ok || sliced_leaves_weighted(w.wo))) {
             // gate|up and lm_head are the register-resident kernel's at every row count; qkv and wo where it measured ahead on a fast AND
             // on a slow box (profiles/r04_labs/README.md: its per-workgroup copy of the rows rides the L2 -> CU path, the part of the chip
-            // that differs most between boxes): qkv up to 16 rows (beyond, the sliced matmul has no reduction launch to lose -- the
-            // attention kernel adds its slices), wo up to 16 and from 33 rows.  Both kinds of producer leave x / h weighted AND plain.
+            // that differs most between boxes): wo up to 16 and from 33 rows (qkv: below).  Both kinds of producer leave x / h weighted AND plain.
             // the weighted rows travel in fragment order from 9 rows (same-box A/B, profiles/r04_labs/README.md: 16 / 32 / 64 sequences
             // -1.5 / -4 / -1.3 % per step; at 8 sequences +2 %: row-major there)
             const bool frag = batch > 8;
-            // (qkv on this kernel beyond 16 rows, rows in fragment order, fast box: 24 / 32 / 64 sequences -1 / -1.1 / -2.9 % per step; without
-            // fragment order on a slow box it cost +4.7 us per layer at 32 rows: not taken)
-            const bool qkv6 = batch <= 16 && qmm6_takes(e, w.wqkv, batch);
+            // qkv on this kernel at every row count since round 5 (rows in fragment order from 9 rows): same-box A/B at 128-token contexts,
+            // two alternating rounds, 24 / 32 / 48 / 64 sequences 1.91 / 1.95 / 2.56 / 2.69 -> 1.87 / 1.89 / 2.50 / 2.59 ms per step
+            // (profiles/r05_labs/batched_qkv_on_qmm6_ab.log; round 4 had measured -1 ... -2.9 % on a fast box and left 17-64 rows on the sliced
+            // matmul, whose slices the attention kernel adds -- that route is now the one behind TL_NO_QMM6=1 only)
+            const bool qkv6 = qmm6_takes(e, w.wqkv, batch);
             const bool wo6 = wo6_ok && (batch <= 16 || batch > 32 || !sliced_leaves_weighted(w.wo));
             KeptPartials parts;
             if (qkv6) {
