@@ -5,8 +5,10 @@ maintenance between the launches (csrc/aql.h, common.h `act_store`, csrc/engine.
 of the same captured step (plain stores, agent-scope fences around every launch).  Same kernels' arithmetic, same order: greedy ids AND
 logits must be bit-identical -- at every attention plan a single sequence goes through (1 / 2 / 4 / 8 windows merged by the wo GEMV,
 16+ windows with the merge launch, the GQA-group walk on the matrix cores), at 2 and 4 sequences (fused GEMV with 2 / 4 rows), across
-a page boundary inside one call (a stream-side poke between two steps), and behind a profiled (eager) step.  5+ sequences run kernels
-outside the route's code objects: the engine must stay on the graph route there, silently and correctly.
+a page boundary inside one call (a stream-side poke between two steps), and behind a profiled (eager) step.  5 .. 64 sequences (since round 5 on
+the route too: the register-resident and K-sliced matmuls with write-through stores, per-layer rows / weighted rows / slice planes) at every
+routing boundary of the batched step (8 | 9 rows: fragment order; 16 | 17 and 32 | 33: the wo projection changes kernels); a plan whose
+attention windows do not fit the per-layer partials must stay on the graph route, silently and correctly.
 Reference loop both routes implement: src/tiny_llm_ref/qwen3_week3.py:55-121,320-338."""
 
 import os
@@ -89,13 +91,34 @@ def test_a_page_boundary_and_a_profiled_step_inside_a_replayed_run(model):
     assert st_a["aql_steps"] >= 70 and ids_a == ids_g and np.array_equal(log_a, log_g)
 
 
-def test_more_rows_than_the_route_covers_stay_on_the_graph_route(model):
-    """8 sequences decode on the register-resident matmul (csrc/qmm6.h), whose kernels are not in the route's code objects: no program, no
-    AQL steps, same results as with the route switched off."""
-    prompts = _prompts([50, 60, 70, 80, 90, 100, 110, 120], 8)
+@pytest.mark.parametrize("n_seqs", [5, 8, 9, 16, 17, 32, 33, 64])
+def test_batched_steps_are_bit_identical_on_both_routes(model, n_seqs):
+    """The batched-matmul step (csrc/qmm6.h, qmm3.h) on the AQL route: same ids and logits as hipGraphLaunch of the same captured step."""
+    rng = np.random.default_rng(n_seqs)
+    lengths = [int(x) for x in rng.integers(20, 300, size=n_seqs)]
+    prompts = _prompts(lengths, n_seqs)
+    ids_a, log_a, st_a = _run(model, "aql", prompts, steps=10)
+    ids_g, log_g, st_g = _run(model, "hipgraph", prompts, steps=10)
+    assert st_a["aql_steps"] >= 10 and st_g["aql_steps"] == 0, (st_a, st_g)
+    assert ids_a == ids_g, f"greedy ids differ between the routes at {n_seqs} sequences"
+    assert np.array_equal(log_a, log_g), f"logits differ between the routes by up to {np.abs(log_a - log_g).max()} at {n_seqs} sequences"
+
+
+def test_batched_steps_over_many_steps_and_page_boundaries(model):
+    """12 sequences, 16-token pages, 60 steps in two calls with a profiled step between them: pokes between steps, the window plan changes."""
+    prompts = _prompts([37, 21, 50, 64, 90, 10, 33, 47, 120, 15, 70, 28], 12)
+    ids_a, log_a, st_a = _run(model, "aql", prompts, steps=30, page=16, chunk=64, profile_between=True, calls=2)
+    ids_g, log_g, st_g = _run(model, "hipgraph", prompts, steps=30, page=16, chunk=64, profile_between=True, calls=2)
+    assert st_a["aql_steps"] >= 40 and ids_a == ids_g and np.array_equal(log_a, log_g)
+
+
+def test_a_plan_beyond_the_per_layer_partials_stays_on_the_graph_route(model):
+    """8 sequences behind 3,000-token prompts: 8 x 16 windows x 32 heads of partials exceed nothing yet, 64 sequences x 16 windows would -- the engine
+    decides per plan; whatever it decides, the results equal the graph route's."""
+    prompts = _prompts([3000] * 8, 88)
     ids_a, log_a, st_a = _run(model, "aql", prompts, steps=6)
     ids_g, log_g, st_g = _run(model, "hipgraph", prompts, steps=6)
-    assert st_a["aql_steps"] == 0 and ids_a == ids_g and np.array_equal(log_a, log_g)
+    assert ids_a == ids_g and np.array_equal(log_a, log_g)
 
 
 def test_tl_aql_1_is_accepted_and_0_is_the_graph_route(model, monkeypatch):

@@ -168,6 +168,23 @@ __device__ __forceinline__ void act_store(T *ptr, T v) {
 #endif
 }
 
+// the same rule for stores that go through a buffer resource (the batched-decode matmuls): the cache-policy operand of a raw buffer store,
+// sc1 = write-through in the route's code objects
+#ifdef TL_COHERENT
+constexpr int ACT_STORE_AUX = 16;
+#else
+constexpr int ACT_STORE_AUX = 0;
+#endif
+// ... and for 16-byte stores: two 8-byte halves in the route's code objects (there is no 16-byte relaxed atomic), one store otherwise
+__device__ __forceinline__ void act_store16(void *ptr, u32x4 v) {
+#ifdef TL_COHERENT
+    act_store(reinterpret_cast<u32x2 *>(ptr), u32x2{v[0], v[1]});
+    act_store(reinterpret_cast<u32x2 *>(ptr) + 1, u32x2{v[2], v[3]});
+#else
+    *reinterpret_cast<u32x4 *>(ptr) = v;
+#endif
+}
+
 // ---- optional in-kernel timing (engine profile step) ---------------------------------------------
 // buf = nullptr in normal operation.  Otherwise buf[2*wg] receives the workgroup's first timestamp and
 // buf[2*wg+1] the maximum end timestamp over its waves (constant-rate wall clock, hipDeviceAttributeWallClockRate).

@@ -145,11 +145,20 @@ struct tl_engine {
     struct LayerAct {
         uint16_t *x_out, *h, *xn, *qkv, *attn, *act;
         float *ss_x_out, *ss_h, *attn_ws;
+        // 5 .. 64 rows (round 5): x_out weighted for the NEXT RMSNorm, and the fp32 slice planes of the layer's K-sliced matmuls
+        // (wo at 17-32 rows, w_down at every row count): written once per step like everything else here
+        uint16_t *xw;
+        float *planes[2];
     };
     std::vector<LayerAct> layer_act;
     char *layer_act_mem = nullptr;
     int layer_act_rows = 0;       // rows the per-layer buffers hold (0: none)
     size_t layer_ws_bytes = 0;    // attention partials per layer
+    size_t layer_plane_bytes[2] = {0, 0};  // slice planes per layer: [0] wo, [1] w_down
+    // the K-sliced matmul writes its fp32 planes here instead of splitk_ws while a per-layer batched step is enqueued (engine_linear)
+    float *planes_now = nullptr;
+    size_t planes_now_bytes = 0;
+    bool step_written_once = false;  // the last enqueued step used the per-layer buffers throughout (enqueue_step)
     // Qwen3-MoE layers (tl_engine_set_moe_layer): router + stacked experts instead of the dense gate|up / w_down of that layer
     std::vector<tl_moe_weights> moe;  // per layer; num_experts == 0: dense
     int moe_k_max = 0, moe_e_max = 0, moe_i_max = 0;
@@ -450,12 +459,13 @@ static int engine_linear(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16
             TL_TRY(tl_rms_norm(a, norm_w, e->xn, M, w.cols, c.rms_norm_eps, TL_BF16, e->stream));
             in = e->xn;
         }
-        TL_TRY(ensure_splitk(e, p3.partial_bytes));
+        if (e->planes_now) TL_REQUIRE(p3.partial_bytes <= e->planes_now_bytes, "engine: per-layer slice planes too small for this shape");
+        else TL_TRY(ensure_splitk(e, p3.partial_bytes));
         Qmm3Args q{};
         q.wt = tiled->second.wt;
         q.sbt = tiled->second.sbt;
         q.a = in;
-        q.partial = (float *)e->splitk_ws;
+        q.partial = e->planes_now ? e->planes_now : (float *)e->splitk_ws;
         q.M = M;
         q.N = w.cols;
         q.K = w.rows;
@@ -760,9 +770,28 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     uint16_t *x_cur = e->x;
     float *ssx_cur = e->ss_x;
     // per-layer hand-over buffers: the fused-GEMV rows of a dense model whose attention partials fit the per-layer workspace
-    bool per_layer = e->layer_act_rows > 0 && batch <= e->layer_act_rows && gemv_takes_rows(e, batch) &&
-                     (sp.n_splits == 1 || (size_t)batch * c.num_heads * sp.n_splits * (c.head_dim + ATTN_WS_PAD) * sizeof(float) <= e->layer_ws_bytes);
-    for (int l = 0; per_layer && l < c.num_layers; ++l) per_layer = !e->is_moe(l);
+    const bool ws_fits = sp.n_splits == 1 || (size_t)batch * c.num_heads * sp.n_splits * (c.head_dim + ATTN_WS_PAD) * sizeof(float) <= e->layer_ws_bytes;
+    bool per_layer = e->layer_act_rows > 0 && batch <= e->layer_act_rows && gemv_takes_rows(e, batch) && ws_fits;
+    // ... and the rows of the batched-matmul step (5 .. 64): every projection on the register-resident or the K-sliced matmul with its
+    // hand-over through weighted rows (the branch below), slice planes inside the per-layer ones
+    bool per_layer_b = e->layer_act_rows > 0 && batch <= e->layer_act_rows && !gemv_takes_rows(e, batch) && ws_fits && e->force_linear == 0;
+    for (int l = 0; l < c.num_layers; ++l) {
+        if (e->is_moe(l)) per_layer = per_layer_b = false;
+        const tl_layer_weights &w = e->layers[l];
+        if (per_layer_b) {  // every condition of the batched branch below, known ahead: no layer may fall out of it half way through a step
+            const bool wo_ok = (qmm6_takes(e, w.wo, batch) && qmm3_takes_ss(w.wo.rows / 16)) ||
+                               (takes_skinny_matmul(e, w.wo, batch) && e->fuse_norm && qmm3_reduce_can_emit_ss(EPI_RESIDUAL, w.wo.rows));
+            const bool down_ok = (takes_skinny_matmul(e, w.wdown, batch) && e->fuse_norm && qmm3_reduce_can_emit_ss(EPI_RESIDUAL, w.wdown.rows)) ||
+                                 (qmm6_takes(e, w.wdown, batch) && qmm3_takes_ss(w.wdown.rows / 16));
+            if (!(w.wgu.weight_dev && qmm6_takes(e, w.wqkv, batch) && qmm6_takes(e, w.wgu, batch) && qmm6_takes(e, e->head(), batch) && wo_ok && down_ok))
+                per_layer_b = false;
+        }
+    }
+    // only a step whose hand-overs all live at addresses written once per step may be replayed without cache maintenance (tl_engine_decode)
+    e->step_written_once = per_layer || per_layer_b;
+    // the residual stream of the batched branch: where x, x weighted for the next RMSNorm and its sums of squares stand
+    uint16_t *bx = e->x, *bxw = e->xn;
+    float *bssx = e->ss_x;
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
         // the sliced matmul as the producer of weighted rows (its reduction writes them): wo here, w_down below
@@ -784,46 +813,74 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             // matmul, whose slices the attention kernel adds -- that route is now the one behind TL_NO_QMM6=1 only)
             const bool qkv6 = qmm6_takes(e, w.wqkv, batch);
             const bool wo6 = wo6_ok && (batch <= 16 || batch > 32 || !sliced_leaves_weighted(w.wo));
+            // this layer's hand-over buffers: the shared ones, or -- the AQL route's per-layer mode -- its own (written once per step)
+            uint16_t *hb = e->h, *hwb = e->xn, *qkvb = e->qkv, *attnb = e->attn, *actb = e->act, *x_out = e->x, *xw_out = e->xn;
+            float *sshb = e->ss_h, *ssx_out = e->ss_x;
+            float *const ws_shared = e->attn_ws;
+            if (per_layer_b) {
+                const tl_engine::LayerAct &la = e->layer_act[l];
+                hb = la.h, hwb = la.xn, qkvb = la.qkv, attnb = la.attn, actb = la.act, x_out = la.x_out, xw_out = la.xw, sshb = la.ss_h, ssx_out = la.ss_x_out;
+                e->attn_ws = la.attn_ws;  // engine_attention reads the member
+            }
+            auto planes = [&](int which) {  // the K-sliced matmul's fp32 planes of the NEXT engine_linear call
+                e->planes_now = per_layer_b ? e->layer_act[l].planes[which] : nullptr;
+                e->planes_now_bytes = per_layer_b ? e->layer_plane_bytes[which] : 0;
+            };
+            auto run_layer_b = [&]() -> int {
             KeptPartials parts;
             if (qkv6) {
                 if (!xw) {
                     const long n8 = (long)batch * c.hidden_size / 8;
-                    hipLaunchKernelGGL(weight_rows_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, e->x, (const uint16_t *)w.input_norm_dev,
+                    hipLaunchKernelGGL(weight_rows_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, e->stream, bx, (const uint16_t *)w.input_norm_dev,
                                        e->xn, n8, c.hidden_size / 8, frag ? 1 : 0);
+                    bxw = e->xn;
                 }
-                TL_TRY(engine_qmm6(e, w.wqkv, e->xn, e->qkv, batch, EPI_STORE, nullptr, pc, 0, e->ss_x, x_ss, nullptr, nullptr, nullptr, nullptr, frag));
+                TL_TRY(engine_qmm6(e, w.wqkv, bxw, qkvb, batch, EPI_STORE, nullptr, pc, 0, bssx, x_ss, nullptr, nullptr, nullptr, nullptr, frag));
             } else {
                 const bool keep_qkv = e->attn_qkv_partials && attn_takes_qkv_partials(c.head_dim, sp.rq);
-                TL_TRY(engine_linear(e, w.wqkv, e->x, e->qkv, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0, e->ss_x, nullptr, nullptr,
+                TL_TRY(engine_linear(e, w.wqkv, bx, qkvb, batch, PRO_RMSNORM, EPI_STORE, w.input_norm_dev, nullptr, pc, 0, bssx, nullptr, nullptr,
                                      keep_qkv ? &parts : nullptr, x_ss));
             }
             bool merged = false;
-            TL_TRY(engine_attention(e, e->qkv, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), e->attn, batch, sp, pc, &parts, &w.wo, &merged));
+            TL_TRY(engine_attention(e, qkvb, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), attnb, batch, sp, pc, &parts, &w.wo, &merged));
             TL_REQUIRE(!merged, "engine: a batched step left its attention windows unmerged");
             int h_ss = 0;
-            if (wo6) TL_TRY(engine_qmm6(e, w.wo, e->attn, e->h, batch, EPI_RESIDUAL, e->x, pc, 1, nullptr, 0, e->ss_h, &h_ss, w.post_norm_dev, e->xn, frag));
-            else TL_TRY(engine_linear(e, w.wo, e->attn, e->h, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->x, pc, 1, nullptr, e->ss_h, nullptr, nullptr, QM3_SS, &h_ss,
-                                      w.post_norm_dev, e->xn, frag));
+            if (wo6) TL_TRY(engine_qmm6(e, w.wo, attnb, hb, batch, EPI_RESIDUAL, bx, pc, 1, nullptr, 0, sshb, &h_ss, w.post_norm_dev, hwb, frag));
+            else {
+                planes(0);
+                TL_TRY(engine_linear(e, w.wo, attnb, hb, batch, PRO_NONE, EPI_RESIDUAL, nullptr, bx, pc, 1, nullptr, sshb, nullptr, nullptr, QM3_SS, &h_ss,
+                                     w.post_norm_dev, hwb, frag));
+            }
             TL_REQUIRE(h_ss > 0 && qmm3_takes_ss(h_ss), "engine: the wo projection left no sums of squares for its weighted rows");
-            TL_TRY(engine_qmm6(e, w.wgu, e->xn, e->act, batch, EPI_SWIGLU, nullptr, pc, 2, e->ss_h, h_ss, nullptr, nullptr, nullptr, nullptr, frag));
+            TL_TRY(engine_qmm6(e, w.wgu, hwb, actb, batch, EPI_SWIGLU, nullptr, pc, 2, sshb, h_ss, nullptr, nullptr, nullptr, nullptr, frag));
             // the rows w_down leaves are weighted for their next reader: the next layer's input norm, or the final norm ahead of lm_head
             const void *next_norm = l + 1 < c.num_layers ? e->layers[l + 1].input_norm_dev : e->final_norm;
             // w_down: 76 groups against 160 tiles -- every workgroup of the register-resident kernel would pull 311 KB of rows for ONE tile
             // (measured 9.0 us at 8 rows, 18.9 at 64, against 6.5 / 13.0 for the K-sliced matmul + reduction): the sliced kernel keeps
             // it wherever its plan exists, and its reduction leaves the weighted rows
+            planes(1);
             if (sliced_leaves_weighted(w.wdown)) {
-                TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, nullptr, nullptr,
-                                     QM3_SS, &x_ss, next_norm, e->xn, frag));
+                TL_TRY(engine_linear(e, w.wdown, actb, x_out, batch, PRO_NONE, EPI_RESIDUAL, nullptr, hb, pc, 3, nullptr, ssx_out, nullptr, nullptr,
+                                     QM3_SS, &x_ss, next_norm, xw_out, frag));
                 xw = x_ss > 0;
             } else if (qmm6_takes(e, w.wdown, batch) && qmm3_takes_ss(w.wdown.rows / 16)) {
-                TL_TRY(engine_qmm6(e, w.wdown, e->act, e->x, batch, EPI_RESIDUAL, e->h, pc, 3, nullptr, 0, e->ss_x, &x_ss, next_norm, e->xn, frag));
+                TL_TRY(engine_qmm6(e, w.wdown, actb, x_out, batch, EPI_RESIDUAL, hb, pc, 3, nullptr, 0, ssx_out, &x_ss, next_norm, xw_out, frag));
                 xw = true;
             } else {
-                TL_TRY(engine_linear(e, w.wdown, e->act, e->x, batch, PRO_NONE, EPI_RESIDUAL, nullptr, e->h, pc, 3, nullptr, e->ss_x, nullptr, nullptr, QM3_SS, &x_ss));
+                TL_TRY(engine_linear(e, w.wdown, actb, x_out, batch, PRO_NONE, EPI_RESIDUAL, nullptr, hb, pc, 3, nullptr, ssx_out, nullptr, nullptr, QM3_SS, &x_ss));
                 xw = false;
             }
+            return TL_OK;
+            };
+            const int rc_b = run_layer_b();
+            e->attn_ws = ws_shared;
+            e->planes_now = nullptr, e->planes_now_bytes = 0;
+            TL_TRY(rc_b);
+            bx = x_out, bxw = xw_out, bssx = ssx_out;
+            x_cur = bx, ssx_cur = bssx;
             continue;
         }
+        // (a layer outside the batched branch reads and writes the shared buffers: a per-layer batched step has none -- per_layer_b above)
         xw = false;
         // this layer's hand-over buffers: the shared ones, or -- per-layer mode -- its own (written once per step)
         uint16_t *x_in = x_cur, *x_out = e->x, *hb = e->h, *xnb = e->xn, *qkvb = e->qkv, *attnb = e->attn, *actb = e->act;
@@ -877,7 +934,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     e->want_tile_max = e->lm_tile_max_on;
     e->tile_max_rows = 0;
     const int head_rc = xw && qmm6_takes(e, e->head(), batch) && qmm3_takes_ss(x_ss)
-                            ? engine_qmm6(e, e->head(), e->xn, e->logits, batch, EPI_STORE, nullptr, pc, 4, e->ss_x, x_ss, nullptr, nullptr, nullptr, nullptr, batch > 8)
+                            ? engine_qmm6(e, e->head(), bxw, e->logits, batch, EPI_STORE, nullptr, pc, 4, bssx, x_ss, nullptr, nullptr, nullptr, nullptr, batch > 8)
                             : engine_linear(e, e->head(), x_cur, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4,
                                             x_ss ? ssx_cur : nullptr, nullptr, nullptr, nullptr, x_ss);
     e->want_tile_max = false;
@@ -1181,15 +1238,24 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
             if (const char *f = getenv("TL_AQL_FENCES")) {
                 if (atoi(f) != 0) e->aql_fences.inner_acquire = e->aql_fences.inner_release = HSA_FENCE_SCOPE_AGENT;
             }
-            // per-layer decode activations for the fused-GEMV rows (1-4): every hand-over address of a step is written once per step
+            // per-layer decode activations (1-4 rows: the fused-GEMV step; 5-64 rows since round 5: the batched-matmul step): every hand-over
+            // address of a step is written once per step.  The attention partials hold 16 windows per row (at most 1,024 row-windows): a plan
+            // beyond that keeps the shared buffers and the graph route.
             {
-                const int rows = std::min(c.max_batch, 4);
+                const int rows = std::min(c.max_batch, 64);
                 const size_t ssr = (size_t)std::max(QM3_SS, c.hidden_size / 16 + 1);
                 const size_t b_x = align_up((size_t)rows * c.hidden_size * 2, 256), b_qkv = align_up((size_t)rows * qkv_dim * 2, 256),
                              b_attn = align_up((size_t)rows * q_dim * 2, 256), b_act = align_up((size_t)rows * c.intermediate_size * 2, 256),
                              b_ss = align_up((size_t)rows * ssr * 4, 256),
-                             b_ws = align_up((size_t)rows * c.num_heads * 64 * (c.head_dim + ATTN_WS_PAD) * 4, 256);
-                const size_t per_layer = 3 * b_x + b_qkv + b_attn + b_act + 2 * b_ss + b_ws;
+                             b_ws = align_up((size_t)std::min(rows * 64, std::max(4 * 64, std::min(rows * 16, 1024))) * c.num_heads * (c.head_dim + ATTN_WS_PAD) * 4, 256);
+                // slice planes of the sliced matmuls a batched step can take (wo, w_down), the largest over 5 .. rows rows
+                size_t b_pl[2] = {0, 0};
+                for (int M = 5; M <= rows; ++M) {
+                    const Qmm3Plan pw = qmm3_plan(M, q_dim, c.hidden_size, -1), pd = qmm3_plan(M, c.intermediate_size, c.hidden_size, -1);
+                    if (pw.ok) b_pl[0] = std::max(b_pl[0], align_up(pw.partial_bytes, 256));
+                    if (pd.ok) b_pl[1] = std::max(b_pl[1], align_up(pd.partial_bytes, 256));
+                }
+                const size_t per_layer = 4 * b_x + b_qkv + b_attn + b_act + 2 * b_ss + b_ws + b_pl[0] + b_pl[1];
                 if (hipMalloc((void **)&e->layer_act_mem, per_layer * c.num_layers) != hipSuccess ||
                     hipMemsetAsync(e->layer_act_mem, 0, per_layer * c.num_layers, e->stream) != hipSuccess) {
                     tl_engine_destroy(e);
@@ -1202,13 +1268,17 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
                     a.x_out = (uint16_t *)m, m += b_x;
                     a.h = (uint16_t *)m, m += b_x;
                     a.xn = (uint16_t *)m, m += b_x;
+                    a.xw = (uint16_t *)m, m += b_x;
                     a.qkv = (uint16_t *)m, m += b_qkv;
                     a.attn = (uint16_t *)m, m += b_attn;
                     a.act = (uint16_t *)m, m += b_act;
                     a.ss_x_out = (float *)m, m += b_ss;
                     a.ss_h = (float *)m, m += b_ss;
-                    a.attn_ws = (float *)m;
+                    a.attn_ws = (float *)m, m += b_ws;
+                    a.planes[0] = (float *)m, m += b_pl[0];
+                    a.planes[1] = (float *)m;
                 }
+                e->layer_plane_bytes[0] = b_pl[0], e->layer_plane_bytes[1] = b_pl[1];
                 e->layer_act_rows = rows;
                 e->layer_ws_bytes = b_ws;
             }
@@ -1915,7 +1985,8 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
                 if (ce != hipSuccess) return fail(TL_ERR_HIP, std::string("engine_decode: graph capture failed: ") + hipGetErrorString(ce));
                 hipGraphExec_t exec = nullptr;
                 const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                if (ie == hipSuccess && e->aql_on) {  // the same nodes as packet templates (aql.h); a plan that cannot be built keeps the graph route
+                if (ie == hipSuccess && e->aql_on && !e->step_written_once) e->aql_why = "a hand-over of this plan lives in a shared buffer (written more than once per step)";
+                if (ie == hipSuccess && e->aql_on && e->step_written_once) {  // the same nodes as packet templates (aql.h); a plan that cannot be built keeps the graph route
                     auto prog = std::make_unique<AqlProgram>();
                     if (aql_program_from_graph(graph, e->stream, *prog, e->aql_why) == 0) e->aql_programs[key] = std::move(prog);
                 }

@@ -1032,7 +1032,7 @@ static __global__ __launch_bounds__(256) void weight_rows_kernel(const uint16_t 
         const int G = chunks_per_row >> 4, gcol = ch >> 4, k8 = ch & 15;  // k8: 8-column run inside the group; c = k8 >> 2, t = k8 & 3
         dst = out + ((((size_t)(row >> 4) * G + gcol) * 4 + (k8 & 3)) * 64 + (size_t)(16 * (k8 >> 2) + (row & 15))) * 8;
     }
-    *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(o);
+    act_store16(dst, *reinterpret_cast<const u32x4 *>(o));  // (read by the qkv projection of layer 0 in the same step)
 }
 
 // gu [T, 2I] with (gate_i, up_i) interleaved -> act [T, I] = bf16(silu(gate) * up)   (I % 4 == 0)

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(QM3_WAVES * 64) void qmm3_kernel(const Qmm3Args p) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = mb * 16 + 4 * c + j;
-                if (row < p.M && (!(QMM3_ABL & 4) || acc[tw][mb][j] == 123.f)) p.partial[((size_t)slice * p.M + row) * K + ocol] = acc[tw][mb][j];
+                if (row < p.M && (!(QMM3_ABL & 4) || acc[tw][mb][j] == 123.f)) act_store(&p.partial[((size_t)slice * p.M + row) * K + ocol], acc[tw][mb][j]);
             }
     }
     prof_end(p.prof, prof_t0);
@@ -453,7 +453,7 @@ __device__ __forceinline__ void qmm3p_body(const Qmm3Args &p, char *smem, const 
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (!(QMM3_ABL & 4) || acc[mb][j] == 123.f)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mb][j]), prs, base + (uint32_t)(mb * 16 + j) * (uint32_t)K * 4u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mb][j]), prs, base + (uint32_t)(mb * 16 + j) * (uint32_t)K * 4u, 0, ACT_STORE_AUX);
         }
     };
     using U0 = std::integral_constant<int, 0>;

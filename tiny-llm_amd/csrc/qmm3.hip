@@ -59,12 +59,12 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
                 const float uv = bf16_round(acc[2 * e + 1]);
                 o[e] = BF16::from_float((gv / (1.0f + expf(-gv))) * uv);
             }
-            *reinterpret_cast<uint2 *>(out + (size_t)m * (K / 2) + (size_t)q * 4) = *reinterpret_cast<const uint2 *>(o);
+            act_store(reinterpret_cast<u32x2 *>(out + (size_t)m * (K / 2) + (size_t)q * 4), *reinterpret_cast<const u32x2 *>(o));
         } else if constexpr (EPI == EPI_RESIDUAL) {
             const uint16_t *rr = reinterpret_cast<const uint16_t *>(&rv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = BF16::from_float(BF16::to_float(rr[e]) + bf16_round(acc[e]));
-            *reinterpret_cast<uint2 *>(out + in0) = *reinterpret_cast<const uint2 *>(o);
+            act_store(reinterpret_cast<u32x2 *>(out + in0), *reinterpret_cast<const u32x2 *>(o));
             if (out_w) {  // uniform: the rows weighted for the next RMSNorm's consumer (qmm6.h), bf16(out * norm_out)
                 const uint16_t *nn = reinterpret_cast<const uint16_t *>(&nv);
                 uint16_t ow[4];
@@ -72,12 +72,12 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
                 for (int e = 0; e < 4; ++e) ow[e] = BF16::from_float(BF16::to_float(o[e]) * BF16::to_float(nn[e]));
                 // fragment order (qmm6.h): the four columns of a thread stay together inside an 8-column run
                 const size_t wo = out_w_frag ? qmm6_frag_offset(m, q * 4, K) : in0;
-                *reinterpret_cast<uint2 *>(out_w + wo) = *reinterpret_cast<const uint2 *>(ow);
+                act_store(reinterpret_cast<u32x2 *>(out_w + wo), *reinterpret_cast<const u32x2 *>(ow));
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = BF16::from_float(acc[e]);
-            *reinterpret_cast<uint2 *>(out + in0) = *reinterpret_cast<const uint2 *>(o);
+            act_store(reinterpret_cast<u32x2 *>(out + in0), *reinterpret_cast<const u32x2 *>(o));
         }
         if constexpr (SS) {
 #pragma unroll
@@ -92,9 +92,9 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
         if ((threadIdx.x & 63) == 0) wave_ss[threadIdx.x >> 6] = w;
         __syncthreads();
         if (threadIdx.x == 0) {
-            ss_out[(size_t)m * QM3_SS + blockIdx.x] = (wave_ss[0] + wave_ss[1]) + (wave_ss[2] + wave_ss[3]);
+            act_store(&ss_out[(size_t)m * QM3_SS + blockIdx.x], (wave_ss[0] + wave_ss[1]) + (wave_ss[2] + wave_ss[3]));
             if (blockIdx.x == 0)
-                for (int i = gridDim.x; i < QM3_SS; ++i) ss_out[(size_t)m * QM3_SS + i] = 0.f;
+                for (int i = gridDim.x; i < QM3_SS; ++i) act_store(&ss_out[(size_t)m * QM3_SS + i], 0.f);
         }
     }
     prof_end(prof, prof_t0);

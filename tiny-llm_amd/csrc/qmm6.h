@@ -428,18 +428,18 @@ __global__ __launch_bounds__(QM6_WAVES * 64, 1) void qmm6_kernel(const Qmm6Args 
                 // silu by the hardware exponential and reciprocal (1 ulp each, far below the bf16 step of the result): the IEEE division
                 // and expf of the other kernels are ~40 instructions per element on a wave that has nothing to overlap them with
                 const float sig = __builtin_amdgcn_rcpf(1.0f + exp2_hw(-1.44269504f * gv));
-                __builtin_amdgcn_raw_buffer_store_b16((short)BF16::from_float((gv * sig) * uv), ors, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((short)BF16::from_float((gv * sig) * uv), ors, off, 0, ACT_STORE_AUX);
             } else if constexpr (EPI == EPI_RESIDUAL) {
                 const uint32_t o = (uint32_t)row * (uint32_t)K + (uint32_t)ocol;
                 const uint16_t ov = BF16::from_float(BF16::to_float(resv[i]) + bf16_round(v));
-                __builtin_amdgcn_raw_buffer_store_b16((short)ov, ors, live ? o * 2u : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((short)ov, ors, live ? o * 2u : DEAD, 0, ACT_STORE_AUX);
                 const uint32_t ow = p.out_w_frag ? (uint32_t)qmm6_frag_offset(row, ocol, K) : o;
-                __builtin_amdgcn_raw_buffer_store_b16((short)BF16::from_float(BF16::to_float(ov) * BF16::to_float(nwo)), wrs, live ? ow * 2u : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((short)BF16::from_float(BF16::to_float(ov) * BF16::to_float(nwo)), wrs, live ? ow * 2u : DEAD, 0, ACT_STORE_AUX);
                 // one partial per (activation row, 16-row tile): the squares of the stored bf16 values (an empty resource when not asked for)
                 const float sq_v = group16_sum(live ? BF16::to_float(ov) * BF16::to_float(ov) : 0.f);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sq_v), srs, (live && r == 0) ? ((uint32_t)row * (uint32_t)tiles + (uint32_t)tile) * 4u : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sq_v), srs, (live && r == 0) ? ((uint32_t)row * (uint32_t)tiles + (uint32_t)tile) * 4u : DEAD, 0, ACT_STORE_AUX);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b16((short)BF16::from_float(v), ors, live ? ((uint32_t)row * (uint32_t)K + (uint32_t)ocol) * 2u : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((short)BF16::from_float(v), ors, live ? ((uint32_t)row * (uint32_t)K + (uint32_t)ocol) * 2u : DEAD, 0, ACT_STORE_AUX);
             }
         }
     };
