@@ -275,35 +275,80 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? QMM_OCC8 : QMM_OCC)) void qmm_m
 }
 
 // partials [split_k][M*K] in T -> fp32 sum -> T   (quantized_matmul.metal:277-293)
+// One thread = 8 consecutive elements (one 16-byte load per slice), the loads of 8 slices in flight together, the slices added in index
+// order per element -- the same sums in the same order as one thread per element, so the results are unchanged; what changed is the time:
+// the reduction behind a 128-row chunk cost 6.4-8.2 us with 2- / 4-byte loads in a loop of unknown length (round 5, profiles/r05_labs).
+template <typename TT>
+__device__ __forceinline__ void splitk_sum8(const uint16_t *__restrict__ partials, size_t elements, size_t i, int split_k, float (&sum)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+    for (int p0 = 0; p0 < split_k; p0 += 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const u32x4 *>(partials + (size_t)min(p0 + j, split_k - 1) * elements + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (p0 + j < split_k) {  // uniform; no load inside
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sum[2 * e] += TT::to_float((uint16_t)(v[j][e] & 0xffffu));
+                    sum[2 * e + 1] += TT::to_float((uint16_t)(v[j][e] >> 16));
+                }
+            }
+        }
+    }
+}
 template <typename TT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const uint16_t *__restrict__ partials,
                                                             uint16_t *__restrict__ out, size_t elements, int split_k) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (i >= elements) return;
-    float sum = 0.f;
-    for (int p = 0; p < split_k; ++p) sum += TT::to_float(partials[(size_t)p * elements + i]);
-    out[i] = TT::from_float(sum);
+    if (i + 8 <= elements && (elements & 7) == 0 && (((uintptr_t)out | (uintptr_t)partials) & 15) == 0) {  // (uniform but for the last thread)
+        float sum[8];
+        splitk_sum8<TT>(partials, elements, i, split_k, sum);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)TT::from_float(sum[2 * e]) | ((uint32_t)TT::from_float(sum[2 * e + 1]) << 16);
+        *reinterpret_cast<u32x4 *>(out + i) = o;
+        return;
+    }
+    for (size_t k = i; k < elements && k < i + 8; ++k) {  // a ragged element count: one element at a time
+        float sum = 0.f;
+        for (int p = 0; p < split_k; ++p) sum += TT::to_float(partials[(size_t)p * elements + k]);
+        out[k] = TT::from_float(sum);
+    }
 }
-// the same with the engine's epilogue on the rounded sum: one thread = two adjacent elements (a gate / up pair under SwiGLU)
+// the same with the engine's epilogue on the rounded sum (elements % 8 == 0: the engine's shapes); adjacent elements are a gate / up pair under SwiGLU
 template <typename TT, int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const uint16_t *__restrict__ partials, uint16_t *__restrict__ out,
                                                                 size_t elements, int split_k, const uint16_t *__restrict__ residual) {
-    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (i >= elements) return;
-    float s0 = 0.f, s1 = 0.f;
-    for (int p = 0; p < split_k; ++p) {
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(partials + (size_t)p * elements + i);
-        s0 += TT::to_float((uint16_t)(v & 0xffffu));
-        s1 += TT::to_float((uint16_t)(v >> 16));
-    }
-    const float r0 = TT::to_float(TT::from_float(s0)), r1 = TT::to_float(TT::from_float(s1));
+    u32x4 rv = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (EPI != EPI_SWIGLU) rv = *reinterpret_cast<const u32x4 *>(residual + i);  // goes out with the first slices
+    float sum[8];
+    splitk_sum8<TT>(partials, elements, i, split_k, sum);
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = TT::to_float(TT::from_float(sum[e]));
     if constexpr (EPI == EPI_SWIGLU) {
-        out[i >> 1] = TT::from_float((r0 / (1.0f + expf(-r0))) * r1);
+        u32x2 o;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint16_t a = TT::from_float((r[4 * e] / (1.0f + expf(-r[4 * e]))) * r[4 * e + 1]);
+            const uint16_t b = TT::from_float((r[4 * e + 2] / (1.0f + expf(-r[4 * e + 2]))) * r[4 * e + 3]);
+            o[e] = (uint32_t)a | ((uint32_t)b << 16);
+        }
+        *reinterpret_cast<u32x2 *>(out + (i >> 1)) = o;
     } else {
-        const uint32_t rv = *reinterpret_cast<const uint32_t *>(residual + i);
-        const uint16_t o0 = TT::from_float(TT::to_float((uint16_t)(rv & 0xffffu)) + r0);
-        const uint16_t o1 = TT::from_float(TT::to_float((uint16_t)(rv >> 16)) + r1);
-        *reinterpret_cast<uint32_t *>(out + i) = (uint32_t)o0 | ((uint32_t)o1 << 16);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint16_t o0 = TT::from_float(TT::to_float((uint16_t)(rv[e] & 0xffffu)) + r[2 * e]);
+            const uint16_t o1 = TT::from_float(TT::to_float((uint16_t)(rv[e] >> 16)) + r[2 * e + 1]);
+            o[e] = (uint32_t)o0 | ((uint32_t)o1 << 16);
+        }
+        *reinterpret_cast<u32x4 *>(out + i) = o;
     }
 }
 
@@ -326,7 +371,9 @@ static int split_k_policy(int M, int N, int K) {
     // against the 2560-row o / down projections) measured 471 / 482 TFLOP/s unsplit against 750 for the wide projections.
     // (two of the 8-wave workgroups fit: 512)
     const int target = mfma_nw(M, K) == 8 ? 512 : 768;
-    constexpr int max_split = 16;
+    // (20 since round 5: the w_down reduction is 76 groups = 4 x 19 -- with 16 as the cap a 128- or 256-row chunk got 4 slices of 38 steps on 80
+    // workgroups; 19 slices of 4 groups put 380 on the chip: 128-row chunks 24.8k -> see profiles/r05_labs/README.md section 8)
+    constexpr int max_split = 20;
     // at least two quantisation groups per slice: a one-group slice is a K loop of 4 MFMA steps behind a full prologue and a
     // reduction pass (the reference's own fallback case -- 128 x 2560 over N = 256 -- must stay unsplit and bit-identical,
     // tests_refsol/test_week_2_day_7.py:80-109)
@@ -405,7 +452,7 @@ static int run_qmm(const void *scales, const void *biases, const void *a, const 
         }
         if (split > 1) {
             const size_t elements = (size_t)M * K;
-            hipLaunchKernelGGL((splitk_reduce_kernel<TT>), dim3(ceil_div(elements, 256)), dim3(256), 0, st,
+            hipLaunchKernelGGL((splitk_reduce_kernel<TT>), dim3(ceil_div(ceil_div(elements, 8), 256)), dim3(256), 0, st,
                                (const uint16_t *)workspace, O, elements, split);
         }
         return TL_OK;
@@ -440,7 +487,9 @@ int qmm_bf16_epilogue(const void *scales, const void *biases, const uint16_t *A,
         else if (mt == 2) hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 2>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr, qmm_xcd_remap());
         else hipLaunchKernelGGL((qmm_mfma_kernel<BF16, 4>), grid, block, 0, st, S, Bi, A, b, dst, M, N, K, psize, pstride, nullptr, qmm_xcd_remap());
         const size_t elements = (size_t)M * K;
-        const dim3 rg(ceil_div(elements / 2, 256));
+        if (elements % 8 != 0 || (((uintptr_t)O | (uintptr_t)dst | (uintptr_t)residual) & 15) != 0)
+            return fail(TL_ERR_INVALID, "qmm_bf16_epilogue: rows x features must be a multiple of 8 and the rows 16-byte aligned");
+        const dim3 rg(ceil_div(elements / 8, 256));
         if (epi == EPI_SWIGLU) hipLaunchKernelGGL((splitk_reduce_epi_kernel<BF16, EPI_SWIGLU>), rg, dim3(256), 0, st, dst, O, elements, split, residual);
         else hipLaunchKernelGGL((splitk_reduce_epi_kernel<BF16, EPI_RESIDUAL>), rg, dim3(256), 0, st, dst, O, elements, split, residual);
         return TL_OK;
