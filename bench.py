@@ -844,15 +844,29 @@ def main() -> None:
                                            "replayed from " + rp["file"] + " (rocprofv3 did not run here) and is not this run's figure")
         else:
             roofline["frac_source"] = "in-kernel device wall-clock stamps (no rocprofv3 summary available): optimistic by ~0.8 us per launch"
+        # HBM bytes by hardware counters.  First choice: the passes over the ENGINE's own decode step (tools/lab/pmc_engine_step.sh drives
+        # the C ABI without Python: rocprofv3's counter mode crashes under this bench); fallback: the GEMV lab's replay of the kernels.
+        engine_traffic = ROOT / "profiles" / "traffic_engine.json"
         traffic_file = ROOT / "profiles" / "traffic.json"
-        if traffic_file.exists():
-            try:
+        try:
+            if engine_traffic.exists():
+                et = json.loads(engine_traffic.read_text())
+                ctx = min(et["contexts"], key=lambda c: abs(int(c) - args.prompt_len))
+                row = et["contexts"][ctx]
+                roofline["traffic"] = row["gemv_hbm_bytes_per_launch"]
+                roofline["traffic_step"] = {"context_tokens": int(ctx), "hbm_read_bytes": row["step_hbm_read_bytes"], "hbm_write_bytes": row["step_hbm_write_bytes"],
+                                            "algorithmic_bytes": row["step_algorithmic_bytes"], "hbm_over_algorithmic": row["hbm_over_algorithmic"],
+                                            "launches": row["launches_per_step"]}
+                roofline["traffic_note"] = ("HBM bytes per GEMV launch (and per whole decode step: traffic_step) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the "
+                                            "engine's own decode step at " + ctx + " tokens of context (tools/lab/engine_step_lab through the C ABI); NOT measured in this run: "
+                                            "replayed from the committed profiles/traffic_engine.json (" + str(et.get("collected", "")) + ")")
+            elif traffic_file.exists():
                 traffic = json.loads(traffic_file.read_text())
                 roofline["traffic"] = traffic.get("qmv_hbm_bytes_per_launch")
-                roofline["traffic_note"] = ("HBM bytes per GEMV launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; NOT measured in "
+                roofline["traffic_note"] = ("HBM bytes per GEMV launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/lab/gemv_lab; NOT measured in "
                                             "this run: replayed from the committed profiles/traffic.json (" + str(traffic.get("collected", "round 3")) + ")")
-            except Exception:
-                roofline["traffic"] = None
+        except Exception:
+            roofline["traffic"] = None
     roofline["step_achieved"] = round(step_gbps, 1)
     roofline["step_frac"] = round(step_gbps / HBM_PEAK_GBPS, 4)
     roofline["step_bytes"] = int(step_bytes)
