@@ -87,6 +87,9 @@ def parse_args(argv=None) -> argparse.Namespace:
     ap.add_argument("--staging-slots", type=int, default=1,
                     help="--batch-decode: prompts prefilled together per turn (1 = one at a time as the reference; > 1 packs them "
                          "into one multi-token pass of at most --prefill-budget rows)")
+    ap.add_argument("--keep-slot-holes", action="store_true",
+                    help="do not move live requests into the decode slots finished requests left (benches/serving.py _close_holes): the step then "
+                         "decodes the prefix up to the highest live slot, as before round 5")
     ap.add_argument("--page-size", type=int, default=128)
     ap.add_argument("--json-output", type=Path)
     args = ap.parse_args(argv)
@@ -184,7 +187,7 @@ def main(argv=None) -> None:
                 metrics = serve_requests(engine, reqs, batch_size=args.batch_size, prefill_step=args.prefill_step,
                                          prefill_budget=args.prefill_budget, page_size=args.page_size,
                                          kv_bytes_per_page=kv_page_bytes, capacity_pages=pages_per_seq * slots + 2,
-                                         staging_slots=args.staging_slots)
+                                         staging_slots=args.staging_slots, compact=not args.keep_slot_holes)
                 return metrics.generated_tokens, metrics.decode_tokens, metrics.prefill_time, metrics.decode_time
             gen = dec = 0
             pt = dt = 0.0

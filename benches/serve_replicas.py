@@ -141,6 +141,9 @@ def parse_args(argv=None) -> argparse.Namespace:
     ap.add_argument("--staging-slots", type=int, default=8,
                     help="prompts prefilled together per turn (1 = the reference's one-at-a-time admission; > 1 packs the admitted "
                          "prompts' chunks into one multi-token pass of at most --prefill-budget rows)")
+    ap.add_argument("--keep-slot-holes", action="store_true",
+                    help="do not move live requests into the decode slots finished requests left (benches/serving.py _close_holes): the step then "
+                         "decodes the prefix up to the highest live slot, as before round 5")
     ap.add_argument("--page-size", type=int, default=128)
     ap.add_argument("--warmup-requests", type=int, default=None, help="requests of an untimed warm-up pass (default: batch size)")
     ap.add_argument("--json-output", type=Path)
@@ -212,7 +215,7 @@ def main(argv=None) -> dict | None:
     def run(reqs):
         return serve_requests(engine, reqs, batch_size=args.batch_size, prefill_step=args.prefill_step,
                               prefill_budget=args.prefill_budget, page_size=args.page_size, kv_bytes_per_page=kv_page_bytes,
-                              capacity_pages=pages_per_seq * slots + 2, clock=clock, staging_slots=args.staging_slots)
+                              capacity_pages=pages_per_seq * slots + 2, clock=clock, staging_slots=args.staging_slots, compact=not args.keep_slot_holes)
 
     warm = args.warmup_requests if args.warmup_requests is not None else args.batch_size
     if warm > 0 and mine:

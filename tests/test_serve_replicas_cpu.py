@@ -165,6 +165,50 @@ def test_packed_admission_schedule_only():
     assert not eng.passes and m.generated_tokens == sum(r.max_new_tokens for r in reqs)
 
 
+def test_hole_closing_keeps_the_decode_prefix_dense():
+    """benches/serving.py _close_holes: before a step the live decode slots are moved into the holes finished requests left whenever
+    that lowers the row bucket -- every step then runs at the bucket of the NUMBER of live requests, each request still gets exactly
+    its tokens and every slot comes back; the counters the reference's report prints do not see slot numbers (same values with the
+    moves switched off), only the clock does."""
+    from benches.serving import ROW_BUCKETS, ScheduleOnlyEngine, serve_requests
+
+    class Spy(ScheduleOnlyEngine):
+        def __init__(self, slots):
+            super().__init__(slots)
+            self.steps, self.moves = [], 0
+
+        def move(self, src, dst):
+            self.moves += 1
+            super().move(src, dst)
+
+        def decode(self, steps, batch=None):
+            live = [i for i, c in enumerate(self.slots[:64]) if c is not None]
+            self.steps.append((batch, len(live), max(live) + 1))
+            assert all(c is None for c in self.slots[batch:64]), "a live request outside the decoded prefix"
+            super().decode(steps, batch=batch)
+
+    reqs = _trace(160)
+    out = {}
+    for compact, staging in ((True, 1), (False, 1), (True, 8), (False, 8)):
+        eng = Spy(64 + staging)
+        m = serve_requests(eng, reqs, batch_size=64, prefill_step=128, prefill_budget=128 if staging == 1 else 1024, clock=eng.clock,
+                           staging_slots=staging, compact=compact)
+        assert m.generated_tokens == sum(r.max_new_tokens for r in reqs) and all(s is None for s in eng.slots)
+        bucket = lambda n: next(b for b in ROW_BUCKETS if b >= n)
+        if compact:
+            assert all(batch == bucket(count) for batch, count, _top in eng.steps), "a step ran at more rows than its live requests need"
+        out[(compact, staging)] = (m, eng.now, eng.moves - len(reqs), sum(b for b, _, _ in eng.steps))
+    for staging in (1, 8):
+        on, off = out[(True, staging)], out[(False, staging)]
+        assert on[2] > 0 and off[2] <= 0, "moves beyond the one admission move per request happen only when closing holes"
+        assert on[3] < off[3] and on[1] < off[1], "fewer decoded rows, shorter virtual makespan"
+    # the reference's schedule (one staging slot): the admission order does not depend on slot numbers, so every reported counter is equal
+    a, b = out[(True, 1)][0], out[(False, 1)][0]
+    for name in ("turns", "prefill_chunks", "decode_tokens", "generated_tokens", "peak_active_requests", "peak_live_pages", "peak_tail_waste_slots",
+                 "decode_step_count", "decode_bytes"):
+        assert getattr(a, name) == getattr(b, name), name
+
+
 def test_profile_week2_kernels_harness_logic(monkeypatch):
     """benches/profile_week2_kernels.py (reference: benches/profile_week2_kernels.py:88-156): the case syntax, the rotated
     group order and the median -- against a fake clock, no GPU."""
