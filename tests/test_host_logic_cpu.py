@@ -443,6 +443,8 @@ def test_batch_generate_ids_decodes_only_the_occupied_slot_prefix():
         assert rows > max(occupied), "a live sequence was left out of the step"
         smaller = [b for b in _DECODE_ROW_BUCKETS if b < rows]
         assert not smaller or smaller[-1] <= max(occupied), "the step covered more rows than the bucket rule allows"
+        # holes finished requests leave are closed whenever that lowers the bucket: a step runs at the bucket of the live COUNT
+        assert rows == min(next(b for b in _DECODE_ROW_BUCKETS if b >= len(occupied)), 16), (rows, occupied)
     assert min(r for r, _ in eng.decode_rows) < 16, "short batches should not step all 16 rows"
 
 

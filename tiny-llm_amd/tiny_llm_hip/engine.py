@@ -336,9 +336,29 @@ def batch_generate_ids(engine: DecodeEngine, prompts: Sequence[Sequence[int]], m
             if any(s is not None for s in slots):
                 # slots fill lowest-first, so rows above the highest occupied one are idle: decode only a bucket that
                 # covers the occupied prefix (the engine keeps one captured graph per row count; buckets bound their number)
+                def bucket(n):
+                    return min(next((b for b in _DECODE_ROW_BUCKETS if b >= n), batch_size), batch_size)
+
                 top = max(i for i, s in enumerate(slots) if s is not None) + 1
-                rows = next((b for b in _DECODE_ROW_BUCKETS if b >= top), batch_size)
-                rows = min(rows, batch_size)
+                count = sum(s is not None for s in slots)
+                if bucket(count) < bucket(top):
+                    # finished requests left holes below the highest live slot and closing them lowers the row bucket (a step
+                    # costs by its rows): hand the highest live slots over to the holes -- block-table row, context length and
+                    # pending token move, no K/V bytes (tl_engine_move); slot numbers are invisible to the results
+                    lo, hi = 0, batch_size - 1
+                    while True:
+                        while lo < hi and slots[lo] is not None:
+                            lo += 1
+                        while hi > lo and slots[hi] is None:
+                            hi -= 1
+                        if lo >= hi:
+                            break
+                        engine.move(hi, lo)
+                        slots[lo], slots[hi] = slots[hi], None
+                        live_slots.discard(hi)
+                        live_slots.add(lo)
+                    top = count
+                rows = bucket(top)
                 engine.decode(1, batch=rows)
                 tokens = engine.read_pending(rows)
                 if on_step is not None:
