@@ -293,17 +293,28 @@ bool AqlQueue::submit(const AqlProgram &p, const AqlFences &f, bool first, bool 
         why = "program larger than the queue";
         return false;
     }
-    if (last) hsa_signal_store_relaxed(done_, 1);
+    if (last && pending_) {  // one signal: two carriers in flight would let the first completion pass for the second
+        why = "AQL submission with a completion signal while the previous one is pending (wait() first)";
+        return false;
+    }
     const uint32_t mask = q_->size - 1;
-    const uint64_t idx = hsa_queue_add_write_index_relaxed(q_, n);
+    // (one producer: room is awaited BEFORE the write index moves, so that a refused submission leaves no reserved, never-written slots
+    // -- invalid headers the packet processor would wait on for ever -- behind)
+    const uint64_t at = hsa_queue_load_write_index_relaxed(q_);
     auto *ring = (hsa_kernel_dispatch_packet_t *)q_->base_address;
     const auto t0 = std::chrono::steady_clock::now();
-    while (idx + n - hsa_queue_load_read_index_scacquire(q_) > q_->size) {  // ring full: the device is several steps behind
+    while (at + n - hsa_queue_load_read_index_scacquire(q_) > q_->size) {  // ring full: the device is several steps behind
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
             why = "AQL queue stayed full for 10 s";
             return false;
         }
     }
+    const uint64_t idx = hsa_queue_add_write_index_relaxed(q_, n);
+    if (idx != at) {
+        why = "AQL queue has a second producer";
+        return false;
+    }
+    if (last) hsa_signal_store_relaxed(done_, 1);
     for (size_t i = 0; i < n; ++i) {
         hsa_kernel_dispatch_packet_t d = p.packets[i];
         const bool head = i == 0, tail = i + 1 == n;
@@ -317,20 +328,70 @@ bool AqlQueue::submit(const AqlProgram &p, const AqlFences &f, bool first, bool 
         __atomic_store_n((uint32_t *)slot, (uint32_t)header | ((uint32_t)d.setup << 16), __ATOMIC_RELEASE);
     }
     hsa_signal_store_screlease(q_->doorbell_signal, (hsa_signal_value_t)(idx + n - 1));
-    if (last) pending_ = true;
+    if (last) {
+        pending_ = true;
+        unsignalled_ = false;  // the queue runs its packets in order (barrier bit): the signal of this one covers all before it
+    } else {
+        unsignalled_ = true;
+    }
+    return true;
+}
+
+// An empty barrier-AND packet (no dependencies, barrier bit set) behind everything in the ring, carrying the completion signal.
+bool AqlQueue::submit_barrier(std::string &why) {
+    if (!q_) {
+        why = "AQL queue missing";
+        return false;
+    }
+    const uint32_t mask = q_->size - 1;
+    const uint64_t at = hsa_queue_load_write_index_relaxed(q_);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (at + 1 - hsa_queue_load_read_index_scacquire(q_) > q_->size) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+            why = "AQL queue stayed full for 10 s";
+            return false;
+        }
+    }
+    const uint64_t idx = hsa_queue_add_write_index_relaxed(q_, 1);
+    if (idx != at) {
+        why = "AQL queue has a second producer";
+        return false;
+    }
+    hsa_signal_store_relaxed(done_, 1);
+    hsa_barrier_and_packet_t b;
+    memset(&b, 0, sizeof(b));
+    b.completion_signal = done_;
+    const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                       (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                       (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+    auto *slot = (hsa_barrier_and_packet_t *)q_->base_address + (idx & mask);
+    static_assert(sizeof(hsa_barrier_and_packet_t) == sizeof(hsa_kernel_dispatch_packet_t), "one ring slot");
+    memcpy((char *)slot + 4, (const char *)&b + 4, sizeof(b) - 4);
+    __atomic_store_n((uint32_t *)slot, (uint32_t)header, __ATOMIC_RELEASE);
+    hsa_signal_store_screlease(q_->doorbell_signal, (hsa_signal_value_t)idx);
+    pending_ = true;
+    unsignalled_ = false;
     return true;
 }
 
 bool AqlQueue::wait(double seconds, std::string &why) {
-    if (!pending_) return true;
     const auto t0 = std::chrono::steady_clock::now();
-    while (hsa_signal_wait_scacquire(done_, HSA_SIGNAL_CONDITION_LT, 1, 2000000, HSA_WAIT_STATE_ACTIVE) >= 1) {
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) {
-            why = "AQL submission did not complete within " + std::to_string(seconds) + " s";
-            return false;
+    auto wait_signal = [&]() {
+        while (hsa_signal_wait_scacquire(done_, HSA_SIGNAL_CONDITION_LT, 1, 2000000, HSA_WAIT_STATE_ACTIVE) >= 1) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) {
+                why = "AQL submission did not complete within " + std::to_string(seconds) + " s";
+                return false;
+            }
         }
+        pending_ = false;
+        return true;
+    };
+    // (one signal: an earlier carrier is waited out before the barrier packet arms it again)
+    if (pending_ && !wait_signal()) return false;
+    if (unsignalled_) {
+        if (!submit_barrier(why)) return false;
+        if (!wait_signal()) return false;
     }
-    pending_ = false;
     return true;
 }
 

@@ -88,13 +88,17 @@ public:
     // copies the program's packets into the ring `times` times (steps back to back); `first` / `last` mark the outermost packets of the
     // whole submission (system-scope fences, completion signal on the very last packet)
     bool submit(const AqlProgram &p, const AqlFences &f, bool first, bool last, std::string &why);
-    bool wait(double seconds, std::string &why);  // for the completion signal of the last submit(..., last = true)
-    bool busy() const { return pending_; }
+    // for everything submitted so far: the completion signal of the last submit(..., last = true), or -- when steps went out without one
+    // (a drain in the middle of a call: a page id changes, a plan leaves the route) -- of a barrier packet put behind them first
+    bool wait(double seconds, std::string &why);
+    bool busy() const { return pending_ || unsignalled_; }
 
 private:
+    bool submit_barrier(std::string &why);
     hsa_queue_t *q_ = nullptr;
     hsa_signal_t done_{};
-    bool pending_ = false;
+    bool pending_ = false;      // a packet carrying the completion signal is in the ring
+    bool unsignalled_ = false;  // packets went out after the last one that carries the signal
 };
 
 }  // namespace tl
