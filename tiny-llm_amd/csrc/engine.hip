@@ -1244,6 +1244,10 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
             {
                 const int rows = std::min(c.max_batch, 64);
                 const size_t ssr = (size_t)std::max(QM3_SS, c.hidden_size / 16 + 1);
+                // (weighted rows lie in 16-row fragment blocks, qmm6.h: a partly filled last block spans all 16 row slots -- sized like the shared xn;
+                // with `rows` itself a batch of 17-24 on a 24-slot engine wrote its block past xn into xw and past xw into qkv: dead bytes at that
+                // moment by the order of the launches, but a second write per step to addresses the replay route reads without cache maintenance)
+                const size_t b_xf = align_up((size_t)((rows + 15) / 16 * 16) * c.hidden_size * 2, 256);
                 const size_t b_x = align_up((size_t)rows * c.hidden_size * 2, 256), b_qkv = align_up((size_t)rows * qkv_dim * 2, 256),
                              b_attn = align_up((size_t)rows * q_dim * 2, 256), b_act = align_up((size_t)rows * c.intermediate_size * 2, 256),
                              b_ss = align_up((size_t)rows * ssr * 4, 256),
@@ -1255,7 +1259,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
                     if (pw.ok) b_pl[0] = std::max(b_pl[0], align_up(pw.partial_bytes, 256));
                     if (pd.ok) b_pl[1] = std::max(b_pl[1], align_up(pd.partial_bytes, 256));
                 }
-                const size_t per_layer = 4 * b_x + b_qkv + b_attn + b_act + 2 * b_ss + b_ws + b_pl[0] + b_pl[1];
+                const size_t per_layer = 2 * b_x + 2 * b_xf + b_qkv + b_attn + b_act + 2 * b_ss + b_ws + b_pl[0] + b_pl[1];
                 if (hipMalloc((void **)&e->layer_act_mem, per_layer * c.num_layers) != hipSuccess ||
                     hipMemsetAsync(e->layer_act_mem, 0, per_layer * c.num_layers, e->stream) != hipSuccess) {
                     tl_engine_destroy(e);
@@ -1267,8 +1271,8 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
                     tl_engine::LayerAct &a = e->layer_act[l];
                     a.x_out = (uint16_t *)m, m += b_x;
                     a.h = (uint16_t *)m, m += b_x;
-                    a.xn = (uint16_t *)m, m += b_x;
-                    a.xw = (uint16_t *)m, m += b_x;
+                    a.xn = (uint16_t *)m, m += b_xf;
+                    a.xw = (uint16_t *)m, m += b_xf;
                     a.qkv = (uint16_t *)m, m += b_qkv;
                     a.attn = (uint16_t *)m, m += b_attn;
                     a.act = (uint16_t *)m, m += b_act;
