@@ -120,3 +120,80 @@ def test_converter_refuses_what_it_cannot_represent(tmp_path):
     (hf_dir / "config.json").write_text(json.dumps(dict(cfg, num_experts=8)))
     with pytest.raises(ValueError, match="MoE"):
         convert(hf_dir, tmp_path / "out2")
+
+
+@pytest.mark.parametrize("tie", [True, False])
+def test_loaded_tree_computes_what_transformers_computes_on_the_same_files(tmp_path, tie):
+    """End to end on the host, two independent readers of ONE converted directory: (a) the loader's attribute tree -> the float64 truth
+    model of this repository (oracle.TruthQwen3, itself pinned to transformers on builder-made weights); (b) the files' tensors taken BY
+    NAME, dequantised, and loaded by transformers' own `load_state_dict` into its Qwen3ForCausalLM in float64.  A projection landing
+    in the wrong attribute, a norm on the wrong layer, a transposed matrix or a mis-read config field separates the two."""
+    import numpy as np
+    from safetensors import safe_open
+
+    from convert_hf_to_mlx4bit import convert
+    from oracle import tiny_oracle as O
+    from test_truth_vs_transformers_cpu import dense64, load_exactly
+    from tiny_llm_hip.loader import load_weights
+
+    hf_dir, mlx_dir = tmp_path / "hf", tmp_path / "mlx4"
+    _hf_checkpoint(hf_dir, tie)
+    convert(hf_dir, mlx_dir, shards=2)
+
+    # (a) through the loader
+    loaded = load_weights(mlx_dir, device="cpu")
+    cfg = {k: getattr(loaded.args, k) for k in ("hidden_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "head_dim",
+                                                "intermediate_size", "vocab_size", "rms_norm_eps", "rope_theta", "tie_word_embeddings",
+                                                "max_position_embeddings")}
+
+    def triple(layer):
+        return (layer.weight.numpy().view(np.uint32), layer.scales.float().numpy(), layer.biases.float().numpy())
+
+    def vec(n):
+        return n.weight.float().numpy()
+
+    w = dict(embed=triple(loaded.model.embed_tokens), norm=vec(loaded.model.norm), layers=[])
+    for layer in loaded.model.layers:
+        a, m = layer.self_attn, layer.mlp
+        w["layers"].append(dict(q=triple(a.q_proj), k=triple(a.k_proj), v=triple(a.v_proj), o=triple(a.o_proj), gate=triple(m.gate_proj),
+                                up=triple(m.up_proj), down=triple(m.down_proj), q_norm=vec(a.q_norm), k_norm=vec(a.k_norm),
+                                input_norm=vec(layer.input_layernorm), post_norm=vec(layer.post_attention_layernorm)))
+    if not tie:
+        w["lm_head"] = triple(loaded.lm_head)
+    truth = O.TruthQwen3(cfg, w)
+
+    # (b) by name, through transformers
+    stored = {}
+    for f in sorted(mlx_dir.glob("*.safetensors")):
+        with safe_open(str(f), framework="pt") as h:
+            for key in h.keys():
+                stored[key] = h.get_tensor(key)
+    tensors = {}
+    for name, t in stored.items():
+        if name.endswith((".scales", ".biases")):
+            continue
+        base = name[: -len(".weight")]
+        if base + ".scales" in stored:
+            tensors[name] = dense64((t.view(torch.int32).numpy().view(np.uint32), stored[base + ".scales"].float().numpy(),
+                                     stored[base + ".biases"].float().numpy()))
+        else:
+            tensors[name] = t.to(torch.float64)
+    hf_cfg = transformers.Qwen3Config(**CFG, tie_word_embeddings=tie, attention_bias=False)
+    hf_cfg._attn_implementation = "eager"
+    model = transformers.Qwen3ForCausalLM(hf_cfg).double().eval()
+    load_exactly(model, tensors)
+
+    prompt = [int(t) for t in np.random.default_rng(5).integers(1, CFG["vocab_size"], size=23)]
+    with torch.no_grad():
+        out = model(torch.tensor([prompt]), use_cache=True)
+    want = truth.forward(prompt, logits_to_keep=None)[0]
+    worst = float(np.abs(out.logits[0].numpy() - want).max())
+    past, tok = out.past_key_values, int(np.argmax(want[-1]))
+    for _ in range(3):
+        with torch.no_grad():
+            out = model(torch.tensor([[tok]]), past_key_values=past, use_cache=True)
+        past = out.past_key_values
+        row = truth.forward([tok])[0, -1]
+        worst = max(worst, float(np.abs(out.logits[0, -1].numpy() - row).max()))
+        tok = int(np.argmax(row))
+    assert worst < 5e-6, worst
