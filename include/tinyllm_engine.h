@@ -177,7 +177,17 @@ int tl_engine_set_token(tl_engine *e, int slot, int32_t token);
  * The step is captured in a hipGraph on first use (re-captured when the
  * attention split bucket or batch changes); use_graph = 0 launches eagerly.
  * Pages are reserved on demand (TL_ERR_INVALID if the pool is exhausted).
- * Does not synchronise. */
+ * Synchronisation depends on the replay route (tl_engine_replay_route): on the
+ * default "aql" route the call waits for the stream before its first captured
+ * step and RETURNS DRAINED -- every step of the call has run (the engine's HSA
+ * queue is not the stream, so nothing stream-ordered may follow undrained steps;
+ * the host waits ~50 us spinning, then blocked on the completion signal).  On the
+ * "hipgraph" route (TL_AQL=0, or a plan the AQL route does not take) and with
+ * use_graph = 0 the call only enqueues on the engine stream and does not
+ * synchronise: a caller that overlaps host work with decode steps (a draft
+ * model free-running beside its target) wants that route.
+ * Must be called with the engine's own device current (the one current at
+ * tl_engine_create): anything else is TL_ERR_INVALID. */
 int tl_engine_decode(tl_engine *e, int batch, int steps, int use_graph);
 
 /* Copy the ids produced by the last `count` decode steps for `slot` to host

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <memory>
+#include <mutex>
 #include <sstream>
 
 #include <dirent.h>
@@ -33,12 +35,20 @@ hsa_status_t collect_gpu(hsa_agent_t a, void *data) {
 
 }  // namespace
 
-AqlRuntime &AqlRuntime::get() {
-    static AqlRuntime rt;
-    return rt;
+namespace {
+std::mutex g_runtime_lock;  // the table of runtimes and every ensure_loaded
+}
+
+AqlRuntime &AqlRuntime::for_device(int hip_device) {
+    static std::map<int, std::unique_ptr<AqlRuntime>> table;
+    std::lock_guard<std::mutex> guard(g_runtime_lock);
+    auto &slot = table[hip_device];
+    if (!slot) slot.reset(new AqlRuntime(hip_device));
+    return *slot;
 }
 
 bool AqlRuntime::ensure_loaded(const std::string &dir) {
+    std::lock_guard<std::mutex> guard(g_runtime_lock);
     if (tried_) return ok_;
     tried_ = true;
     hsa_status_t s = hsa_init();  // reference-counted: HIP holds the runtime already
@@ -46,9 +56,8 @@ bool AqlRuntime::ensure_loaded(const std::string &dir) {
     AgentPick pick;
     hsa_iterate_agents(collect_gpu, &pick);
     if (pick.gpus.empty()) return fail("no HSA GPU agent");
-    // the agent of the CURRENT HIP device: by PCI bus / device / function, else by ordinal
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return fail("hipGetDevice failed");
+    // the agent of THIS runtime's HIP device: by PCI bus / device / function, else by ordinal
+    const int dev = device_;
     char bus_id[64] = {0};
     unsigned want_bdf = ~0u;
     if (hipDeviceGetPCIBusId(bus_id, sizeof(bus_id), dev) == hipSuccess) {
@@ -151,8 +160,7 @@ AqlProgram::~AqlProgram() {
     if (kernarg_dev) (void)hipFree(kernarg_dev);
 }
 
-int aql_program_from_graph(hipGraph_t graph, hipStream_t stream, AqlProgram &out, std::string &why) {
-    const AqlRuntime &rt = AqlRuntime::get();
+int aql_program_from_graph(const AqlRuntime &rt, hipGraph_t graph, hipStream_t stream, AqlProgram &out, std::string &why) {
     if (!rt.ok()) {
         why = "AQL runtime not loaded: " + rt.why();
         return -1;
@@ -264,8 +272,7 @@ AqlQueue::~AqlQueue() {
     if (done_.handle) hsa_signal_destroy(done_);
 }
 
-bool AqlQueue::create(std::string &why, uint32_t packets) {
-    const AqlRuntime &rt = AqlRuntime::get();
+bool AqlQueue::create(const AqlRuntime &rt, std::string &why, uint32_t packets) {
     if (!rt.ok()) {
         why = "AQL runtime not loaded: " + rt.why();
         return false;
@@ -377,7 +384,12 @@ bool AqlQueue::submit_barrier(std::string &why) {
 bool AqlQueue::wait(double seconds, std::string &why) {
     const auto t0 = std::chrono::steady_clock::now();
     auto wait_signal = [&]() {
-        while (hsa_signal_wait_scacquire(done_, HSA_SIGNAL_CONDITION_LT, 1, 2000000, HSA_WAIT_STATE_ACTIVE) >= 1) {
+        // spin for the first 100 ms (a timed run of decode steps ends inside it: no wake-up latency on the metric's path), after that the
+        // host thread sleeps on the signal's interrupt instead of burning a core per engine for the rest of a long call
+        for (;;) {
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const hsa_wait_state_t how = waited < 0.1 ? HSA_WAIT_STATE_ACTIVE : HSA_WAIT_STATE_BLOCKED;
+            if (hsa_signal_wait_scacquire(done_, HSA_SIGNAL_CONDITION_LT, 1, 2000000, how) < 1) break;
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) {
                 why = "AQL submission did not complete within " + std::to_string(seconds) + " s";
                 return false;

@@ -33,18 +33,25 @@ struct AqlKernelInfo {
     std::vector<std::pair<uint32_t, uint32_t>> args;  // explicit arguments: (offset, size)
 };
 
-// process-wide: HSA agent of the current HIP device, the loaded code objects
+// One per HIP DEVICE (process-wide table, created on first use under a lock): the HSA agent of that device and the code objects
+// loaded on it.  An engine keeps the runtime of the device it was created on; queues, kernel objects and programs of one runtime
+// are only ever used with buffers of that device (round 5's single instance bound itself to whichever device was current at the
+// first engine creation: a second engine on another GPU of the same process would have dispatched on the wrong agent).
 class AqlRuntime {
 public:
-    static AqlRuntime &get();
-    // loads every tl_kernels_*.hsaco + tl_kernels.meta of `dir` once; false (and why()) when anything is missing
+    static AqlRuntime &for_device(int hip_device);
+    // loads every tl_kernels_*.hsaco + tl_kernels.meta of `dir` on this runtime's device, once; false (and why()) when anything is
+    // missing.  Thread-safe.
     bool ensure_loaded(const std::string &dir);
+    int device() const { return device_; }
     const AqlKernelInfo *find(const std::string &mangled) const;
     hsa_agent_t agent() const { return agent_; }
     const std::string &why() const { return why_; }
     bool ok() const { return ok_; }
 
 private:
+    explicit AqlRuntime(int dev) : device_(dev) {}
+    int device_ = 0;
     bool ok_ = false, tried_ = false;
     std::string why_;
     hsa_agent_t agent_{};
@@ -71,7 +78,7 @@ struct AqlProgram {
 
 // Builds a program from the kernel nodes of a captured graph (a linear chain: anything else is refused).  Returns 0, or a negative
 // code with `why` set: the caller keeps the hipGraph route.
-int aql_program_from_graph(hipGraph_t graph, hipStream_t stream, AqlProgram &out, std::string &why);
+int aql_program_from_graph(const AqlRuntime &rt, hipGraph_t graph, hipStream_t stream, AqlProgram &out, std::string &why);
 
 struct AqlFences {
     // fence scopes (hsa_fence_scope_t) of the packets INSIDE a step; the first packet of a submission always acquires at system scope
@@ -84,7 +91,7 @@ struct AqlFences {
 class AqlQueue {
 public:
     ~AqlQueue();
-    bool create(std::string &why, uint32_t packets = 8192);
+    bool create(const AqlRuntime &rt, std::string &why, uint32_t packets = 8192);
     // copies the program's packets into the ring `times` times (steps back to back); `first` / `last` mark the outermost packets of the
     // whole submission (system-scope fences, completion signal on the very last packet)
     bool submit(const AqlProgram &p, const AqlFences &f, bool first, bool last, std::string &why);

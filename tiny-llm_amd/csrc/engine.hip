@@ -135,6 +135,8 @@ struct tl_engine {
     // AQL replay (aql.h; TL_AQL=1 at create): a captured step also becomes a program of hand-written dispatch packets on the engine's own
     // HSA queue; a plan without a program (a kernel outside the device-only code objects, a node that is not a kernel) stays on hipGraphLaunch
     bool aql_on = false;
+    int device = 0;                  // the HIP device the engine was created on: its buffers, its stream, its AQL runtime
+    AqlRuntime *aql_rt = nullptr;    // the runtime of that device (aql.h: one per device, process-wide)
     std::unique_ptr<AqlQueue> aql_queue;
     std::map<std::pair<int, long>, std::unique_ptr<AqlProgram>> aql_programs;
     AqlFences aql_fences;
@@ -880,7 +882,10 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             x_cur = bx, ssx_cur = bssx;
             continue;
         }
-        // (a layer outside the batched branch reads and writes the shared buffers: a per-layer batched step has none -- per_layer_b above)
+        // (a layer outside the batched branch reads and writes the shared buffers: a per-layer batched step has none -- per_layer_b above.
+        // The pre-check restates the branch's conditions; should the two ever diverge -- the row's sums of squares missing, say -- the step
+        // must not be captured as "written once": it would be replayed without cache maintenance over buffers written several times)
+        TL_REQUIRE(!per_layer_b, "engine: a layer fell out of the batched branch of a step planned on the per-layer buffers");
         xw = false;
         // this layer's hand-over buffers: the shared ones, or -- per-layer mode -- its own (written once per step)
         uint16_t *x_in = x_cur, *x_out = e->x, *hb = e->h, *xnb = e->xn, *qkvb = e->qkv, *attnb = e->attn, *actb = e->act;
@@ -1089,6 +1094,10 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
 
     auto *e = new tl_engine();
     e->cfg = c;
+    if (hipGetDevice(&e->device) != hipSuccess) {
+        delete e;
+        return fail(TL_ERR_HIP, "engine_create: hipGetDevice failed");
+    }
     e->layers.assign(layers, layers + c.num_layers);
     e->embed = *embed;
     if (lm_head) e->lm_head = *lm_head;
@@ -1217,10 +1226,11 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const char *aql_env = getenv("TL_AQL");
     if (aql_env == nullptr || atoi(aql_env) != 0) {
         {
-            AqlRuntime &rt = AqlRuntime::get();
+            AqlRuntime &rt = AqlRuntime::for_device(e->device);
+            e->aql_rt = &rt;
             std::string why;
             e->aql_queue = std::make_unique<AqlQueue>();
-            if (!rt.ensure_loaded(library_dir()) || !e->aql_queue->create(why)) {
+            if (!rt.ensure_loaded(library_dir()) || !e->aql_queue->create(rt, why)) {
                 e->aql_why = rt.ok() ? why : rt.why();
                 e->aql_queue.reset();
                 if (aql_env != nullptr) {
@@ -1936,6 +1946,11 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
     TL_REQUIRE(batch > 0 && batch <= e->cfg.max_batch, "engine_decode: batch out of range");
     TL_REQUIRE(steps >= 0, "engine_decode: steps must be nonnegative");
     if (steps == 0) return TL_OK;
+    {  // launches go to the CURRENT device's copy of a kernel, the AQL packets to the engine's own agent: both must be the engine's device
+        int dev_now = -1;
+        TL_HIP(hipGetDevice(&dev_now));
+        TL_REQUIRE(dev_now == e->device, "engine_decode: the current HIP device is not the device this engine was created on");
+    }
     const tl_engine_config &c = e->cfg;
     // input activations of the first step come from the pending token ids
     hipLaunchKernelGGL(embed_slots_kernel, dim3(batch), dim3(256), 0, e->stream, e->tokens, e->embed.weight_dev,
@@ -1992,7 +2007,7 @@ extern "C" int tl_engine_decode(tl_engine *e, int batch, int steps, int use_grap
                 if (ie == hipSuccess && e->aql_on && !e->step_written_once) e->aql_why = "a hand-over of this plan lives in a shared buffer (written more than once per step)";
                 if (ie == hipSuccess && e->aql_on && e->step_written_once) {  // the same nodes as packet templates (aql.h); a plan that cannot be built keeps the graph route
                     auto prog = std::make_unique<AqlProgram>();
-                    if (aql_program_from_graph(graph, e->stream, *prog, e->aql_why) == 0) e->aql_programs[key] = std::move(prog);
+                    if (aql_program_from_graph(*e->aql_rt, graph, e->stream, *prog, e->aql_why) == 0) e->aql_programs[key] = std::move(prog);
                 }
                 (void)hipGraphDestroy(graph);
                 if (ie != hipSuccess) return fail(TL_ERR_HIP, std::string("engine_decode: graph instantiate failed: ") + hipGetErrorString(ie));
