@@ -247,7 +247,8 @@ void tl_tiled_w4_destroy(tl_tiled_w4 *t);
 
 /* Which kernel a projection ran: 1 = fused MFMA GEMV (qmv3: p = MR, KS, CW, LM, workgroups), 2 = skinny MFMA matmul +
  * slice reduction (qmm3: p = MB, TW, LM, slices, tile groups), 3 = packed-dot GEMV fallback, 4 = prefill GEMM path,
- * 5 = register-resident batched matmul (qmm6: p = MB, groups per wave, weight sets, row blocks, workgroups). */
+ * 5 = register-resident batched matmul (qmm6: p = MB, groups per wave, weight sets, row blocks, workgroups),
+ * 6 = row-streaming batched matmul (qmm7: p = MB, groups per wave, tiles per workgroup, row blocks, workgroups). */
 typedef struct tl_linear_info {
     int kernel;
     int launches;
@@ -261,7 +262,8 @@ typedef struct tl_linear_info {
  *   2 SwiGLU over interleaved (gate_i, up_i) rows -> out [M, rows/2].
  *   kernel 0 = the routing of a single projection by M and matrix size, 1 = force the fused GEMV (M <= 8), 2 = force the skinny matmul
  *   (grid chosen by shape as the engine does), 3 / 4 = the skinny matmul on its one-shot / persistent grid, 5 = the register-resident
- *   matmul of a batched decode step (csrc/qmm6.h; prologue 0, or 3 through tl_decode_linear_ex).
+ *   matmul of a batched decode step (csrc/qmm6.h; prologue 0, or 3 through tl_decode_linear_ex), 6 = the row-streaming matmul
+ *   (csrc/qmm7.h; prologue 3 with epilogue 0 or 2 through tl_decode_linear_ex -- bit-identical to kernel 5 on the same inputs).
  * The engine uses the pairs (1,0) qkv / lm_head, (0,1) wo / w_down, (1,2) gate|up, (0,0) -- and at 5..64 rows, through kernel 5,
  * (3,0) qkv / lm_head, (0,1) + ss_out + out_w for wo / w_down, (3,2) gate|up: rows travel weighted between the projections. */
 size_t tl_decode_linear_workspace_bytes(int M, int rows, int cols);
@@ -322,6 +324,12 @@ int tl_decode_gemv_variant_compiled(int MR, int KS, int CW, int LM);
  * the kernel takes the shape.  tl_decode_batched_variant_compiled: 1 when the library holds a kernel for (row blocks, groups per wave). */
 int tl_decode_batched_plan(int M, int rows, int cols, int *out6);
 int tl_decode_batched_variant_compiled(int MB, int GPW);
+/* The row-streaming matmul of a batched decode step (csrc/qmm7.h; gate|up and qkv where its plan exists): M rows against [rows, cols]
+ * -> out4 = {16-row blocks, tiles per workgroup, quantisation groups per wave, workgroups}; returns 1 when the kernel takes the shape.
+ * tl_decode_streaming_variant_compiled: 1 when the library holds the kernels for (tiles per workgroup, groups per wave) -- each pair
+ * exists for 1 .. 4 row blocks and the store / SwiGLU epilogues. */
+int tl_decode_streaming_plan(int M, int rows, int cols, int *out4);
+int tl_decode_streaming_variant_compiled(int T, int GPW);
 int tl_decode_attention_plan(int batch, int max_context, int num_heads, int num_kv_heads, int *out3);
 
 typedef struct tl_attention_info {

@@ -1,5 +1,5 @@
 """CPU tier: the device-only code objects of the AQL replay route (csrc/aql.h) as the build leaves them next to the library --
-tl_kernels_{engine,qmv3,attn_mfma,qmm6,qmm3}.hsaco + tl_kernels.meta (tools/kernel_meta.py).  No GPU: the files are read with llvm-readelf /
+tl_kernels_{engine,qmv3,attn_mfma,qmm6,qmm7,qmm3}.hsaco + tl_kernels.meta (tools/kernel_meta.py).  No GPU: the files are read with llvm-readelf /
 llvm-objdump.  What the route relies on and a toolchain change could silently break:
   * every kernel a single-sequence decode step launches is in the code objects, under the name the HIP fat binary uses, with its
     explicit arguments and -- where it reads gridDim -- the code-object-v5 implicit block at the offsets csrc/aql.cpp fills;
@@ -19,7 +19,9 @@ LLVM = Path("/opt/rocm/lib/llvm/bin")
 STEP_KERNELS = ["qmv3_kernelILi1E", "attn_decode_fused_kernelILi8ELi4ELi1E", "attn_decode_mfma_kernel", "attn_merge_cols_kernel", "attn_merge_kernelILi",
                 "step_end_kernel",
                 # the batched-matmul step of 5 .. 64 sequences (round 5)
-                "qmm6_kernel", "qmm3_kernel", "qmm3_reduce_kernel", "weight_rows_kernel"]
+                "qmm6_kernel", "qmm3_kernel", "qmm3_reduce_kernel", "weight_rows_kernel",
+                # the row-streaming matmul of gate|up / qkv (round 6)
+                "qmm7_kernel"]
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +36,7 @@ def meta(built_libs):
 
 
 def test_code_objects_and_layouts_are_built(meta):
-    for name in ("engine", "qmv3", "attn_mfma", "qmm6", "qmm3"):
+    for name in ("engine", "qmv3", "attn_mfma", "qmm6", "qmm7", "qmm3"):
         assert (OUT / f"tl_kernels_{name}.hsaco").stat().st_size > 10_000
     for part in STEP_KERNELS:
         assert any(part in k for k in meta), f"no kernel matching {part} in tl_kernels.meta"
@@ -76,7 +78,7 @@ def test_the_code_objects_are_the_write_through_build(built_libs):
     assert loads and not any(" sc0 sc1" in l or " sc1" in l for l in loads), "loads stay plain: every hand-over address is written once per step"
     assert "flat_load" not in text and "flat_store" not in text, "no volatile accesses"
     # the batched-decode matmuls store through buffer resources: every buffer store of their code objects carries sc1
-    for obj, kern in (("qmm6", "qmm6_kernel"), ("qmm3", "qmm3_kernel")):
+    for obj, kern in (("qmm6", "qmm6_kernel"), ("qmm7", "qmm7_kernel"), ("qmm3", "qmm3_kernel")):
         a6 = subprocess.run([str(LLVM / "llvm-objdump"), "-d", "--mcpu=gfx950", str(OUT / f"tl_kernels_{obj}.hsaco")], check=True, capture_output=True, text=True).stdout
         bs = [l for l in a6.splitlines() if "buffer_store" in l]
         assert bs and all(" sc1" in l for l in bs), f"{kern}: a buffer store without sc1 in the write-through build"

@@ -166,6 +166,54 @@ def test_the_batched_planners_variant_predicate_is_the_instantiation_table(lib):
     assert table == {(1, 2), (1, 4), (1, 5), (1, 8), (1, 19), (2, 2), (2, 4), (2, 5), (2, 8), (4, 2), (4, 4), (4, 5)}
 
 
+def streaming_plan(lib, M, rows, cols):
+    out = (ctypes.c_int * 4)()
+    ok = lib.tl_decode_streaming_plan(M, rows, cols, out)
+    return ok, tuple(out)
+
+
+def test_row_streaming_matmul_plans_at_qwen3_4b_shapes(lib):
+    """csrc/qmm7.h (round 6): gate|up and qkv of a 2,560-wide model -- a workgroup owns T tiles, a wave 5 of the 20 groups; row blocks are
+    EXACTLY ceil(M / 16), 3 included (a 33-row step does not pay for 64); one workgroup per CU at most.  wo (4,096 columns: 8 groups per
+    wave), w_down (19) and lm_head (37 tiles per CU) stay with the register-resident / K-sliced kernels."""
+    for M in (5, 8, 9, 16, 17, 32, 33, 48, 49, 64):
+        for name, T in (("qkv", 2), ("gate_up", 5)):
+            rows, cols = QWEN3_4B[name]
+            ok, (MB, Tp, GPW, wgs) = streaming_plan(lib, M, rows, cols)
+            assert ok == 1 and (MB, Tp, GPW) == ((M + 15) // 16, T, 5), f"{name} at {M} rows: {(ok, MB, Tp, GPW)}"
+            assert wgs <= 256 and wgs * Tp >= rows // 16 > (wgs - 1) * Tp, f"{name} at {M} rows: {wgs} workgroups x {Tp} tiles for {rows // 16}"
+            assert lib.tl_decode_streaming_variant_compiled(Tp, GPW) == 1
+        for name in ("wo", "down", "lm_head"):
+            rows, cols = QWEN3_4B[name]
+            assert streaming_plan(lib, M, rows, cols)[0] == 0, f"{name} at {M} rows"
+    assert streaming_plan(lib, 65, 6144, 2560)[0] == 0 and streaming_plan(lib, 8, 100, 2560)[0] == 0 and streaming_plan(lib, 8, 2560, 100)[0] == 0
+
+
+@pytest.mark.parametrize("model", list(MODEL_SHAPES))
+def test_every_taken_streaming_plan_has_a_compiled_kernel(lib, model):
+    hidden, q_dim, qkv_dim, inter, vocab = MODEL_SHAPES[model]
+    projections = {"qkv": (qkv_dim, hidden), "wo": (hidden, q_dim), "gate_up": (2 * inter, hidden), "down": (hidden, inter), "lm_head": (vocab, hidden)}
+    for name, (rows, cols) in projections.items():
+        for M in (5, 8, 16, 17, 32, 33, 48, 64):
+            ok, (MB, T, GPW, wgs) = streaming_plan(lib, M, rows, cols)
+            if ok:
+                assert lib.tl_decode_streaming_variant_compiled(T, GPW) == 1, f"{model} {name} at {M} rows: {(T, GPW)} is taken but not compiled"
+                assert GPW * 4 >= (cols + 127) // 128 and 1 <= MB <= 4 and wgs * T >= rows // 16, f"{model} {name} at {M} rows"
+
+
+def test_the_streaming_planners_variant_predicate_is_the_instantiation_table(lib):
+    table = {(t, gpw) for t in range(1, 17) for gpw in range(1, 33) if lib.tl_decode_streaming_variant_compiled(t, gpw)}
+    assert table == {(2, 5), (5, 5)}
+    reached = set()
+    out = (ctypes.c_int * 4)()
+    for M in (5, 16, 17, 33, 64):
+        for G in range(1, 80):
+            for tiles in list(range(1, 64)) + [96, 128, 160, 192, 256, 320, 384, 512, 608, 640, 768, 1024, 1216, 1280, 2048, 4748, 9496]:
+                if lib.tl_decode_streaming_plan(M, tiles * 16, G * 128, out) == 1:
+                    reached.add(tuple(out)[1:3])
+    assert reached == table, f"planner reaches {sorted(reached)}, compiled {sorted(table)}"
+
+
 def test_every_compiled_gemv_variant_is_reached_by_some_shape(lib):
     """The other direction of the test above (round-4 review, item 8): an instantiation no planner rule selects is dead weight in the
     library (round 4 carried 98 GEMV combinations x 5 fused variants; 45 of the 98 could only be reached through lab-only overrides).

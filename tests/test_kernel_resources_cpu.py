@@ -65,7 +65,7 @@ def test_the_hot_kernels_are_in_the_library_with_the_expected_footprint():
     """The kernels the bench line runs through, by name: present, within the 512-register file of a gfx950 lane, static LDS
     under the 160 KiB of a CU (dynamic LDS is sized at launch and checked by the planners)."""
     kernels = {k["name"]: k for k in kernel_metadata()}
-    for tag in ("qmv3_kernelILi1E", "qmm3_kernelILi1E", "qmm3p_kernelILi4E", "qmm6_kernelILi4ELi5E", "qmm6_kernelILi1ELi5E", "attn_decode_fused_kernelILi8ELi4ELi1E",
+    for tag in ("qmv3_kernelILi1E", "qmm3_kernelILi1E", "qmm3p_kernelILi4E", "qmm6_kernelILi4ELi5E", "qmm6_kernelILi1ELi5E", "qmm7_kernelILi4ELi5ELi5E", "qmm7_kernelILi3ELi2ELi5E", "attn_decode_fused_kernelILi8ELi4ELi1E",
                 "attn_decode_fused_kernelILi8ELi4ELi4E", "paged_fa_bf16_d128_kernel", "qmm_mfma_kernel", "step_end_kernel"):
         found = [k for n, k in kernels.items() if tag in n]
         assert found, f"no kernel matching {tag}"

@@ -17,6 +17,7 @@
 #include "qmv3.h"
 #include "qmm3.h"
 #include "qmm6.h"
+#include "qmm7.h"
 #include "attn_mfma.h"
 #include "aql.h"
 
@@ -103,6 +104,10 @@ struct tl_engine {
     // 5 .. 64 rows: the register-resident matmul (qmm6.h) takes every projection whose plan fits; rows travel WEIGHTED between the
     // projections (qkv <- w_down / the embedding, gate|up <- wo).  TL_NO_QMM6=1 at create: the K-sliced skinny matmul as before.
     bool use_qmm6 = true;
+    // ... and, where its plan exists (round 6: gate|up and qkv of a 2,560-wide model), the row-streaming matmul (qmm7.h) instead of the
+    // register-resident one: the rows' arrival overlaps the walk, a step costs by its 16-row blocks (3 included).  force_qmm7: the
+    // kernel-level entry point asked for it by name (an error where it does not apply).
+    bool use_qmm7 = true, force_qmm7 = false;
     int attn_rq = 0;             // query heads per decode-attention workgroup; 0 = by context (TL_ATTN_RQ at create: 1 or 4)
     int attn_rq1_ctx = 4096;     // contexts up to this many tokens use one query head per workgroup
     int attn_rq1_batch = 2;      // ... and up to this many sequences; at 4 the re-read windows cost 261 vs 180 us
@@ -358,6 +363,13 @@ static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
 static bool qmm6_takes(const tl_engine *e, const tl_w4 &w, int M) {
     return e->use_qmm6 && e->force_linear == 0 && M >= e->qmm3_min_rows && M <= 64 && e->tiled.count(w.weight_dev) != 0 && qmm6_plan(M, w.cols, w.rows).ok;
 }
+// The weighted rows of a batched step (5 .. 64 rows) travel in fragment order (qmm6.h) from 9 rows -- and from 5 where the row-streaming
+// matmul (qmm7.h) is the consumer: ONE answer per (engine, batch) for every producer and consumer of a step.
+static bool rows_travel_in_fragment_order(const tl_engine *e, int batch) {
+    if (batch > 8) return true;
+    if (!e->use_qmm7 || e->layers.empty() || !e->layers[0].wgu.weight_dev) return false;
+    return qmm7_plan(batch, e->layers[0].wgu.cols, e->layers[0].wgu.rows).ok && qmm7_plan(batch, e->layers[0].wqkv.cols, e->layers[0].wqkv.rows).ok;
+}
 // One projection through qmm6: `a` plain rows, or (ss_in given) WEIGHTED rows whose 1 / rms scales the result.  EPI_RESIDUAL: ss_out
 // receives rows / 16 partial sums of squares per row, out_w the rows weighted for the next RMSNorm (norm_out).
 static int engine_qmm6(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int epi, const uint16_t *residual,
@@ -368,8 +380,11 @@ static int engine_qmm6(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
     if (ss_out_n) *ss_out_n = 0;
     const auto tiled = e->tiled.find(w.weight_dev);
     TL_REQUIRE(tiled != e->tiled.end(), "engine: the register-resident matmul needs the tiled weights");
-    const Qmm6Plan pl = qmm6_plan(M, w.cols, w.rows, frag && ss_in != nullptr && epi != EPI_RESIDUAL);
-    TL_REQUIRE(pl.ok, "engine: the register-resident matmul does not cover this shape");
+    const bool a_frag = frag && ss_in != nullptr && epi != EPI_RESIDUAL;
+    const Qmm7Plan p7 = (e->use_qmm7 || e->force_qmm7) && a_frag && out_w == nullptr ? qmm7_plan(M, w.cols, w.rows) : Qmm7Plan{};
+    TL_REQUIRE(p7.ok || !e->force_qmm7, "engine: the row-streaming matmul takes weighted rows in fragment order (store / SwiGLU) at the shapes of qmm7_plan");
+    const Qmm6Plan pl = qmm6_plan(M, w.cols, w.rows, a_frag);
+    TL_REQUIRE(p7.ok || pl.ok, "engine: the register-resident matmul does not cover this shape");
     Qmm6Args q{};
     q.wt = tiled->second.wt;
     q.sbt = tiled->second.sbt;
@@ -386,9 +401,22 @@ static int engine_qmm6(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
     q.N = w.cols;
     q.K = w.rows;
     q.prof = pc ? pc->buf : nullptr;
-    q.a_frag = frag && ss_in != nullptr && epi != EPI_RESIDUAL;
+    q.a_frag = a_frag;
     q.out_w_frag = (out_w_frag >= 0 ? out_w_frag != 0 : frag) && out_w != nullptr;
     int n_wg = 0;
+    if (p7.ok) {
+        if (launch_qmm7_bf16(q, epi, e->stream, &n_wg) != 0) return fail(TL_ERR_UNSUPPORTED, "engine: row-streaming matmul launch failed");
+        if (pc) prof_after(e, pc, kind, n_wg);
+        if (e->linfo) {
+            tl_linear_info &li = *e->linfo;
+            li.kernel = 6;
+            li.launches += 1;
+            li.rows_per_pass = p7.MB * 16;
+            li.p[0] = p7.MB, li.p[1] = p7.GPW, li.p[2] = p7.T, li.p[3] = p7.row_blocks, li.p[4] = n_wg;
+        }
+        TL_CHECK_LAUNCH("engine row-streaming matmul");
+        return TL_OK;
+    }
     if (launch_qmm6_bf16(q, epi, e->stream, &n_wg) != 0) return fail(TL_ERR_UNSUPPORTED, "engine: register-resident matmul launch failed");
     if (pc) prof_after(e, pc, kind, n_wg);
     if (ss_out_n && q.ss_out) *ss_out_n = w.rows / 16;
@@ -808,7 +836,8 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             // that differs most between boxes): wo up to 16 and from 33 rows (qkv: below).  Both kinds of producer leave x / h weighted AND plain.
             // the weighted rows travel in fragment order from 9 rows (same-box A/B, profiles/r04_labs/README.md: 16 / 32 / 64 sequences
             // -1.5 / -4 / -1.3 % per step; at 8 sequences +2 %: row-major there)
-            const bool frag = batch > 8;
+            // (round 6: from 5 rows wherever the row-streaming matmul takes the layer's gate|up -- it reads nothing else)
+            const bool frag = rows_travel_in_fragment_order(e, batch);
             // qkv on this kernel at every row count since round 5 (rows in fragment order from 9 rows): same-box A/B at 128-token contexts,
             // two alternating rounds, 24 / 32 / 48 / 64 sequences 1.91 / 1.95 / 2.56 / 2.69 -> 1.87 / 1.89 / 2.50 / 2.59 ms per step
             // (profiles/r05_labs/batched_qkv_on_qmm6_ab.log; round 4 had measured -1 ... -2.9 % on a fast box and left 17-64 rows on the sliced
@@ -939,7 +968,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
     e->want_tile_max = e->lm_tile_max_on;
     e->tile_max_rows = 0;
     const int head_rc = xw && qmm6_takes(e, e->head(), batch) && qmm3_takes_ss(x_ss)
-                            ? engine_qmm6(e, e->head(), bxw, e->logits, batch, EPI_STORE, nullptr, pc, 4, bssx, x_ss, nullptr, nullptr, nullptr, nullptr, batch > 8)
+                            ? engine_qmm6(e, e->head(), bxw, e->logits, batch, EPI_STORE, nullptr, pc, 4, bssx, x_ss, nullptr, nullptr, nullptr, nullptr, rows_travel_in_fragment_order(e, batch))
                             : engine_linear(e, e->head(), x_cur, e->logits, batch, PRO_RMSNORM, EPI_STORE, e->final_norm, nullptr, pc, 4,
                                             x_ss ? ssx_cur : nullptr, nullptr, nullptr, nullptr, x_ss);
     e->want_tile_max = false;
@@ -1217,6 +1246,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;
     e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
     e->use_qmm6 = getenv("TL_NO_QMM6") == nullptr;
+    e->use_qmm7 = getenv("TL_NO_QMM7") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
     read_attention_knobs(e);
     // Decode steps replay as AQL packets on the engine's own HSA queue (aql.h) unless TL_AQL=0: the same captured step, without the
@@ -2249,14 +2279,14 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
     TL_REQUIRE(prologue == PRO_ATTN_MERGE || a_dev, "decode_linear: null activation rows");
     TL_REQUIRE(prologue != PRO_RMSNORM || norm_w_dev, "decode_linear: the RMSNorm prologue needs its weight");
     TL_REQUIRE(epilogue != EPI_RESIDUAL || residual_dev, "decode_linear: the residual epilogue needs the residual rows");
-    TL_REQUIRE(kernel >= 0 && kernel <= 5,
-               "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV), 2 (skinny matmul), 3 / 4 (its one-shot / persistent grid), 5 (register-resident matmul)");
+    TL_REQUIRE(kernel >= 0 && kernel <= 6,
+               "decode_linear: kernel is 0 (engine routing), 1 (fused GEMV), 2 (skinny matmul), 3 / 4 (its one-shot / persistent grid), 5 (register-resident matmul), 6 (row-streaming matmul)");
     TL_REQUIRE(epilogue != EPI_SWIGLU || w->w.rows % 2 == 0, "decode_linear: SwiGLU needs an even number of weight rows");
     // the engine's own fused variants: RMSNorm+store (qkv, lm_head), residual (wo, w_down), RMSNorm+SwiGLU (gate|up), plain;
     // through tl_decode_linear_ex also: merged attention partials + residual (wo of one row), weighted rows + SwiGLU (gate|up)
     TL_REQUIRE((prologue == PRO_NONE && epilogue != EPI_SWIGLU) || (prologue == PRO_RMSNORM && epilogue != EPI_RESIDUAL) ||
                    (prologue == PRO_ATTN_MERGE && epilogue == EPI_RESIDUAL) || (prologue == PRO_RMS_WEIGHTED && epilogue == EPI_SWIGLU) ||
-                   (kernel == 5 && prologue == PRO_RMS_WEIGHTED && epilogue == EPI_STORE),
+                   ((kernel == 5 || kernel == 6) && prologue == PRO_RMS_WEIGHTED && epilogue == EPI_STORE),
                "decode_linear: no fused variant for this prologue / epilogue pair");
     const size_t need = tl_decode_linear_workspace_bytes(M, w->w.rows, w->w.cols);
     TL_REQUIRE(workspace_dev && workspace_bytes >= need, "decode_linear: workspace is missing or too small");
@@ -2268,7 +2298,8 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
     const size_t xn_bytes = align_up((size_t)((M + 15) / 16 * 16) * w->w.cols * 2, 256);
     e.splitk_ws = (char *)workspace_dev + xn_bytes;
     e.splitk_ws_bytes = workspace_bytes - xn_bytes;
-    e.force_linear = kernel >= 2 && kernel <= 4 ? 2 : (kernel == 5 ? 0 : kernel);
+    e.force_linear = kernel >= 2 && kernel <= 4 ? 2 : (kernel >= 5 ? 0 : kernel);
+    e.use_qmm7 = false, e.force_qmm7 = kernel == 6;  // 5 and 6 name their kernel
     e.qmm3_mode = kernel == 3 ? 0 : (kernel == 4 ? 1 : -1);
     tl_linear_info li{};
     e.linfo = &li;
@@ -2280,7 +2311,9 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
         if (info) *info = li;
         return code;
     };
-    if (kernel == 5) {  // qmm6.h: plain rows, or weighted rows with their partial sums of squares
+    if (kernel == 6 && (prologue != PRO_RMS_WEIGHTED || epilogue == EPI_RESIDUAL))
+        return done(fail(TL_ERR_INVALID, "decode_linear: the row-streaming matmul takes weighted rows with ss_in (prologue 3) and stores or applies SwiGLU (epilogue 0 / 2)"));
+    if (kernel == 5 || kernel == 6) {  // qmm6.h / qmm7.h: plain rows (qmm6 only), or weighted rows with their partial sums of squares
         const bool weighted = prologue == PRO_RMS_WEIGHTED;
         if (prologue == PRO_RMSNORM || prologue == PRO_ATTN_MERGE)
             return done(fail(TL_ERR_INVALID, "decode_linear: the register-resident matmul takes plain rows (prologue 0) or weighted rows with ss_in (prologue 3)"));
@@ -2288,8 +2321,10 @@ static int decode_linear_impl(const tl_tiled_w4 *w, const void *a_dev, void *out
             return done(fail(TL_ERR_INVALID, "decode_linear_ex: weighted rows need ss_in (a multiple of 4, at most 256 partials per row)"));
         if (ex && ((ex->out_w_dev != nullptr) != (ex->norm_out_dev != nullptr) || ((ex->out_w_dev || ex->ss_out_dev) && epilogue != EPI_RESIDUAL)))
             return done(fail(TL_ERR_INVALID, "decode_linear_ex: ss_out / (norm_out, out_w) belong to the residual epilogue; norm_out and out_w come together"));
-        if (!qmm6_plan(M, w->w.cols, w->w.rows).ok)
+        if (kernel == 5 && !qmm6_plan(M, w->w.cols, w->w.rows).ok)
             return done(fail(TL_ERR_UNSUPPORTED, "decode_linear: the register-resident matmul does not cover this shape"));
+        if (kernel == 6 && !qmm7_plan(M, w->w.cols, w->w.rows).ok)
+            return done(fail(TL_ERR_UNSUPPORTED, "decode_linear: the row-streaming matmul does not cover this shape"));
         // weighted rows enter the kernel in fragment order (qmm6.h): as the caller left them (ex->fragment_order), or re-ordered here
         const uint16_t *a6 = (const uint16_t *)a_dev;
         if (weighted && !ex->fragment_order) {
@@ -2451,6 +2486,13 @@ extern "C" int tl_decode_batched_plan(int M, int rows, int cols, int *out6) {
     return pl.ok ? 1 : 0;
 }
 extern "C" int tl_decode_batched_variant_compiled(int MB, int GPW) { return qmm6_variant_in_table(MB, GPW) ? 1 : 0; }
+extern "C" int tl_decode_streaming_plan(int M, int rows, int cols, int *out4) {
+    if (!out4 || M < 1 || rows <= 0 || cols <= 0) return 0;
+    const Qmm7Plan pl = qmm7_plan(M, cols, rows);
+    out4[0] = pl.MB, out4[1] = pl.T, out4[2] = pl.GPW, out4[3] = pl.wgs;
+    return pl.ok ? 1 : 0;
+}
+extern "C" int tl_decode_streaming_variant_compiled(int T, int GPW) { return qmm7_variant_in_table(T, GPW) ? 1 : 0; }
 extern "C" int tl_decode_attention_plan(int batch, int max_context, int num_heads, int num_kv_heads, int *out3) {
     if (!out3 || batch < 1 || max_context < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0) return 0;
     tl_engine e;

@@ -14,11 +14,17 @@ bool qmm7_variant_in_table(int T, int GPW) {
     return false;
 }
 
+#ifndef QM7_LAB_NB
+#define QM7_LAB_NB 0
+#endif
+#ifndef QM7_LAB_OCC
+#define QM7_LAB_OCC 1
+#endif
 template <int MB, int T, int GPW, int EPI>
 static int launch_one7(const Qmm6Args &a, const Qmm7Plan &pl, hipStream_t st) {
-    auto kern = qmm7_kernel<MB, T, GPW, EPI>;
+    auto kern = qmm7_kernel<MB, T, GPW, EPI, QM7_LAB_NB, QM7_LAB_OCC>;
     if (pl.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-    hipLaunchKernelGGL(kern, dim3(pl.wgs), dim3(QM7_WAVES * 64), pl.lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(pl.wgs, pl.row_blocks), dim3(QM7_WAVES * 64), pl.lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <int T, int GPW, int EPI>
@@ -44,8 +50,11 @@ int launch_qmm7_bf16(const Qmm6Args &args, int epi, hipStream_t st, int *n_wg) {
     if (!args.a_frag || !args.ss) return -1;  // weighted rows in fragment order, with their sums of squares
     if (args.ss_n <= 0 || args.ss_n > QM6_SS_MAX || args.ss_n % 4 != 0) return -1;
     if (args.out_w || args.ss_out || args.residual) return -1;
-    const Qmm7Plan pl = qmm7_plan(args.M, args.N, args.K);
+    Qmm7Plan pl = qmm7_plan(args.M, args.N, args.K);
     if (!pl.ok) return -1;
+#if QM7_LAB_OCC == 2  // lab: the step's row blocks in two halves, two workgroups per CU
+    if (pl.MB == 4 || pl.MB == 2) pl.MB /= 2, pl.row_blocks = 2, pl.lds = qmm7_lds_bytes(pl.MB, pl.T);
+#endif
     if (n_wg) *n_wg = pl.wgs;
     if (epi == EPI_STORE) return launch_variant7<EPI_STORE>(args, pl, st);
     if (epi == EPI_SWIGLU) return launch_variant7<EPI_SWIGLU>(args, pl, st);

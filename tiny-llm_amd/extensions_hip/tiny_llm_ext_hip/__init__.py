@@ -141,6 +141,8 @@ _SIGNATURES.update({
     "tl_decode_gemv_plan": (_c_int, [_c_int, _c_int, _c_int, _P(_c_int)]),
     "tl_decode_batched_plan": (_c_int, [_c_int, _c_int, _c_int, _P(_c_int)]),
     "tl_decode_batched_variant_compiled": (_c_int, [_c_int, _c_int]),
+    "tl_decode_streaming_plan": (_c_int, [_c_int, _c_int, _c_int, _P(_c_int)]),
+    "tl_decode_streaming_variant_compiled": (_c_int, [_c_int, _c_int]),
     "tl_decode_attention_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _P(_c_int)]),
     "tl_engine_destroy": (None, [_c_void_p]),
     "tl_engine_synchronize": (_c_int, [_c_void_p]),

@@ -19,7 +19,7 @@ for p in (ROOT, ROOT / "tiny-llm_amd", ROOT / "tiny-llm_amd" / "extensions_hip")
     sys.path.insert(0, str(p))
 
 KNOBS = ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS", "TL_QMM3_MIN_M", "TL_NO_QMM3", "TL_GEMM_FUSED_EPILOGUE", "TL_ATTN_QKV_PARTIALS",
-         "TL_LMHEAD_TILE_MAX", "TL_NO_QMM6", "TL_ATTN_MFMA")  # every knob the library still reads
+         "TL_LMHEAD_TILE_MAX", "TL_NO_QMM6", "TL_NO_QMM7", "TL_ATTN_MFMA")  # every knob the library still reads
 
 
 def main():

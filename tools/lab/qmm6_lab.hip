@@ -10,6 +10,7 @@
 #include <vector>
 #include "../../tiny-llm_amd/csrc/qmm3.h"
 #include "../../tiny-llm_amd/csrc/qmm6.h"
+#include "../../tiny-llm_amd/csrc/qmm7.h"
 using namespace tl;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 namespace tl { int fail(int c, const std::string &) { return c; } void set_error(const std::string &) {} }
@@ -74,6 +75,42 @@ int main(int argc, char **argv) {
         CK(hipEventElapsedTime(&ms3, e0, e1));
         printf("%-8s rows %2d  qmm6%s <MB %d GPW %2d sets %d> %3d x %d wg, %2d tiles each: %6.2f us   |   qmm3 + reduction (%d slices): %6.2f us\n", sh.name, M, frag ? " (fragment order)" : "", pl.MB, pl.GPW,
                pl.NSETS, pl.wgs, pl.row_blocks, pl.tiles_per_wg, ms6 * 1000.f / iters, p3.slices, ms3 * 1000.f / iters);
+        {   // the row-streaming matmul (qmm7.h) on the same inputs: time, and bit equality with the register-resident kernel's output
+            const Qmm7Plan p7 = qmm7_plan(M, N, K);
+            if (frag && p7.ok && epi != EPI_RESIDUAL) {
+                const size_t ob = (size_t)M * (epi == EPI_SWIGLU ? K / 2 : K) * 2;
+                std::vector<uint16_t> o6(ob / 2), o7(ob / 2);
+                mm6(0, nullptr); CK(hipDeviceSynchronize()); CK(hipMemcpy(o6.data(), out, ob, hipMemcpyDeviceToHost));
+                CK(hipMemset(out, 0xff, ob));
+                auto mm7 = [&](int i) {
+                    Qmm6Args q{}; q.wt = w + (size_t)(i % copies) * wwords; q.sbt = sb + (size_t)(i % copies) * swords; q.a = a; q.out = out; q.M = M; q.N = N; q.K = K; q.eps = 1e-6f;
+                    q.ss = ss; q.ss_n = 160; q.a_frag = 1;
+                    if (launch_qmm7_bf16(q, epi, 0) != 0) { printf("qmm7 launch failed\n"); exit(1); } };
+                mm7(0); CK(hipDeviceSynchronize()); CK(hipMemcpy(o7.data(), out, ob, hipMemcpyDeviceToHost));
+                size_t diff = 0; for (size_t i = 0; i < o6.size(); ++i) diff += o6[i] != o7[i];
+                float ms7;
+                for (int i = 0; i < 3; ++i) mm7(i);
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0, 0)); for (int i = 0; i < iters; ++i) mm7(i); CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+                CK(hipEventElapsedTime(&ms7, e0, e1));
+                printf("         qmm7 <MB %d T %d GPW %d> %3d wg: %6.2f us   (elements that differ from qmm6: %zu of %zu)\n", p7.MB, p7.T, p7.GPW, p7.wgs, ms7 * 1000.f / iters, diff, o6.size());
+#ifdef QMM7_TRACE
+                {
+                    const size_t nw7 = (size_t)p7.wgs * QM7_WAVES;
+                    unsigned long long *pb7 = nullptr; CK(hipMalloc(&pb7, nw7 * 16 * 8)); CK(hipMemset(pb7, 0, nw7 * 16 * 8));
+                    Qmm6Args q{}; q.wt = w; q.sbt = sb; q.a = a; q.out = out; q.M = M; q.N = N; q.K = K; q.eps = 1e-6f; q.ss = ss; q.ss_n = 160; q.a_frag = 1; q.prof = pb7;
+                    launch_qmm7_bf16(q, epi, 0); CK(hipDeviceSynchronize());
+                    std::vector<unsigned long long> hp(nw7 * 16); CK(hipMemcpy(hp.data(), pb7, nw7 * 16 * 8, hipMemcpyDeviceToHost));
+                    double sum[16] = {0}; size_t cnt[16] = {0}; unsigned long long tmin = ~0ull, tmax = 0, smax = 0;
+                    for (size_t i = 0; i < nw7; ++i) if (hp[i * 16]) { tmin = std::min(tmin, hp[i * 16]); smax = std::max(smax, hp[i * 16]); for (int k = 1; k < 14; ++k) { if (hp[i * 16 + k]) { sum[k] += (double)(hp[i * 16 + k] - hp[i * 16]); cnt[k]++; tmax = std::max(tmax, hp[i * 16 + k]); } } }
+                    printf("         qmm7 stamps: first wave start -> last stamp %.2f us, start spread %.2f us; mean us since the wave's start (requests out, groups 0.., met, stored):\n        ", (double)(tmax - tmin) * 1000.0 / rate, (double)(smax - tmin) * 1000.0 / rate);
+                    for (int k = 1; k < 14; ++k) if (cnt[k]) printf(" %5.2f", sum[k] / cnt[k] * 1000.0 / rate);
+                    printf("\n");
+                    CK(hipFree(pb7));
+                }
+#endif
+            }
+        }
 #ifdef QMM6_TRACE
         mm6(0, pb); CK(hipDeviceSynchronize());
         std::vector<unsigned long long> hp(nwaves * 16); CK(hipMemcpy(hp.data(), pb, nwaves * 16 * 8, hipMemcpyDeviceToHost));
