@@ -234,6 +234,25 @@ typedef struct tl_step_profile {
 } tl_step_profile;
 int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *out);
 
+/* Test aid for the AQL replay route's invariant (csrc/aql.h: inside a replayed step no cache is written back or invalidated between
+ * the launches, which is correct because every address one launch hands to a later launch of the step is WRITTEN ONCE PER STEP and
+ * read only after it).  Runs ONE real decode step eagerly -- the kernels and the state update of tl_engine_decode(e, batch, 1, 0) --
+ * with the per-layer hand-over buffers poisoned (every element a NaN) at the start and a checker behind every launch that compares
+ * the hand-over regions (the shared activations of the arena; the per-layer buffers) with a shadow copy, element by 2-byte element:
+ *   double_writes      elements a launch changed that an earlier launch of the step had already written (0 = the invariant holds for
+ *                      this plan); first_launch / first_kind (tl_step_profile's kinds) / first_region (0 shared, 1 per-layer) /
+ *                      first_offset (element index inside the region) name one offence of the earliest offending launch;
+ *   written_once_plan  1 when the plan uses the per-layer buffers throughout -- the only plans the engine replays as AQL packets;
+ *   a value read before the step wrote it is a NaN: the caller checks the logits (finite, and equal to an unchecked engine's).
+ * A rewrite of an element with the value it already holds is not seen (and cannot be read stale).  Synchronises. */
+typedef struct tl_step_check {
+    int launches, written_once_plan, n_splits;
+    long double_writes, elements_written;
+    int first_launch, first_kind, first_region;
+    long first_offset;
+} tl_step_check;
+int tl_engine_check_step(tl_engine *e, int batch, tl_step_check *out);
+
 /* ===== kernel-level entry points of the decode path ===========================================
  * The launch code the engine runs per projection and per layer, on caller-owned device buffers: what the operator
  * microbenches time (reference benches/bench_week2_operators.py:355-358, bench_week3_attention.py:74-77) and what the

@@ -16,7 +16,7 @@ sys.path.insert(0, str(ROOT / "tiny-llm_amd" / "extensions_hip"))
 PAIRS = {  # C struct -> ctypes class
     "tl_w4": "TlW4", "tl_layer_weights": "TlLayerWeights", "tl_moe_weights": "TlMoeWeights", "tl_engine_config": "TlEngineConfig",
     "tl_engine_stats": "TlEngineStats", "tl_step_profile": "TlStepProfile", "tl_linear_info": "TlLinearInfo",
-    "tl_attention_info": "TlAttentionInfo", "tl_linear_ex": "TlLinearEx",
+    "tl_attention_info": "TlAttentionInfo", "tl_linear_ex": "TlLinearEx", "tl_step_check": "TlStepCheck",
 }
 
 

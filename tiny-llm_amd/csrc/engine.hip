@@ -166,6 +166,18 @@ struct tl_engine {
     float *planes_now = nullptr;
     size_t planes_now_bytes = 0;
     bool step_written_once = false;  // the last enqueued step used the per-layer buffers throughout (enqueue_step)
+    // tl_engine_check_step (test-only): the hand-over regions -- [0] the shared activations of the arena, [1] the per-layer buffers -- with
+    // a shadow copy and one "written this step" byte per 2-byte element each, alive only inside the call
+    struct WrittenOnceCheck {
+        bool on = false;
+        char *region[2] = {nullptr, nullptr};
+        size_t bytes[2] = {0, 0};
+        uint32_t *shadow[2] = {nullptr, nullptr};
+        uint8_t *written[2] = {nullptr, nullptr};
+        unsigned long long *report = nullptr;
+    } check;
+    size_t arena_act_off = 0;        // where the activations start inside the arena (behind the state words)
+    size_t layer_act_bytes = 0;      // size of layer_act_mem
     // Qwen3-MoE layers (tl_engine_set_moe_layer): router + stacked experts instead of the dense gate|up / w_down of that layer
     std::vector<tl_moe_weights> moe;  // per layer; num_experts == 0: dense
     int moe_k_max = 0, moe_e_max = 0, moe_i_max = 0;
@@ -1007,6 +1019,11 @@ static void prof_after(tl_engine *e, ProfCtx *pc, int kind, int n_wg) {
     if (idx >= pc->cap) return;
     hipLaunchKernelGGL(prof_reduce_kernel, dim3(1), dim3(1024), 0, e->stream, pc->buf, n_wg, pc->pairs + 2 * (size_t)idx);
     pc->kinds.push_back(kind);
+    if (e->check.on)  // tl_engine_check_step: what this launch (and any unstamped one ahead of it) stored, against "written once per step"
+        for (int rg = 0; rg < 2; ++rg)
+            if (e->check.bytes[rg])
+                hipLaunchKernelGGL(written_once_check_kernel, dim3(1024), dim3(256), 0, e->stream, (const uint32_t *)e->check.region[rg], e->check.shadow[rg],
+                                   e->check.written[rg], e->check.bytes[rg] / 4, idx, rg, e->check.report);
 }
 
 // ---- page ownership: a page is shared by every sequence forked from a common prefix and returns to the free list when
@@ -1161,6 +1178,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const size_t o_sctx = carve(64);
     const size_t o_ptok = carve(R * 4);
     const size_t o_x = carve(R * c.hidden_size * 2);
+    e->arena_act_off = o_x;
     const size_t o_h = carve(R * c.hidden_size * 2);
     const size_t o_xn = carve((R + 15) / 16 * 16 * c.hidden_size * 2);  // weighted rows of a batched step lie in 16-row fragment blocks (qmm6.h)
     const size_t o_tmp = carve(R * c.hidden_size * 2);
@@ -1323,6 +1341,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
                     a.planes[1] = (float *)m;
                 }
                 e->layer_plane_bytes[0] = b_pl[0], e->layer_plane_bytes[1] = b_pl[1];
+                e->layer_act_bytes = per_layer * c.num_layers;
                 e->layer_act_rows = rows;
                 e->layer_ws_bytes = b_ws;
             }
@@ -2211,6 +2230,100 @@ extern "C" int tl_engine_profile_step(tl_engine *e, int batch, tl_step_profile *
     return TL_OK;
 }
 
+
+// One REAL decode step, launched eagerly like tl_engine_profile_step, with the written-once checker behind every launch (header).
+extern "C" int tl_engine_check_step(tl_engine *e, int batch, tl_step_check *out) {
+    TL_REQUIRE(e && out, "engine_check_step: null argument");
+    TL_REQUIRE(batch > 0 && batch <= e->cfg.max_batch, "engine_check_step: batch out of range");
+    const tl_engine_config &c = e->cfg;
+    *out = tl_step_check{};
+    out->first_launch = -1, out->first_kind = -1, out->first_region = -1, out->first_offset = -1;
+    TL_TRY(aql_drain(e));
+    TL_HIP(hipStreamSynchronize(e->stream));
+    tl_engine::WrittenOnceCheck &ck = e->check;
+    ck = tl_engine::WrittenOnceCheck{};
+    ck.region[0] = e->arena + e->arena_act_off, ck.bytes[0] = (e->arena_bytes - e->arena_act_off) / 4 * 4;
+    ck.region[1] = e->layer_act_mem, ck.bytes[1] = e->layer_act_mem ? e->layer_act_bytes / 4 * 4 : 0;
+    const int max_wg = std::max(c.vocab_size / 4 + 64, 64 * 4 * c.num_kv_heads * batch) + 1024;
+    ProfCtx pc;
+    pc.cap = c.num_layers * 12 + 8;
+    auto cleanup = [&]() {
+        for (int rg = 0; rg < 2; ++rg) {
+            if (ck.shadow[rg]) (void)hipFree(ck.shadow[rg]);
+            if (ck.written[rg]) (void)hipFree(ck.written[rg]);
+        }
+        if (ck.report) (void)hipFree(ck.report);
+        if (pc.buf) (void)hipFree(pc.buf);
+        if (pc.pairs) (void)hipFree(pc.pairs);
+        ck = tl_engine::WrittenOnceCheck{};
+    };
+    auto bail = [&](int code, const std::string &msg) {
+        (void)hipStreamSynchronize(e->stream);
+        cleanup();
+        return fail(code, msg);
+    };
+    bool ok = hipMalloc((void **)&pc.buf, (size_t)max_wg * 2 * sizeof(prof_t)) == hipSuccess && hipMalloc((void **)&pc.pairs, (size_t)pc.cap * 2 * sizeof(prof_t)) == hipSuccess &&
+              hipMalloc((void **)&ck.report, 8 * sizeof(unsigned long long)) == hipSuccess;
+    for (int rg = 0; rg < 2 && ok; ++rg)
+        if (ck.bytes[rg]) ok = hipMalloc((void **)&ck.shadow[rg], ck.bytes[rg]) == hipSuccess && hipMalloc((void **)&ck.written[rg], ck.bytes[rg] / 2) == hipSuccess;
+    if (!ok) return bail(TL_ERR_HIP, "engine_check_step: hipMalloc of the shadow buffers failed");
+    // the per-layer buffers start the step POISONED (every 16-bit and 32-bit pattern a NaN): a value read before this step wrote it
+    // reaches the logits as NaN; the shared activations carry state between steps (x, its sums of squares) and keep their contents
+    const unsigned long long report0[8] = {0, ~0ull, 0, 0, 0, 0, 0, 0};
+    ok = hipMemsetAsync(pc.buf, 0, (size_t)max_wg * 2 * sizeof(prof_t), e->stream) == hipSuccess &&
+         hipMemcpyAsync(ck.report, report0, sizeof(report0), hipMemcpyHostToDevice, e->stream) == hipSuccess;
+    if (ok && ck.bytes[1]) ok = hipMemsetAsync(ck.region[1], 0xff, ck.bytes[1], e->stream) == hipSuccess;
+    if (!ok) return bail(TL_ERR_HIP, "engine_check_step: initialisation failed");
+    hipLaunchKernelGGL(embed_slots_kernel, dim3(batch), dim3(256), 0, e->stream, e->tokens, e->embed.weight_dev,
+                       (const uint16_t *)e->embed.scales_dev, (const uint16_t *)e->embed.biases_dev, e->x, c.hidden_size,
+                       c.vocab_size, e->context_lens, e->rope_table, e->rope_cur, e->rope_positions, c.head_dim / 2, e->ss_x);
+    // the shadows = the regions as the step finds them; nothing written yet
+    for (int rg = 0; rg < 2 && ok; ++rg)
+        if (ck.bytes[rg]) ok = hipMemcpyAsync(ck.shadow[rg], ck.region[rg], ck.bytes[rg], hipMemcpyDeviceToDevice, e->stream) == hipSuccess &&
+                               hipMemsetAsync(ck.written[rg], 0, ck.bytes[rg] / 2, e->stream) == hipSuccess;
+    if (!ok) return bail(TL_ERR_HIP, "engine_check_step: shadow copy failed");
+    std::vector<std::pair<int32_t *, int32_t>> pk;
+    int max_ctx = 1;
+    int rc = reserve_step_locked(e, batch, pk, &max_ctx);
+    if (rc == TL_OK && !pk.empty()) rc = poke(e, pk);
+    const SplitPlan sp = pick_decode_splits(e, batch, max_ctx);
+    if (rc == TL_OK) {
+        ck.on = true;
+        rc = enqueue_step(e, batch, sp, &pc);
+        ck.on = false;
+    }
+    if (rc != TL_OK) {
+        (void)hipStreamSynchronize(e->stream);
+        cleanup();
+        return rc;
+    }
+    e->warmed = true;
+    for (int b = 0; b < batch; ++b) {
+        if (!e->slot_live[b]) continue;
+        e->slot_ctx[b] += 1;
+        e->slot_produced[b] += 1;
+    }
+    e->stats.decode_steps++;
+    e->logits_rows = batch;
+    unsigned long long report[8] = {0};
+    hipError_t he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = hipMemcpy(report, ck.report, sizeof(report), hipMemcpyDeviceToHost);
+    const std::vector<int> kinds = pc.kinds;
+    cleanup();
+    if (he != hipSuccess) return fail(TL_ERR_HIP, std::string("engine_check_step: ") + hipGetErrorString(he));
+    out->launches = (int)kinds.size();
+    out->written_once_plan = e->step_written_once ? 1 : 0;
+    out->n_splits = sp.n_splits;
+    out->double_writes = (long)report[0];
+    out->elements_written = (long)report[3];
+    if (report[0]) {
+        out->first_launch = (int)report[1];
+        out->first_kind = report[1] < kinds.size() ? kinds[report[1]] : -1;
+        out->first_region = (int)report[2];
+        out->first_offset = (long)report[4];
+    }
+    return TL_OK;
+}
 
 // ================================================================================================
 // Kernel-level entry points of the decode path (include/tinyllm_engine.h, last section): the SAME launch code the engine

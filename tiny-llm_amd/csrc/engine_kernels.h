@@ -905,6 +905,35 @@ static __global__ __launch_bounds__(1024) void argmax_rows_kernel(const uint16_t
     }
 }
 
+// tl_engine_check_step (test-only): what did the launch before this one store?  Compares a region of hand-over buffers word by word with
+// the shadow copy taken after the previous launch; a 2-byte element that changed was written by that launch -- a second write of the
+// step to the same element is counted (the AQL replay route reads these addresses without cache maintenance: "written once per step"
+// is what makes that correct, csrc/aql.h) -- and the shadow follows.  report: [0] double writes, [1] first offending launch (min),
+// [2] region of the first offence, [3] elements written, [4 .. 5] 64-bit element offset of one offence of the first offending launch.
+static __global__ __launch_bounds__(256) void written_once_check_kernel(const uint32_t *__restrict__ region, uint32_t *__restrict__ shadow,
+                                                                         uint8_t *__restrict__ written, size_t words, int launch_idx, int region_id,
+                                                                         unsigned long long *report) {
+    unsigned long long doubles = 0, fresh = 0, at = ~0ull;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) {
+        const uint32_t cur = region[i], old = shadow[i];
+        if (cur == old) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (((cur ^ old) >> (16 * h)) & 0xffffu) {
+                if (written[2 * i + h]) ++doubles, at = 2 * i + h;
+                else written[2 * i + h] = 1, ++fresh;
+            }
+        }
+        shadow[i] = cur;
+    }
+    if (fresh) atomicAdd(&report[3], fresh);
+    if (doubles) {
+        atomicAdd(&report[0], doubles);
+        const unsigned long long before = atomicMin(&report[1], (unsigned long long)launch_idx);
+        if ((unsigned long long)launch_idx <= before) report[2] = (unsigned long long)region_id, report[4] = at;
+    }
+}
+
 // (start, end) of one instrumented launch: min over workgroup starts, max over ends; clears the buffer.
 static __global__ __launch_bounds__(1024) void prof_reduce_kernel(prof_t *buf, int n_wg, prof_t *out_pair) {
     __shared__ prof_t s_min[16], s_max[16];

@@ -107,6 +107,12 @@ class TlStepProfile(ctypes.Structure):
                 ("span_us", ctypes.c_double), ("clock_khz", _c_int), ("n_splits", _c_int)]
 
 
+class TlStepCheck(ctypes.Structure):
+    _fields_ = [("launches", _c_int), ("written_once_plan", _c_int), ("n_splits", _c_int), ("double_writes", ctypes.c_long),
+                ("elements_written", ctypes.c_long), ("first_launch", _c_int), ("first_kind", _c_int), ("first_region", _c_int),
+                ("first_offset", ctypes.c_long)]
+
+
 class TlLinearInfo(ctypes.Structure):
     _fields_ = [("kernel", _c_int), ("launches", _c_int), ("rows_per_pass", _c_int), ("p", _c_int * 5)]
 
@@ -135,6 +141,7 @@ _SIGNATURES.update({
     "tl_decode_attention_fused": (_c_int, [_c_void_p] * 8 + [_c_int] * 6 + [_c_float, _c_float, _c_int, _c_void_p, _c_size_t,
                                                              _c_void_p, _P(TlAttentionInfo)]),
     "tl_engine_profile_step": (_c_int, [_c_void_p, _c_int, _P(TlStepProfile)]),
+    "tl_engine_check_step": (_c_int, [_c_void_p, _c_int, _P(TlStepCheck)]),
     "tl_engine_create": (_c_int, [_P(TlEngineConfig), _P(TlLayerWeights), _P(TlW4), _c_void_p, _P(TlW4), _c_void_p,
                                   _P(_c_void_p)]),
     "tl_engine_set_moe_layer": (_c_int, [_c_void_p, _c_int, _P(TlMoeWeights)]),

@@ -255,6 +255,12 @@ class DecodeEngine:
                                   "bytes": p.gemv_bytes[i] if i < 5 else 0.0}
         return out
 
+    def check_step(self, batch: int | None = None) -> dict:
+        """One real decode step with the written-once checker behind every launch (tl_engine_check_step; test aid of the AQL route)."""
+        c = _ext.TlStepCheck()
+        _ext.check(_lib.tl_engine_check_step(self._h, batch or self.max_batch, ctypes.byref(c)))
+        return {name: getattr(c, name) for name, _ in c._fields_}
+
     def replay_route(self) -> str:
         """"aql" (captured steps replay as AQL packets on the engine's own HSA queue) or "hipgraph: <why>" (include/tinyllm_engine.h)."""
         return (_lib.tl_engine_replay_route(self._h) or b"").decode()
