@@ -448,6 +448,21 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
         gpu_logits.append(engine.logits(1)[0].float().cpu().numpy())
     n_splits_checked = engine.profile_step(1)["n_splits"]  # the attention plan of the steps just checked (one more step, unchecked)
     engine.release(0)
+    # The same sample once more with the prompt prefilled the way the TIMED run prefills it -- whole chunks through the tile GEMM (rows > 8:
+    # quantize.py:54-65 -> quantized_matmul.metal:96-249, weights rounded to bf16 first, split-K partials in bf16) and the FlashAttention
+    # kernel -- so that the line's own check also covers the prefill kernels the timed numbers use (round-5 review).  Same truth; the
+    # reference-mandated extra roundings of that path sit in the cached K/V, so its distance is reported beside the matvec-form one, not
+    # folded into it.
+    gemm_chunk = max(int(getattr(engine, "timed_prefill_chunk", 0) or 0), 9)
+    gemm_logits = []
+    engine.begin(0)
+    engine.prefill(0, prompt, chunk=gemm_chunk)
+    gemm_logits.append(engine.logits(1)[0].float().cpu().numpy())
+    for s in range(truth_steps):
+        engine.set_token(0, cpu_ids[s])
+        engine.decode(1, batch=1)
+        gemm_logits.append(engine.logits(1)[0].float().cpu().numpy())
+    engine.release(0)
     worst, worst_logit = 0.0, 0.0
     for cl, gl in zip(cpu_logits, gpu_logits):
         worst = max(worst, float(np.abs(logsm(cl) - logsm(gl)).max()))
@@ -457,6 +472,8 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
     # the same comparison on a statistic that does not hang on ONE of 151,936 x steps logits: root mean square error over all of them
     rms_gpu = float(np.sqrt(np.mean([np.mean((np.asarray(g, np.float64) - t) ** 2) for g, t in zip(gpu_logits, truth_logits)])))
     rms_cpu = float(np.sqrt(np.mean([np.mean((np.asarray(c, np.float64) - t) ** 2) for c, t in zip(cpu_logits, truth_logits)])))
+    e_gemm = max(float(np.abs(np.asarray(g, np.float64) - t).max()) for g, t in zip(gemm_logits, truth_logits))
+    rms_gemm = float(np.sqrt(np.mean([np.mean((np.asarray(g, np.float64) - t) ** 2) for g, t in zip(gemm_logits, truth_logits)])))
     # greedy ids: the engine's choice must be the truth's argmax or lie within the engine's own measured error of it
     near, exact = 0, 0
     for gi, t in zip(gpu_ids, truth_logits):
@@ -476,6 +493,11 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
             "rms_logit_gpu_vs_truth": round(rms_gpu, 5), "rms_logit_cpu_vs_truth": round(rms_cpu, 5),
             "gpu_rms_error_over_cpu_rms_error": round(rms_gpu / rms_cpu, 3) if rms_cpu > 0 else None,
             "max_abs_logit_gpu_vs_cpu": round(worst_logit, 5), "gpu_vs_cpu_max_logprob_diff": round(worst, 4),
+            "gemm_prefill_sample": {"engine_prefill_rows_per_pass": min(gemm_chunk, sample_prompt), "steps": len(gemm_logits),
+                                    "what": "the same prompt prefilled in whole chunks (tile GEMM + FlashAttention: the timed run's prefill kernels), then the same teacher-forced steps",
+                                    "max_abs_logit_gpu_vs_truth": round(e_gemm, 5), "rms_logit_gpu_vs_truth": round(rms_gemm, 5),
+                                    "gpu_error_over_cpu_error": round(e_gemm / e_cpu, 3) if e_cpu > 0 else None,
+                                    "gpu_rms_error_over_cpu_rms_error": round(rms_gemm / rms_cpu, 3) if rms_cpu > 0 else None},
             "gpu_greedy_ids_vs_truth": f"{exact}/{len(truth_logits)} are the truth's argmax, {near}/{len(truth_logits)} within "
                                        f"2 x the engine's measured error of it"}
 
@@ -627,6 +649,119 @@ def extra_configs_leg(mlx_model, cfg: dict, device: str, seed: int, page: int = 
     return out
 
 
+def gpu_clocks(device_index: int = 0) -> dict:
+    """Shader / memory clock, power and power cap of one GPU as rocm-smi reports them NOW (one call, bounded at 10 s): read before and after
+    the timed region so that a box whose matrix-core-heavy legs run slow (profiles/README.md: the 64-sequence step measured 2.5 ms on
+    three boxes of the pool and 4.3-4.5 ms on two others with the same binaries) can be told from the line itself."""
+    import shutil
+    import subprocess
+
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        r = subprocess.run([exe, "-d", str(device_index), "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=10)
+        card = next(iter(json.loads(r.stdout).values()))
+        out = {}
+        for key, val in card.items():
+            k = key.lower()
+            mhz = "".join(ch for ch in str(val) if ch.isdigit())
+            if "sclk clock speed" in k: out["sclk_mhz"] = int(mhz) if mhz else val
+            elif "mclk clock speed" in k: out["mclk_mhz"] = int(mhz) if mhz else val
+            elif "fclk clock speed" in k: out["fclk_mhz"] = int(mhz) if mhz else val
+            elif "max graphics package power" in k: out["power_cap_w"] = float(val)
+            elif "power" in k and "(w)" in k and "max" not in k: out["power_w"] = float(val)
+            elif "performance level" in k: out["perf_level"] = val
+        return out or {"why": "rocm-smi --json returned no clock field", "keys": sorted(card)[:12]}
+    except Exception as exc:
+        return {"why": f"{type(exc).__name__}: {exc}"}
+
+
+def gpu_clocks_under_load(device: str, device_index: int) -> dict:
+    """The same reading while the GPU runs ~0.7 s of bf16 matrix products (torch.mm, enqueued first): the shader clock the matrix cores
+    actually get on THIS box -- an idle reading says 95 MHz on every box."""
+    import torch
+
+    try:
+        a = torch.randn((8192, 8192), dtype=torch.bfloat16, device=device)
+        b = torch.randn((8192, 8192), dtype=torch.bfloat16, device=device)
+        for _ in range(8):
+            c = a @ b
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(64):
+            c = a @ b
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t0) / 64
+        n = max(64, min(4096, int(1.2 / per)))
+        for _ in range(n):
+            c = a @ b
+        time.sleep(0.25)
+        out = gpu_clocks(device_index)
+        torch.cuda.synchronize()
+        del a, b, c
+        out["load"] = "torch.mm 8192^3 bf16, %.0f TFLOP/s" % (2 * 8192 ** 3 / per / 1e12)
+        return out
+    except Exception as exc:
+        return {"why": f"{type(exc).__name__}: {exc}"}
+
+
+def serving64_leg(mlx_model, cfg: dict, device: str, seed: int, page: int = 128) -> dict:
+    """BASELINE.json configs[3] on ONE GPU as the reference runs it (benches/bench.py:351-572 -> benches/serving.py): the reference's
+    serving trace scaled to 64 decode slots -- `--num-seqs 128 --batch-size 64`, 128-1,024 tokens in / 32-128 out, 128-token chunks,
+    seed 0 (book/src/appendix-performance.md:22-27,528-541) -- under the reference's admission rule (one chunk of one request per turn)
+    and under the 2,048-token admission budget with 8 staging slots (one packed multi-token pass per turn).  GPU only, after the timed
+    region; one engine for both; a complete-request warm-up of 32 requests first (graph captures of every row bucket)."""
+    import torch
+    from random import Random
+
+    from benches.bench import build_requests
+    from benches.serving import serve_requests, nearest_rank, median
+    from tiny_llm_hip.engine import DecodeEngine
+
+    B, staging = 64, 8
+    trace = build_requests(rng=Random(0), num_seqs=128, vocab_size=cfg["vocab_size"], eos_token_id=cfg["vocab_size"] - 1,
+                           min_input_len=128, max_input_len=1024, min_output_len=32, max_output_len=128)
+    longest = max(len(r.prompt_token_ids) + r.max_new_tokens for r in trace)
+    pages_per_seq = (longest + page - 1) // page + 1
+    slots = B + staging
+    kv_page_bytes = 2 * cfg["num_hidden_layers"] * cfg["num_key_value_heads"] * page * cfg["head_dim"] * 2
+    out = {"requests": len(trace), "decode_slots": B, "prompt_tokens": sum(len(r.prompt_token_ids) for r in trace),
+           "shape": "128-1,024 tokens in / 32-128 out, 128-token chunks, seed 0 (the reference's serving trace at 64 slots)"}
+    eng = None
+    try:
+        eng = DecodeEngine(mlx_model, page_size=page, num_pages=pages_per_seq * slots + 2, max_batch=slots, max_pages_per_seq=pages_per_seq,
+                           max_prefill_rows=2048)
+        for name, kw in (("reference_admission", dict(prefill_step=128, prefill_budget=128, staging_slots=1)),
+                         ("budget_2048", dict(prefill_step=512, prefill_budget=2048, staging_slots=staging))):
+            def run(reqs):
+                return serve_requests(eng, reqs, batch_size=B, page_size=page, kv_bytes_per_page=kv_page_bytes, capacity_pages=pages_per_seq * slots + 2, **kw)
+            run(trace[:32])
+            eng.synchronize()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m = run(trace)
+            eng.synchronize()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            steps = m.decode_step_ms
+            out[name] = {"admission": "one 128-token chunk of one request per turn (batch.py:48-76)" if name == "reference_admission"
+                                      else "up to 2,048 prompt tokens per turn over 8 staging slots, one packed pass",
+                         "wall_s": round(wall, 3), "output_tok_s": round(m.generated_tokens / wall, 1),
+                         "total_tok_s": round((out["prompt_tokens"] + m.generated_tokens) / wall, 1),
+                         "decode_tok_s": round(m.decode_tokens / m.decode_time, 1) if m.decode_time else None,
+                         "prefill_tok_s": round(out["prompt_tokens"] / m.prefill_time, 1) if m.prefill_time else None,
+                         "req_s": round(len(trace) / wall, 2), "step_p50_ms": round(median(steps), 3) if steps else None,
+                         "step_p95_ms": round(nearest_rank(steps, 0.95), 3) if steps else None, "decode_steps": m.decode_step_count,
+                         "peak_active_requests": m.peak_active_requests,
+                         "decode_bytes_per_step": int(m.decode_bytes / m.decode_step_count) if m.decode_step_count else None}
+    except Exception as exc:
+        out["why"] = f"{type(exc).__name__}: {exc}"
+    finally:
+        if eng is not None:
+            eng.close()
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -715,6 +850,7 @@ def main() -> None:
                               max_prefill_rows=max(args.prefill_step, 8))
     prompt = build_prompt(random.Random(args.seed * 1000 + rank), args.prompt_len, cfg["vocab_size"])
     use_graph = not args.no_graph
+    engine.timed_prefill_chunk = args.prefill_step  # cpu_baseline_leg checks a second sample prefilled at this chunk size
 
     def sync():
         engine.synchronize()
@@ -733,19 +869,28 @@ def main() -> None:
     engine.decode(max(args.warmup, 2), batch=1, use_graph=use_graph)  # >= 2: eager warm step + graph capture
     sync()
     bytes_first = engine.step_bytes(1)
+    clocks = None if dry else {"before": gpu_clocks(local_rank)}
     progress("timed region")
     elapsed, local_elapsed = timed_steps(lambda k: engine.decode(k, batch=1, use_graph=use_graph), sync, args.steps, dist, device)
     bytes_last = engine.step_bytes(1)
+    if clocks is not None:
+        clocks["after"] = gpu_clocks(local_rank)
+        if rank == 0:
+            clocks["under_matmul_load"] = gpu_clocks_under_load(device, local_rank)
+    route_here = engine.replay_route() if hasattr(engine, "replay_route") else "none"
     per_rank = None
     if dist is not None:  # every rank's own clock over the timed region (one all_gather AFTER it): a straggler GPU shows here
-        t = torch.tensor([local_elapsed], dtype=torch.float64, device=device)
+        # ... and every rank's replay route: a rank that fell back to hipGraphLaunch (no code objects, no HSA agent for its device) is slower
+        # by ~6 % and would otherwise show only as a slower entry (1 = AQL packets, 0 = anything else)
+        t = torch.tensor([local_elapsed, 1.0 if route_here == "aql" else (0.0 if route_here.startswith("hipgraph") else -1.0)], dtype=torch.float64, device=device)
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
-        secs = [float(g.item()) for g in gathered]
+        secs = [float(g[0].item()) for g in gathered]
         rates = [args.steps / x for x in secs]
         per_rank = {"ms_per_step": [round(x * 1e3 / args.steps, 4) for x in secs], "tokens_per_s": [round(r, 2) for r in rates],
                     "min_tokens_per_s": round(min(rates), 2), "max_tokens_per_s": round(max(rates), 2),
-                    "slowest_rank": int(max(range(world), key=lambda i: secs[i]))}
+                    "slowest_rank": int(max(range(world), key=lambda i: secs[i])),
+                    "replay_route": [{1.0: "aql", 0.0: "hipgraph"}.get(float(g[1].item()), "none") for g in gathered]}
     ids = engine.read_tokens(0, 8)
 
     # ---- roofline leg: per-kernel device-clock durations of real decode steps (not part of the timed region)
@@ -875,7 +1020,13 @@ def main() -> None:
     if args.gpus == 1 and not dry and args.config == 2 and not args.no_extra_configs:
         progress("extra configs: 8k, 32k, 64 sequences")
         extra = extra_configs_leg(mlx_model, cfg, device, args.seed, page)
-        progress("extra configs done")
+        progress("extra configs done; serving trace at 64 slots")
+        try:
+            with time_box(90):
+                extra["serving64"] = serving64_leg(mlx_model, cfg, device, args.seed, page)
+        except Exception as exc:
+            extra["serving64"] = {"why": f"{type(exc).__name__}: {exc}"}
+        progress("serving trace done")
 
     cpu = None
     if args.gpus == 1 and not args.no_cpu_baseline:
@@ -946,6 +1097,7 @@ def main() -> None:
         "roofline": roofline,
         "cpu_baseline": cpu,
         "extra_configs": extra,
+        "clocks": clocks,
         "engine": dict({k: stats[k] for k in ("graph_captures", "graph_replays", "decode_steps", "kv_bytes")}, aql_steps=stats.get("aql_steps"),
                        replay_route=replay_route),
         "first_ids": ids,

@@ -89,6 +89,9 @@ def test_load_reproduces_every_tensor(tmp_path, weights, shards):
     (lambda cfg, path: cfg.update(num_hidden_layers=3), "model.layers.2"),
     (lambda cfg, path: cfg.update(intermediate_size=1024), "do not describe"),
     (lambda cfg, path: cfg.pop("rms_norm_eps"), "lacks"),
+    # scaled RoPE variants are refused even when a converter has hoisted rope_theta to the top level (round-5 review)
+    (lambda cfg, path: cfg.update(rope_theta=1e6, rope_parameters={"rope_theta": 1e6, "rope_type": "yarn", "factor": 4.0}), "rope_type='yarn'"),
+    (lambda cfg, path: cfg.update(rope_theta=1e6, rope_scaling={"type": "linear", "factor": 2.0}), "rope_scaling"),
 ])
 def test_load_rejects_what_the_hot_path_cannot_run(tmp_path, weights, mutate, message):
     loader = _loader()

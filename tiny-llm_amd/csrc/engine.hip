@@ -1490,6 +1490,16 @@ extern "C" int tl_engine_set_moe_layer(tl_engine *e, int layer, const tl_moe_wei
         e->stats.workspace_bytes = e->arena_bytes + e->tiled_bytes + e->moe_ws_bytes;
     }
     e->moe[layer] = *w;
+    // a model with a sparse layer never takes the per-layer decode buffers (enqueue_step: its steps stay on the shared buffers and the
+    // hipGraph route): give the 17 MB per layer back (nothing captured holds them yet -- checked above)
+    if (e->layer_act_mem) {
+        TL_HIP(hipStreamSynchronize(e->stream));
+        (void)hipFree(e->layer_act_mem);
+        e->layer_act_mem = nullptr;
+        e->layer_act.clear();
+        e->layer_act_rows = 0, e->layer_act_bytes = 0, e->layer_ws_bytes = 0;
+        e->layer_plane_bytes[0] = e->layer_plane_bytes[1] = 0;
+    }
     return TL_OK;
 }
 

@@ -101,14 +101,17 @@ def load_weights(model_dir: str | Path, device: str = "cuda") -> SimpleNamespace
         raise ValueError(f"config.json lacks {missing}")
     group_size, bits = _quantization(config)
     config.setdefault("head_dim", config["hidden_size"] // config["num_attention_heads"])
-    if "rope_theta" not in config:
-        # transformers >= 5 writes {"rope_parameters": {"rope_theta": ..., "rope_type": "default"}} instead of the top-level key mlx_lm's
-        # ModelArgs (and the reference, qwen3_week3.py:230) reads; a scaled variant (yarn, ...) is not what the hot path computes
-        rp = config.get("rope_parameters")
-        if isinstance(rp, dict) and "rope_theta" in rp:
-            if rp.get("rope_type", "default") not in ("default", None):
-                raise ValueError(f"unsupported rope_parameters.rope_type={rp.get('rope_type')!r}: only plain RoPE is supported")
-            config["rope_theta"] = rp["rope_theta"]
+    # Only plain RoPE is what the hot path computes (reference qwen3_week3.py:230: theta alone): a scaled variant -- transformers >= 5's
+    # {"rope_parameters": {"rope_type": "yarn" | "linear" | ...}} or the legacy {"rope_scaling": {...}} -- is refused whether or not a
+    # top-level rope_theta is present (a converter may have hoisted it), instead of loading silently as plain RoPE
+    rp = config.get("rope_parameters")
+    if isinstance(rp, dict) and rp.get("rope_type", "default") not in ("default", None):
+        raise ValueError(f"unsupported rope_parameters.rope_type={rp.get('rope_type')!r}: only plain RoPE is supported")
+    rs = config.get("rope_scaling")
+    if isinstance(rs, dict) and (rs.get("rope_type") or rs.get("type") or "default") != "default":
+        raise ValueError(f"unsupported rope_scaling={rs!r}: only plain RoPE is supported")
+    if "rope_theta" not in config and isinstance(rp, dict) and "rope_theta" in rp:
+        config["rope_theta"] = rp["rope_theta"]  # transformers >= 5 nests it; mlx_lm's ModelArgs (and the reference) read the top-level key
     config.setdefault("rope_theta", 1000000)
     config.setdefault("tie_word_embeddings", True)
     config.setdefault("max_position_embeddings", 40960)

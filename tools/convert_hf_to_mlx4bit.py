@@ -67,6 +67,11 @@ def convert(src: Path, dst: Path, group_size: int = 128, shards: int = 1) -> dic
             report["copied"].append(name)
     config = dict(config, quantization={"group_size": group_size, "bits": 4})
     rp = config.get("rope_parameters")
+    if isinstance(rp, dict) and rp.get("rope_type", "default") not in ("default", None):
+        raise ValueError(f"rope_parameters.rope_type={rp.get('rope_type')!r}: the loader (and the reference, qwen3_week3.py:230) compute plain RoPE only")
+    rs = config.get("rope_scaling")
+    if isinstance(rs, dict) and (rs.get("rope_type") or rs.get("type") or "default") != "default":
+        raise ValueError(f"rope_scaling={rs!r}: the loader (and the reference) compute plain RoPE only")
     if "rope_theta" not in config and isinstance(rp, dict) and "rope_theta" in rp:
         config["rope_theta"] = rp["rope_theta"]  # transformers >= 5 nests it; mlx_lm's ModelArgs (the reference's loader) reads the top-level key
     (dst / "config.json").write_text(json.dumps(config, indent=1))
