@@ -118,6 +118,14 @@ int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weights *layers
  * MLP runs as the reference's op sequence inside the captured step: RMSNorm, router GEMV, route kernel, gathered gate and up
  * GEMVs (one launch each, an expert per row), SiLU x up, gathered down GEMV, weighted sum + residual. */
 int tl_engine_set_moe_layer(tl_engine *e, int layer, const tl_moe_weights *w);
+/* Test / lab hook: switch a route that has an A/B twin, per engine, before its first prefill / decode (an error afterwards: captured
+ * steps hold the routes they were captured with).  value 0 = off, anything else = on.  Options (defaults in brackets):
+ *   "qmm3" [1] rows > 8 of a decode step on the K-sliced skinny matmul (0: the prefill GEMM's op sequence);  "qmm6" [1] the
+ *   register-resident batched matmul (0: the K-sliced one everywhere);  "qmm7" [1] the row-streaming matmul for gate|up / qkv (0: qmm6);
+ *   "attn_qkv_partials" [1] the decode attention adds the qkv slice planes itself;  "lmhead_tile_max" [1] per-tile maxima from the lm_head
+ *   GEMV;  "gemm_fused_epilogue" [1] residual / SwiGLU inside the prefill GEMM;  "aql_fences" [0] HIP's agent-scope fences back on every
+ *   packet of the AQL route.  Not part of the reference's surface: product code never calls it. */
+int tl_engine_set_option(tl_engine *e, const char *name, int value);
 void tl_engine_destroy(tl_engine *e);
 /* Block the host until everything enqueued on the engine stream has finished. */
 int tl_engine_synchronize(tl_engine *e);

@@ -329,16 +329,16 @@ def test_batched_decode_skinny_matmul_matches_solo(ckpt, err, monkeypatch, n_seq
     """9..64 decode rows run the K-sliced skinny MFMA matmul (csrc/qmm3.h): the GEMV's algebraic form (reference
     quantized_matmul.metal:510-521) with the slices summed in fp32, so a sequence must decode to (nearly) the same
     logits alone and in a batch -- the band of two HIP paths that share every rounding point."""
-    monkeypatch.delenv("TL_NO_QMM3", raising=False)
+    monkeypatch.delenv("TL_ENGINE_OPTIONS", raising=False)
     got, solo = _solo_vs_batch(ckpt[1], n_seq)
     assert float(np.abs(got - solo).max()) <= err["hip_vs_hip"]
 
 
 def test_batched_decode_reference_gemm_path(ckpt, err, monkeypatch):
-    """TL_NO_QMM3=1: more than 8 decode rows go through RMSNorm + W4 MFMA GEMM + SwiGLU/residual kernels (reference
+    """Engine option "qmm3" = 0: more than 8 decode rows go through RMSNorm + W4 MFMA GEMM + SwiGLU/residual kernels (reference
     quantize.py:54-65 sends rows > 8 to the matmul path, whose weights are rounded to bf16 first): logits within
     1.5 x (E of the GEMV oracle + E of the all-GEMM oracle) of solo decoding, both E measured against the float64 truth."""
-    monkeypatch.setenv("TL_NO_QMM3", "1")
+    monkeypatch.setenv("TL_ENGINE_OPTIONS", "qmm3=0")  # (tl_engine_set_option through the host mirror)
     got, solo = _solo_vs_batch(ckpt[1], 12)
     assert float(np.abs(got - solo).max()) <= err["gemv_vs_gemm"]
 
@@ -650,7 +650,7 @@ def test_packed_prefill_of_several_slots(ckpt, err):
 @pytest.mark.parametrize("n_prompt,rows", [(300, 512), (77, 80), (40, 64), (600, 256)])
 def test_prefill_gemm_fused_epilogue_is_bit_identical(ckpt, monkeypatch, n_prompt, rows, wide):
     """Residual add / SwiGLU folded into the prefill GEMM's store (unsplit reduction) or into its split-K reduction
-    (csrc/qmm.hip qmm_bf16_epilogue) against the separate elementwise launches (TL_GEMM_FUSED_EPILOGUE=0): the epilogue is
+    (csrc/qmm.hip qmm_bf16_epilogue) against the separate elementwise launches (engine option "gemm_fused_epilogue" = 0): the epilogue is
     applied to the same bf16-rounded matmul result with the same expressions, so every logit must be IDENTICAL -- over chunk
     lengths that exercise row tiles of 32 / 64 / 128 and both the split and the unsplit reduction."""
     if wide:
@@ -658,8 +658,8 @@ def test_prefill_gemm_fused_epilogue_is_bit_identical(ckpt, monkeypatch, n_promp
     else:
         cfg, model = TINY_CFG, ckpt[1]
     prompt = [int(t) for t in np.random.default_rng(n_prompt).integers(1, cfg["vocab_size"], size=n_prompt)]
-    monkeypatch.setenv("TL_GEMM_FUSED_EPILOGUE", "0")
+    monkeypatch.setenv("TL_ENGINE_OPTIONS", "gemm_fused_epilogue=0")
     separate = _prefill_logits(model, prompt, rows)
-    monkeypatch.setenv("TL_GEMM_FUSED_EPILOGUE", "1")
+    monkeypatch.setenv("TL_ENGINE_OPTIONS", "gemm_fused_epilogue=1")
     fused = _prefill_logits(model, prompt, rows)
     assert np.array_equal(separate, fused), f"{int((separate != fused).sum())} logits differ, max {np.abs(separate - fused).max()}"

@@ -177,7 +177,7 @@ def test_greedy_ids_from_tile_maxima_equal_the_full_argmax(model_and_weights, n_
     """Round 4: the lm_head GEMV leaves, per 16-logit tile, the largest stored bf16 logit and the lowest index holding it, and
     step_end_kernel picks the greedy id from those 9,496 pairs instead of re-reading 151,936 logits.  Same rule as mx.argmax over
     the row (first maximum wins, reference benches/bench.py:234-243): on the FLAT checkpoint, where exact ties between bf16 logits
-    do occur, the ids and the logits of 12 steps must be identical with the route on and off (TL_LMHEAD_TILE_MAX)."""
+    do occur, the ids and the logits of 12 steps must be identical with the route on and off (engine option "lmhead_tile_max")."""
     from tiny_llm_hip.engine import DecodeEngine
 
     model, _ = model_and_weights
@@ -185,7 +185,7 @@ def test_greedy_ids_from_tile_maxima_equal_the_full_argmax(model_and_weights, n_
     prompts = [[int(t) for t in rng.integers(256, CFG["vocab_size"], size=20 + 7 * i)] for i in range(n_seq)]
     runs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("TL_LMHEAD_TILE_MAX", flag)
+        monkeypatch.setenv("TL_ENGINE_OPTIONS", f"lmhead_tile_max={flag}")
         eng = DecodeEngine(model, page_size=128, num_pages=n_seq + 2, max_batch=n_seq, max_prefill_rows=64)
         try:
             for i, p in enumerate(prompts):

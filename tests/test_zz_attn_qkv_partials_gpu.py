@@ -1,6 +1,6 @@
-"""GPU tier (collected last): the default route wherever the qkv projection of a batched step runs on the K-sliced matmul (TL_ATTN_QKV_PARTIALS=0 turns it
+"""GPU tier (collected last): the default route wherever the qkv projection of a batched step runs on the K-sliced matmul (engine option "attn_qkv_partials" = 0 turns it
 off) -- 5..64 rows of any model whose shapes the register-resident matmul of csrc/qmm6.h does not take, and of every model with that kernel switched
-off (TL_NO_QMM6=1: the Qwen3-4B-shape cases below; since round 5 qmm6 takes qkv at every row count there and leaves no slices): the qkv projection's slice-reduction launch is
+off (engine option "qmm6" = 0: the Qwen3-4B-shape cases below; since round 5 qmm6 takes qkv at every row count there and leaves no slices): the qkv projection's slice-reduction launch is
 dropped and the decode-attention kernel adds the skinny matmul's fp32 slice partials itself (csrc/engine_kernels.h, QP; csrc/engine.hip
 engine_linear `keep`).  The kernel adds the slices in the reduction kernel's order and rounds once like it, so the two routes must
 agree BIT FOR BIT: same greedy tokens, same final logits, over several decode steps (the appended K/V rows feed later steps).
@@ -18,7 +18,7 @@ from helpers import QWEN4B_CFG, TINY_CFG, to_mlx_shaped
 from oracle import tiny_oracle as O
 
 # All cases have run on the device (round 3: profiles/r03_labs/opt_in_route_tests_first_run.log); the route is the default now,
-# and TL_ATTN_QKV_PARTIALS=0 is the route with the reduction launch it is compared with.
+# and option "attn_qkv_partials" = 0 is the route with the reduction launch it is compared with.
 pytestmark = [pytest.mark.gpu]
 
 
@@ -27,20 +27,12 @@ def run(model, cfg, n_seq, steps, page_size, partials, profile=False, prompt_bas
 
     rng = np.random.default_rng(500 + n_seq)
     prompts = [[int(t) for t in rng.integers(1, cfg["vocab_size"], size=prompt_base + (7 * i) % prompt_spread)] for i in range(n_seq)]
-    old = os.environ.pop("TL_ATTN_QKV_PARTIALS", None)
-    old6 = os.environ.pop("TL_NO_QMM6", None)
-    os.environ["TL_ATTN_QKV_PARTIALS"] = "1" if partials else "0"  # read when the engine is created (default since round 3: 1)
+    # routes with a twin are engine options (tl_engine_set_option): the attention kernel adding the qkv slice planes itself (default since
+    # round 3) against the reduction launch; qmm6 = 0 is the K-sliced route of rounds 2-3, where qkv leaves fp32 slice planes
+    options = {"attn_qkv_partials": 1 if partials else 0}
     if no_qmm6:
-        os.environ["TL_NO_QMM6"] = "1"  # the K-sliced route of rounds 2-3: qkv leaves fp32 slice planes
-    try:
-        eng = DecodeEngine(model, page_size=page_size, num_pages=n_seq * 3 + 2, max_batch=n_seq, max_prefill_rows=32)
-    finally:
-        os.environ.pop("TL_ATTN_QKV_PARTIALS", None)
-        os.environ.pop("TL_NO_QMM6", None)
-        if old is not None:
-            os.environ["TL_ATTN_QKV_PARTIALS"] = old
-        if old6 is not None:
-            os.environ["TL_NO_QMM6"] = old6
+        options["qmm6"] = 0
+    eng = DecodeEngine(model, page_size=page_size, num_pages=n_seq * 3 + 2, max_batch=n_seq, max_prefill_rows=32, options=options)
     try:
         for i, p in enumerate(prompts):
             eng.begin(i)

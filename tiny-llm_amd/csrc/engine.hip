@@ -73,14 +73,14 @@ struct tl_engine {
     float *attn_ws = nullptr;
     int last_attn_launches = 0;
     // lm_head GEMV of a 1-4-row decode step: per 16-logit tile (max, lowest index) pairs for step_end_kernel (qmv3.h tile_max);
-    // TL_LMHEAD_TILE_MAX=0: step_end reads the logits row again
+    // tl_engine_set_option "lmhead_tile_max" = 0: step_end reads the logits row again
     f32x2 *lm_tile_max = nullptr;            // [8][vocab / 16]
     bool lm_tile_max_on = true, want_tile_max = false;
     int tile_max_rows = 0;                   // rows of the last lm_head launch that left pairs (0 = none)
     float *ss_x = nullptr, *ss_h = nullptr;  // [max_batch][QM3_SS] partial sums of squares of the rows of x / h (qmm3.h)
     // At 5 .. 64 decode rows the qkv projection's slice reduction is not launched; the decode-attention kernel adds the fp32 slice
     // partials itself (engine_kernels.h, QP).  Measured in round 3 (profiles/r03_labs/batched_decode_status.jsonl): 5 / 8 / 16 / 64
-    // sequences 1.87 -> 1.81, 1.91 -> 1.89, 2.08 -> 2.03, 3.63 -> 3.52 ms per step.  TL_ATTN_QKV_PARTIALS=0 launches the reduction.
+    // sequences 1.87 -> 1.81, 1.91 -> 1.89, 2.08 -> 2.03, 3.63 -> 3.52 ms per step.  tl_engine_set_option "attn_qkv_partials" = 0 launches the reduction.
     bool attn_qkv_partials = true;
     // Single-row decode with the context split 2 / 4 / 8 ways: no merge launch behind the attention kernel -- the wo GEMV forms the
     // merged row from the split partials while it stages it (qmv3.h, PRO_ATTN_MERGE).  Measured in round 3
@@ -100,9 +100,9 @@ struct tl_engine {
     bool fuse_norm = true;                   // the skinny matmul normalises its own slice whenever its producer left sums of squares
     int32_t *verify_ids = nullptr;  // greedy ids of the rows of the last tl_engine_verify
     int qmm3_min_rows = 5;  // rows from which a projection uses the K-sliced skinny matmul instead of the GEMV (TL_QMM3_MIN_M)
-    bool use_qmm3 = true;   // TL_NO_QMM3=1 at create: rows > 8 go through the prefill GEMM path instead
+    bool use_qmm3 = true;   // tl_engine_set_option "qmm3" = 0: rows > 8 go through the prefill GEMM path instead
     // 5 .. 64 rows: the register-resident matmul (qmm6.h) takes every projection whose plan fits; rows travel WEIGHTED between the
-    // projections (qkv <- w_down / the embedding, gate|up <- wo).  TL_NO_QMM6=1 at create: the K-sliced skinny matmul as before.
+    // projections (qkv <- w_down / the embedding, gate|up <- wo).  tl_engine_set_option "qmm6" = 0: the K-sliced skinny matmul as before.
     bool use_qmm6 = true;
     // ... and, where its plan exists (round 6: gate|up and qkv of a 2,560-wide model), the row-streaming matmul (qmm7.h) instead of the
     // register-resident one: the rows' arrival overlaps the walk, a step costs by its 16-row blocks (3 included).  force_qmm7: the
@@ -120,7 +120,7 @@ struct tl_engine {
     tl_linear_info *linfo = nullptr;    // kernel-level entry points: which kernel a projection ran
     int force_linear = 0;               // kernel-level entry points: 1 = fused GEMV, 2 = skinny matmul
     int qmm3_mode = -1;                 // skinny matmul grid: -1 by shape (qmm3_plan), 0 one-shot, 1 persistent
-    bool gemm_fused_epilogue = true;    // TL_GEMM_FUSED_EPILOGUE=0: residual / SwiGLU of the prefill GEMM as separate launches
+    bool gemm_fused_epilogue = true;    // tl_engine_set_option "gemm_fused_epilogue" = 0: residual / SwiGLU of the prefill GEMM as separate launches
     size_t attn_ws_bytes = 0;
     int rows_cap = 0;
     int ring_cap = 4096;
@@ -445,7 +445,7 @@ static int engine_qmm6(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
 
 // One projection of the decode step over `M` activation rows.  Up to 4 rows: the fused MFMA GEMV (weights streamed once,
 // RMSNorm / residual / SwiGLU inside).  5 .. 64 rows: the skinny matmul (qmm3.h) for every projection -- at 8 rows the GEMV
-// re-stages all rows in every workgroup (qkv 10.3 us against 4.8 + reduction; profiles/r02_labs/batched_rows_routing.log).  More rows, or TL_NO_QMM3: the
+// re-stages all rows in every workgroup (qkv 10.3 us against 4.8 + reduction; profiles/r02_labs/batched_rows_routing.log).  More rows, or option "qmm3" = 0: the
 // reference's own op sequence -- RMSNorm kernel, W4 MFMA GEMM (quantize.py:54-65 routes rows > 8 to the matmul path),
 // then SwiGLU / residual kernels.
 // ss_in: partial sums of squares of the rows of `a` when its producer emitted them (fused RMSNorm of the skinny matmul),
@@ -853,7 +853,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             // qkv on this kernel at every row count since round 5 (rows in fragment order from 9 rows): same-box A/B at 128-token contexts,
             // two alternating rounds, 24 / 32 / 48 / 64 sequences 1.91 / 1.95 / 2.56 / 2.69 -> 1.87 / 1.89 / 2.50 / 2.59 ms per step
             // (profiles/r05_labs/batched_qkv_on_qmm6_ab.log; round 4 had measured -1 ... -2.9 % on a fast box and left 17-64 rows on the sliced
-            // matmul, whose slices the attention kernel adds -- that route is now the one behind TL_NO_QMM6=1 only)
+            // matmul, whose slices the attention kernel adds -- that route is now the one behind option "qmm6" = 0 only)
             const bool qkv6 = qmm6_takes(e, w.wqkv, batch);
             const bool wo6 = wo6_ok && (batch <= 16 || batch > 32 || !sliced_leaves_weighted(w.wo));
             // this layer's hand-over buffers: the shared ones, or -- the AQL route's per-layer mode -- its own (written once per step)
@@ -1198,8 +1198,8 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     const size_t o_ssh = carve((size_t)c.max_batch * ss_per_row * 4);
     // attention partials: decode (batch*Hq rows x 64 splits) or the L<=8 operator path during short prefills
     // decode partials: at most 64 splits per row with many sequences, at most 256 split-rows per head with few (pick_decode_splits)
-    e->attn_ws_bytes = std::max((size_t)std::max(c.max_batch * 64, 4 * 256) * c.num_heads * (c.head_dim + ATTN_WS_PAD) * 4,
-                                (size_t)c.num_heads * 8 * 64 * (c.head_dim + ATTN_WS_PAD) * 4);
+    const size_t ws_row = (size_t)c.head_dim + ATTN_WS_PAD;
+    e->attn_ws_bytes = std::max((size_t)std::max(c.max_batch * 64, 4 * 256) * c.num_heads * ws_row * 4, (size_t)c.num_heads * 8 * 64 * ws_row * 4);
     for (int L = 1; L <= c.max_prefill_rows; ++L)  // the paged attention operator may split the context for any chunk length
         e->attn_ws_bytes = std::max(e->attn_ws_bytes, tl_paged_attention_workspace_bytes(c.num_heads, L, c.head_dim, c.page_size,
                                                                                          c.max_pages_per_seq, c.num_heads,
@@ -1259,12 +1259,6 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->lm_tile_max = (f32x2 *)(A + o_tmax);
     e->ss_x = (float *)(A + o_ssx);
     e->ss_h = (float *)(A + o_ssh);
-    if (const char *q = getenv("TL_ATTN_QKV_PARTIALS")) e->attn_qkv_partials = atoi(q) != 0;
-    if (const char *q = getenv("TL_LMHEAD_TILE_MAX")) e->lm_tile_max_on = atoi(q) != 0;
-    if (const char *q = getenv("TL_GEMM_FUSED_EPILOGUE")) e->gemm_fused_epilogue = atoi(q) != 0;
-    e->use_qmm3 = getenv("TL_NO_QMM3") == nullptr;
-    e->use_qmm6 = getenv("TL_NO_QMM6") == nullptr;
-    e->use_qmm7 = getenv("TL_NO_QMM7") == nullptr;
     if (const char *q = getenv("TL_QMM3_MIN_M")) e->qmm3_min_rows = std::max(1, atoi(q));
     read_attention_knobs(e);
     // Decode steps replay as AQL packets on the engine's own HSA queue (aql.h) unless TL_AQL=0: the same captured step, without the
@@ -1291,11 +1285,8 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
         if (e->aql_queue) {
             e->aql_on = true;
             // the route's code objects are compiled with TL_COHERENT (common.h): no cache maintenance between the launches of a step.
-            // TL_AQL_FENCES=1 puts HIP's agent-scope fences back on every packet (A/B: what the maintenance costs).
+            // (tl_engine_set_option "aql_fences" = 1 puts HIP's agent-scope fences back on every packet: the A/B of what the maintenance costs)
             e->aql_fences.inner_acquire = e->aql_fences.inner_release = HSA_FENCE_SCOPE_NONE;
-            if (const char *f = getenv("TL_AQL_FENCES")) {
-                if (atoi(f) != 0) e->aql_fences.inner_acquire = e->aql_fences.inner_release = HSA_FENCE_SCOPE_AGENT;
-            }
             // per-layer decode activations (1-4 rows: the fused-GEMV step; 5-64 rows since round 5: the batched-matmul step): every hand-over
             // address of a step is written once per step.  The attention partials hold 16 windows per row (at most 1,024 row-windows): a plan
             // beyond that keeps the shared buffers and the graph route.
@@ -1309,7 +1300,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
                 const size_t b_x = align_up((size_t)rows * c.hidden_size * 2, 256), b_qkv = align_up((size_t)rows * qkv_dim * 2, 256),
                              b_attn = align_up((size_t)rows * q_dim * 2, 256), b_act = align_up((size_t)rows * c.intermediate_size * 2, 256),
                              b_ss = align_up((size_t)rows * ssr * 4, 256),
-                             b_ws = align_up((size_t)std::min(rows * 64, std::max(4 * 64, std::min(rows * 16, 1024))) * c.num_heads * (c.head_dim + ATTN_WS_PAD) * 4, 256);
+                             b_ws = align_up((size_t)std::min(rows * 64, std::max(4 * 64, std::min(rows * 16, 1024))) * c.num_heads * ws_row * 4, 256);
                 // slice planes of the sliced matmuls a batched step can take (wo, w_down), the largest over 5 .. rows rows
                 size_t b_pl[2] = {0, 0};
                 for (int M = 5; M <= rows; ++M) {
@@ -1500,6 +1491,24 @@ extern "C" int tl_engine_set_moe_layer(tl_engine *e, int layer, const tl_moe_wei
         e->layer_act_rows = 0, e->layer_act_bytes = 0, e->layer_ws_bytes = 0;
         e->layer_plane_bytes[0] = e->layer_plane_bytes[1] = 0;
     }
+    return TL_OK;
+}
+
+// Test / lab hook (header): routes that have an A/B twin, switched per engine before its first step.
+extern "C" int tl_engine_set_option(tl_engine *e, const char *name, int value) {
+    TL_REQUIRE(e && name, "engine_set_option: null argument");
+    TL_REQUIRE(e->graphs.empty() && e->stats.decode_steps == 0 && e->stats.prefill_tokens == 0,
+               "engine_set_option: call it before the first prefill / decode (captured steps hold the routes they were captured with)");
+    const std::string n = name;
+    const bool on = value != 0;
+    if (n == "qmm3") e->use_qmm3 = on;
+    else if (n == "qmm6") e->use_qmm6 = on;
+    else if (n == "qmm7") e->use_qmm7 = on;
+    else if (n == "attn_qkv_partials") e->attn_qkv_partials = on;
+    else if (n == "lmhead_tile_max") e->lm_tile_max_on = on;
+    else if (n == "gemm_fused_epilogue") e->gemm_fused_epilogue = on;
+    else if (n == "aql_fences") e->aql_fences.inner_acquire = e->aql_fences.inner_release = on ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
+    else return fail(TL_ERR_INVALID, "engine_set_option: unknown option '" + n + "' (qmm3, qmm6, qmm7, attn_qkv_partials, lmhead_tile_max, gemm_fused_epilogue, aql_fences)");
     return TL_OK;
 }
 

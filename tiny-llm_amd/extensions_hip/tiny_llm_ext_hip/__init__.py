@@ -151,6 +151,7 @@ _SIGNATURES.update({
     "tl_decode_streaming_plan": (_c_int, [_c_int, _c_int, _c_int, _P(_c_int)]),
     "tl_decode_streaming_variant_compiled": (_c_int, [_c_int, _c_int]),
     "tl_decode_attention_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _P(_c_int)]),
+    "tl_engine_set_option": (_c_int, [_c_void_p, ctypes.c_char_p, _c_int]),
     "tl_engine_destroy": (None, [_c_void_p]),
     "tl_engine_synchronize": (_c_int, [_c_void_p]),
     "tl_engine_begin": (_c_int, [_c_void_p, _c_int]),

@@ -13,6 +13,7 @@ rows interleaved) and then exposes a request-level API: ``begin`` / ``prefill`` 
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Any, Sequence
 
 import torch
@@ -59,7 +60,9 @@ class DecodeEngine:
     """Owns the fused weights, the paged KV pools and the captured decode graphs for one model on one GPU."""
 
     def __init__(self, mlx_model: Any, *, page_size: int = 128, num_pages: int = 512, max_batch: int = 1,
-                 max_pages_per_seq: int | None = None, max_prefill_rows: int = 2048):
+                 max_pages_per_seq: int | None = None, max_prefill_rows: int = 2048, options: dict | None = None):
+        """``options`` (tests / lab tools only): routes with an A/B twin, by the names of tl_engine_set_option (include/tinyllm_engine.h),
+        e.g. {"qmm7": 0}; the environment variable TL_ENGINE_OPTIONS ("qmm7=0,aql_fences=1") adds to them for the A/B scripts under tools/."""
         args = mlx_model.args
         if not torch.cuda.is_available():
             raise RuntimeError("DecodeEngine: the course extension is GPU-only")
@@ -111,6 +114,10 @@ class DecodeEngine:
             ctypes.byref(cfg), layers, ctypes.byref(embed_c), final_norm.data_ptr(),
             ctypes.byref(head_c) if head_c is not None else None, None, ctypes.byref(handle)))
         self._h = handle
+        opts = dict(item.split("=", 1) for item in os.environ.get("TL_ENGINE_OPTIONS", "").replace("+", ",").split(",") if "=" in item)
+        opts.update(options or {})
+        for name, value in opts.items():
+            _ext.check(_lib.tl_engine_set_option(self._h, str(name).strip().encode(), int(value)))
         for i, mlp in moe_layers.items():
             self._attach_moe(i, mlp, args)
 

@@ -34,12 +34,12 @@ def main() -> None:
     model = synthetic_qwen3(cfg, seed=0, sigma=0.02, device="cuda:0")
     rng = random.Random(0)
     prompt = [rng.randrange(256, cfg["vocab_size"]) for _ in range(args.prompt)]
-    env = {"graph": {"TL_AQL": "0"}, "aql": {"TL_AQL": "1"}, "aql_fences": {"TL_AQL": "1", "TL_AQL_FENCES": "1"},
+    env = {"graph": {"TL_AQL": "0"}, "aql": {"TL_AQL": "1"}, "aql_fences": {"TL_AQL": "1", "TL_ENGINE_OPTIONS": "aql_fences=1"},
            "default": {}}
     results = {}
     for rnd in range(args.rounds):
         for mode in args.modes.split(","):
-            for k in ("TL_AQL", "TL_AQL_FENCES"):
+            for k in ("TL_AQL", "TL_ENGINE_OPTIONS"):
                 os.environ.pop(k, None)
             os.environ.update(env[mode])
             eng = DecodeEngine(model, page_size=128, num_pages=(args.prompt + args.steps + 80) // 128 + 3, max_batch=1, max_prefill_rows=128)

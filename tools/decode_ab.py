@@ -18,8 +18,8 @@ ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT, ROOT / "tiny-llm_amd", ROOT / "tiny-llm_amd" / "extensions_hip"):
     sys.path.insert(0, str(p))
 
-KNOBS = ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS", "TL_QMM3_MIN_M", "TL_NO_QMM3", "TL_GEMM_FUSED_EPILOGUE", "TL_ATTN_QKV_PARTIALS",
-         "TL_LMHEAD_TILE_MAX", "TL_NO_QMM6", "TL_NO_QMM7", "TL_ATTN_MFMA")  # every knob the library still reads
+# every knob the library still reads + the host mirror's TL_ENGINE_OPTIONS ("qmm7=0+aql_fences=1": tl_engine_set_option)
+KNOBS = ("TL_AQL", "TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS", "TL_QMM3_MIN_M", "TL_ATTN_MFMA", "TL_ENGINE_OPTIONS")
 
 
 def main():
@@ -48,7 +48,7 @@ def main():
             os.environ.pop(k, None)
         if variant != "-":
             for kv in variant.split(","):
-                k, v = kv.split("=")
+                k, v = kv.split("=", 1)  # (TL_ENGINE_OPTIONS=qmm7=0+aql_fences=1: options joined by "+")
                 os.environ[k] = v
         eng = DecodeEngine(model, page_size=page, num_pages=per_seq * args.batch + 2, max_batch=args.batch,
                            max_pages_per_seq=per_seq, max_prefill_rows=max(min(args.prefill_step, args.prompt_len), 8))

@@ -1,6 +1,6 @@
 python -m pytest tests/test_zz_streaming_matmul_gpu.py tests/test_zz_batched_matmul_gpu.py tests/test_zz_aql_route_gpu.py tests/test_engine_qwen4b_gpu.py tests/test_engine_gpu.py -x -q 2>&1 | tail -8 > gpurun_out/r06_q7_pytest.txt
 tail -4 gpurun_out/r06_q7_pytest.txt
-for b in 5 8 16 17 32 33 48 64; do python tools/decode_ab.py --batch $b --steps 64 --profile-steps 2 - TL_NO_QMM7=1 - TL_NO_QMM7=1 2>/dev/null | python -c "
+for b in 5 8 16 17 32 33 48 64; do python tools/decode_ab.py --batch $b --steps 64 --profile-steps 2 - TL_ENGINE_OPTIONS=qmm7=0 - TL_ENGINE_OPTIONS=qmm7=0 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     try: d=json.loads(l)
