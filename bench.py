@@ -579,7 +579,7 @@ def extra_configs_leg(mlx_model, cfg: dict, device: str, seed: int, page: int = 
         e.synchronize()
         torch.cuda.synchronize()
 
-    for name, plen, steps, chunk in (("config3", 8192, 16, 2048), ("config5", 32768, 16, 2048)):
+    for name, plen, steps, chunk in (("config3", 8192, 16, 4096), ("config5", 32768, 16, 4096)):
         eng = None
         try:
             with time_box(60):
@@ -798,9 +798,11 @@ def main() -> None:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(sys.argv[1:], args.gpus)  # does not return
     workload = {2: ("Qwen3-4B int4 single-prompt KV-cache decode (BASELINE.json configs[1])", 128, 128, 256),
-                3: ("Qwen3-4B int4 chunked-prefill 8k + paged-KV decode (BASELINE.json configs[2])", 8192, 2048, 64),
+                # (4,096-token prefill chunks since round 6: from 3,072 rows a chunk's projections run on the plain bf16 GEMM over the bf16 weight
+                # copy -- csrc/gemm8.h --, 987 against 742 TFLOP/s for a layer; --prefill-step 2048 is the round-5 shape)
+                3: ("Qwen3-4B int4 chunked-prefill 8k + paged-KV decode (BASELINE.json configs[2])", 8192, 4096, 64),
                 5: ("Qwen3-4B 32k long-context paged FlashAttention prefill + split-K decode (BASELINE.json configs[4])",
-                    32768, 2048, 32)}[args.config]
+                    32768, 4096, 32)}[args.config]
     if args.prompt_len is None:
         args.prompt_len = workload[1]
     if args.prefill_step is None:

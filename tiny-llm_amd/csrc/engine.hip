@@ -18,6 +18,7 @@
 #include "qmm3.h"
 #include "qmm6.h"
 #include "qmm7.h"
+#include "gemm8.h"
 #include "attn_mfma.h"
 #include "aql.h"
 
@@ -65,6 +66,12 @@ struct tl_engine {
     };
     std::map<const uint32_t *, Tiled> tiled;
     size_t tiled_bytes = 0;
+    // Prefill chunks of GEMM8_MIN_ROWS rows and more (an engine created with max_prefill_rows that large): the layer matrices once more as
+    // bf16 -- bf16(q * s + beta), the B operand the reference's tile GEMM forms in threadgroup memory (quantized_matmul.metal:96-249) -- for
+    // the plain bf16 GEMM of gemm8.h (256 x 256 tiles by LDS-DMA, no dequantisation in the loop).  7.3 GB at Qwen3-4B, of 288.
+    std::map<const uint32_t *, uint16_t *> bf16w;
+    size_t bf16w_bytes = 0;
+    bool use_gemm8 = true;  // tl_engine_set_option "gemm8" = 0: every chunk through the W4 GEMM (qmm.hip), the twin
 
     int32_t *block_table = nullptr, *context_lens = nullptr, *tokens = nullptr, *live = nullptr, *produced = nullptr,
             *ring = nullptr, *scratch_ctx = nullptr, *prefill_tokens = nullptr;
@@ -348,8 +355,19 @@ static int engine_qmm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
 // out = epilogue(a @ W^T) for any number of rows (chunked prefill, batches above 64): the reference's own op sequence --
 // W4 MFMA GEMM over the checkpoint layout (quantize.py:54-65 routes rows > 8 to the matmul path, whose tile kernel rounds
 // the dequantised weights to bf16 first), then SwiGLU / residual as separate launches.
+constexpr int GEMM8_MIN_ROWS = 3072;  // below, 256 x 256 tiles leave too many CUs idle (2,048 rows x 2,560 columns = 80 tiles): the W4 GEMM's 128 x 128 tiles win
 static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int epi,
                        const uint16_t *residual) {
+    if (e->use_gemm8 && M >= GEMM8_MIN_ROWS) {
+        const auto wb = e->bf16w.find(w.weight_dev);
+        if (wb != e->bf16w.end() && gemm8_applicable(M, w.rows, w.cols)) {
+            Gemm8Args g{};
+            g.a = a, g.w = wb->second, g.out = out, g.residual = residual, g.M = M, g.N = w.rows, g.K = w.cols;
+            if (launch_gemm8_bf16(g, epi, e->stream) != 0) return fail(TL_ERR_UNSUPPORTED, "engine: bf16 GEMM launch failed");
+            TL_CHECK_LAUNCH("engine bf16 matmul");
+            return TL_OK;
+        }
+    }
     if (epi != EPI_STORE && M > 8 && e->gemm_fused_epilogue) {  // residual / SwiGLU inside the GEMM store or its split-K reduction
         const size_t need = tl_quantized_matmul_workspace_bytes(M, w.cols, w.rows, TL_BF16, 1, 1);
         TL_TRY(ensure_splitk(e, need));
@@ -1218,6 +1236,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
             (void)hipFree(kv.second.wt);
             (void)hipFree(kv.second.sbt);
         }
+        for (auto &kv : e->bf16w) (void)hipFree(kv.second);
         if (e->owns_stream) (void)hipStreamDestroy(e->stream);
         delete e;
         return fail(TL_ERR_HIP, msg);
@@ -1389,6 +1408,31 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
         ok = ok && add_tiled(e->head());
         if (!ok) return cleanup_fail("engine_create: hipMalloc(tiled weights) failed");
     }
+    if (c.max_prefill_rows >= GEMM8_MIN_ROWS) {  // the caller asked for chunks the plain bf16 GEMM takes: expand the layer matrices once
+        auto add_bf16 = [&](const tl_w4 &w) -> bool {
+            if (!w.weight_dev || w.cols % 128 != 0 || e->bf16w.count(w.weight_dev) || !gemm8_applicable(c.max_prefill_rows, w.rows, w.cols)) return true;
+            uint16_t *wb = nullptr;
+            const size_t bytes = (size_t)w.rows * w.cols * 2;
+            if (hipMalloc((void **)&wb, bytes) != hipSuccess) return false;
+            if (dequant_w4_to_bf16(w.weight_dev, (const uint16_t *)w.scales_dev, (const uint16_t *)w.biases_dev, wb, w.rows, w.cols, e->stream) != 0) {
+                (void)hipFree(wb);
+                return false;
+            }
+            e->bf16w[w.weight_dev] = wb;
+            e->bf16w_bytes += bytes;
+            return true;
+        };
+        bool ok = true;
+        for (const auto &l : e->layers) {
+            ok = ok && add_bf16(l.wqkv) && add_bf16(l.wo);
+            if (l.wgu.weight_dev) ok = ok && add_bf16(l.wgu) && add_bf16(l.wdown);
+        }
+        if (!ok) {
+            for (auto &kv : e->bf16w) (void)hipFree(kv.second);
+            e->bf16w.clear();
+            return cleanup_fail("engine_create: hipMalloc(bf16 weights for the prefill GEMM) failed");
+        }
+    }
 
     {
         // Workspace of every matmul the engine can launch, allocated once: fp32 slice partials of the skinny matmul
@@ -1428,7 +1472,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     e->page_refs.assign(c.num_pages, 0);
     e->stats.pages_free = c.num_pages;
     e->stats.kv_bytes = e->kv_bytes;
-    e->stats.workspace_bytes = e->arena_bytes + e->tiled_bytes;
+    e->stats.workspace_bytes = e->arena_bytes + e->tiled_bytes + e->bf16w_bytes;
     *out = e;
     return TL_OK;
 }
@@ -1507,8 +1551,9 @@ extern "C" int tl_engine_set_option(tl_engine *e, const char *name, int value) {
     else if (n == "attn_qkv_partials") e->attn_qkv_partials = on;
     else if (n == "lmhead_tile_max") e->lm_tile_max_on = on;
     else if (n == "gemm_fused_epilogue") e->gemm_fused_epilogue = on;
+    else if (n == "gemm8") e->use_gemm8 = on;
     else if (n == "aql_fences") e->aql_fences.inner_acquire = e->aql_fences.inner_release = on ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
-    else return fail(TL_ERR_INVALID, "engine_set_option: unknown option '" + n + "' (qmm3, qmm6, qmm7, attn_qkv_partials, lmhead_tile_max, gemm_fused_epilogue, aql_fences)");
+    else return fail(TL_ERR_INVALID, "engine_set_option: unknown option '" + n + "' (qmm3, qmm6, qmm7, gemm8, attn_qkv_partials, lmhead_tile_max, gemm_fused_epilogue, aql_fences)");
     return TL_OK;
 }
 
@@ -1531,6 +1576,7 @@ extern "C" void tl_engine_destroy(tl_engine *e) {
         (void)hipFree(kv.second.wt);
         (void)hipFree(kv.second.sbt);
     }
+    for (auto &kv : e->bf16w) (void)hipFree(kv.second);
     if (e->owns_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -2535,6 +2581,29 @@ extern "C" int tl_decode_linear_ex(const tl_tiled_w4 *w, const void *a_dev, void
     TL_REQUIRE(ex, "decode_linear_ex: null extension block (use tl_decode_linear)");
     return decode_linear_impl(w, a_dev, out_dev, M, prologue, epilogue, norm_w_dev, residual_dev, eps, kernel, workspace_dev,
                               workspace_bytes, stream, ex, info);
+}
+
+// The prefill projection of large chunks on caller buffers (header): W4 -> bf16 expansion, then the plain bf16 GEMM of gemm8.h.
+extern "C" int tl_prefill_weights_bf16(const tl_w4 *w, void *out_dev, void *stream) {
+    TL_REQUIRE(w && out_dev, "prefill_weights_bf16: null argument");
+    TL_TRY(check_w4(*w, w->rows, w->cols, "prefill_weights_bf16"));
+    TL_REQUIRE(w->cols % 128 == 0, "prefill_weights_bf16: columns must be a multiple of the quantisation group (128)");
+    if (dequant_w4_to_bf16(w->weight_dev, (const uint16_t *)w->scales_dev, (const uint16_t *)w->biases_dev, (uint16_t *)out_dev, w->rows, w->cols, (hipStream_t)stream) != 0)
+        return fail(TL_ERR_HIP, "prefill_weights_bf16: launch failed");
+    return TL_OK;
+}
+extern "C" int tl_prefill_matmul_bf16(const void *a_dev, const void *w_bf16_dev, void *out_dev, int M, int rows, int cols, int epilogue,
+                                      const void *residual_dev, void *stream) {
+    TL_REQUIRE(a_dev && w_bf16_dev && out_dev, "prefill_matmul_bf16: null argument");
+    TL_REQUIRE(epilogue == EPI_STORE || epilogue == EPI_RESIDUAL || epilogue == EPI_SWIGLU, "prefill_matmul_bf16: epilogue is 0 (store), 1 (residual add) or 2 (SwiGLU over interleaved rows)");
+    TL_REQUIRE(epilogue != EPI_RESIDUAL || residual_dev, "prefill_matmul_bf16: the residual epilogue needs the residual rows");
+    TL_REQUIRE(gemm8_applicable(M, rows, cols), "prefill_matmul_bf16: needs M >= 1, an even number of weight rows and columns in whole 64-wide steps");
+    Gemm8Args g{};
+    g.a = (const uint16_t *)a_dev, g.w = (const uint16_t *)w_bf16_dev, g.out = (uint16_t *)out_dev, g.residual = (const uint16_t *)residual_dev;
+    g.M = M, g.N = rows, g.K = cols;
+    if (launch_gemm8_bf16(g, epilogue, (hipStream_t)stream) != 0) return fail(TL_ERR_UNSUPPORTED, "prefill_matmul_bf16: launch failed");
+    TL_CHECK_LAUNCH("prefill_matmul_bf16");
+    return TL_OK;
 }
 
 // (cos, sin) of each row's position = its context length, the same expression as rope_table_kernel

@@ -136,6 +136,8 @@ _SIGNATURES.update({
                                   _c_int, _c_void_p, _c_size_t, _c_void_p, _P(TlLinearInfo)]),
     "tl_decode_linear_ex": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_float,
                                      _c_int, _c_void_p, _c_size_t, _c_void_p, _P(TlLinearEx), _P(TlLinearInfo)]),
+    "tl_prefill_weights_bf16": (_c_int, [_P(TlW4), _c_void_p, _c_void_p]),
+    "tl_prefill_matmul_bf16": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "tl_decode_gemv_variant_compiled": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
     "tl_decode_attention_fused_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "tl_decode_attention_fused": (_c_int, [_c_void_p] * 8 + [_c_int] * 6 + [_c_float, _c_float, _c_int, _c_void_p, _c_size_t,
@@ -689,6 +691,29 @@ def decode_linear(w: TiledW4, a: torch.Tensor | None, *, prologue: int = PRO_NON
         _check(_lib.tl_decode_linear_ex(*common, ctypes.byref(ex), ctypes.byref(info)))
     return out, {"kernel": info.kernel, "kernel_name": LINEAR_KERNELS.get(info.kernel, "?"), "launches": info.launches,
                  "rows_per_pass": info.rows_per_pass, "p": list(info.p), **extra}
+
+
+def prefill_weights_bf16(weight: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor) -> torch.Tensor:
+    """W4 [rows, cols/8] -> bf16 [rows, cols] = bf16(q * scale + bias): the B operand of the reference's tile GEMM (tl_prefill_weights_bf16)."""
+    _require_gpu("prefill_weights_bf16", weight, scales, biases)
+    rows, cols = int(weight.shape[0]), int(weight.shape[1]) * 8
+    w4 = TlW4(_ptr(weight.contiguous()), _ptr(scales.contiguous()), _ptr(biases.contiguous()), rows, cols)
+    out = torch.empty((rows, cols), dtype=torch.bfloat16, device=weight.device)
+    _check(_lib.tl_prefill_weights_bf16(ctypes.byref(w4), _ptr(out), _stream()))
+    return out
+
+
+def prefill_matmul_bf16(a: torch.Tensor, w_bf16: torch.Tensor, *, epilogue: int = 0, residual: torch.Tensor | None = None) -> torch.Tensor:
+    """out = epilogue(a @ w_bf16^T): the plain bf16 GEMM large prefill chunks run on (tl_prefill_matmul_bf16, csrc/gemm8.h)."""
+    _require_gpu("prefill_matmul_bf16", a, w_bf16)
+    if a.dtype != torch.bfloat16 or w_bf16.dtype != torch.bfloat16 or a.dim() != 2 or w_bf16.dim() != 2 or a.shape[1] != w_bf16.shape[1]:
+        raise RuntimeError("prefill_matmul_bf16: a [M, cols] and w_bf16 [rows, cols] must be bfloat16 with the same cols")
+    M, rows, cols = int(a.shape[0]), int(w_bf16.shape[0]), int(a.shape[1])
+    out = torch.empty((M, rows // 2 if epilogue == 2 else rows), dtype=torch.bfloat16, device=a.device)
+    res = residual.contiguous() if residual is not None else None
+    _check(_lib.tl_prefill_matmul_bf16(_ptr(a.contiguous()), _ptr(w_bf16.contiguous()), _ptr(out), M, rows, cols, int(epilogue),
+                                       _ptr(res) if res is not None else None, _stream()))
+    return out
 
 
 def fragment_order_of(rows: torch.Tensor) -> torch.Tensor:
