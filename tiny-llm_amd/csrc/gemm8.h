@@ -71,6 +71,28 @@ constexpr size_t gemm8_lds_bytes(int BM, int BN) { return (size_t)2 * (BM + BN) 
 #undef G8_WN
 #undef G8_TM
 #undef G8_TN
+#define G8_NAME gemm8_kernel_128x160
+#define G8_WM 4
+#define G8_WN 2
+#define G8_TM 2
+#define G8_TN 5
+#include "gemm8_body.inc"
+#undef G8_NAME
+#undef G8_WM
+#undef G8_WN
+#undef G8_TM
+#undef G8_TN
+#define G8_NAME gemm8_kernel_128x256
+#define G8_WM 2
+#define G8_WN 4
+#define G8_TM 4
+#define G8_TN 4
+#include "gemm8_body.inc"
+#undef G8_NAME
+#undef G8_WM
+#undef G8_WN
+#undef G8_TM
+#undef G8_TN
 
 // gemm8.hip
 struct Gemm8Plan {

@@ -46,9 +46,13 @@ Gemm8Plan gemm8_plan(int M, int N, int K) {
     Gemm8Plan best{};
     if (!gemm8_applicable(M, N, K)) return best;
     const int cus = std::max(1, qmm3_num_cus());
-    const struct { int bm, bn; double eff; } cand[3] = {{256, 256, 1.0}, {256, 192, 0.97}, {256, 160, 0.92}};
+#ifndef G8_LAB_CANDS
+#define G8_LAB_CANDS 5
+#endif
+    const struct { int bm, bn; double eff; } cand[5] = {{256, 256, 1.0}, {256, 192, 0.97}, {256, 160, 0.92}, {128, 160, 0.80}, {128, 256, 0.86}};
     double best_cost = 0.0;
-    for (const auto &c : cand) {
+    for (int ci = 0; ci < G8_LAB_CANDS; ++ci) {
+        const auto &c = cand[ci];
         const int tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
         const double cost = (double)((tiles + cus - 1) / cus) * c.bm * c.bn / c.eff;
         if (!best.ok || cost < best_cost) best = Gemm8Plan{c.bm, c.bn, tiles, true}, best_cost = cost;
@@ -65,9 +69,11 @@ static int launch8(KernelT kern, const Gemm8Args &a, const Gemm8Plan &pl, hipStr
 }
 template <int EPI>
 static int launch8_tile(const Gemm8Args &a, const Gemm8Plan &pl, hipStream_t st) {
-    if (pl.BN == 256) return launch8(gemm8_kernel_256x256<EPI>, a, pl, st);
-    if (pl.BN == 192) return launch8(gemm8_kernel_256x192<EPI>, a, pl, st);
-    if (pl.BN == 160) return launch8(gemm8_kernel_256x160<EPI>, a, pl, st);
+    if (pl.BM == 256 && pl.BN == 256) return launch8(gemm8_kernel_256x256<EPI>, a, pl, st);
+    if (pl.BM == 256 && pl.BN == 192) return launch8(gemm8_kernel_256x192<EPI>, a, pl, st);
+    if (pl.BM == 256 && pl.BN == 160) return launch8(gemm8_kernel_256x160<EPI>, a, pl, st);
+    if (pl.BM == 128 && pl.BN == 160) return launch8(gemm8_kernel_128x160<EPI>, a, pl, st);
+    if (pl.BM == 128 && pl.BN == 256) return launch8(gemm8_kernel_128x256<EPI>, a, pl, st);
     return -1;
 }
 

@@ -69,6 +69,7 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(e0, 0)); for (int i = 0; i < iters; ++i) launch_gemm8_bf16(g, EPI_STORE, 0); CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1000.0 / iters, flop = 2.0 * Mx * N * K;
+        { const Gemm8Plan pl = gemm8_plan(Mx, N, K); printf("[%dx%d, %d tiles] ", pl.BM, pl.BN, pl.tiles); }
         printf("%-8s M=%d N=%d K=%d: %8.1f us  %7.1f TFLOP/s   sampled outputs off: %d of %d (max err %.4g at scale %.3g)\n", sh.name, Mx, N, K, us, flop / us / 1e6, bad, ns, worst, scale);
         if (strcmp(sh.name, "square") != 0) layer_us += us, layer_flop += flop;
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(dr)); CK(hipFree(dc)); CK(hipFree(dref));
