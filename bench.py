@@ -187,7 +187,7 @@ def rocprof_live(args) -> Path | None:
     cmd = [exe, "--kernel-trace", "--stats", "-d", tmp, "-o", "bench", "--output-format", "csv", "--", sys.executable,
            str(Path(__file__).resolve()), "--config", str(args.config), "--steps", "20", "--warmup", "5", "--seed", str(args.seed),
            "--model", args.model, "--prompt-len", str(args.prompt_len), "--prefill-step", str(args.prefill_step),
-           "--no-cpu-baseline", "--no-extra-configs", "--profile-steps", "0", "--rocprof", "off"]
+           "--no-cpu-baseline", "--no-extra-configs", "--no-clocks", "--profile-steps", "0", "--rocprof", "off"]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -785,6 +785,7 @@ def main() -> None:
                          "128 checks the engine at the timed steps' own attention plan (4 windows) -- the GPU suite holds that plan against "
                          "the float64 truth in tests/test_zz_engine_windows_vs_truth_gpu.py")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (for rocprofv3 kernel traces)")
+    ap.add_argument("--no-clocks", action="store_true", help="skip the rocm-smi clock / power readings (the rocprofv3 child of this command: its trace should hold the bench's own kernels only)")
     ap.add_argument("--rocprof-stats", default=None,
                     help="rocprofv3 --kernel-trace --stats CSV of this command to recompute the GEMV rate from (default: the newest "
                          "committed profiles/r*_rocprofv3/bench_config<N>_kernel_stats.csv; 'none' to leave the block out)")
@@ -871,7 +872,7 @@ def main() -> None:
     engine.decode(max(args.warmup, 2), batch=1, use_graph=use_graph)  # >= 2: eager warm step + graph capture
     sync()
     bytes_first = engine.step_bytes(1)
-    clocks = None if dry else {"before": gpu_clocks(local_rank)}
+    clocks = None if dry or args.no_clocks else {"before": gpu_clocks(local_rank)}
     progress("timed region")
     elapsed, local_elapsed = timed_steps(lambda k: engine.decode(k, batch=1, use_graph=use_graph), sync, args.steps, dist, device)
     bytes_last = engine.step_bytes(1)

@@ -66,7 +66,7 @@ struct tl_engine {
     };
     std::map<const uint32_t *, Tiled> tiled;
     size_t tiled_bytes = 0;
-    // Prefill chunks of GEMM8_MIN_ROWS (2,048) rows and more (an engine created with max_prefill_rows that large): the layer matrices once more as
+    // Prefill chunks of GEMM8_MIN_ROWS (1,536) rows and more (an engine created with max_prefill_rows that large): the layer matrices once more as
     // bf16 -- bf16(q * s + beta), the B operand the reference's tile GEMM forms in threadgroup memory (quantized_matmul.metal:96-249) -- for
     // the plain bf16 GEMM of gemm8.h (256 x 256 tiles by LDS-DMA, no dequantisation in the loop).  7.3 GB at Qwen3-4B, of 288.
     std::map<const uint32_t *, uint16_t *> bf16w;
@@ -355,12 +355,18 @@ static int engine_qmm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
 // out = epilogue(a @ W^T) for any number of rows (chunked prefill, batches above 64): the reference's own op sequence --
 // W4 MFMA GEMM over the checkpoint layout (quantize.py:54-65 routes rows > 8 to the matmul path, whose tile kernel rounds
 // the dequantised weights to bf16 first), then SwiGLU / residual as separate launches.
-// From this many rows a chunk's projections run on the plain bf16 GEMM (gemm8.h): a 2,048-row layer 477 against the W4 GEMM's 543 us (its 128-row
-// tile shapes fill the CUs where 256 x 256 tiles leave 80-tile grids), 4,096 rows 833 against 1,114; below, the W4 GEMM's 128 x 128 tiles win.
-constexpr int GEMM8_MIN_ROWS = 2048;
+// From this many rows a chunk's projections run on the plain bf16 GEMM (gemm8.h).  A layer's four projections, W4 GEMM against gemm8, in the lab
+// (back-to-back launches on one weight matrix, which then sits in the 256-MB Infinity Cache): 4,096 rows 1,114 / 833 us, 2,048 rows 543 / 477, 1,536
+// rows 413 / 386, 1,024 rows 311 / 321.  In the engine every layer streams its own 202 MB of bf16 weights from HBM (~40 us per layer and chunk
+// whatever the rows): 4,096-row chunks keep most of the gain (8k prefill 74.1k -> 86.9k tokens/s), 2,048-row chunks are neutral (72.3k -> 72.8k).
+constexpr int GEMM8_MIN_ROWS = 1536;
+static bool gemm8_wins(int M, int out_features) {
+    (void)out_features;
+    return M >= GEMM8_MIN_ROWS;
+}
 static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int epi,
                        const uint16_t *residual) {
-    if (e->use_gemm8 && M >= GEMM8_MIN_ROWS) {
+    if (e->use_gemm8 && gemm8_wins(M, w.rows)) {
         const auto wb = e->bf16w.find(w.weight_dev);
         if (wb != e->bf16w.end() && gemm8_applicable(M, w.rows, w.cols)) {
             Gemm8Args g{};
