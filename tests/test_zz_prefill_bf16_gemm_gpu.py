@@ -2,11 +2,11 @@
 
 The reference's tile GEMM (quantized_matmul_simdgroup_w4a16_g128: src/extensions_ref/src/quantized_matmul.metal:96-249) rounds every
 dequantised weight to bf16 -- T(q * scale + bias) -- before a bf16 MMA with fp32 accumulation over the whole reduction.  The engine forms
-that B operand once (tl_prefill_weights_bf16) and multiplies chunks of 3,072 rows and more against it with a 256 x 256-tile GEMM whose
+that B operand once (tl_prefill_weights_bf16) and multiplies chunks of 1,536 rows and more against it with a 256-wide-tile GEMM whose
 operands both arrive by LDS-DMA (tl_prefill_matmul_bf16).  Held here
 
   * the expansion against the numpy oracle's dequantisation: BIT-identical;
-  * the product at the Qwen3-4B shapes, 4,096-row chunks and ragged row counts, against oracle.quantized_matmul_tile (split_k = 1: weights
+  * the product at the Qwen3-4B shapes, 1,536- to 4,096-row chunks (every tile shape of the planner) and ragged row counts, against oracle.quantized_matmul_tile (split_k = 1: weights
     rounded first, one rounding of the fp32 sum) on sampled rows -- one bf16 step of the oracle's value + 2^-20 of the absolute sum for the
     other summation order -- for the store, residual and SwiGLU epilogues;
   * the engine: a 4,096-token prompt prefilled in one chunk through this GEMM against the same prompt through the W4 GEMM (engine option
@@ -63,7 +63,7 @@ def test_the_bf16_weight_copy_is_the_oracles_dequantisation(ext, name):
     assert np.array_equal(got, want), f"{name}: {int((got != want).sum())} of {got.size} weights differ from bf16(q * s + beta)"
 
 
-@pytest.mark.parametrize("M", [3072, 4096, 4099])
+@pytest.mark.parametrize("M", [1536, 2048, 3072, 4096, 4099])
 @pytest.mark.parametrize("name", list(SHAPES))
 def test_product_against_the_tile_oracle(ext, name, M):
     packed, scales, biases, wb = _matrix(ext, name)
@@ -100,7 +100,7 @@ def test_product_against_the_tile_oracle(ext, name, M):
 
 
 def test_engine_prefill_of_a_4096_token_chunk_against_the_w4_gemm_and_the_truth():
-    """One 4,096-row chunk through the bf16 GEMM (max_prefill_rows >= 3,072 makes the engine keep the bf16 copy) against the same chunk through
+    """One 4,096-row chunk through the bf16 GEMM (max_prefill_rows >= 1,536 makes the engine keep the bf16 copy) against the same chunk through
     the W4 GEMM (option "gemm8" = 0) -- two summation orders of the same rounded operands: within the band of two HIP paths -- and both
     against the float64 truth of a shorter prompt's last row (TINY model: the truth of 4,096 tokens would take minutes on the CPU, so the
     truth check runs at 3,100 tokens, still one gemm8 chunk)."""
@@ -132,3 +132,33 @@ def test_engine_prefill_of_a_4096_token_chunk_against_the_w4_gemm_and_the_truth(
     want, exact = ref.forward(prompt)[0, -1][None], truth.forward(prompt)[0, -1][None]
     rec = check_against_truth(runs[(3100, 1)][0][None], want, exact, what="engine prefill, one 3,100-row chunk through the bf16 GEMM")
     log_parity({"what": "gemm8_engine_prefill_vs_truth", **rec})
+
+
+@pytest.mark.parametrize("name,M", [("qkv", 4096), ("wo", 2048), ("gate_up", 1536), ("down", 4096), ("gate_up", 6000)])
+def test_repeated_launches_under_memory_load_are_bit_identical(ext, name, M):
+    """Race screen for the LDS-DMA pipeline (a stage is refilled while the matrix pipe still works on fragments read from it; the only
+    ordering is the counted wait + the one barrier per step): the kernel is deterministic, so ANY difference between two launches on the
+    same inputs is a stage read before its DMA landed or overwritten before it was read.  60 launches per shape (every tile shape of the
+    planner: 256 x 192, 128 x 160, 256 x 256, 256 x 160, and a ragged 6,000 rows), half of them racing a copy kernel on a second stream
+    that keeps HBM and the L2s busy, against the first launch -- and the first launch against torch's fp32 product on sampled rows."""
+    packed, scales, biases, wb = _matrix(ext, name)
+    rows_w, cols = SHAPES[name]
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(17 * M + rows_w)
+    a = torch.randn((M, cols), generator=gen, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    first = ext.prefill_matmul_bf16(a, wb, epilogue=0)
+    idx = torch.tensor(sorted(set([0, M - 1] + [int(x) for x in np.linspace(1, M - 2, 29)])), device=DEV)
+    want = (a[idx].float() @ wb.float().T)
+    assert torch.allclose(first[idx].float(), want, rtol=2 ** -7, atol=2e-3), f"{name} M={M}: first launch off by {float((first[idx].float() - want).abs().max())}"
+    side = torch.cuda.Stream()
+    junk = torch.empty((256 * 1024 * 1024,), dtype=torch.uint8, device=DEV)
+    for i in range(60):
+        if i % 2:
+            with torch.cuda.stream(side):
+                junk.copy_(junk.flip(0) if i % 4 == 1 else junk)
+        again = ext.prefill_matmul_bf16(a, wb, epilogue=0)
+        if not torch.equal(again, first):
+            bad = (again != first)
+            raise AssertionError(f"{name} M={M}: launch {i} differs from the first in {int(bad.sum())} elements "
+                                 f"(first at flat index {int(bad.flatten().nonzero()[0])})")
+    torch.cuda.synchronize()
