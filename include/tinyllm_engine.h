@@ -114,6 +114,18 @@ typedef struct tl_moe_weights {
  * stream cannot be graph-captured) after a device-wide synchronise. */
 int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weights *layers, const tl_w4 *embed,
                      const void *final_norm_dev, const tl_w4 *lm_head, void *stream, tl_engine **out);
+/* The same engine with its KV pages in another format ("quantized-KV"; NO reference interface is
+ * replaced -- the reference lists quantised KV caches as not covered, README.md:134-135).  TL_KV_FP8_E4M3 (head_dim 128 only):
+ * every K / V row is stored as 128 OCP FP8 E4M3 codes + one power-of-two float32 scale (include/tinyllm_hip.h, csrc/kv8.h,
+ * oracle/kv_fp8.py): 132 bytes per row instead of 256.  Rows are quantised where they are written (prefill's qkv_post launch, the
+ * decode attention's append) and every attention kernel reads the codes; the token being decoded is quantised before it is attended
+ * to.  The model's arithmetic is otherwise unchanged: attention over the dequantised rows, which are exact bfloat16 values.
+ * tl_engine_create == tl_engine_create_kv(..., TL_KV_BF16, ...). */
+enum { TL_KV_BF16 = 0, TL_KV_FP8_E4M3 = 1 };
+int tl_engine_create_kv(const tl_engine_config *cfg, const tl_layer_weights *layers, const tl_w4 *embed, const void *final_norm_dev,
+                        const tl_w4 *lm_head, void *stream, int kv_format, tl_engine **out);
+/* TL_KV_BF16 or TL_KV_FP8_E4M3 */
+int tl_engine_kv_format(const tl_engine *e);
 /* Make `layer` a mixture-of-experts layer (after tl_engine_create, before the first prefill / decode of the engine).  The layer's
  * dense wgu / wdown may be null in tl_engine_create's `layers` then; a layer with neither is an error at its first use.  The MoE
  * MLP runs as the reference's op sequence inside the captured step: RMSNorm, router GEMV, route kernel, gathered gate and up
@@ -381,6 +393,14 @@ int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm_dev, const
                               void *out_dev, int batch, int num_heads, int num_kv_heads, int head_dim, int page_size,
                               int max_pages, float rope_theta, float eps, int max_context, void *workspace_dev,
                               size_t workspace_bytes, void *stream, tl_attention_info *info);
+/* ... over FP8 (E4M3) pages: key_pages / value_pages [P, Hkv, page, 128] uint8 + key_scales / value_scales [P, Hkv, page] float32
+ * (tl_engine_create_kv, include/tinyllm_hip.h "FP8 KV pages"); the appended row is quantised, head_dim 128 */
+int tl_decode_attention_fused_fp8(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev, void *key_pages_dev,
+                                  float *key_scales_dev, void *value_pages_dev, float *value_scales_dev,
+                                  const int32_t *block_table_dev, const int32_t *context_lens_dev, void *out_dev, int batch,
+                                  int num_heads, int num_kv_heads, int head_dim, int page_size, int max_pages, float rope_theta,
+                                  float eps, int max_context, void *workspace_dev, size_t workspace_bytes, void *stream,
+                                  tl_attention_info *info);
 
 #ifdef __cplusplus
 }

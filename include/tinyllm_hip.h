@@ -130,6 +130,28 @@ int tl_paged_attention(const void *q, const void *key_pages, const void *value_p
 size_t tl_paged_attention_workspace_bytes(int N, int L, int D, int page_size, int max_pages, int num_heads,
                                           int num_kv_heads, int max_context_hint);
 
+/* ===== FP8 (E4M3) KV pages -- SURVEY.md section 8f row 4, "quantized-KV" ========
+ * NO reference interface is replaced: the reference lists quantised KV caches as
+ * not covered (README.md:134-135).  These are the quantised twins of the two
+ * paged entry points above (paged_attention.cpp:14-70, :77-225), for the page
+ * format oracle/kv_fp8.py states and csrc/kv8.h implements:
+ *   pages  [P,H,page_size,128] uint8  -- OCP FP8 E4M3 codes, the bf16 layout at one byte per element
+ *   scales [P,H,page_size]     float  -- one power of two per (page, head, slot) row: the smallest with amax / s <= 448
+ * A dequantised value code * s is exactly a bfloat16 value; attention over FP8
+ * pages is tl_paged_attention's arithmetic over the dequantised rows.  bfloat16
+ * values / queries / outputs, head dimension 128 only. */
+/* values [rows,128] bf16 -> codes [rows,128] + scales [rows]; and back (out [rows,128] bf16, exact) */
+int tl_kv_fp8_quantize_rows(const void *values, void *codes, float *scales, long rows, int head_dim, void *stream);
+int tl_kv_fp8_dequantize_rows(const void *codes, const float *scales, void *out, long rows, int head_dim, void *stream);
+/* pages / page_scales written IN PLACE at (page_id, start .. start + length); values [1,H,length,128] bf16 */
+int tl_paged_cache_update_fp8(void *pages, float *page_scales, const void *values, int num_pages, int heads, int page_size,
+                              int head_dim, int length, int page_id, int start, void *stream);
+/* as tl_paged_attention (same routing by L, same workspace rule); q, out bf16 */
+int tl_paged_attention_fp8(const void *q, const void *key_pages, const float *key_scales, const void *value_pages,
+                           const float *value_scales, const int32_t *block_table, const int32_t *context_lens, void *out, int N,
+                           int L, int D, int num_pages, int page_size, int max_pages, int num_heads, int num_kv_heads, float scale,
+                           int is_causal, int max_context_hint, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ===== fused decode fast path (not visible through the reference API) ========
  * One Qwen3 decode step = the layer loop of Qwen3ModelWeek2/3.__call__
  * (qwen3_week2.py:357-392, qwen3_week3.py:320-338) for L=1, with the

@@ -2,7 +2,10 @@
 // split-context paged decode attention (+merge) and paged FlashAttention on
 // bf16 MFMA.  Reference: week2_kernels.metal:119-235, paged_attention.metal:82-506,
 // host dispatch week2_kernels.cpp:176-211 and paged_attention.cpp:129-225.
+#include <type_traits>
+
 #include "common.h"
+#include "kv8.h"
 
 namespace tl {
 
@@ -124,6 +127,42 @@ __global__ __launch_bounds__(256) void paged_cache_update_kernel(const char *__r
 }
 
 // ---------------------------------------------------------------------------
+// FP8 (E4M3) pages (kv8.h; no reference counterpart): the quantising twin of the scatter above -- rows of 128 bf16 values
+// [H, len, 128] -> codes pages[page_id, h, start + t, :] + one scale per row -- and the inverse.  One aligned group of 16 lanes per
+// row (8 values per lane), the row's largest magnitude by DPP.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kv8_quantize_rows_kernel(const uint16_t *__restrict__ values, uint8_t *__restrict__ pages,
+                                                                float *__restrict__ scales, long rows, int length, int page_size,
+                                                                long page_row0, int start) {
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int t = threadIdx.x & 15;
+    const long r = min(row, rows - 1);  // every lane takes part in the row reduction
+    const u32x4 raw = *reinterpret_cast<const u32x4 *>(values + r * 128 + t * 8);
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[2 * i] = __uint_as_float(raw[i] << 16);
+        x[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
+    }
+    u32x2 codes;
+    float sc, deq[8];
+    kv8_quantize_row16(x, codes, sc, deq);
+    if (row >= rows) return;
+    const long h = r / length, tt = r - h * length;
+    const long dst = page_row0 + h * page_size + start + tt;
+    *reinterpret_cast<u32x2 *>(pages + dst * 128 + t * 8) = codes;
+    if (t == 0) scales[dst] = sc;
+}
+
+__global__ __launch_bounds__(256) void kv8_dequantize_rows_kernel(const uint8_t *__restrict__ codes, const float *__restrict__ scales,
+                                                                  uint16_t *__restrict__ out, long rows) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // a chunk of 8 elements
+    if (i >= rows * 16) return;
+    const u32x2 c = *reinterpret_cast<const u32x2 *>(codes + i * 8);
+    *reinterpret_cast<u32x4 *>(out + i * 8) = kv8_to_bf16x8(c, scales[i >> 4]);
+}
+
+// ---------------------------------------------------------------------------
 // Paged decode attention, split over the context (flash-decoding).
 //   grid = (n_splits * n_row_chunks, Hkv, B); workgroup = 16 groups x 16 lanes.
 //   A workgroup owns one KV head, RQ=4 query rows of that head's GQA group
@@ -136,13 +175,17 @@ __global__ __launch_bounds__(256) void paged_cache_update_kernel(const char *__r
 // ---------------------------------------------------------------------------
 constexpr int PD_RQ = 4;
 
-template <typename TT, int VD, bool VEC>
+// KV8 (bf16 queries, D = 128): the pages hold E4M3 codes, one byte per element of the same layout, with one power-of-two float32
+// scale per (page, kv head, slot) row in key_scales / value_scales (kv8.h); the row scales are folded into the score and into the
+// softmax weight -- bit for bit the arithmetic of this kernel over the dequantised rows.
+template <typename TT, int VD, bool VEC, bool KV8 = false>
 __global__ __launch_bounds__(256) void paged_decode_kernel(
     const typename TT::storage *__restrict__ q, const typename TT::storage *__restrict__ key_pages,
     const typename TT::storage *__restrict__ value_pages, const int32_t *__restrict__ block_table,
     const int32_t *__restrict__ context_lens, typename TT::storage *__restrict__ out, float *__restrict__ ws, int L,
     int D, int page_size, int max_pages, int num_heads, int num_kv_heads, float scale, int is_causal, int n_splits,
-    int n_row_chunks) {
+    int n_row_chunks, const float *__restrict__ key_scales = nullptr, const float *__restrict__ value_scales = nullptr) {
+    static_assert(!KV8 || (VD == 8 && VEC), "FP8 pages: head dimension 128");
     using S = typename TT::storage;
     extern __shared__ __attribute__((aligned(16))) float psm[];  // [16][RQ][D+2]
     const int split = blockIdx.x % n_splits;
@@ -194,7 +237,15 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
         if (page_id < 0) continue;
         const long off = (((long)page_id * num_kv_heads + kvh) * page_size + slot) * D;
         float kf[VD], vf[VD];
-        if constexpr (VEC) {
+        float k_s = 1.f, v_s = 1.f;  // KV8: the rows' scales
+        if constexpr (KV8) {
+            const u32x2 kc = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const uint8_t *>(key_pages) + off + t * VD);
+            const u32x2 vc = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const uint8_t *>(value_pages) + off + t * VD);
+            k_s = key_scales[off / D];
+            v_s = value_scales[off / D];
+            kv8_unpack8(kc, kf);
+            kv8_unpack8(vc, vf);
+        } else if constexpr (VEC) {
             S kr[VD], vr[VD];
             constexpr int BYTES = VD * sizeof(S);
             if constexpr (BYTES == 16) {
@@ -227,14 +278,15 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
             float part = 0.f;
 #pragma unroll
             for (int i = 0; i < VD; ++i) part += qv[r][i] * kf[i];
-            const float score = group16_sum(part);
+            const float score = KV8 ? group16_sum(part) * k_s : group16_sum(part);
             if (tok < rq_vis[r]) {
                 const float nm = fmaxf(m[r], score);
                 const float of = exp2_hw(m[r] - nm);
                 const float sf = exp2_hw(score - nm);
                 l[r] = l[r] * of + sf;
+                const float sfv = KV8 ? sf * v_s : sf;
 #pragma unroll
-                for (int i = 0; i < VD; ++i) acc[r][i] = acc[r][i] * of + sf * vf[i];
+                for (int i = 0; i < VD; ++i) acc[r][i] = acc[r][i] * of + sfv * vf[i];
                 m[r] = nm;
             }
         }
@@ -341,13 +393,21 @@ constexpr int FA_VROW = 128 + 32;    // bf16 elements per row of the row-major V
 // (~20 VALU instructions per chunk, as much as the softmax of the stage) disappear.
 // QR = 32-row query blocks per wave (round 3): with two, every K and V fragment read from LDS feeds two MFMAs and a workgroup
 // covers 4 heads x 64 query rows per K/V tile it stages -- half the staging, half the fragment reads per flop; one wave per SIMD.
-template <bool ONEPAGE, int QR = 1>
+// KV8: the pages hold E4M3 codes (one byte per element of the same layout) and key_scales / value_scales one power-of-two float32 per
+// (page, kv head, slot) row (kv8.h).  A thread requests 8 bytes per chunk instead of 16, plus its rows' scales, and converts to the bf16
+// values a bf16 page would hold (exact) when it stores the chunk into the LDS tiles: everything behind the staging is unchanged.
+template <bool ONEPAGE, int QR = 1, bool KV8 = false>
 __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kernel(
-    const uint16_t *__restrict__ q, const uint16_t *__restrict__ key_pages, const uint16_t *__restrict__ value_pages,
+    const uint16_t *__restrict__ q, const void *__restrict__ key_pages_v, const void *__restrict__ value_pages_v,
     const int32_t *__restrict__ block_table, const int32_t *__restrict__ context_lens, uint16_t *__restrict__ out,
     float *__restrict__ ws, int n_splits, int L, int page_size, int page_shift, int max_pages, int num_heads, int num_kv_heads,
-    float scale, int is_causal, int xcd_remap) {
+    float scale, int is_causal, int xcd_remap, const float *__restrict__ key_scales = nullptr,
+    const float *__restrict__ value_scales = nullptr) {
     constexpr int D = 128;
+    using KVE = typename std::conditional<KV8, uint8_t, uint16_t>::type;  // a page element
+    using KVC = typename std::conditional<KV8, u32x2, u32x4>::type;        // a chunk of 8 of them
+    const KVE *__restrict__ key_pages = reinterpret_cast<const KVE *>(key_pages_v);
+    const KVE *__restrict__ value_pages = reinterpret_cast<const KVE *>(value_pages_v);
     __shared__ __attribute__((aligned(16))) uint16_t ks[FA_BK * D];     // [token][dim] swizzled
     __shared__ __attribute__((aligned(16))) uint16_t vs[FA_BK * FA_VROW];  // [token][dim] as it lies in the page; read transposed
     __shared__ int tile_page[2][FA_BK];
@@ -436,7 +496,8 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
     // staging: thread -> (token = c/16, chunk = c%16) for c = tid, tid+256
     // A STAGE is FA_BK tokens (FA_SUB sub-tiles of 32): one pair of barriers and one global round trip per stage.  With
     // 32-token stages the MFMA work of a stage (~0.5 us) could not cover the latency of the next stage's rows.
-    u32x4 kreg[FA_CPT], vreg[FA_CPT];
+    KVC kreg[FA_CPT], vreg[FA_CPT];
+    float ksc[KV8 ? FA_CPT : 1], vsc[KV8 ? FA_CPT : 1];  // KV8: the scale of each chunk's row
     // page ids travel one stage ahead of the K/V rows they address: a stage's loads are then ONE global round trip behind
     // the MFMAs of the previous stage instead of two dependent ones (block table, then rows)
     // K and V chunk c = tid + 256 i  ->  (token c / 16, 16-byte chunk c % 16): coalesced rows, b128 stores into the swizzled K tile
@@ -476,18 +537,26 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
             const int page = pid_in[0] ? __builtin_amdgcn_readfirstlane(page_next) : -1;
             const int slot0 = (stage * FA_BK) & (page_size - 1);
             const long base = (((long)max(page, 0) * num_kv_heads + kvh) * page_size + slot0) * D;  // uniform
-            const uint16_t *kbase = key_pages + base;
-            const uint16_t *vbase = value_pages + base;
+            const KVE *kbase = key_pages + base;
+            const KVE *vbase = value_pages + base;
             stage_full = page >= 0 && (stage + 1) * FA_BK <= ctx;  // uniform: nothing to zero when the store comes
 #pragma unroll
             for (int i = 0; i < FA_CPT; ++i) {
                 const int c = tid + i * 256;  // token c / 16, chunk c % 16: the stage's 64 K rows are contiguous
-                kreg[i] = *reinterpret_cast<const u32x4 *>(kbase + (size_t)c * 8);
+                kreg[i] = *reinterpret_cast<const KVC *>(kbase + (size_t)c * 8);
                 kv_ok[i] = page >= 0 && stage * FA_BK + (c >> 4) < ctx;  // rows past the context are zeroed in LDS as before
                 if ((c & 15) == 0) tile_page[stage & 1][c >> 4] = kv_ok[i] ? page : -1;
             }
 #pragma unroll
-            for (int i = 0; i < FA_CPT; ++i) vreg[i] = *reinterpret_cast<const u32x4 *>(vbase + (size_t)(tid + i * 256) * 8);
+            for (int i = 0; i < FA_CPT; ++i) vreg[i] = *reinterpret_cast<const KVC *>(vbase + (size_t)(tid + i * 256) * 8);
+            if constexpr (KV8) {
+                const long row0 = base / D;  // uniform
+#pragma unroll
+                for (int i = 0; i < FA_CPT; ++i) {
+                    ksc[i] = key_scales[row0 + ((tid + i * 256) >> 4)];
+                    vsc[i] = value_scales[row0 + ((tid + i * 256) >> 4)];
+                }
+            }
             return;
         }
 #pragma unroll
@@ -502,8 +571,12 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
             // unconditional loads from a clamped address (a divergent branch around a load makes hipcc wait for it at the
             // join, i.e. before the MFMAs it should overlap); rows of unused pages are zeroed when they are stored to LDS
             const long off = (((long)max(page_id, 0) * num_kv_heads + kvh) * page_size + slot) * D + ch * 8;
-            kreg[i] = *reinterpret_cast<const u32x4 *>(key_pages + off);
-            vreg[i] = *reinterpret_cast<const u32x4 *>(value_pages + off);
+            kreg[i] = *reinterpret_cast<const KVC *>(key_pages + off);
+            vreg[i] = *reinterpret_cast<const KVC *>(value_pages + off);
+            if constexpr (KV8) {
+                ksc[i] = key_scales[off / D];
+                vsc[i] = value_scales[off / D];
+            }
             kv_ok[i] = page_id >= 0;
             if (ch == 0) tile_page[stage & 1][tok_in] = page_id;  // read one iteration later, after two barriers
         }
@@ -515,14 +588,20 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
             const int c = tid + i * 256;
             const int tok_in = c >> 4;
             const int ch = c & 15;
-            if (!(ONEPAGE && stage_full) && !kv_ok[i]) kreg[i] = u32x4{0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4 *>(&ks[tok_in * D + ((ch ^ (tok_in & 15)) * 8)]) = kreg[i];
+            u32x4 kk;
+            if constexpr (KV8) kk = kv8_to_bf16x8(kreg[i], ksc[i]);
+            else kk = kreg[i];
+            if (!(ONEPAGE && stage_full) && !kv_ok[i]) kk = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4 *>(&ks[tok_in * D + ((ch ^ (tok_in & 15)) * 8)]) = kk;
         }
 #pragma unroll
         for (int i = 0; i < FA_CPT; ++i) {  // V rows as they lie in the page: one b128 store per chunk (the PV fragments are read transposed)
             const int c = tid + i * 256;
-            if (!(ONEPAGE && stage_full) && !kv_ok[i]) vreg[i] = u32x4{0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4 *>(&vs[(c >> 4) * FA_VROW + (c & 15) * 8]) = vreg[i];
+            u32x4 vv;
+            if constexpr (KV8) vv = kv8_to_bf16x8(vreg[i], vsc[i]);
+            else vv = vreg[i];
+            if (!(ONEPAGE && stage_full) && !kv_ok[i]) vv = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4 *>(&vs[(c >> 4) * FA_VROW + (c & 15) * 8]) = vv;
         }
     };
 
@@ -793,11 +872,13 @@ extern "C" size_t tl_paged_attention_workspace_bytes(int N, int L, int D, int pa
     return (size_t)N * L * splits * (D + 2) * sizeof(float);
 }
 
-extern "C" int tl_paged_attention(const void *q, const void *key_pages, const void *value_pages,
-                                  const int32_t *block_table, const int32_t *context_lens, void *out, int N, int L,
-                                  int D, int num_pages, int page_size, int max_pages, int num_heads, int num_kv_heads,
-                                  float scale, int is_causal, int max_context_hint, tl_dtype dtype, void *workspace,
-                                  size_t workspace_bytes, void *stream) {
+// key_scales != nullptr: FP8 pages (bf16 queries, head dimension 128)
+static int paged_attention_impl(const void *q, const void *key_pages, const void *value_pages, const float *key_scales,
+                                const float *value_scales, const int32_t *block_table, const int32_t *context_lens, void *out, int N,
+                                int L, int D, int num_pages, int page_size, int max_pages, int num_heads, int num_kv_heads, float scale,
+                                int is_causal, int max_context_hint, tl_dtype dtype, void *workspace, size_t workspace_bytes,
+                                void *stream) {
+    const bool kv8 = key_scales != nullptr;
     TL_REQUIRE(dtype == TL_F32 || dtype == TL_BF16,
                "paged_attention: q, key_pages, and value_pages must have the same float32 or bfloat16 dtype");
     TL_REQUIRE(q && key_pages && value_pages && block_table && context_lens && out, "paged_attention: null pointer");
@@ -832,13 +913,16 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
         int page_shift = -1;
         for (int sh = 0; sh < 30; ++sh)
             if ((1 << sh) == page_size) page_shift = sh;
-#define FA_LAUNCH(ONEP, QRv)                                                                                                    \
-        hipLaunchKernelGGL((paged_fa_bf16_d128_kernel<ONEP, QRv>), grid, dim3(256), 0, st, (const uint16_t *)q,                 \
-                           (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens,                \
-                           (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, page_shift, max_pages, num_heads,      \
-                           num_kv_heads, scale, is_causal, fa_xcd_remap)
-        if (page_shift >= 6) FA_LAUNCH(true, 1);  // a 64-token stage never straddles pages
-        else FA_LAUNCH(false, 1);
+#define FA_LAUNCH(ONEP, QRv, K8)                                                                                                \
+        hipLaunchKernelGGL((paged_fa_bf16_d128_kernel<ONEP, QRv, K8>), grid, dim3(256), 0, st, (const uint16_t *)q, key_pages,  \
+                           value_pages, block_table, context_lens, (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, \
+                           page_shift, max_pages, num_heads, num_kv_heads, scale, is_causal, fa_xcd_remap, key_scales,            \
+                           value_scales)
+        if (kv8) {
+            if (page_shift >= 6) FA_LAUNCH(true, 1, true);
+            else FA_LAUNCH(false, 1, true);
+        } else if (page_shift >= 6) FA_LAUNCH(true, 1, false);  // a 64-token stage never straddles pages
+        else FA_LAUNCH(false, 1, false);
 #undef FA_LAUNCH
         TL_CHECK_LAUNCH("paged_attention(prefill)");
         if (fa_splits > 1) {
@@ -864,7 +948,12 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
                        (const typename TT::storage *)key_pages, (const typename TT::storage *)value_pages,         \
                        block_table, context_lens, (typename TT::storage *)out, ws, L, D, page_size, max_pages,     \
                        num_heads, num_kv_heads, scale, is_causal, splits, row_chunks)
-    if (dtype == TL_BF16) {
+    if (kv8) {
+        hipLaunchKernelGGL((paged_decode_kernel<BF16, 8, true, true>), grid, block, lds, st, (const uint16_t *)q,
+                           (const uint16_t *)key_pages, (const uint16_t *)value_pages, block_table, context_lens, (uint16_t *)out, ws,
+                           L, D, page_size, max_pages, num_heads, num_kv_heads, scale, is_causal, splits, row_chunks, key_scales,
+                           value_scales);
+    } else if (dtype == TL_BF16) {
         if (D == 128) PD_LAUNCH(BF16, 8, true);
         else if (D == 64) PD_LAUNCH(BF16, 4, true);
         else PD_LAUNCH(BF16, 8, false);
@@ -885,4 +974,63 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
     }
     (void)paged_uses_fa;
     return TL_OK;
+}
+
+extern "C" int tl_paged_attention(const void *q, const void *key_pages, const void *value_pages,
+                                  const int32_t *block_table, const int32_t *context_lens, void *out, int N, int L,
+                                  int D, int num_pages, int page_size, int max_pages, int num_heads, int num_kv_heads,
+                                  float scale, int is_causal, int max_context_hint, tl_dtype dtype, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+    return paged_attention_impl(q, key_pages, value_pages, nullptr, nullptr, block_table, context_lens, out, N, L, D, num_pages, page_size,
+                                max_pages, num_heads, num_kv_heads, scale, is_causal, max_context_hint, dtype, workspace, workspace_bytes,
+                                stream);
+}
+
+// ---- FP8 (E4M3) KV pages: the quantised twins of paged_cache_update / paged_attention (kv8.h, include/tinyllm_hip.h) ----------------
+extern "C" int tl_kv_fp8_quantize_rows(const void *values, void *codes, float *scales, long rows, int head_dim, void *stream) {
+    TL_REQUIRE(values && codes && scales, "kv_fp8_quantize_rows: null pointer");
+    TL_REQUIRE(head_dim == 128 && rows >= 0, "kv_fp8_quantize_rows: rows of 128 bfloat16 values");
+    if (rows == 0) return TL_OK;
+    hipLaunchKernelGGL(kv8_quantize_rows_kernel, dim3(ceil_div(rows, 16)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)values,
+                       (uint8_t *)codes, scales, rows, (int)std::min<long>(rows, 1 << 30), (int)std::min<long>(rows, 1 << 30), 0L, 0);
+    TL_CHECK_LAUNCH("kv_fp8_quantize_rows");
+    return TL_OK;
+}
+
+extern "C" int tl_kv_fp8_dequantize_rows(const void *codes, const float *scales, void *out, long rows, int head_dim, void *stream) {
+    TL_REQUIRE(codes && scales && out, "kv_fp8_dequantize_rows: null pointer");
+    TL_REQUIRE(head_dim == 128 && rows >= 0, "kv_fp8_dequantize_rows: rows of 128 codes");
+    if (rows == 0) return TL_OK;
+    hipLaunchKernelGGL(kv8_dequantize_rows_kernel, dim3(ceil_div(rows * 16, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)codes, scales, (uint16_t *)out, rows);
+    TL_CHECK_LAUNCH("kv_fp8_dequantize_rows");
+    return TL_OK;
+}
+
+extern "C" int tl_paged_cache_update_fp8(void *pages, float *page_scales, const void *values, int num_pages, int heads, int page_size,
+                                         int head_dim, int length, int page_id, int start, void *stream) {
+    TL_REQUIRE(pages && page_scales && values, "paged_cache_update_fp8: null pointer");
+    TL_REQUIRE(head_dim == 128, "paged_cache_update_fp8: FP8 pages need head dimension 128");
+    TL_REQUIRE(heads > 0 && page_size > 0 && length >= 0,
+               "paged_cache_update_fp8: expected pages [P, H, page_size, 128] and bfloat16 values [1, H, length, 128]");
+    TL_REQUIRE(page_id >= 0 && page_id < num_pages && start >= 0 && start + length <= page_size,
+               "paged_cache_update_fp8: destination slice is outside page storage");
+    if (length == 0) return TL_OK;
+    const long rows = (long)heads * length;
+    hipLaunchKernelGGL(kv8_quantize_rows_kernel, dim3(ceil_div(rows, 16)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)values,
+                       (uint8_t *)pages, page_scales, rows, length, page_size, (long)page_id * heads * page_size, start);
+    TL_CHECK_LAUNCH("paged_cache_update_fp8");
+    return TL_OK;
+}
+
+extern "C" int tl_paged_attention_fp8(const void *q, const void *key_pages, const float *key_scales, const void *value_pages,
+                                      const float *value_scales, const int32_t *block_table, const int32_t *context_lens, void *out,
+                                      int N, int L, int D, int num_pages, int page_size, int max_pages, int num_heads, int num_kv_heads,
+                                      float scale, int is_causal, int max_context_hint, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
+    TL_REQUIRE(key_scales && value_scales, "paged_attention_fp8: null scale pointer");
+    TL_REQUIRE(D == 128, "paged_attention_fp8: FP8 pages need head dimension 128");
+    return paged_attention_impl(q, key_pages, value_pages, key_scales, value_scales, block_table, context_lens, out, N, L, D, num_pages,
+                                page_size, max_pages, num_heads, num_kv_heads, scale, is_causal, max_context_hint, TL_BF16, workspace,
+                                workspace_bytes, stream);
 }

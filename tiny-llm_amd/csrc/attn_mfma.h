@@ -36,8 +36,12 @@ constexpr int AM_OFF_QP = AM_OFF_Q + AD_RQ * 128 * 2;
 static_assert(AM_OFF_K % 16 == 0 && AM_OFF_Q % 16 == 0 && AM_OFF_QP % 16 == 0, "16-byte LDS rows");
 constexpr size_t attn_mfma_lds_bytes(bool qp) { return (size_t)AM_OFF_QP + (qp ? (2 + AD_RQ) * 128 * 2 : 0); }
 
-template <bool QP>
+// KV8 = FP8 pages (kv8.h): a lane requests 8 bytes of codes per row instead of 16 of bf16, and the scales of its 8 tokens as two
+// 16-byte words per pool.  Codes become bf16 UNSCALED on their way into the K image / the V operands (exact); the K row's scale
+// multiplies its score, the V row's its softmax weight -- powers of two, so this is bit for bit the walk over the dequantised rows.
+template <bool QP, bool KV8 = false>
 __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeArgs p) {
+    using KVC = typename std::conditional<KV8, u32x2, u32x4>::type;  // a lane's chunk of a K / V row as requested
     constexpr int VD = 8, D = 128, RQ = AD_RQ, STRIDE = D + 2, WT = 32, ST = 4 * WT;  // tokens per wave / workgroup and stage
     extern __shared__ __attribute__((aligned(16))) float psm[];  // [AM_NSLOT][RQ][STRIDE] | K rows | q rows | (QP) staged rows
     char *lds = reinterpret_cast<char *>(psm);
@@ -124,18 +128,34 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
     // The resource ends behind the last VISIBLE row of the wave's 32 (context length, window end, an unmapped page: none): rows past it
     // come back as zeros from the range check -- a masked token's weight is 0, but 0 x NaN is NaN, and a recycled or caller-provided
     // page may hold anything behind the context (scalar arithmetic only: nothing is added to the walk)
-    auto issue_rows = [&](const uint16_t *pool, int tb, int pg, u32x4(&rows)[8]) {
-        const long rowbase = (((long)max(pg, 0) * Hkv + kvh) * p.page_size + (tb & (p.page_size - 1))) * D;  // uniform
+    // KV8: the same rows at one byte per element, and the scales of the lane's 8 tokens (rows 4 g .. 4 g + 3 and 16 + 4 g .. + 3 of the wave's 32)
+    struct Scales {
+        f32x4 lo, hi;
+    };
+    auto issue_rows = [&](const uint16_t *pool, const float *scales, int tb, int pg, KVC(&rows)[8], Scales &sc) {
+        const long prow0 = ((long)max(pg, 0) * Hkv + kvh) * p.page_size + (tb & (p.page_size - 1));  // uniform
         const int end = (pg >= 0 && page_of(tb) < p.max_pages && live) ? min(ctx, t_begin + C) : 0;
         const int visible = min(max(end - tb, 0), WT);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(pool + rowbase), 0, visible * D * 2, 0x00020000);
+        if constexpr (KV8) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t *>(reinterpret_cast<const uint8_t *>(pool) + prow0 * D), 0, visible * D, 0x00020000);
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            rows[e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes + ((e < 4) ? e : 12 + e) * D * 2, 0, 0));
+            for (int e = 0; e < 8; ++e)
+                rows[e] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes / 2 + ((e < 4) ? e : 12 + e) * D, 0, 0));
+            const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(scales + prow0), 0, visible * 4, 0x00020000);
+            sc.lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rss, 16 * g, 0, 0));
+            sc.hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rss, 64 + 16 * g, 0, 0));
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(pool + prow0 * D), 0, visible * D * 2, 0x00020000);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                rows[e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes + ((e < 4) ? e : 12 + e) * D * 2, 0, 0));
+        }
     };
-    u32x4 kr[8], va[8], vb[8];
-    issue_rows(p.key_pages, wave_base(0), pg_cur, kr);
-    issue_rows(p.value_pages, wave_base(0), pg_cur, va);
+    KVC kr[8], va[8], vb[8];
+    Scales ksa, ksb, vsa, vsb;  // KV8: the scales travel with the V register sets (a stage's K scales are used after the next stage's K rows are requested)
+    issue_rows(p.key_pages, p.key_scales, wave_base(0), pg_cur, kr, ksa);
+    issue_rows(p.value_pages, p.value_scales, wave_base(0), pg_cur, va, vsa);
 
     if constexpr (QP) {
         uint16_t *qs = reinterpret_cast<uint16_t *>(lds + AM_OFF_QP);
@@ -191,6 +211,22 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
     };
     float k_new[VD];
     norm_rope(kraw_new, kw, k_new);
+    // KV8: the new rows as the page will hold them; this step attends to the dequantised values
+    float v_new[VD];
+#pragma unroll
+    for (int i = 0; i < VD; ++i) v_new[i] = BF16::to_float(vraw_new.v[i]);
+    u32x2 k_new_c = u32x2{0u, 0u}, v_new_c = u32x2{0u, 0u};
+    float k_new_s = 1.f, v_new_s = 1.f;
+    if constexpr (KV8) {
+        float kd[8], vd[8];
+        kv8_quantize_row16(k_new, k_new_c, k_new_s, kd);
+        kv8_quantize_row16(v_new, v_new_c, v_new_s, vd);
+#pragma unroll
+        for (int i = 0; i < VD; ++i) {
+            k_new[i] = kd[i];
+            v_new[i] = vd[i];
+        }
+    }
     uint16_t *qrows = reinterpret_cast<uint16_t *>(lds + AM_OFF_Q);
     const bool with_new = split == 0 && live;
 #pragma unroll
@@ -206,7 +242,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
             store_row<VD>(qrows + r * D + t * VD, qn);  // (bf16 values: exact)
             float *dst = psm + (long)r * STRIDE;
 #pragma unroll
-            for (int i = 0; i < VD; ++i) dst[t * VD + i] = with_new ? BF16::to_float(vraw_new.v[i]) : 0.f;
+            for (int i = 0; i < VD; ++i) dst[t * VD + i] = with_new ? v_new[i] : 0.f;
             if (t == 0) {
                 dst[D] = with_new ? score : -1e30f;
                 dst[D + 1] = with_new ? 1.f : 0.f;
@@ -232,12 +268,17 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -1e30f, l_run = 0.f;
-    auto walk_stage = [&](int it, u32x4(&vc)[8], u32x4(&vn)[8]) {
+    auto walk_stage = [&](int it, KVC(&vraw)[8], KVC(&vn)[8], Scales &ksc, Scales &vsc, Scales &ksn, Scales &vsn) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) *reinterpret_cast<u32x4 *>(kl + (4 * g + ((e < 4) ? e : 12 + e)) * AM_KROW + 16 * c) = kr[e];
+        for (int e = 0; e < 8; ++e) {
+            u32x4 kk;
+            if constexpr (KV8) kk = kv8_to_bf16x8(kr[e], 1.0f);
+            else kk = kr[e];
+            *reinterpret_cast<u32x4 *>(kl + (4 * g + ((e < 4) ? e : 12 + e)) * AM_KROW + 16 * c) = kk;
+        }
         const int nx = min(it + 1, n_it - 1);
-        issue_rows(p.key_pages, wave_base(nx), pg_nxt, kr);
-        issue_rows(p.value_pages, wave_base(nx), pg_nxt, vn);
+        issue_rows(p.key_pages, p.key_scales, wave_base(nx), pg_nxt, kr, ksn);
+        issue_rows(p.value_pages, p.value_scales, wave_base(nx), pg_nxt, vn, vsn);
         sload_i32(brow + min(page_of(wave_base(min(it + 2, n_it - 1))), p.max_pages - 1), pg_new);  // waited for at the end of this stage
         // S^T = K . Q^T for the two 16-token tiles
         f32x4 s[2];
@@ -263,7 +304,8 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int tok = tb + 16 * ab + 4 * g + i;
-                sv[4 * ab + i] = tok < limit ? s[ab][i] * scale_log2 : -3e38f;
+                if constexpr (KV8) sv[4 * ab + i] = tok < limit ? s[ab][i] * scale_log2 * (ab ? ksc.hi[i] : ksc.lo[i]) : -3e38f;
+                else sv[4 * ab + i] = tok < limit ? s[ab][i] * scale_log2 : -3e38f;
                 tm = fmaxf(tm, sv[4 * ab + i]);
             }
         tm = fmaxf(tm, lane_xor16(tm, lane));
@@ -278,6 +320,17 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
             psum += pw[e];
         }
         l_run = l_run * of + psum;
+        u32x4 vc[8];  // the V chunks as bf16
+        if constexpr (KV8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pw[e] *= (e < 4) ? vsc.lo[e & 3] : vsc.hi[e & 3];  // the V row's scale rides on the weight (a masked row: 0 x 0)
+                vc[e] = kv8_to_bf16x8(vraw[e], 1.0f);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vc[e] = vraw[e];
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -308,9 +361,9 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
     };
     // (the odd tail leaves the loop instead of skipping to its latch: the back edge carries ONE order of pending requests)
     for (int it = 0;; it += 2) {
-        walk_stage(it, va, vb);
+        walk_stage(it, va, vb, ksa, vsa, ksb, vsb);
         if (it + 1 >= n_it) break;
-        walk_stage(it + 1, vb, va);
+        walk_stage(it + 1, vb, va, ksb, vsb, ksa, vsa);
         if (it + 2 >= n_it) break;
     }
 
@@ -360,9 +413,19 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
     }
     sload_wait(wpage);
     if (live && wp < p.max_pages && wpage >= 0 && split == 0 && chunk == 0 && g16 == 0) {
-        const long off = (((long)wpage * Hkv + kvh) * p.page_size + wslot) * D + t * VD;
-        store_row<VD>(p.key_pages + off, k_new);
-        store_raw<VD>(p.value_pages + off, vraw_new);
+        const long prow = ((long)wpage * Hkv + kvh) * p.page_size + wslot;
+        const long off = prow * D + t * VD;
+        if constexpr (KV8) {
+            *reinterpret_cast<u32x2 *>(reinterpret_cast<uint8_t *>(p.key_pages) + off) = k_new_c;
+            *reinterpret_cast<u32x2 *>(reinterpret_cast<uint8_t *>(p.value_pages) + off) = v_new_c;
+            if (t == 0) {
+                p.key_scales[prow] = k_new_s;
+                p.value_scales[prow] = v_new_s;
+            }
+        } else {
+            store_row<VD>(p.key_pages + off, k_new);
+            store_raw<VD>(p.value_pages + off, vraw_new);
+        }
     }
     prof_end(p.prof, prof_t0);
 }

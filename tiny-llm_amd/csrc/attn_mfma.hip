@@ -9,8 +9,14 @@ bool attn_decode_mfma_applicable(const AttnDecodeArgs &a, int head_dim, int rq) 
 }
 
 void launch_attn_decode_mfma(const AttnDecodeArgs &a, dim3 grid, hipStream_t st) {
-    if (a.qkv_partial != nullptr) hipLaunchKernelGGL(attn_decode_mfma_kernel<true>, grid, dim3(256), attn_mfma_lds_bytes(true), st, a);
-    else hipLaunchKernelGGL(attn_decode_mfma_kernel<false>, grid, dim3(256), attn_mfma_lds_bytes(false), st, a);
+    const bool kv8 = a.key_scales != nullptr;  // FP8 pages (kv8.h)
+    if (a.qkv_partial != nullptr) {
+        if (kv8) hipLaunchKernelGGL((attn_decode_mfma_kernel<true, true>), grid, dim3(256), attn_mfma_lds_bytes(true), st, a);
+        else hipLaunchKernelGGL((attn_decode_mfma_kernel<true, false>), grid, dim3(256), attn_mfma_lds_bytes(true), st, a);
+    } else {
+        if (kv8) hipLaunchKernelGGL((attn_decode_mfma_kernel<false, true>), grid, dim3(256), attn_mfma_lds_bytes(false), st, a);
+        else hipLaunchKernelGGL((attn_decode_mfma_kernel<false, false>), grid, dim3(256), attn_mfma_lds_bytes(false), st, a);
+    }
 }
 
 }  // namespace tl

@@ -58,6 +58,13 @@ struct tl_engine {
     size_t arena_bytes = 0;
     uint16_t *kpool = nullptr, *vpool = nullptr;  // [layers][P, Hkv, page, D]
     size_t layer_pool_elems = 0, kv_bytes = 0;
+    // FP8 pages (tl_engine_create_kv, kv8.h): the pools hold one byte per element and the rows' scales live beside them
+    int kv_format = TL_KV_BF16;
+    float *kscale_pool = nullptr, *vscale_pool = nullptr;  // [layers][P, Hkv, page]
+    size_t layer_scale_elems = 0;
+    size_t kv_elem_bytes() const { return kv_format == TL_KV_FP8_E4M3 ? 1 : 2; }
+    float *layer_ks(int l) const { return kscale_pool ? kscale_pool + (size_t)l * layer_scale_elems : nullptr; }
+    float *layer_vs(int l) const { return vscale_pool ? vscale_pool + (size_t)l * layer_scale_elems : nullptr; }
     void *splitk_ws = nullptr;
     size_t splitk_ws_bytes = 0;
     // decode-path copy of every W4 matrix in the tiled MFMA layout (qmv3.h); keyed by the checkpoint pointer
@@ -200,8 +207,8 @@ struct tl_engine {
     int qkv_dim() const { return (cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim; }
     int q_dim() const { return cfg.num_heads * cfg.head_dim; }
     const tl_w4 &head() const { return lm_head.weight_dev ? lm_head : embed; }
-    uint16_t *layer_k(int l) const { return kpool + (size_t)l * layer_pool_elems; }
-    uint16_t *layer_v(int l) const { return vpool + (size_t)l * layer_pool_elems; }
+    uint16_t *layer_k(int l) const { return (uint16_t *)((char *)kpool + (size_t)l * layer_pool_elems * kv_elem_bytes()); }
+    uint16_t *layer_v(int l) const { return (uint16_t *)((char *)vpool + (size_t)l * layer_pool_elems * kv_elem_bytes()); }
 };
 
 static int aql_drain(tl_engine *e);
@@ -656,6 +663,14 @@ template <int VD, bool SP, bool IP = false>
 static void launch_attn_decode_sp(const AttnDecodeArgs &a, dim3 grid, hipStream_t st, int rq) {
     const size_t lds = (size_t)16 * rq * (16 * VD + 2) * sizeof(float);
     if constexpr (VD == 8) {
+        if (a.key_scales != nullptr) {  // FP8 pages (kv8.h)
+            if (a.qkv_partial != nullptr && rq == AD_RQ) {
+                const size_t staged = (size_t)(2 + AD_RQ) * 16 * VD * sizeof(uint16_t);
+                hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP, true, true>), grid, dim3(256), lds + staged, st, a);
+            } else if (rq == 1) hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, 1, SP, IP, false, true>), grid, dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP, false, true>), grid, dim3(256), lds, st, a);
+            return;
+        }
         if (a.qkv_partial != nullptr && rq == AD_RQ) {
             const size_t staged = (size_t)(2 + AD_RQ) * 16 * VD * sizeof(uint16_t);
             hipLaunchKernelGGL((attn_decode_fused_kernel<VD, 4, AD_RQ, SP, IP, true>), grid, dim3(256), lds + staged, st, a);
@@ -729,7 +744,8 @@ static int engine_wo_merge(tl_engine *e, const tl_w4 &wo, const uint16_t *residu
 // is split).  qkv [batch, (Hq + 2 Hkv) D] -> out [batch, Hq D]; partials in e->attn_ws.
 static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_norm, const void *k_norm, uint16_t *key_pages,
                             uint16_t *value_pages, uint16_t *out, int batch, const SplitPlan &sp, ProfCtx *pc,
-                            const KeptPartials *qkv_parts = nullptr, const tl_w4 *merging_wo = nullptr, bool *merge_left = nullptr) {
+                            const KeptPartials *qkv_parts = nullptr, const tl_w4 *merging_wo = nullptr, bool *merge_left = nullptr,
+                            float *key_scales = nullptr, float *value_scales = nullptr) {
     if (merge_left) *merge_left = false;
     const tl_engine_config &c = e->cfg;
     const int D = c.head_dim;
@@ -742,6 +758,9 @@ static int engine_attention(tl_engine *e, const uint16_t *qkv, const void *q_nor
     a.k_norm_w = (const uint16_t *)k_norm;
     a.key_pages = key_pages;
     a.value_pages = value_pages;
+    a.key_scales = key_scales;
+    a.value_scales = value_scales;
+    TL_REQUIRE(key_scales == nullptr || D == 128, "engine: FP8 pages need head_dim 128");
     a.block_table = e->block_table;
     a.context_lens = e->context_lens;
     a.out = out;
@@ -911,7 +930,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
                                      keep_qkv ? &parts : nullptr, x_ss));
             }
             bool merged = false;
-            TL_TRY(engine_attention(e, qkvb, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), attnb, batch, sp, pc, &parts, &w.wo, &merged));
+            TL_TRY(engine_attention(e, qkvb, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), attnb, batch, sp, pc, &parts, &w.wo, &merged, e->layer_ks(l), e->layer_vs(l)));
             TL_REQUIRE(!merged, "engine: a batched step left its attention windows unmerged");
             int h_ss = 0;
             if (wo6) TL_TRY(engine_qmm6(e, w.wo, attnb, hb, batch, EPI_RESIDUAL, bx, pc, 1, nullptr, 0, sshb, &h_ss, w.post_norm_dev, hwb, frag));
@@ -971,7 +990,7 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
                              x_ss ? ssx_in : nullptr, nullptr, nullptr, keep_qkv ? &qkv_parts : nullptr, x_ss));
         bool merge_left = false;
         TL_TRY(engine_attention(e, qkvb, w.q_norm_dev, w.k_norm_dev, e->layer_k(l), e->layer_v(l), attnb, batch, sp, pc, &qkv_parts,
-                                &w.wo, &merge_left));
+                                &w.wo, &merge_left, e->layer_ks(l), e->layer_vs(l)));
         int h_ss = 0;
         if (e->is_moe(l)) {  // wo + residual, then the MoE MLP as its own launches (no producer-side sums for the next layer)
             if (merge_left) TL_TRY(engine_wo_merge(e, w.wo, x_in, hb, sp.n_splits, pc, nullptr, nullptr));
@@ -1074,12 +1093,19 @@ static void drop_page(tl_engine *e, int id) {
 // K and V rows of one page, every layer (device to device, stream ordered)
 static int copy_page(tl_engine *e, int from, int to) {
     const tl_engine_config &c = e->cfg;
-    const size_t page_elems = (size_t)c.num_kv_heads * c.page_size * c.head_dim;
+    const size_t page_bytes = (size_t)c.num_kv_heads * c.page_size * c.head_dim * e->kv_elem_bytes();
+    const size_t page_rows = (size_t)c.num_kv_heads * c.page_size;  // FP8 pages: one scale per row
     for (int l = 0; l < c.num_layers; ++l) {
-        TL_HIP(hipMemcpyAsync(e->layer_k(l) + (size_t)to * page_elems, e->layer_k(l) + (size_t)from * page_elems,
-                              page_elems * 2, hipMemcpyDeviceToDevice, e->stream));
-        TL_HIP(hipMemcpyAsync(e->layer_v(l) + (size_t)to * page_elems, e->layer_v(l) + (size_t)from * page_elems,
-                              page_elems * 2, hipMemcpyDeviceToDevice, e->stream));
+        TL_HIP(hipMemcpyAsync((char *)e->layer_k(l) + (size_t)to * page_bytes, (char *)e->layer_k(l) + (size_t)from * page_bytes, page_bytes,
+                              hipMemcpyDeviceToDevice, e->stream));
+        TL_HIP(hipMemcpyAsync((char *)e->layer_v(l) + (size_t)to * page_bytes, (char *)e->layer_v(l) + (size_t)from * page_bytes, page_bytes,
+                              hipMemcpyDeviceToDevice, e->stream));
+        if (e->kv_format == TL_KV_FP8_E4M3) {
+            TL_HIP(hipMemcpyAsync(e->layer_ks(l) + (size_t)to * page_rows, e->layer_ks(l) + (size_t)from * page_rows, page_rows * 4,
+                                  hipMemcpyDeviceToDevice, e->stream));
+            TL_HIP(hipMemcpyAsync(e->layer_vs(l) + (size_t)to * page_rows, e->layer_vs(l) + (size_t)from * page_rows, page_rows * 4,
+                                  hipMemcpyDeviceToDevice, e->stream));
+        }
     }
     return TL_OK;
 }
@@ -1137,8 +1163,15 @@ static int slot_check(const tl_engine *e, int slot, bool must_be_live) {
 // ================================================================================================
 extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weights *layers, const tl_w4 *embed,
                                 const void *final_norm_dev, const tl_w4 *lm_head, void *stream, tl_engine **out) {
+    return tl_engine_create_kv(cfg, layers, embed, final_norm_dev, lm_head, stream, TL_KV_BF16, out);
+}
+
+extern "C" int tl_engine_create_kv(const tl_engine_config *cfg, const tl_layer_weights *layers, const tl_w4 *embed,
+                                   const void *final_norm_dev, const tl_w4 *lm_head, void *stream, int kv_format, tl_engine **out) {
     TL_REQUIRE(cfg && layers && embed && final_norm_dev && out, "engine_create: null argument");
     const tl_engine_config &c = *cfg;
+    TL_REQUIRE(kv_format == TL_KV_BF16 || kv_format == TL_KV_FP8_E4M3, "engine_create: kv_format must be TL_KV_BF16 or TL_KV_FP8_E4M3");
+    TL_REQUIRE(kv_format == TL_KV_BF16 || c.head_dim == 128, "engine_create: FP8 KV pages need head_dim 128");
     TL_REQUIRE(c.num_layers > 0 && c.hidden_size > 0 && c.hidden_size % 128 == 0, "engine_create: hidden_size must be a positive multiple of 128");
     TL_REQUIRE(c.num_heads > 0 && c.num_kv_heads > 0 && c.num_heads % c.num_kv_heads == 0,
                "engine_create: num_heads must be divisible by num_kv_heads");
@@ -1166,6 +1199,7 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
 
     auto *e = new tl_engine();
     e->cfg = c;
+    e->kv_format = kv_format;
     if (hipGetDevice(&e->device) != hipSuccess) {
         delete e;
         return fail(TL_ERR_HIP, "engine_create: hipGetDevice failed");
@@ -1237,6 +1271,8 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
         if (e->arena) (void)hipFree(e->arena);
         if (e->kpool) (void)hipFree(e->kpool);
         if (e->vpool) (void)hipFree(e->vpool);
+        if (e->kscale_pool) (void)hipFree(e->kscale_pool);
+        if (e->vscale_pool) (void)hipFree(e->vscale_pool);
         if (e->rope_table) (void)hipFree(e->rope_table);
         if (e->rope_cur) (void)hipFree(e->rope_cur);
         if (e->splitk_ws) (void)hipFree(e->splitk_ws);
@@ -1251,10 +1287,21 @@ extern "C" int tl_engine_create(const tl_engine_config *cfg, const tl_layer_weig
     };
     if (hipMalloc((void **)&e->arena, e->arena_bytes) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(arena) failed");
     e->layer_pool_elems = (size_t)c.num_pages * c.num_kv_heads * c.page_size * c.head_dim;
-    const size_t pool_bytes = e->layer_pool_elems * 2 * c.num_layers;
+    const size_t pool_bytes = e->layer_pool_elems * e->kv_elem_bytes() * c.num_layers;
     if (hipMalloc((void **)&e->kpool, pool_bytes) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(key pages) failed");
     if (hipMalloc((void **)&e->vpool, pool_bytes) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(value pages) failed");
     e->kv_bytes = 2 * pool_bytes;
+    if (kv_format == TL_KV_FP8_E4M3) {
+        // one float32 scale per (page, kv head, slot) row; zero like the codes (a zero scale times a zero code is the zero the bf16 pool holds)
+        e->layer_scale_elems = (size_t)c.num_pages * c.num_kv_heads * c.page_size;
+        const size_t scale_bytes = e->layer_scale_elems * 4 * c.num_layers;
+        if (hipMalloc((void **)&e->kscale_pool, scale_bytes) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(key scales) failed");
+        if (hipMalloc((void **)&e->vscale_pool, scale_bytes) != hipSuccess) return cleanup_fail("engine_create: hipMalloc(value scales) failed");
+        if (hipMemsetAsync(e->kscale_pool, 0, scale_bytes, e->stream) != hipSuccess ||
+            hipMemsetAsync(e->vscale_pool, 0, scale_bytes, e->stream) != hipSuccess)
+            return cleanup_fail("engine_create: memset(KV scales) failed");
+        e->kv_bytes += 2 * scale_bytes;
+    }
     // Masked (out-of-context) token slots are still loaded and multiplied by a zero weight in the decode kernel,
     // so the pools must never hold NaN/Inf bit patterns: start from zeros (kernels only ever write finite values).
     if (hipMemsetAsync(e->kpool, 0, pool_bytes, e->stream) != hipSuccess ||
@@ -1577,6 +1624,8 @@ extern "C" void tl_engine_destroy(tl_engine *e) {
     if (e->arena) (void)hipFree(e->arena);
     if (e->kpool) (void)hipFree(e->kpool);
     if (e->vpool) (void)hipFree(e->vpool);
+    if (e->kscale_pool) (void)hipFree(e->kscale_pool);
+    if (e->vscale_pool) (void)hipFree(e->vscale_pool);
     if (e->splitk_ws) (void)hipFree(e->splitk_ws);
     if (e->rope_table) (void)hipFree(e->rope_table);
     if (e->rope_cur) (void)hipFree(e->rope_cur);
@@ -1588,6 +1637,8 @@ extern "C" void tl_engine_destroy(tl_engine *e) {
     if (e->owns_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
+
+extern "C" int tl_engine_kv_format(const tl_engine *e) { return e ? e->kv_format : TL_KV_BF16; }
 
 extern "C" const char *tl_engine_replay_route(const tl_engine *e) {
     static thread_local std::string text;
@@ -1777,6 +1828,31 @@ extern "C" int tl_engine_set_token(tl_engine *e, int slot, int32_t token) {
 
 // logits_mode: 0 = none, 1 = last row (greedy id recorded as the slot's pending token), 2 = every row (n <= 8: greedy ids
 // land in e->verify_ids, nothing is recorded; speculative verification)
+// the paged attention operator over layer l's pages, by the engine's page format
+static int engine_paged_attention(tl_engine *e, int l, const uint16_t *q_t, const int32_t *block_row, const int32_t *ctx_dev, uint16_t *attn_t,
+                                  int n, int ctx_hint) {
+    const tl_engine_config &c = e->cfg;
+    const int D = c.head_dim, Hq = c.num_heads, Hkv = c.num_kv_heads;
+    if (e->kv_format == TL_KV_FP8_E4M3)
+        return tl_paged_attention_fp8(q_t, e->layer_k(l), e->layer_ks(l), e->layer_v(l), e->layer_vs(l), block_row, ctx_dev, attn_t, Hq, n, D,
+                                      c.num_pages, c.page_size, c.max_pages_per_seq, Hq, Hkv, 1.0f / sqrtf((float)D), 1, ctx_hint, e->attn_ws,
+                                      e->attn_ws_bytes, e->stream);
+    return tl_paged_attention(q_t, e->layer_k(l), e->layer_v(l), block_row, ctx_dev, attn_t, Hq, n, D, c.num_pages, c.page_size,
+                              c.max_pages_per_seq, Hq, Hkv, 1.0f / sqrtf((float)D), 1, ctx_hint, TL_BF16, e->attn_ws, e->attn_ws_bytes, e->stream);
+}
+static void launch_qkv_post(tl_engine *e, int l, QkvPostArgs &q, int n) {
+    q.key_scales = e->layer_ks(l);
+    q.value_scales = e->layer_vs(l);
+    switch (e->cfg.head_dim) {
+        case 128:
+            if (e->kv_format == TL_KV_FP8_E4M3) hipLaunchKernelGGL((qkv_post_kernel<8, true>), dim3(n), dim3(256), 0, e->stream, q);
+            else hipLaunchKernelGGL((qkv_post_kernel<8>), dim3(n), dim3(256), 0, e->stream, q);
+            break;
+        case 64: hipLaunchKernelGGL((qkv_post_kernel<4>), dim3(n), dim3(256), 0, e->stream, q); break;
+        default: hipLaunchKernelGGL((qkv_post_kernel<2>), dim3(n), dim3(256), 0, e->stream, q); break;
+    }
+}
+
 static int prefill_impl(tl_engine *e, int slot, const int32_t *tokens, int n, int logits_mode) {
     const int want_logits = logits_mode == 1;
     TL_TRY(slot_check(e, slot, true));
@@ -1819,15 +1895,9 @@ static int prefill_impl(tl_engine *e, int slot, const int32_t *tokens, int n, in
         q.num_kv_heads = Hkv;
         q.eps = c.rms_norm_eps;
         q.rope_base = c.rope_theta;
-        switch (D) {
-            case 128: hipLaunchKernelGGL((qkv_post_kernel<8>), dim3(n), dim3(256), 0, e->stream, q); break;
-            case 64: hipLaunchKernelGGL((qkv_post_kernel<4>), dim3(n), dim3(256), 0, e->stream, q); break;
-            default: hipLaunchKernelGGL((qkv_post_kernel<2>), dim3(n), dim3(256), 0, e->stream, q); break;
-        }
+        launch_qkv_post(e, l, q, n);
         TL_CHECK_LAUNCH("engine qkv_post");
-        TL_TRY(tl_paged_attention(e->q_t, e->layer_k(l), e->layer_v(l), block_row, e->scratch_ctx, e->attn_t, Hq, n, D,
-                                  c.num_pages, c.page_size, c.max_pages_per_seq, Hq, Hkv, 1.0f / sqrtf((float)D), 1, start + n,
-                                  TL_BF16, e->attn_ws, e->attn_ws_bytes, e->stream));
+        TL_TRY(engine_paged_attention(e, l, e->q_t, block_row, e->scratch_ctx, e->attn_t, n, start + n));
         {
             const long total = (long)Hq * n * (D / 8);
             hipLaunchKernelGGL(heads_to_rows_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, e->stream, e->attn_t, e->attn, Hq, n, D);
@@ -1959,11 +2029,9 @@ static int prefill_packed_impl(tl_engine *e, int n_seqs, const int *slots, const
             q.num_kv_heads = Hkv;
             q.eps = c.rms_norm_eps;
             q.rope_base = c.rope_theta;
-            hipLaunchKernelGGL((qkv_post_kernel<8>), dim3(n), dim3(256), 0, e->stream, q);
+            launch_qkv_post(e, l, q, n);
             TL_CHECK_LAUNCH("engine qkv_post");
-            TL_TRY(tl_paged_attention(q_t, e->layer_k(l), e->layer_v(l), block_row, e->scratch_ctx + i, attn_t, Hq, n, D, c.num_pages,
-                                      c.page_size, c.max_pages_per_seq, Hq, Hkv, 1.0f / sqrtf((float)D), 1, start[i] + n, TL_BF16,
-                                      e->attn_ws, e->attn_ws_bytes, e->stream));
+            TL_TRY(engine_paged_attention(e, l, q_t, block_row, e->scratch_ctx + i, attn_t, n, start[i] + n));
             const long items = (long)Hq * n * (D / 8);
             hipLaunchKernelGGL(heads_to_rows_kernel, dim3(ceil_div(items, 256)), dim3(256), 0, e->stream, attn_t,
                                e->attn + (size_t)row0[i] * Hq * D, Hq, n, D);
@@ -2634,12 +2702,12 @@ extern "C" size_t tl_decode_attention_fused_workspace_bytes(int batch, int num_h
            (size_t)batch * num_heads * 256 * (head_dim + ATTN_WS_PAD) * sizeof(float);
 }
 
-extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,
-                                         void *key_pages_dev, void *value_pages_dev, const int32_t *block_table_dev,
-                                         const int32_t *context_lens_dev, void *out_dev, int batch, int num_heads,
-                                         int num_kv_heads, int head_dim, int page_size, int max_pages, float rope_theta,
-                                         float eps, int max_context, void *workspace_dev, size_t workspace_bytes,
-                                         void *stream, tl_attention_info *info) {
+static int decode_attention_fused_impl(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev, void *key_pages_dev,
+                                       float *key_scales_dev, void *value_pages_dev, float *value_scales_dev,
+                                       const int32_t *block_table_dev, const int32_t *context_lens_dev, void *out_dev, int batch,
+                                       int num_heads, int num_kv_heads, int head_dim, int page_size, int max_pages, float rope_theta,
+                                       float eps, int max_context, void *workspace_dev, size_t workspace_bytes, void *stream,
+                                       tl_attention_info *info) {
     TL_REQUIRE(qkv_dev && q_norm_dev && k_norm_dev && key_pages_dev && value_pages_dev && block_table_dev && context_lens_dev &&
                    out_dev, "decode_attention_fused: null pointer");
     TL_REQUIRE(batch >= 1 && batch <= 256, "decode_attention_fused: between 1 and 256 sequences");
@@ -2669,7 +2737,8 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
     TL_CHECK_LAUNCH("decode_attention_fused rope");
     const SplitPlan sp = pick_decode_splits(&e, batch, std::max(1, max_context + 1));
     const int rc = engine_attention(&e, (const uint16_t *)qkv_dev, q_norm_dev, k_norm_dev, (uint16_t *)key_pages_dev,
-                                    (uint16_t *)value_pages_dev, (uint16_t *)out_dev, batch, sp, nullptr);
+                                    (uint16_t *)value_pages_dev, (uint16_t *)out_dev, batch, sp, nullptr, nullptr, nullptr, nullptr,
+                                    key_scales_dev, value_scales_dev);
     e.rope_cur = nullptr;  // borrowed
     if (info) {
         info->n_splits = sp.n_splits;
@@ -2678,6 +2747,30 @@ extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm
         info->launches = e.last_attn_launches;
     }
     return rc;
+}
+
+extern "C" int tl_decode_attention_fused(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev,
+                                         void *key_pages_dev, void *value_pages_dev, const int32_t *block_table_dev,
+                                         const int32_t *context_lens_dev, void *out_dev, int batch, int num_heads,
+                                         int num_kv_heads, int head_dim, int page_size, int max_pages, float rope_theta,
+                                         float eps, int max_context, void *workspace_dev, size_t workspace_bytes,
+                                         void *stream, tl_attention_info *info) {
+    return decode_attention_fused_impl(qkv_dev, q_norm_dev, k_norm_dev, key_pages_dev, nullptr, value_pages_dev, nullptr, block_table_dev,
+                                       context_lens_dev, out_dev, batch, num_heads, num_kv_heads, head_dim, page_size, max_pages, rope_theta,
+                                       eps, max_context, workspace_dev, workspace_bytes, stream, info);
+}
+
+extern "C" int tl_decode_attention_fused_fp8(const void *qkv_dev, const void *q_norm_dev, const void *k_norm_dev, void *key_pages_dev,
+                                             float *key_scales_dev, void *value_pages_dev, float *value_scales_dev,
+                                             const int32_t *block_table_dev, const int32_t *context_lens_dev, void *out_dev, int batch,
+                                             int num_heads, int num_kv_heads, int head_dim, int page_size, int max_pages,
+                                             float rope_theta, float eps, int max_context, void *workspace_dev, size_t workspace_bytes,
+                                             void *stream, tl_attention_info *info) {
+    TL_REQUIRE(key_scales_dev && value_scales_dev, "decode_attention_fused_fp8: null scale pointer");
+    TL_REQUIRE(head_dim == 128, "decode_attention_fused_fp8: FP8 pages need head_dim 128");
+    return decode_attention_fused_impl(qkv_dev, q_norm_dev, k_norm_dev, key_pages_dev, key_scales_dev, value_pages_dev, value_scales_dev,
+                                       block_table_dev, context_lens_dev, out_dev, batch, num_heads, num_kv_heads, head_dim, page_size,
+                                       max_pages, rope_theta, eps, max_context, workspace_dev, workspace_bytes, stream, info);
 }
 
 // ---- host-only: the plans the decode path would pick (no device, no launch): what the CPU tests and a binding's dry run read -------

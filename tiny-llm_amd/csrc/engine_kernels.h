@@ -5,6 +5,7 @@
 #pragma once
 #include <type_traits>
 #include "common.h"
+#include "kv8.h"
 
 namespace tl {
 
@@ -168,6 +169,16 @@ struct AttnDecodeArgs {
     const float *qkv_partial;
     int qkv_slices;
     long qkv_plane;
+    // KV8 instantiations (FP8 pages, kv8.h): key_pages / value_pages hold E4M3 codes, one byte per element of the same layout, and these
+    // the rows' power-of-two scales [P, Hkv, page] -- folded into the scores and the softmax weights of the walk
+    float *key_scales, *value_scales;
+};
+
+// a K or V chunk of a row as it travels from the page to the walk: 8 bf16 values, or (KV8) 8 codes + the row's scale
+template <int VD>
+struct Kv8Row {
+    u32x2 c;
+    float s;
 };
 
 // Scalar (wave-uniform) 32-bit load through the scalar cache, and the wait that makes its result usable.  The address must
@@ -237,8 +248,13 @@ __device__ __forceinline__ void store_raw(uint16_t *dst, const RawRow<VD> &r) {
 // of bf16 rows: the (2 + RQ) D values a workgroup needs are 4-column chunks shared out over its threads (one global round
 // trip, all slices of a chunk in flight together), summed in slice order, rounded to bf16 and handed to every 16-lane group
 // through LDS -- the qkv projection's slice-reduction launch (a dependent phase of ~3.3 us per layer) is gone.
-template <int VD, int U, int RQ, bool SP, bool IP = false, bool QP = false>
+// KV8 = FP8 pages (head dimension 128): a lane requests 8 bytes of codes per row chunk and the row's scale; scores and weights take the
+// scales as one multiply per (token, head) -- bit for bit this kernel's arithmetic over the dequantised rows (kv8.h).  The token being
+// decoded is quantised in registers: this step attends to what the page will hold.
+template <int VD, int U, int RQ, bool SP, bool IP = false, bool QP = false, bool KV8 = false>
 static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnDecodeArgs p) {
+    static_assert(!KV8 || VD == 8, "FP8 pages: head dimension 128");
+    using KVRow = typename std::conditional<KV8, Kv8Row<VD>, RawRow<VD>>::type;
     constexpr int D = 16 * VD;
     constexpr int STRIDE = D + 2;
     extern __shared__ __attribute__((aligned(16))) float psm[];  // [16][RQ][STRIDE] (+ QP: [(2 + RQ)][D] bf16 staged rows)
@@ -337,32 +353,42 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
     const int wslot = ctx - wp * p.page_size;
     int wpage;
     sload_i32(brow + min(wp, p.max_pages - 1), wpage);  // waited for at the very end of the kernel
-    RawRow<VD> kr[U], vr[U], kr_next[U], vr_next[U];
+    KVRow kr[U], vr[U], kr_next[U], vr_next[U];
     bool ok[U];
-    auto issue_kv = [&](int base, const int (&ids)[U], RawRow<VD> (&kk)[U], RawRow<VD> (&vv)[U], bool (&valid)[U]) {
+    // (prow = the row's index in the page layout, off = the lane's element offset in it)
+    auto load_kv = [&](long prow, long off, KVRow &kk, KVRow &vv) {
+        if constexpr (KV8) {
+            kk.c = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const uint8_t *>(p.key_pages) + off);
+            vv.c = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const uint8_t *>(p.value_pages) + off);
+            kk.s = p.key_scales[prow];
+            vv.s = p.value_scales[prow];
+        } else {
+            load_raw<VD>(p.key_pages + off, kk);
+            load_raw<VD>(p.value_pages + off, vv);
+        }
+    };
+    auto issue_kv = [&](int base, const int (&ids)[U], KVRow (&kk)[U], KVRow (&vv)[U], bool (&valid)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int tok = base + u * 16 + g;
             const int lp = page_of(tok);
             const int slot = tok - lp * p.page_size;
             valid[u] = tok < ctx && tok < t_begin + C && lp < p.max_pages && ids[u] >= 0;
-            const long off = (((long)max(ids[u], 0) * Hkv + kvh) * p.page_size + slot) * D + t * VD;
-            load_raw<VD>(p.key_pages + off, kk[u]);
-            load_raw<VD>(p.value_pages + off, vv[u]);
+            const long prow = ((long)max(ids[u], 0) * Hkv + kvh) * p.page_size + slot;
+            load_kv(prow, prow * D + t * VD, kk[u], vv[u]);
         }
     };
     const int lane_row = g * D + t * VD;  // IP: element offset of this lane's 16 bytes inside a stage's first 16 rows
-    auto issue_kv_stage = [&](int base, int pg, RawRow<VD> (&kk)[U], RawRow<VD> (&vv)[U], bool (&valid)[U]) {
+    auto issue_kv_stage = [&](int base, int pg, KVRow (&kk)[U], KVRow (&vv)[U], bool (&valid)[U]) {
         const int lp = page_of(base);  // uniform
         const bool page_ok = lp < p.max_pages && pg >= 0;
-        const long rowbase = (((long)max(pg, 0) * Hkv + kvh) * p.page_size + (base - lp * p.page_size)) * D;  // uniform
-        const uint16_t *kb = p.key_pages + rowbase, *vb = p.value_pages + rowbase;
+        const long prow0 = ((long)max(pg, 0) * Hkv + kvh) * p.page_size + (base - lp * p.page_size);  // uniform
+        const long rowbase = prow0 * D;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int tok = base + u * 16 + g;
             valid[u] = tok < ctx && tok < t_begin + C && page_ok;
-            load_raw<VD>(kb + lane_row + u * 16 * D, kk[u]);
-            load_raw<VD>(vb + lane_row + u * 16 * D, vv[u]);
+            load_kv(prow0 + g + u * 16, rowbase + lane_row + u * 16 * D, kk[u], vv[u]);
         }
     };
     if constexpr (IP) issue_kv_stage(t_begin, pid_s, kr, vr, ok);
@@ -426,6 +452,19 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
     norm_rope(kraw_new, kw, k_new);
 #pragma unroll
     for (int i = 0; i < VD; ++i) v_new[i] = BF16::to_float(vraw_new.v[i]);
+    // KV8: the new rows as the page will hold them (every 16-lane group holds the whole row: the same codes and scale in each)
+    u32x2 k_new_c = u32x2{0u, 0u}, v_new_c = u32x2{0u, 0u};
+    float k_new_s = 1.f, v_new_s = 1.f;
+    if constexpr (KV8) {
+        float kd[8], vd[8];
+        kv8_quantize_row16(k_new, k_new_c, k_new_s, kd);
+        kv8_quantize_row16(v_new, v_new_c, v_new_s, vd);
+#pragma unroll
+        for (int i = 0; i < VD; ++i) {
+            k_new[i] = kd[i];
+            v_new[i] = vd[i];
+        }
+    }
     float qv[RQ][VD], acc[RQ][VD], m[RQ], l[RQ];
 #pragma unroll
     for (int r = 0; r < RQ; ++r) {
@@ -448,8 +487,7 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
     // read).  A branch around those loads is a control-flow join, and at a join hipcc's wait bookkeeping loses the issue order of pending
     // loads: the first use of THIS stage's rows then waited for the rows just requested for the next one (round 4, found in the ISA:
     // vmcnt(7) .. vmcnt(0) behind the prefetch) -- a stage cost one memory round trip whatever was prefetched.
-    auto walk_stage = [&](int it, RawRow<VD>(&kc)[U], RawRow<VD>(&vc)[U], bool(&okc)[U], RawRow<VD>(&kn)[U], RawRow<VD>(&vn)[U],
-                          bool(&okn)[U]) {
+    auto walk_stage = [&](int it, KVRow(&kc)[U], KVRow(&vc)[U], bool(&okc)[U], KVRow(&kn)[U], KVRow(&vn)[U], bool(&okn)[U]) {
         const bool more = it + 1 < n_it;
         const int nx = min(it + 1, n_it - 1);
         if constexpr (IP) {
@@ -467,15 +505,27 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
         // caller-provided page may hold anything behind the context
         float vf[U][VD];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+            if constexpr (KV8) {
+                float raw[8];
+                kv8_unpack8(vc[u].c, raw);
 #pragma unroll
-            for (int i = 0; i < VD; ++i) vf[u][i] = (okc[u] && live) ? BF16::to_float(vc[u].v[i]) : 0.f;
+                for (int i = 0; i < VD; ++i) vf[u][i] = (okc[u] && live) ? raw[i] : 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < VD; ++i) vf[u][i] = (okc[u] && live) ? BF16::to_float(vc[u].v[i]) : 0.f;
+            }
+        }
         float sc[RQ][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float kf[VD];
+            if constexpr (KV8) {
+                kv8_unpack8(kc[u].c, kf);
+            } else {
 #pragma unroll
-            for (int i = 0; i < VD; ++i) kf[i] = BF16::to_float(kc[u].v[i]);
+                for (int i = 0; i < VD; ++i) kf[i] = BF16::to_float(kc[u].v[i]);
+            }
 #pragma unroll
             for (int r = 0; r < RQ; ++r) {
                 float part = 0.f;
@@ -504,7 +554,8 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 sc[r][u] += row_ror<1>(sc[r][u]);
-                sc[r][u] = (okc[u] && live) ? sc[r][u] : -1e30f;
+                if constexpr (KV8) sc[r][u] = (okc[u] && live) ? sc[r][u] * kc[u].s : -1e30f;  // the K row's scale: a power of two
+                else sc[r][u] = (okc[u] && live) ? sc[r][u] : -1e30f;
             }
 #pragma unroll
         for (int r = 0; r < RQ; ++r) {
@@ -520,8 +571,10 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
             for (int u = 0; u < U; ++u) {
                 const float pw = (okc[u] && live) ? exp2_hw(sc[r][u] - nm) : 0.f;
                 l[r] += pw;
+                float pwv = pw;
+                if constexpr (KV8) pwv = (okc[u] && live) ? pw * vc[u].s : 0.f;  // the V row's scale rides on the weight
 #pragma unroll
-                for (int i = 0; i < VD; ++i) acc[r][i] += pw * vf[u][i];
+                for (int i = 0; i < VD; ++i) acc[r][i] += pwv * vf[u][i];
             }
         }
         if constexpr (IP) {
@@ -599,9 +652,19 @@ static __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const Att
     // the context length never sits on the critical path
     sload_wait(wpage);
     if (live && wp < p.max_pages && wpage >= 0 && split == 0 && chunk == 0 && g == 0) {
-        const long off = (((long)wpage * Hkv + kvh) * p.page_size + wslot) * D + t * VD;
-        store_row<VD>(p.key_pages + off, k_new);
-        store_raw<VD>(p.value_pages + off, vraw_new);
+        const long prow = ((long)wpage * Hkv + kvh) * p.page_size + wslot;
+        const long off = prow * D + t * VD;
+        if constexpr (KV8) {
+            *reinterpret_cast<u32x2 *>(reinterpret_cast<uint8_t *>(p.key_pages) + off) = k_new_c;
+            *reinterpret_cast<u32x2 *>(reinterpret_cast<uint8_t *>(p.value_pages) + off) = v_new_c;
+            if (t == 0) {
+                p.key_scales[prow] = k_new_s;
+                p.value_scales[prow] = v_new_s;
+            }
+        } else {
+            store_row<VD>(p.key_pages + off, k_new);
+            store_raw<VD>(p.value_pages + off, vraw_new);
+        }
     }
     prof_end(p.prof, prof_t0);
 }
@@ -977,10 +1040,12 @@ struct QkvPostArgs {
     const int32_t *block_row;  // this slot's block-table row [max_pages]
     int T, start, page_size, max_pages, num_heads, num_kv_heads;
     float eps, rope_base;
+    float *key_scales, *value_scales;  // KV8: the row scales of FP8 pages (kv8.h); key_pages / value_pages then hold bytes
 };
 
-template <int VD>
+template <int VD, bool KV8 = false>
 static __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs p) {
+    static_assert(!KV8 || VD == 8, "FP8 pages: head dimension 128");
     constexpr int D = 16 * VD;
     const int r = blockIdx.x;
     const int g = threadIdx.x >> 4;
@@ -1000,13 +1065,30 @@ static __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostArgs 
             store_row<VD>(p.q_t + ((long)h * p.T + r) * D + t * VD, v);
         } else if (h < Hq + Hkv) {
             head_norm_rope<VD>(row + (long)h * D, p.k_norm_w, t, p.eps, cs, sn, v);
-            if (page_id >= 0)
-                store_row<VD>(p.key_pages + (((long)page_id * Hkv + (h - Hq)) * p.page_size + slot) * D + t * VD, v);
+            const long prow = ((long)max(page_id, 0) * Hkv + (h - Hq)) * p.page_size + slot;
+            if constexpr (KV8) {
+                u32x2 codes;
+                float sc, deq[8];
+                kv8_quantize_row16(v, codes, sc, deq);
+                if (page_id >= 0) {
+                    *reinterpret_cast<u32x2 *>(reinterpret_cast<uint8_t *>(p.key_pages) + prow * D + t * VD) = codes;
+                    if (t == 0) p.key_scales[prow] = sc;
+                }
+            } else if (page_id >= 0)
+                store_row<VD>(p.key_pages + prow * D + t * VD, v);
         } else {
             load_row<VD>(row + (long)h * D + t * VD, v);
-            if (page_id >= 0)
-                store_row<VD>(p.value_pages + (((long)page_id * Hkv + (h - Hq - Hkv)) * p.page_size + slot) * D + t * VD,
-                              v);
+            const long prow = ((long)max(page_id, 0) * Hkv + (h - Hq - Hkv)) * p.page_size + slot;
+            if constexpr (KV8) {
+                u32x2 codes;
+                float sc, deq[8];
+                kv8_quantize_row16(v, codes, sc, deq);
+                if (page_id >= 0) {
+                    *reinterpret_cast<u32x2 *>(reinterpret_cast<uint8_t *>(p.value_pages) + prow * D + t * VD) = codes;
+                    if (t == 0) p.value_scales[prow] = sc;
+                }
+            } else if (page_id >= 0)
+                store_row<VD>(p.value_pages + prow * D + t * VD, v);
         }
     }
 }

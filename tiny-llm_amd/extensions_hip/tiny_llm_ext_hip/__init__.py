@@ -62,6 +62,14 @@ _SIGNATURES = {
         [_c_void_p] * 6 + [_c_int] * 8 + [_c_float, _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p],
     ),
     "tl_paged_attention_workspace_bytes": (_c_size_t, [_c_int] * 8),
+    # FP8 (E4M3) KV pages (include/tinyllm_hip.h, last operator section; no reference counterpart)
+    "tl_kv_fp8_quantize_rows": (_c_int, [_c_void_p, _c_void_p, _c_void_p, ctypes.c_long, _c_int, _c_void_p]),
+    "tl_kv_fp8_dequantize_rows": (_c_int, [_c_void_p, _c_void_p, _c_void_p, ctypes.c_long, _c_int, _c_void_p]),
+    "tl_paged_cache_update_fp8": (_c_int, [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p]),
+    "tl_paged_attention_fp8": (
+        _c_int,
+        [_c_void_p] * 8 + [_c_int] * 8 + [_c_float, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p],
+    ),
 }
 
 
@@ -146,6 +154,11 @@ _SIGNATURES.update({
     "tl_engine_check_step": (_c_int, [_c_void_p, _c_int, _P(TlStepCheck)]),
     "tl_engine_create": (_c_int, [_P(TlEngineConfig), _P(TlLayerWeights), _P(TlW4), _c_void_p, _P(TlW4), _c_void_p,
                                   _P(_c_void_p)]),
+    "tl_engine_create_kv": (_c_int, [_P(TlEngineConfig), _P(TlLayerWeights), _P(TlW4), _c_void_p, _P(TlW4), _c_void_p, _c_int,
+                                     _P(_c_void_p)]),
+    "tl_engine_kv_format": (_c_int, [_c_void_p]),
+    "tl_decode_attention_fused_fp8": (_c_int, [_c_void_p] * 10 + [_c_int] * 6 + [_c_float, _c_float, _c_int, _c_void_p, _c_size_t,
+                                                                  _c_void_p, _P(TlAttentionInfo)]),
     "tl_engine_set_moe_layer": (_c_int, [_c_void_p, _c_int, _P(TlMoeWeights)]),
     "tl_decode_gemv_plan": (_c_int, [_c_int, _c_int, _c_int, _P(_c_int)]),
     "tl_decode_batched_plan": (_c_int, [_c_int, _c_int, _c_int, _P(_c_int)]),
@@ -762,4 +775,120 @@ def decode_attention_fused(qkv: torch.Tensor, q_norm: torch.Tensor, k_norm: torc
                                           _ptr(block_table.contiguous()), _ptr(context_lens), _ptr(out), B, num_heads,
                                           num_kv_heads, D, page, int(block_table.shape[1]), float(rope_theta), float(eps),
                                           int(max_context), _ptr(ws), ws.numel(), _stream(), ctypes.byref(info)))
+    return out, {name: getattr(info, name) for name, _ in info._fields_}
+
+
+# ---- FP8 (E4M3) KV pages: the quantised twins of paged_cache_update / paged_attention -------------------------------------
+# (include/tinyllm_hip.h "FP8 KV pages"; SURVEY section 8f row 4 -- the reference has no quantised cache, README.md:134-135, so these
+# are NOT part of the reference's interface and stay out of __all__)
+KV_BF16, KV_FP8_E4M3 = 0, 1
+
+
+def kv_fp8_quantize_rows(values: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """values [..., 128] bfloat16 -> (codes [..., 128] uint8, scales [...] float32): OCP E4M3 codes and one power-of-two scale per row."""
+    _require_gpu("kv_fp8_quantize_rows", values)
+    if values.dtype != torch.bfloat16 or values.shape[-1] != 128 or not values.is_contiguous():
+        raise RuntimeError("kv_fp8_quantize_rows: contiguous bfloat16 rows of 128 values")
+    rows = values.numel() // 128
+    codes = torch.empty(values.shape, dtype=torch.uint8, device=values.device)
+    scales = torch.empty(values.shape[:-1], dtype=torch.float32, device=values.device)
+    _check(_lib.tl_kv_fp8_quantize_rows(_ptr(values), _ptr(codes), _ptr(scales), rows, 128, _stream()))
+    return codes, scales
+
+
+def kv_fp8_dequantize_rows(codes: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """(codes [..., 128] uint8, scales [...] float32) -> bfloat16 [..., 128] (exact)."""
+    _require_gpu("kv_fp8_dequantize_rows", codes, scales)
+    if codes.dtype != torch.uint8 or scales.dtype != torch.float32 or codes.shape[-1] != 128 or tuple(codes.shape[:-1]) != tuple(scales.shape) \
+            or not codes.is_contiguous() or not scales.is_contiguous():
+        raise RuntimeError("kv_fp8_dequantize_rows: contiguous uint8 codes [..., 128] and float32 scales [...]")
+    out = torch.empty(codes.shape, dtype=torch.bfloat16, device=codes.device)
+    _check(_lib.tl_kv_fp8_dequantize_rows(_ptr(codes), _ptr(scales), _ptr(out), codes.numel() // 128, 128, _stream()))
+    return out
+
+
+def paged_cache_update_fp8(pages: torch.Tensor, page_scales: torch.Tensor, values: torch.Tensor, page_id: int,
+                           start: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """In-place quantising write of bfloat16 ``values[1,H,len,128]`` into ``pages[P,H,page,128]`` uint8 + ``page_scales[P,H,page]``."""
+    if pages.dtype != torch.uint8 or page_scales.dtype != torch.float32 or values.dtype != torch.bfloat16:
+        raise RuntimeError("paged_cache_update_fp8: uint8 pages, float32 page_scales, bfloat16 values")
+    if pages.dim() != 4 or values.dim() != 4 or values.shape[0] != 1 or tuple(page_scales.shape) != tuple(pages.shape[:3]):
+        raise RuntimeError("paged_cache_update_fp8: expected pages [P, H, page_size, 128], page_scales [P, H, page_size] and values [1, H, length, 128]")
+    if values.shape[1] != pages.shape[1] or values.shape[3] != pages.shape[3]:
+        raise RuntimeError("paged_cache_update_fp8: values must match the page head count and head dimension")
+    if page_id < 0 or page_id >= pages.shape[0] or start < 0 or start + values.shape[2] > pages.shape[2]:
+        raise RuntimeError("paged_cache_update_fp8: destination slice is outside page storage")
+    _require_gpu("paged_cache_update_fp8", pages, page_scales, values)
+    if not pages.is_contiguous() or not values.is_contiguous() or not page_scales.is_contiguous():
+        raise RuntimeError("paged_cache_update_fp8: pages, page_scales and values must be contiguous")
+    P, H, page_size, D = pages.shape
+    _check(_lib.tl_paged_cache_update_fp8(_ptr(pages), _ptr(page_scales), _ptr(values), P, H, page_size, D, values.shape[2],
+                                          int(page_id), int(start), _stream()))
+    return pages, page_scales
+
+
+def paged_attention_fp8(query: torch.Tensor, key_pages: torch.Tensor, key_scales: torch.Tensor, value_pages: torch.Tensor,
+                        value_scales: torch.Tensor, block_table: torch.Tensor, context_lens: torch.Tensor, scale: float = 1.0,
+                        is_causal: bool = False, *, num_kv_heads: int, num_heads: int, max_context_hint: int = 0) -> torch.Tensor:
+    """paged_attention over FP8 pages: bfloat16 ``query`` [B * Hq, L, 128], uint8 pages [P, Hkv, page, 128], float32 scales [P, Hkv, page]."""
+    if query.dtype != torch.bfloat16 or key_pages.dtype != torch.uint8 or value_pages.dtype != torch.uint8 \
+            or key_scales.dtype != torch.float32 or value_scales.dtype != torch.float32:
+        raise RuntimeError("paged_attention_fp8: bfloat16 q, uint8 pages, float32 scales")
+    if block_table.dtype != torch.int32 or context_lens.dtype != torch.int32:
+        raise RuntimeError("paged_attention_fp8: block_table and context_lens must be int32")
+    if query.dim() != 3 or key_pages.dim() != 4 or key_pages.shape != value_pages.shape or block_table.dim() != 2 or context_lens.dim() != 1:
+        raise RuntimeError("paged_attention_fp8: q [B * H_q, L, D], pages [P, H_kv, page_size, D], block_table [B, max_pages], context_lens [B]")
+    if tuple(key_scales.shape) != tuple(key_pages.shape[:3]) or tuple(value_scales.shape) != tuple(value_pages.shape[:3]):
+        raise RuntimeError("paged_attention_fp8: scales must be [P, H_kv, page_size]")
+    if num_heads % num_kv_heads != 0 or query.shape[0] % num_heads != 0 or key_pages.shape[1] != num_kv_heads:
+        raise RuntimeError("paged_attention_fp8: incompatible head counts")
+    if query.shape[2] != 128 or key_pages.shape[3] != 128:
+        raise RuntimeError("paged_attention_fp8: FP8 pages need head dimension 128")
+    if query.shape[0] // num_heads != block_table.shape[0] or block_table.shape[0] != context_lens.shape[0]:
+        raise RuntimeError("paged_attention_fp8: q batch size must match block_table and context_lens")
+    tensors = (query, key_pages, key_scales, value_pages, value_scales, block_table, context_lens)
+    _require_gpu("paged_attention_fp8", *tensors)
+    if not all(t.is_contiguous() for t in tensors):
+        raise RuntimeError("paged_attention_fp8: every tensor must be contiguous")
+    N, L, D = query.shape
+    P, _, page_size, _ = key_pages.shape
+    max_pages = block_table.shape[1]
+    out = torch.empty_like(query)
+    ws_bytes = _lib.tl_paged_attention_workspace_bytes(N, L, D, page_size, max_pages, num_heads, num_kv_heads, int(max_context_hint))
+    ws = _workspace(ws_bytes, query.device)
+    _check(_lib.tl_paged_attention_fp8(
+        _ptr(query), _ptr(key_pages), _ptr(key_scales), _ptr(value_pages), _ptr(value_scales), _ptr(block_table), _ptr(context_lens),
+        _ptr(out), N, L, D, P, page_size, max_pages, int(num_heads), int(num_kv_heads), float(scale), int(bool(is_causal)),
+        int(max_context_hint), _ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0, _stream()))
+    return out
+
+
+def decode_attention_fused_fp8(qkv: torch.Tensor, q_norm: torch.Tensor, k_norm: torch.Tensor, key_pages: torch.Tensor,
+                               key_scales: torch.Tensor, value_pages: torch.Tensor, value_scales: torch.Tensor,
+                               block_table: torch.Tensor, context_lens: torch.Tensor, *, num_heads: int, num_kv_heads: int,
+                               rope_theta: float, eps: float, max_context: int) -> tuple[torch.Tensor, dict]:
+    """decode_attention_fused over FP8 pages (tl_decode_attention_fused_fp8): the appended K / V rows are quantised in place."""
+    _require_gpu("decode_attention_fused_fp8", qkv, q_norm, k_norm, key_pages, key_scales, value_pages, value_scales, block_table, context_lens)
+    B = int(qkv.shape[0])
+    P, Hkv, page, D = (int(x) for x in key_pages.shape)
+    if D != 128 or Hkv != num_kv_heads or tuple(value_pages.shape) != tuple(key_pages.shape) \
+            or tuple(key_scales.shape) != (P, Hkv, page) or tuple(value_scales.shape) != (P, Hkv, page):
+        raise RuntimeError("decode_attention_fused_fp8: pages [P, num_kv_heads, page_size, 128] uint8 and scales [P, num_kv_heads, page_size]")
+    if qkv.dim() != 2 or qkv.shape[1] != (num_heads + 2 * num_kv_heads) * D:
+        raise RuntimeError("decode_attention_fused_fp8: qkv must be [batch, (Hq + 2 Hkv) * D]")
+    for name, t, dt in (("qkv", qkv, torch.bfloat16), ("q_norm", q_norm, torch.bfloat16), ("k_norm", k_norm, torch.bfloat16),
+                        ("key_pages", key_pages, torch.uint8), ("value_pages", value_pages, torch.uint8),
+                        ("key_scales", key_scales, torch.float32), ("value_scales", value_scales, torch.float32)):
+        if t.dtype != dt or not t.is_contiguous():
+            raise RuntimeError(f"decode_attention_fused_fp8: {name} must be contiguous {dt}")
+    if block_table.dtype != torch.int32 or context_lens.dtype != torch.int32 or block_table.dim() != 2 \
+            or block_table.shape[0] != B or tuple(context_lens.shape) != (B,):
+        raise RuntimeError("decode_attention_fused_fp8: block_table [B, max_pages] and context_lens [B] must be int32")
+    out = torch.empty((B, num_heads * D), dtype=torch.bfloat16, device=qkv.device)
+    ws = _workspace(_lib.tl_decode_attention_fused_workspace_bytes(B, num_heads, D), qkv.device)
+    info = TlAttentionInfo()
+    _check(_lib.tl_decode_attention_fused_fp8(_ptr(qkv), _ptr(q_norm), _ptr(k_norm), _ptr(key_pages), _ptr(key_scales), _ptr(value_pages),
+                                              _ptr(value_scales), _ptr(block_table.contiguous()), _ptr(context_lens), _ptr(out), B,
+                                              num_heads, num_kv_heads, D, page, int(block_table.shape[1]), float(rope_theta), float(eps),
+                                              int(max_context), _ptr(ws), ws.numel(), _stream(), ctypes.byref(info)))
     return out, {name: getattr(info, name) for name, _ in info._fields_}

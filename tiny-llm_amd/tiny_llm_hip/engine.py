@@ -60,8 +60,11 @@ class DecodeEngine:
     """Owns the fused weights, the paged KV pools and the captured decode graphs for one model on one GPU."""
 
     def __init__(self, mlx_model: Any, *, page_size: int = 128, num_pages: int = 512, max_batch: int = 1,
-                 max_pages_per_seq: int | None = None, max_prefill_rows: int = 2048, options: dict | None = None):
-        """``options`` (tests / lab tools only): routes with an A/B twin, by the names of tl_engine_set_option (include/tinyllm_engine.h),
+                 max_pages_per_seq: int | None = None, max_prefill_rows: int = 2048, options: dict | None = None,
+                 kv_format: str = "bf16"):
+        """``kv_format``: "bf16" (the reference's cache) or "fp8" -- K / V pages as OCP FP8 E4M3 codes with one power-of-two scale per
+        row (tl_engine_create_kv; head_dim 128; the reference has no quantised cache, README.md:134-135: an extension, off by default).
+        ``options`` (tests / lab tools only): routes with an A/B twin, by the names of tl_engine_set_option (include/tinyllm_engine.h),
         e.g. {"qmm7": 0}; the environment variable TL_ENGINE_OPTIONS ("qmm7=0,aql_fences=1") adds to them for the A/B scripts under tools/."""
         args = mlx_model.args
         if not torch.cuda.is_available():
@@ -110,9 +113,13 @@ class DecodeEngine:
         handle = ctypes.c_void_p()
         embed_c = embed.c()
         head_c = head.c() if head is not None else None
-        _ext.check(_lib.tl_engine_create(
+        if kv_format not in ("bf16", "fp8"):
+            raise ValueError("DecodeEngine: kv_format must be 'bf16' or 'fp8'")
+        self.kv_format = kv_format
+        _ext.check(_lib.tl_engine_create_kv(
             ctypes.byref(cfg), layers, ctypes.byref(embed_c), final_norm.data_ptr(),
-            ctypes.byref(head_c) if head_c is not None else None, None, ctypes.byref(handle)))
+            ctypes.byref(head_c) if head_c is not None else None, None,
+            _ext.KV_FP8_E4M3 if kv_format == "fp8" else _ext.KV_BF16, ctypes.byref(handle)))
         self._h = handle
         opts = dict(item.split("=", 1) for item in os.environ.get("TL_ENGINE_OPTIONS", "").replace("+", ",").split(",") if "=" in item)
         opts.update(options or {})
