@@ -387,7 +387,7 @@ def walk_prompt_bounded(models, prompt: list[int], budget_s: float, floor: int =
     return fed, last
 
 
-def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_steps: int, prefill_chunk: int = 8) -> dict:
+def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_steps: int, prefill_chunk: int = 8, fp8_engine=None) -> dict:
     """Time the plain-C port (oracle/) on the host cores on a bounded sample and use it as a checker: the engine is prefilled
     through the bench's own path (`prefill_chunk` rows per pass) and decodes at the bench's own attention plan."""
     import numpy as np
@@ -463,6 +463,25 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
         engine.decode(1, batch=1)
         gemm_logits.append(engine.logits(1)[0].float().cpu().numpy())
     engine.release(0)
+    # ... and once more on an engine whose K / V pages are FP8 (E4M3) codes (an extension -- the reference has no
+    # quantised cache): the same prompt, the same teacher-forced steps, the same truth.  What the quantised cache costs in logits.
+    fp8_sample = None
+    if fp8_engine is not None:
+        fp8_logits = []
+        fp8_engine.begin(0)
+        fp8_engine.prefill(0, prompt, chunk=prefill_chunk)
+        fp8_logits.append(fp8_engine.logits(1)[0].float().cpu().numpy())
+        for s in range(truth_steps):
+            fp8_engine.set_token(0, cpu_ids[s])
+            fp8_engine.decode(1, batch=1)
+            fp8_logits.append(fp8_engine.logits(1)[0].float().cpu().numpy())
+        fp8_engine.release(0)
+        e8 = max(float(np.abs(np.asarray(g, np.float64) - t).max()) for g, t in zip(fp8_logits, truth_logits))
+        rms8 = float(np.sqrt(np.mean([np.mean((np.asarray(g, np.float64) - t) ** 2) for g, t in zip(fp8_logits, truth_logits)])))
+        same_ids = sum(int(np.argmax(g) == np.argmax(b)) for g, b in zip(fp8_logits, gpu_logits))
+        fp8_sample = {"what": "the same prompt and teacher-forced steps on an engine with FP8 (E4M3) K / V pages (tl_engine_create_kv; extension, no reference behaviour)",
+                      "steps": len(fp8_logits), "max_abs_logit_gpu_vs_truth": round(e8, 5), "rms_logit_gpu_vs_truth": round(rms8, 5),
+                      "greedy_ids_equal_the_bf16_engine": f"{same_ids}/{len(fp8_logits)}"}
     worst, worst_logit = 0.0, 0.0
     for cl, gl in zip(cpu_logits, gpu_logits):
         worst = max(worst, float(np.abs(logsm(cl) - logsm(gl)).max()))
@@ -498,6 +517,7 @@ def cpu_baseline_leg(mlx_model, cfg: dict, engine, sample_prompt: int, sample_st
                                     "max_abs_logit_gpu_vs_truth": round(e_gemm, 5), "rms_logit_gpu_vs_truth": round(rms_gemm, 5),
                                     "gpu_error_over_cpu_error": round(e_gemm / e_cpu, 3) if e_cpu > 0 else None,
                                     "gpu_rms_error_over_cpu_rms_error": round(rms_gemm / rms_cpu, 3) if rms_cpu > 0 else None},
+            "kv_fp8_sample": fp8_sample,
             "gpu_greedy_ids_vs_truth": f"{exact}/{len(truth_logits)} are the truth's argmax, {near}/{len(truth_logits)} within "
                                        f"2 x the engine's measured error of it"}
 
@@ -535,6 +555,19 @@ def peaked_checkpoint_leg(cfg: dict, device: str, seed: int, steps: int = 8) -> 
         eng.release(0)
     finally:
         eng.close()
+    # the same walk on an engine whose K / V pages are FP8 (E4M3) codes (an extension): its own ids, its own first logits
+    fp8_ids, fp8_first = None, None
+    if cfg.get("head_dim") == 128:
+        eng = DecodeEngine(model, page_size=128, num_pages=4, max_batch=1, max_prefill_rows=8, kv_format="fp8")
+        try:
+            eng.begin(0)
+            eng.prefill(0, prompt, chunk=8)
+            fp8_first = eng.logits(1)[0].float().cpu().numpy()
+            eng.decode(steps, batch=1)
+            fp8_ids = eng.read_tokens(0, steps + 1)
+            eng.release(0)
+        finally:
+            eng.close()
     cores = min(os.cpu_count() or 1, 32)
     weights = host_weights(model)
     head = model.lm_head
@@ -545,6 +578,7 @@ def peaked_checkpoint_leg(cfg: dict, device: str, seed: int, steps: int = 8) -> 
     for t in prompt:
         tid, tl = truth.step(t)
     truth_ids, margins = [tid], []
+    first_tl = tl
     first_err = float(np.abs(gpu_logits[0].astype(np.float64) - tl).max())
     for _ in range(steps):
         top2 = np.partition(tl, -2)[-2:]
@@ -554,8 +588,12 @@ def peaked_checkpoint_leg(cfg: dict, device: str, seed: int, steps: int = 8) -> 
     truth.close()
     same = sum(int(a == b) for a, b in zip(gpu_ids, truth_ids))
     ratio = min(margins) / first_err if first_err > 0 else None
+    fp8 = None
+    if fp8_ids is not None:
+        fp8 = {"greedy_ids_equal_truth": f"{sum(int(a == b) for a, b in zip(fp8_ids, truth_ids))}/{len(truth_ids)}",
+               "max_abs_logit_gpu_vs_truth_first_step": round(float(np.abs(fp8_first.astype(np.float64) - first_tl).max()), 4)}
     return {"checked": True, "recipe": "embed_sigma 0.25, residual_gain 0.2 (o_proj, down_proj), untied head = embedding rows permuted by t -> 48271 t + 11 mod V, else N(0, 0.02); W4 g128",
-            "greedy_ids_equal_truth": f"{same}/{len(truth_ids)}", "all_equal": same == len(truth_ids),
+            "greedy_ids_equal_truth": f"{same}/{len(truth_ids)}", "all_equal": same == len(truth_ids), "kv_fp8_pages": fp8,
             "distinct_ids": len(set(int(t) for t in truth_ids)),
             "min_top2_margin_of_truth": round(min(margins), 3), "max_abs_logit_gpu_vs_truth_first_step": round(first_err, 4),
             "margin_over_error": None if ratio is None else round(ratio, 1),
@@ -579,11 +617,16 @@ def extra_configs_leg(mlx_model, cfg: dict, device: str, seed: int, page: int = 
         e.synchronize()
         torch.cuda.synchronize()
 
-    for name, plen, steps, chunk in (("config3", 8192, 16, 4096), ("config5", 32768, 16, 4096)):
+    # config5_kv_fp8: configs[4] once more with the K / V pages as FP8 E4M3 codes + one power-of-two scale per row (SURVEY section 8 f4,
+    # tl_engine_create_kv): NOT the reference's arithmetic (it has no quantised cache, README.md:134-135) -- an opt-in extension reported
+    # beside the bf16 figure, never instead of it; its algorithmic bytes are its own (132 instead of 256 bytes per cached row)
+    for name, plen, steps, chunk, kv_format in (("config3", 8192, 16, 4096, "bf16"), ("config5", 32768, 16, 4096, "bf16"),
+                                                ("config5_kv_fp8", 32768, 16, 4096, "fp8")):
         eng = None
         try:
             with time_box(60):
-                eng = DecodeEngine(mlx_model, page_size=page, num_pages=(plen + steps + 96 + page - 1) // page + 2, max_batch=1, max_prefill_rows=chunk)
+                eng = DecodeEngine(mlx_model, page_size=page, num_pages=(plen + steps + 96 + page - 1) // page + 2, max_batch=1, max_prefill_rows=chunk,
+                                   kv_format=kv_format)
                 prompt = build_prompt(rng, plen, cfg["vocab_size"])
                 eng.begin(0)  # one chunk, untimed: code objects and workspaces of the full-chunk prefill kernels
                 eng.prefill(0, prompt[:chunk], chunk=chunk)
@@ -607,7 +650,7 @@ def extra_configs_leg(mlx_model, cfg: dict, device: str, seed: int, page: int = 
                 g_bytes = sum(v["bytes"] for k, v in kinds.items() if k.startswith("gemv_"))
                 kv_bytes = max(step_bytes - g_bytes, 0.0)
                 attn_us = kinds["attention"]["us"] + kinds["attention_merge"]["us"]
-                out[name] = {"prompt_tokens": plen, "decode_steps": steps, "prefill_step": chunk,
+                out[name] = {"prompt_tokens": plen, "decode_steps": steps, "prefill_step": chunk, "kv_pages": kv_format,
                              "ms_per_step": round(dt * 1e3 / steps, 4), "tokens_per_s": round(steps / dt, 1),
                              "prefill_tokens_per_s": round(plen / prefill_s, 1),
                              "step_bytes": int(step_bytes), "step_frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -621,31 +664,32 @@ def extra_configs_leg(mlx_model, cfg: dict, device: str, seed: int, page: int = 
         finally:
             if eng is not None:
                 eng.close()
-    eng = None
-    try:
-        with time_box(60):
-            B, plen, steps = 64, 128, 16
-            per_seq = (plen + steps + 8 + 2 * page) // page + 1
-            eng = DecodeEngine(mlx_model, page_size=page, num_pages=per_seq * B + 2, max_batch=B, max_prefill_rows=128)
-            for slot in range(B):
-                eng.begin(slot)
-                eng.prefill(slot, build_prompt(rng, plen, cfg["vocab_size"]), chunk=128)
-            eng.decode(4, batch=B)
-            sync(eng)
-            b0 = eng.step_bytes(B)
-            t0 = time.perf_counter()
-            eng.decode(steps, batch=B)
-            sync(eng)
-            dt = time.perf_counter() - t0
-            step_bytes = 0.5 * (b0 + eng.step_bytes(B))
-            out["batch64"] = {"sequences": B, "prompt_tokens": plen, "decode_steps": steps,
-                              "ms_per_step": round(dt * 1e3 / steps, 4), "tokens_per_s": round(B * steps / dt, 1),
-                              "step_bytes": int(step_bytes), "step_frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBPS, 4)}
-    except Exception as exc:
-        out["batch64"] = {"ms_per_step": None, "why": f"{type(exc).__name__}: {exc}"}
-    finally:
-        if eng is not None:
-            eng.close()
+    for name, kv_format in (("batch64", "bf16"), ("batch64_kv_fp8", "fp8")):
+        eng = None
+        try:
+            with time_box(60):
+                B, plen, steps = 64, 128, 16
+                per_seq = (plen + steps + 8 + 2 * page) // page + 1
+                eng = DecodeEngine(mlx_model, page_size=page, num_pages=per_seq * B + 2, max_batch=B, max_prefill_rows=128, kv_format=kv_format)
+                for slot in range(B):
+                    eng.begin(slot)
+                    eng.prefill(slot, build_prompt(rng, plen, cfg["vocab_size"]), chunk=128)
+                eng.decode(4, batch=B)
+                sync(eng)
+                b0 = eng.step_bytes(B)
+                t0 = time.perf_counter()
+                eng.decode(steps, batch=B)
+                sync(eng)
+                dt = time.perf_counter() - t0
+                step_bytes = 0.5 * (b0 + eng.step_bytes(B))
+                out[name] = {"sequences": B, "prompt_tokens": plen, "decode_steps": steps, "kv_pages": kv_format,
+                             "ms_per_step": round(dt * 1e3 / steps, 4), "tokens_per_s": round(B * steps / dt, 1),
+                             "step_bytes": int(step_bytes), "step_frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBPS, 4)}
+        except Exception as exc:
+            out[name] = {"ms_per_step": None, "why": f"{type(exc).__name__}: {exc}"}
+        finally:
+            if eng is not None:
+                eng.close()
     return out
 
 
@@ -1042,7 +1086,19 @@ def main() -> None:
                 # the checked engine is prefilled in 8-row passes: rows <= 8 take the matvec arithmetic (quantize.py:54-65), which is what the
                 # C port walks the prompt with -- a 128-row chunk takes the tile GEMM, whose weights are rounded to bf16 first
                 # (quantized_matmul.metal:96-249): reference-mandated extra rounding in the cached K/V that is not the decode kernels' error
-                cpu = cpu_baseline_leg(mlx_model, cfg, engine, sample_prompt=sample_prompt, sample_steps=16, prefill_chunk=8)
+                fp8_engine = None
+                if device != "cpu" and cfg.get("head_dim") == 128:
+                    try:
+                        from tiny_llm_hip.engine import DecodeEngine as _DE
+
+                        fp8_engine = _DE(mlx_model, page_size=page, num_pages=4, max_batch=1, max_prefill_rows=8, kv_format="fp8")
+                    except Exception:
+                        fp8_engine = None
+                try:
+                    cpu = cpu_baseline_leg(mlx_model, cfg, engine, sample_prompt=sample_prompt, sample_steps=16, prefill_chunk=8, fp8_engine=fp8_engine)
+                finally:
+                    if fp8_engine is not None:
+                        fp8_engine.close()
         except Exception as exc:
             cpu = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {type(exc).__name__}: {exc}"}
         cpu["n_splits_timed"] = prof.get("n_splits") if prof else None

@@ -2281,7 +2281,9 @@ extern "C" size_t tl_engine_step_bytes(const tl_engine *e, int batch) {
     size_t total = 0;
     for (const auto &l : e->layers) total += w4_bytes(l.wqkv) + w4_bytes(l.wo) + w4_bytes(l.wgu) + w4_bytes(l.wdown);
     total += w4_bytes(e->head());
-    const size_t kv_per_token = (size_t)2 * c.num_layers * c.num_kv_heads * c.head_dim * 2;
+    // K and V rows of a cached token, all layers: 2 bytes per element, or (FP8 pages) one byte per element + a 4-byte scale per row
+    const size_t kv_per_token = e->kv_format == TL_KV_FP8_E4M3 ? (size_t)2 * c.num_layers * c.num_kv_heads * (c.head_dim + 4)
+                                                               : (size_t)2 * c.num_layers * c.num_kv_heads * c.head_dim * 2;
     for (int b = 0; b < batch && b < c.max_batch; ++b)
         if (e->slot_live[b]) total += kv_per_token * (size_t)e->slot_ctx[b];
     return total;

@@ -3,7 +3,7 @@
 // `rocprofv3 --pmc` (which crashes under the full Python bench on this image) can count HBM bytes on the ENGINE's own decode step
 // instead of on tools/lab/gemv_lab's replay of its GEMV kernels.  A pure stream kernel of known size runs first: its FETCH_SIZE
 // calibrates the counter's unit (guides/MI355X_MICROARCH.md, HBM section).
-//   usage: engine_step_lab [context tokens = 128] [decode steps = 20] [batch = 1]
+//   usage: engine_step_lab [context tokens = 128] [decode steps = 20] [batch = 1] [kv pages: 0 = bf16, 1 = FP8 E4M3]
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -68,6 +68,7 @@ int main(int argc, char **argv) {
     const int context = argc > 1 ? atoi(argv[1]) : 128;
     const int steps = argc > 2 ? atoi(argv[2]) : 20;
     const int batch = argc > 3 ? atoi(argv[3]) : 1;
+    const int kv_format = argc > 4 && atoi(argv[4]) == 1 ? TL_KV_FP8_E4M3 : TL_KV_BF16;
     const int H = 2560, L = 36, HQ = 32, HKV = 8, D = 128, I = 9728, V = 151936, page = 128;
 
     // calibration stream first: 1 GiB read 4 times (far beyond the 256 MiB infinity cache)
@@ -106,7 +107,7 @@ int main(int argc, char **argv) {
     cfg.page_size = page; cfg.num_pages = per_seq * batch + 2; cfg.max_batch = batch; cfg.max_pages_per_seq = per_seq;
     cfg.max_prefill_rows = context < 2048 ? (context < 8 ? 8 : context) : 2048;
     tl_engine *e = nullptr;
-    TL(tl_engine_create(&cfg, layers.data(), &embed, final_norm, nullptr, nullptr, &e));
+    TL(tl_engine_create_kv(&cfg, layers.data(), &embed, final_norm, nullptr, nullptr, kv_format, &e));
 
     std::vector<int32_t> prompt(context);
     for (int b = 0; b < batch; ++b) {
@@ -124,8 +125,8 @@ int main(int argc, char **argv) {
     TL(tl_engine_synchronize(e));
     const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     tl_engine_stats st{}; TL(tl_engine_get_stats(e, &st));
-    printf("engine: qwen3-4b shape, context %d, batch %d, %d timed steps, route %s, %.4f ms per step (host-bracketed), algorithmic bytes per step %zu\n",
-           context, batch, steps, tl_engine_replay_route(e), ms / steps, tl_engine_step_bytes(e, batch));
+    printf("engine: qwen3-4b shape, %s pages, context %d, batch %d, %d timed steps, route %s, %.4f ms per step (host-bracketed), algorithmic bytes per step %zu\n",
+           kv_format == TL_KV_FP8_E4M3 ? "FP8 E4M3" : "bf16", context, batch, steps, tl_engine_replay_route(e), ms / steps, tl_engine_step_bytes(e, batch));
     std::vector<int32_t> ids(steps);
     TL(tl_engine_read_tokens(e, 0, steps < 8 ? steps : 8, ids.data()));
     printf("first ids of slot 0:");
