@@ -129,6 +129,10 @@ int tl_paged_attention(const void *q, const void *key_pages, const void *value_p
                        int max_context_hint, tl_dtype dtype, void *workspace, size_t workspace_bytes, void *stream);
 size_t tl_paged_attention_workspace_bytes(int N, int L, int D, int page_size, int max_pages, int num_heads,
                                           int num_kv_heads, int max_context_hint);
+/* test / lab hook: waves per workgroup of the bf16 FlashAttention prefill kernel -- 8 (default: one workgroup per CU, the K/V tile
+ * double-buffered and shared by 8 (head, query block) items; pages of 64+ tokens, chunks of 64+ rows) or 4 (its twin, bit-identical
+ * results).  Returns the previous value; any other argument only reads it. */
+int tl_paged_attention_waves(int waves);
 
 /* ===== FP8 (E4M3) KV pages -- SURVEY.md section 8f row 4, "quantized-KV" ========
  * NO reference interface is replaced: the reference lists quantised KV caches as

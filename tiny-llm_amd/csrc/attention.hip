@@ -383,7 +383,6 @@ __global__ __launch_bounds__(128) void paged_merge_kernel(const float *__restric
 #endif
 constexpr int FA_BK = 64;            // tokens staged per barrier phase (two 32-token MFMA sub-tiles)
 constexpr int FA_SUB = FA_BK / 32;
-constexpr int FA_CPT = FA_BK / 16;    // 16-byte K (and V) chunks per thread and stage
 constexpr int FA_VROW = 128 + 32;    // bf16 elements per row of the row-major V tile: rows 320 B apart put the 4 rows x 16 dims a
                                      // 16-lane group gathers with ds_read_b64_tr_b16 on distinct banks (16 r + 8 g + 2 q + {0, 1})
 
@@ -396,8 +395,19 @@ constexpr int FA_VROW = 128 + 32;    // bf16 elements per row of the row-major V
 // KV8: the pages hold E4M3 codes (one byte per element of the same layout) and key_scales / value_scales one power-of-two float32 per
 // (page, kv head, slot) row (kv8.h).  A thread requests 8 bytes per chunk instead of 16, plus its rows' scales, and converts to the bf16
 // values a bf16 page would hold (exact) when it stores the chunk into the LDS tiles: everything behind the staging is unchanged.
-template <bool ONEPAGE, int QR = 1, bool KV8 = false>
-__global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kernel(
+// NW = waves per workgroup.  4: two workgroups per CU, a single-buffered K/V tile, two barriers per stage, the next stage's rows requested
+// into registers behind the second one.  8 (round 6, ONEPAGE only): ONE workgroup per CU whose 8 waves -- the 4 query heads of the KV head x two
+// consecutive 32-row query blocks -- share the staged tile (half the requests and half the staging stores per flop), the tile DOUBLE-buffered
+// in LDS: per stage ONE barrier, then the rows of stage s + 2 are requested (two register sets: a stage's rows have a whole stage AND its
+// compute to arrive, not one), stage s is computed from buffer s & 1, and the rows of stage s + 1 are stored into the other buffer.  The
+// arithmetic of a (head, query block) is the same instruction sequence in both: the results are bit-identical.
+// wave-uniform 32-bit load through the scalar cache (its own counter: it neither waits for nor delays the vector loads in flight)
+__device__ __forceinline__ void fa_sload_i32(const int32_t *ptr, int &dst) { asm volatile("s_load_dword %0, %1, 0x0" : "=s"(dst) : "s"(ptr)); }
+__device__ __forceinline__ void fa_sload_wait(int &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
+constexpr int FA_KS_ELEMS = FA_BK * 128, FA_VS_ELEMS = FA_BK * FA_VROW;
+constexpr size_t fa_pipe_lds_bytes() { return (size_t)2 * (FA_KS_ELEMS + FA_VS_ELEMS) * 2 + 2 * FA_BK * sizeof(int); }
+template <bool ONEPAGE, int QR = 1, bool KV8 = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (QR == 1 && NW == 4) ? 2 : 1) void paged_fa_bf16_d128_kernel(
     const uint16_t *__restrict__ q, const void *__restrict__ key_pages_v, const void *__restrict__ value_pages_v,
     const int32_t *__restrict__ block_table, const int32_t *__restrict__ context_lens, uint16_t *__restrict__ out,
     float *__restrict__ ws, int n_splits, int L, int page_size, int page_shift, int max_pages, int num_heads, int num_kv_heads,
@@ -408,9 +418,17 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
     using KVC = typename std::conditional<KV8, u32x2, u32x4>::type;        // a chunk of 8 of them
     const KVE *__restrict__ key_pages = reinterpret_cast<const KVE *>(key_pages_v);
     const KVE *__restrict__ value_pages = reinterpret_cast<const KVE *>(value_pages_v);
-    __shared__ __attribute__((aligned(16))) uint16_t ks[FA_BK * D];     // [token][dim] swizzled
-    __shared__ __attribute__((aligned(16))) uint16_t vs[FA_BK * FA_VROW];  // [token][dim] as it lies in the page; read transposed
-    __shared__ int tile_page[2][FA_BK];
+    constexpr bool PIPE = NW == 8;
+    static_assert(NW == 4 || (NW == 8 && ONEPAGE && QR == 1), "8 waves: pages of 64+ tokens, one row block per wave");
+    constexpr int NT = 64 * NW;                  // threads
+    constexpr int CPT = FA_BK * 16 / NT;         // 16-byte K (and V) chunks per thread and stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char fa_dyn[];  // PIPE: K[2] | V[2] | tile_page[2]
+    __shared__ __attribute__((aligned(16))) uint16_t ks_one[PIPE ? 8 : FA_KS_ELEMS];  // [token][dim] swizzled
+    __shared__ __attribute__((aligned(16))) uint16_t vs_one[PIPE ? 8 : FA_VS_ELEMS];  // [token][dim] as it lies in the page; read transposed
+    __shared__ int tile_page_one[PIPE ? 2 : 2 * FA_BK];
+    uint16_t *const ks = PIPE ? reinterpret_cast<uint16_t *>(fa_dyn) : ks_one;
+    uint16_t *const vs = PIPE ? reinterpret_cast<uint16_t *>(fa_dyn) + 2 * FA_KS_ELEMS : vs_one;
+    int *const tile_page = PIPE ? reinterpret_cast<int *>(fa_dyn + (size_t)2 * (FA_KS_ELEMS + FA_VS_ELEMS) * 2) : tile_page_one;  // [2][FA_BK]
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -437,7 +455,7 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
     // range is cut into n_splits pieces, one workgroup each, merged by paged_merge_kernel (flash-decoding style)
     const int split = bx % n_splits;
     const int item_block = bx / n_splits;
-    const int item = item_block * 4 + wave;
+    const int item = item_block * NW + wave;
     const bool wave_live = item < items;
     const int hq = wave_live ? item % rep : 0;
     const int qb = wave_live ? item / rep : 0;
@@ -482,7 +500,7 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
     int blk_tiles;
     {
         // items of a block differ at most in q-block; the last wave_live item has the largest limit
-        const int last_item = min(item_block * 4 + 3, items - 1);
+        const int last_item = min(item_block * NW + NW - 1, items - 1);
         const int last_qb = last_item / rep;
         if (is_causal) {
             const int lq = min((last_qb + 1) * 32 * QR, L) - 1;
@@ -496,31 +514,36 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
     // staging: thread -> (token = c/16, chunk = c%16) for c = tid, tid+256
     // A STAGE is FA_BK tokens (FA_SUB sub-tiles of 32): one pair of barriers and one global round trip per stage.  With
     // 32-token stages the MFMA work of a stage (~0.5 us) could not cover the latency of the next stage's rows.
-    KVC kreg[FA_CPT], vreg[FA_CPT];
-    float ksc[KV8 ? FA_CPT : 1], vsc[KV8 ? FA_CPT : 1];  // KV8: the scale of each chunk's row
+    struct Stg {  // a stage's rows on their way from the page to the LDS tiles
+        KVC k[CPT], v[CPT];
+        float ksc[KV8 ? CPT : 1], vsc[KV8 ? CPT : 1];  // KV8: the scale of each chunk's row
+        bool ok[CPT];
+        int pg[CPT];        // the page each chunk's token lives on (-1: none); ONEPAGE: pg[0] for all
+        bool full;          // ONEPAGE: every row of the stage is a live token (no zeroing at the store)
+    };
+    Stg sa, sb;
     // page ids travel one stage ahead of the K/V rows they address: a stage's loads are then ONE global round trip behind
     // the MFMAs of the previous stage instead of two dependent ones (block table, then rows)
     // K and V chunk c = tid + 256 i  ->  (token c / 16, 16-byte chunk c % 16): coalesced rows, b128 stores into the swizzled K tile
     // and into the row-major V tile (round 3: the PV fragments are gathered by ds_read_b64_tr_b16; until then V was stored
     // transposed with 16 ds_write_b32 per thread and stage).
-    int pid_reg[FA_CPT];
-    bool kv_ok[FA_CPT];
+    int pid_reg[CPT];
 #pragma unroll
-    for (int i = 0; i < FA_CPT; ++i) kv_ok[i] = false;
+    for (int i = 0; i < CPT; ++i) sa.ok[i] = sb.ok[i] = false;
+    sa.full = sb.full = false;
     // page_shift = log2(page_size), or -1 (integer division, ~30 VALU ops each, 16 of them per stage and thread)
     auto logical_page = [&](int tok) { return page_shift >= 0 ? (tok >> page_shift) : tok / page_size; };
     // The id is NOT touched here (no "in ? id : -1"): any use of the loaded word right behind the load makes the compiler wait
     // for it on the spot -- and, loads returning in issue order, for the K/V rows of the next stage requested just before it,
     // i.e. the stage prefetch stopped overlapping the MFMAs (r02: found in the ISA as vmcnt(0) behind load_pids).  Whether the
     // token has a page at all is kept as a flag computed from the token index alone and applied where the id is used.
-    bool pid_in[FA_CPT];
+    bool pid_in[CPT];
     auto page_of_token = [&](int tok, bool &in) {
         const int lp = logical_page(tok);
         in = tok < ctx && lp < max_pages;
         return block_table[(long)b * max_pages + (in ? lp : 0)];  // unconditional load from a clamped address
     };
     int page_next = -1;  // ONEPAGE: the (uniform) page id of the stage whose rows are requested next
-    bool stage_full = false;  // ONEPAGE: every row of the stage in the registers is a live token (no zeroing at the store)
     auto load_pids = [&](int stage) {
         if constexpr (ONEPAGE) {
             const int lp = (stage * FA_BK) >> page_shift;
@@ -529,39 +552,39 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
             pid_in[0] = lp < max_pages;
         } else {
 #pragma unroll
-            for (int i = 0; i < FA_CPT; ++i) pid_reg[i] = page_of_token(stage * FA_BK + ((tid + i * 256) >> 4), pid_in[i]);
+            for (int i = 0; i < CPT; ++i) pid_reg[i] = page_of_token(stage * FA_BK + ((tid + i * NT) >> 4), pid_in[i]);
         }
     };
-    auto stage_load = [&](int stage) {
+    auto stage_load = [&](int stage, Stg &g, int page_arg = -1) {
         if constexpr (ONEPAGE) {
-            const int page = pid_in[0] ? __builtin_amdgcn_readfirstlane(page_next) : -1;
+            const int page = PIPE ? page_arg : (pid_in[0] ? __builtin_amdgcn_readfirstlane(page_next) : -1);
             const int slot0 = (stage * FA_BK) & (page_size - 1);
             const long base = (((long)max(page, 0) * num_kv_heads + kvh) * page_size + slot0) * D;  // uniform
             const KVE *kbase = key_pages + base;
             const KVE *vbase = value_pages + base;
-            stage_full = page >= 0 && (stage + 1) * FA_BK <= ctx;  // uniform: nothing to zero when the store comes
+            g.full = page >= 0 && (stage + 1) * FA_BK <= ctx;  // uniform: nothing to zero when the store comes
+            g.pg[0] = page;
 #pragma unroll
-            for (int i = 0; i < FA_CPT; ++i) {
-                const int c = tid + i * 256;  // token c / 16, chunk c % 16: the stage's 64 K rows are contiguous
-                kreg[i] = *reinterpret_cast<const KVC *>(kbase + (size_t)c * 8);
-                kv_ok[i] = page >= 0 && stage * FA_BK + (c >> 4) < ctx;  // rows past the context are zeroed in LDS as before
-                if ((c & 15) == 0) tile_page[stage & 1][c >> 4] = kv_ok[i] ? page : -1;
+            for (int i = 0; i < CPT; ++i) {
+                const int c = tid + i * NT;  // token c / 16, chunk c % 16: the stage's 64 K rows are contiguous
+                g.k[i] = *reinterpret_cast<const KVC *>(kbase + (size_t)c * 8);
+                g.ok[i] = page >= 0 && stage * FA_BK + (c >> 4) < ctx;  // rows past the context are zeroed in LDS as before
             }
 #pragma unroll
-            for (int i = 0; i < FA_CPT; ++i) vreg[i] = *reinterpret_cast<const KVC *>(vbase + (size_t)(tid + i * 256) * 8);
+            for (int i = 0; i < CPT; ++i) g.v[i] = *reinterpret_cast<const KVC *>(vbase + (size_t)(tid + i * NT) * 8);
             if constexpr (KV8) {
                 const long row0 = base / D;  // uniform
 #pragma unroll
-                for (int i = 0; i < FA_CPT; ++i) {
-                    ksc[i] = key_scales[row0 + ((tid + i * 256) >> 4)];
-                    vsc[i] = value_scales[row0 + ((tid + i * 256) >> 4)];
+                for (int i = 0; i < CPT; ++i) {
+                    g.ksc[i] = key_scales[row0 + ((tid + i * NT) >> 4)];
+                    g.vsc[i] = value_scales[row0 + ((tid + i * NT) >> 4)];
                 }
             }
             return;
         }
 #pragma unroll
-        for (int i = 0; i < FA_CPT; ++i) {
-            const int c = tid + i * 256;
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * NT;
             const int tok_in = c >> 4;
             const int ch = c & 15;
             const int tok = stage * FA_BK + tok_in;
@@ -571,37 +594,40 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
             // unconditional loads from a clamped address (a divergent branch around a load makes hipcc wait for it at the
             // join, i.e. before the MFMAs it should overlap); rows of unused pages are zeroed when they are stored to LDS
             const long off = (((long)max(page_id, 0) * num_kv_heads + kvh) * page_size + slot) * D + ch * 8;
-            kreg[i] = *reinterpret_cast<const KVC *>(key_pages + off);
-            vreg[i] = *reinterpret_cast<const KVC *>(value_pages + off);
+            g.k[i] = *reinterpret_cast<const KVC *>(key_pages + off);
+            g.v[i] = *reinterpret_cast<const KVC *>(value_pages + off);
             if constexpr (KV8) {
-                ksc[i] = key_scales[off / D];
-                vsc[i] = value_scales[off / D];
+                g.ksc[i] = key_scales[off / D];
+                g.vsc[i] = value_scales[off / D];
             }
-            kv_ok[i] = page_id >= 0;
-            if (ch == 0) tile_page[stage & 1][tok_in] = page_id;  // read one iteration later, after two barriers
+            g.ok[i] = page_id >= 0;
+            g.pg[i] = page_id;
         }
     };
 
-    auto stage_store = [&]() {
+    // a stage's rows into K / V tile `buf` (PIPE: 0 / 1; else 0) and its page ids into tile_page[tp]
+    auto stage_store = [&](const Stg &g, int buf, int tp) {
+        uint16_t *ksb = ks + buf * FA_KS_ELEMS, *vsb = vs + buf * FA_VS_ELEMS;
 #pragma unroll
-        for (int i = 0; i < FA_CPT; ++i) {
-            const int c = tid + i * 256;
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * NT;
             const int tok_in = c >> 4;
             const int ch = c & 15;
             u32x4 kk;
-            if constexpr (KV8) kk = kv8_to_bf16x8(kreg[i], ksc[i]);
-            else kk = kreg[i];
-            if (!(ONEPAGE && stage_full) && !kv_ok[i]) kk = u32x4{0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4 *>(&ks[tok_in * D + ((ch ^ (tok_in & 15)) * 8)]) = kk;
+            if constexpr (KV8) kk = kv8_to_bf16x8(g.k[i], g.ksc[i]);
+            else kk = g.k[i];
+            if (!(ONEPAGE && g.full) && !g.ok[i]) kk = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4 *>(&ksb[tok_in * D + ((ch ^ (tok_in & 15)) * 8)]) = kk;
+            if (ch == 0) tile_page[tp * FA_BK + tok_in] = ONEPAGE ? (g.ok[i] ? g.pg[0] : -1) : g.pg[i];  // read behind the next barrier
         }
 #pragma unroll
-        for (int i = 0; i < FA_CPT; ++i) {  // V rows as they lie in the page: one b128 store per chunk (the PV fragments are read transposed)
-            const int c = tid + i * 256;
+        for (int i = 0; i < CPT; ++i) {  // V rows as they lie in the page: one b128 store per chunk (the PV fragments are read transposed)
+            const int c = tid + i * NT;
             u32x4 vv;
-            if constexpr (KV8) vv = kv8_to_bf16x8(vreg[i], vsc[i]);
-            else vv = vreg[i];
-            if (!(ONEPAGE && stage_full) && !kv_ok[i]) vv = u32x4{0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4 *>(&vs[(c >> 4) * FA_VROW + (c & 15) * 8]) = vv;
+            if constexpr (KV8) vv = kv8_to_bf16x8(g.v[i], g.vsc[i]);
+            else vv = g.v[i];
+            if (!(ONEPAGE && g.full) && !g.ok[i]) vv = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4 *>(&vsb[(c >> 4) * FA_VROW + (c & 15) * 8]) = vv;
         }
     };
 
@@ -615,19 +641,11 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
     const int stages_per_split = (total_stages + n_splits - 1) / n_splits;
     const int stage_begin = split * stages_per_split;
     const int stage_end = min(stage_begin + stages_per_split, blk_stages);
-    if (stage_begin < stage_end) {
-        load_pids(stage_begin);
-        stage_load(stage_begin);
-        if (stage_begin + 1 < stage_end) load_pids(stage_begin + 1);
-    }
-    for (int stage = stage_begin; stage < stage_end; ++stage) {
-        __syncthreads();  // previous stage's LDS reads are complete
-        if (!(FA_ABL & 8) || stage == stage_begin) stage_store();
-        __syncthreads();
-        if (stage + 1 < stage_end && !(FA_ABL & 16)) {
-            stage_load(stage + 1);
-            if (stage + 2 < stage_end) load_pids(stage + 2);
-        }
+    // one stage's two products and its softmax, from K / V tile `buf` and the page ids in tile_page[tp]
+    auto compute_stage = [&](int stage, int buf, int tp) {
+        const uint16_t *ksb = ks + buf * FA_KS_ELEMS;
+        const uint16_t *vtrb = vtr + buf * FA_VS_ELEMS;
+        const int *tpb = tile_page + tp * FA_BK;
 #pragma unroll
         for (int sub = 0; sub < FA_SUB; ++sub) {
         const int tile = stage * FA_SUB + sub;
@@ -643,7 +661,7 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int ch = (2 * s + h) ^ (l32 & 15);
-            const u32x4 kf = *reinterpret_cast<const u32x4 *>(&ks[(tb + l32) * D + ch * 8]);
+            const u32x4 kf = *reinterpret_cast<const u32x4 *>(&ksb[(tb + l32) * D + ch * 8]);
 #pragma unroll
             for (int rb = 0; rb < QR; ++rb) {
                 if constexpr (FA_ABL & 4) sacc[rb][s] += __uint_as_float((kf[0] ^ qf[rb][s][1]) & 0x3f800000u);
@@ -659,7 +677,7 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
         // Interior tiles (wave-uniform test: every token is inside the context, on one live page, and at or below the causal
         // diagonal of the row block's FIRST query row) need no per-element test: most tiles of a long context are interior.
         float tmax = -INFINITY;
-        const bool interior = page_shift >= 5 && tile * 32 + 31 < ctx && tile_page[stage & 1][tb] >= 0 &&
+        const bool interior = page_shift >= 5 && tile * 32 + 31 < ctx && tpb[tb] >= 0 &&
                               (!is_causal || tile * 32 + 31 <= (qb * QR + rb) * 32 + (ctx - L));
         if (interior) {  // raw scores here; the scale goes into the exponent's FMA below (16 multiplies fewer per tile)
 #pragma unroll
@@ -669,7 +687,7 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tok = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                bool valid = q_valid[rb] && tok < ctx && tile_page[stage & 1][tb + (r & 3) + 8 * (r >> 2) + 4 * h] >= 0;
+                bool valid = q_valid[rb] && tok < ctx && tpb[tb + (r & 3) + 8 * (r >> 2) + 4 * h] >= 0;
                 if (is_causal) valid = valid && tok <= qrow[rb] + (ctx - L);
                 sacc[rb][r] = valid ? sacc[rb][r] * scale_log2 : -INFINITY;
                 tmax = fmaxf(tmax, sacc[rb][r]);
@@ -724,8 +742,8 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
                 // A fragment of V^T: lane (dim db*32 + l32, half h) needs tokens tb + 16 s + 4 h + {0..3} and + 8 + {0..3} of its dim.
                 // ds_read_b64_tr_b16: in a 16-lane group lane c hands in the address of [row c >> 2][4 dims from 4 (c & 3)] of a
                 // [4 tokens][16 dims] block and receives the block's column c (tools/lab/tr_probe.hip) -- V stays row-major.
-                const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16 *)(vtr + (tb + 16 * s) * FA_VROW + db * 32));
-                const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16 *)(vtr + (tb + 16 * s + 8) * FA_VROW + db * 32));
+                const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16 *)(vtrb + (tb + 16 * s) * FA_VROW + db * 32));
+                const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16 *)(vtrb + (tb + 16 * s + 8) * FA_VROW + db * 32));
                 const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
                 const u32x4 vf = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
 #pragma unroll
@@ -738,6 +756,55 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
             }
         }
         }  // sub-tile
+    };
+
+    if constexpr (!PIPE) {
+        if (stage_begin < stage_end) {
+            load_pids(stage_begin);
+            stage_load(stage_begin, sa);
+            if (stage_begin + 1 < stage_end) load_pids(stage_begin + 1);
+        }
+        for (int stage = stage_begin; stage < stage_end; ++stage) {
+            __syncthreads();  // previous stage's LDS reads are complete
+            if (!(FA_ABL & 8) || stage == stage_begin) stage_store(sa, 0, stage & 1);
+            __syncthreads();
+            if (stage + 1 < stage_end && !(FA_ABL & 16)) {
+                stage_load(stage + 1, sa);
+                if (stage + 2 < stage_end) load_pids(stage + 2);
+            }
+            compute_stage(stage, 0, stage & 1);
+        }
+    } else if (stage_begin < stage_end) {
+        // page ids by scalar loads, one stage ahead of the rows they address; every row request stands outside any branch (a stage past the
+        // end requests the last one again: the rows are not stored)
+        const int32_t *brow = block_table + (long)b * max_pages;
+        const int last = stage_end - 1;
+        auto page_slot = [&](int stage) { return brow + min((stage * FA_BK) >> page_shift, max_pages - 1); };
+        auto page_live = [&](int stage, int id) { return ((stage * FA_BK) >> page_shift) < max_pages ? id : -1; };
+        int pg0, pg1, pg_n;
+        fa_sload_i32(page_slot(stage_begin), pg0);
+        fa_sload_i32(page_slot(min(stage_begin + 1, last)), pg1);
+        fa_sload_i32(page_slot(min(stage_begin + 2, last)), pg_n);
+        fa_sload_wait(pg0);
+        fa_sload_wait(pg1);
+        fa_sload_wait(pg_n);
+        stage_load(stage_begin, sa, page_live(stage_begin, pg0));
+        stage_store(sa, 0, 0);
+        stage_load(min(stage_begin + 1, last), sa, page_live(min(stage_begin + 1, last), pg1));
+        // iteration of stage s (r = s - stage_begin): `next` holds the rows of s + 1 (requested one iteration ago), `free` takes those of s + 2
+        auto iter = [&](int stage, int r, Stg &next, Stg &free) {
+            __syncthreads();  // stage s is in tile r & 1; everyone is done reading the other tile
+            const int s2 = min(stage + 2, last);
+            if (!(FA_ABL & 16)) stage_load(s2, free, page_live(s2, pg_n));
+            fa_sload_i32(page_slot(min(stage + 3, last)), pg_n);  // waited for at the end of this iteration
+            compute_stage(stage, r & 1, r & 1);
+            if (stage + 1 < stage_end && !(FA_ABL & 8)) stage_store(next, (r + 1) & 1, (r + 1) & 1);
+            fa_sload_wait(pg_n);
+        };
+        for (int stage = stage_begin, r = 0; stage < stage_end; stage += 2, r += 2) {
+            iter(stage, r, sa, sb);
+            if (stage + 1 < stage_end) iter(stage + 1, r + 1, sb, sa);
+        }
     }
 
 #pragma unroll
@@ -775,10 +842,10 @@ __global__ __launch_bounds__(256, QR == 1 ? 2 : 1) void paged_fa_bf16_d128_kerne
 }
 
 // context splits of the MFMA prefill kernel: only when the (head, query block) items alone leave most CUs idle, and never
-// below 256 tokens per split
-static int pick_fa_splits(int B, int Hkv, int item_blocks, int max_ctx) {
+// below 256 tokens per split.  `wg_target`: 512 workgroups of 4 waves (two per CU) or 256 of 8.
+static int pick_fa_splits(int B, int Hkv, int item_blocks, int max_ctx, int wg_target = 512) {
     const int base = std::max(1, B * Hkv * item_blocks);
-    int s = 512 / base;
+    int s = wg_target / base;
     s = std::min(s, std::max(1, max_ctx / 256));
     s = std::min(s, 32);
     return std::max(s, 1);
@@ -857,6 +924,14 @@ extern "C" int tl_paged_cache_update(void *pages, const void *values, int num_pa
 }
 
 static bool paged_uses_fa(int L, int D, tl_dtype dtype) { return L > 8 && dtype == TL_BF16 && D == 128; }
+// waves per workgroup of the FlashAttention prefill kernel: 8 (default) takes pages of 64+ tokens and chunks of 64+ query rows; 4 is the
+// twin (and what everything else runs on).  tl_paged_attention_waves: test / lab hook, returns the previous value.
+static int g_fa_waves = 8;
+extern "C" int tl_paged_attention_waves(int waves) {
+    const int before = g_fa_waves;
+    if (waves == 4 || waves == 8) g_fa_waves = waves;
+    return before;
+}
 
 extern "C" size_t tl_paged_attention_workspace_bytes(int N, int L, int D, int page_size, int max_pages, int num_heads,
                                                      int num_kv_heads, int max_context_hint) {
@@ -903,27 +978,48 @@ static int paged_attention_impl(const void *q, const void *key_pages, const void
         // profiles/r03_labs/prefill_fa_two_row_blocks.log; only QR = 1 is instantiated)
         constexpr int qr = 1;
         const int items = rep * ((L + 32 * qr - 1) / (32 * qr));
-        const int item_blocks = (items + 3) / 4;
+        int page_shift = -1;
+        for (int sh = 0; sh < 30; ++sh)
+            if ((1 << sh) == page_size) page_shift = sh;
+        // 8 waves sharing a double-buffered tile (one workgroup per CU): whole groups of 8 (head, query block) items, pages of 64+ tokens
+        const bool w8 = g_fa_waves == 8 && page_shift >= 6 && L >= 64 && rep * 2 <= 8 && 8 % rep == 0;
+        const int nw = w8 ? 8 : 4;
+        const int item_blocks = (items + nw - 1) / nw;
         const int max_ctx_fa = max_context_hint > 0 ? max_context_hint : max_pages * page_size;
-        int fa_splits = pick_fa_splits(B, num_kv_heads, item_blocks, max_ctx_fa);
+        int fa_splits = pick_fa_splits(B, num_kv_heads, item_blocks, max_ctx_fa, w8 ? 256 : 512);
         const size_t fa_need = fa_splits > 1 ? (size_t)N * L * fa_splits * (D + 2) * sizeof(float) : 0;
         if (fa_need > 0 && (!workspace || workspace_bytes < fa_need)) fa_splits = 1;  // no workspace: one pass, still correct
         const dim3 grid(item_blocks * fa_splits, num_kv_heads, B);
         const int fa_xcd_remap = 1;  // one KV head per XCD (round 3 A/B: +2 % at 8k prefill)
-        int page_shift = -1;
-        for (int sh = 0; sh < 30; ++sh)
-            if ((1 << sh) == page_size) page_shift = sh;
 #define FA_LAUNCH(ONEP, QRv, K8)                                                                                                \
         hipLaunchKernelGGL((paged_fa_bf16_d128_kernel<ONEP, QRv, K8>), grid, dim3(256), 0, st, (const uint16_t *)q, key_pages,  \
                            value_pages, block_table, context_lens, (uint16_t *)out, (float *)workspace, fa_splits, L, page_size, \
                            page_shift, max_pages, num_heads, num_kv_heads, scale, is_causal, fa_xcd_remap, key_scales,            \
                            value_scales)
-        if (kv8) {
+#define FA_LAUNCH8(K8)                                                                                                           \
+        do {                                                                                                                         \
+            static bool attr_set = false;                                                                                            \
+            if (!attr_set) {                                                                                                         \
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&paged_fa_bf16_d128_kernel<true, 1, K8, 8>),                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)fa_pipe_lds_bytes()) != hipSuccess)         \
+                    return fail(TL_ERR_HIP, "paged_attention: cannot size the prefill kernel's LDS");                               \
+                attr_set = true;                                                                                                     \
+            }                                                                                                                        \
+            hipLaunchKernelGGL((paged_fa_bf16_d128_kernel<true, 1, K8, 8>), grid, dim3(512), fa_pipe_lds_bytes(), st,                \
+                               (const uint16_t *)q, key_pages, value_pages, block_table, context_lens, (uint16_t *)out,             \
+                               (float *)workspace, fa_splits, L, page_size, page_shift, max_pages, num_heads, num_kv_heads, scale,   \
+                               is_causal, fa_xcd_remap, key_scales, value_scales);                                                   \
+        } while (0)
+        if (w8) {
+            if (kv8) FA_LAUNCH8(true);
+            else FA_LAUNCH8(false);
+        } else if (kv8) {
             if (page_shift >= 6) FA_LAUNCH(true, 1, true);
             else FA_LAUNCH(false, 1, true);
         } else if (page_shift >= 6) FA_LAUNCH(true, 1, false);  // a 64-token stage never straddles pages
         else FA_LAUNCH(false, 1, false);
 #undef FA_LAUNCH
+#undef FA_LAUNCH8
         TL_CHECK_LAUNCH("paged_attention(prefill)");
         if (fa_splits > 1) {
             hipLaunchKernelGGL((paged_merge_kernel<BF16>), dim3(N * L), dim3(128), 0, st, (const float *)workspace,

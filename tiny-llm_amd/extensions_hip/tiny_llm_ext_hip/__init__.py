@@ -62,6 +62,7 @@ _SIGNATURES = {
         [_c_void_p] * 6 + [_c_int] * 8 + [_c_float, _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p],
     ),
     "tl_paged_attention_workspace_bytes": (_c_size_t, [_c_int] * 8),
+    "tl_paged_attention_waves": (_c_int, [_c_int]),
     # FP8 (E4M3) KV pages (include/tinyllm_hip.h, last operator section; no reference counterpart)
     "tl_kv_fp8_quantize_rows": (_c_int, [_c_void_p, _c_void_p, _c_void_p, ctypes.c_long, _c_int, _c_void_p]),
     "tl_kv_fp8_dequantize_rows": (_c_int, [_c_void_p, _c_void_p, _c_void_p, ctypes.c_long, _c_int, _c_void_p]),
@@ -892,3 +893,8 @@ def decode_attention_fused_fp8(qkv: torch.Tensor, q_norm: torch.Tensor, k_norm: 
                                               num_heads, num_kv_heads, D, page, int(block_table.shape[1]), float(rope_theta), float(eps),
                                               int(max_context), _ptr(ws), ws.numel(), _stream(), ctypes.byref(info)))
     return out, {name: getattr(info, name) for name, _ in info._fields_}
+
+
+def paged_attention_waves(waves: int = 0) -> int:
+    """Test / lab hook (tl_paged_attention_waves): 8 or 4 waves per workgroup in the bf16 FlashAttention prefill kernel; returns the previous value."""
+    return int(_lib.tl_paged_attention_waves(int(waves)))
