@@ -454,7 +454,8 @@ __global__ __launch_bounds__(64 * NW, (QR == 1 && NW == 4) ? 2 : 1) void paged_f
     // bx = item block * n_splits + context split: with few query rows (chunked prefill of a long prompt) the KV
     // range is cut into n_splits pieces, one workgroup each, merged by paged_merge_kernel (flash-decoding style)
     const int split = bx % n_splits;
-    const int item_block = bx / n_splits;
+    // causal chunks: the LAST query blocks see the most tokens -- they go first (launch order = dispatch order), the light ones fill the tail
+    const int item_block = is_causal ? ((int)gridDim.x / n_splits - 1 - bx / n_splits) : bx / n_splits;
     const int item = item_block * NW + wave;
     const bool wave_live = item < items;
     const int hq = wave_live ? item % rep : 0;
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(64 * NW, (QR == 1 && NW == 4) ? 2 : 1) void paged_f
         int pg[CPT];        // the page each chunk's token lives on (-1: none); ONEPAGE: pg[0] for all
         bool full;          // ONEPAGE: every row of the stage is a live token (no zeroing at the store)
     };
-    Stg sa, sb;
+    Stg sa;
     // page ids travel one stage ahead of the K/V rows they address: a stage's loads are then ONE global round trip behind
     // the MFMAs of the previous stage instead of two dependent ones (block table, then rows)
     // K and V chunk c = tid + 256 i  ->  (token c / 16, 16-byte chunk c % 16): coalesced rows, b128 stores into the swizzled K tile
@@ -529,8 +530,8 @@ __global__ __launch_bounds__(64 * NW, (QR == 1 && NW == 4) ? 2 : 1) void paged_f
     // transposed with 16 ds_write_b32 per thread and stage).
     int pid_reg[CPT];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) sa.ok[i] = sb.ok[i] = false;
-    sa.full = sb.full = false;
+    for (int i = 0; i < CPT; ++i) sa.ok[i] = false;
+    sa.full = false;
     // page_shift = log2(page_size), or -1 (integer division, ~30 VALU ops each, 16 of them per stage and thread)
     auto logical_page = [&](int tok) { return page_shift >= 0 ? (tok >> page_shift) : tok / page_size; };
     // The id is NOT touched here (no "in ? id : -1"): any use of the loaded word right behind the load makes the compiler wait
@@ -646,77 +647,93 @@ __global__ __launch_bounds__(64 * NW, (QR == 1 && NW == 4) ? 2 : 1) void paged_f
         const uint16_t *ksb = ks + buf * FA_KS_ELEMS;
         const uint16_t *vtrb = vtr + buf * FA_VS_ELEMS;
         const int *tpb = tile_page + tp * FA_BK;
+        static_assert(FA_SUB == 2, "a stage is two 32-token sub-tiles");
+        const int tile0 = stage * FA_SUB;
+        if (tile0 >= my_tiles) return;          // wave-uniform: this wave's rows see nothing in this stage
+        const bool two = tile0 + 1 < my_tiles;  // ... or only its first 32 tokens (the causal diagonal)
+
+        // S^T = K Q^T for BOTH sub-tiles first (round 6): 16 independent-of-the-softmax MFMAs in a row, then ONE softmax update per 64
+        // tokens -- one running-maximum step, one rescale of the output tile, two cross-half exchanges instead of four -- then the 16 MFMAs
+        // of the second product.  (Until then: product, softmax, product per 32 tokens.)  A K fragment feeds the MFMA of every row block.
+        f32x16 sacc[FA_SUB][QR];
 #pragma unroll
         for (int sub = 0; sub < FA_SUB; ++sub) {
-        const int tile = stage * FA_SUB + sub;
-        if (tile >= my_tiles) continue;  // wave-uniform: this wave's rows see nothing here
-        const int tb = sub * 32;         // token offset of the sub-tile inside the stage
-
-        // S^T = K Q^T: a K fragment read from LDS feeds the MFMA of every row block of the wave
-        f32x16 sacc[QR];
 #pragma unroll
-        for (int rb = 0; rb < QR; ++rb)
+            for (int rb = 0; rb < QR; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[rb][r] = 0.f;
+                for (int r = 0; r < 16; ++r) sacc[sub][rb][r] = 0.f;
+            if (sub == 1 && !two) continue;
+            const int tb = sub * 32;  // token offset of the sub-tile inside the stage
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int ch = (2 * s + h) ^ (l32 & 15);
-            const u32x4 kf = *reinterpret_cast<const u32x4 *>(&ksb[(tb + l32) * D + ch * 8]);
+            for (int s = 0; s < 8; ++s) {
+                const int ch = (2 * s + h) ^ (l32 & 15);
+                const u32x4 kf = *reinterpret_cast<const u32x4 *>(&ksb[(tb + l32) * D + ch * 8]);
 #pragma unroll
-            for (int rb = 0; rb < QR; ++rb) {
-                if constexpr (FA_ABL & 4) sacc[rb][s] += __uint_as_float((kf[0] ^ qf[rb][s][1]) & 0x3f800000u);
-                else
-                sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
-                                                                   __builtin_bit_cast(bf16x8_t, qf[rb][s]), sacc[rb], 0, 0, 0);
+                for (int rb = 0; rb < QR; ++rb) {
+                    if constexpr (FA_ABL & 4) sacc[sub][rb][s] += __uint_as_float((kf[0] ^ qf[rb][s][1]) & 0x3f800000u);
+                    else
+                    sacc[sub][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                                             __builtin_bit_cast(bf16x8_t, qf[rb][s]), sacc[sub][rb], 0, 0, 0);
+                }
             }
         }
-        u32x4 pf[QR][2];
+        u32x4 pf[FA_SUB][QR][2];
 #pragma unroll
         for (int rb = 0; rb < QR; ++rb) {
-        // mask + scale ; lane holds tokens (r&3)+8(r>>2)+4h of query row qrow[rb].
-        // Interior tiles (wave-uniform test: every token is inside the context, on one live page, and at or below the causal
-        // diagonal of the row block's FIRST query row) need no per-element test: most tiles of a long context are interior.
+        // mask + scale ; lane holds tokens (r&3)+8(r>>2)+4h of each sub-tile for query row qrow[rb].
+        // Interior stages (wave-uniform test: every token is inside the context, on a live page, and at or below the causal diagonal of
+        // the row block's FIRST query row) need no per-element test: most stages of a long context are interior.
         float tmax = -INFINITY;
-        const bool interior = page_shift >= 5 && tile * 32 + 31 < ctx && tpb[tb] >= 0 &&
-                              (!is_causal || tile * 32 + 31 <= (qb * QR + rb) * 32 + (ctx - L));
-        if (interior) {  // raw scores here; the scale goes into the exponent's FMA below (16 multiplies fewer per tile)
+        const int last_tok = tile0 * 32 + FA_BK - 1;
+        const bool interior = two && page_shift >= 5 && last_tok < ctx && tpb[0] >= 0 && tpb[32] >= 0 &&
+                              (!is_causal || last_tok <= (qb * QR + rb) * 32 + (ctx - L));
+        if (interior) {  // raw scores here; the scale goes into the exponent's FMA below
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[rb][r]);
+            for (int sub = 0; sub < FA_SUB; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[sub][rb][r]);
             tmax *= scale_log2;  // scale > 0: max and scaling commute
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tok = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                bool valid = q_valid[rb] && tok < ctx && tpb[tb + (r & 3) + 8 * (r >> 2) + 4 * h] >= 0;
-                if (is_causal) valid = valid && tok <= qrow[rb] + (ctx - L);
-                sacc[rb][r] = valid ? sacc[rb][r] * scale_log2 : -INFINITY;
-                tmax = fmaxf(tmax, sacc[rb][r]);
-            }
+            for (int sub = 0; sub < FA_SUB; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int in_stage = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int tok = tile0 * 32 + in_stage;
+                    bool valid = (sub == 0 || two) && q_valid[rb] && tok < ctx && tpb[in_stage] >= 0;
+                    if (is_causal) valid = valid && tok <= qrow[rb] + (ctx - L);
+                    sacc[sub][rb][r] = valid ? sacc[sub][rb][r] * scale_log2 : -INFINITY;
+                    tmax = fmaxf(tmax, sacc[sub][rb][r]);
+                }
         }
         if constexpr (FA_ABL & 1) {
-            run_sum[rb] += sacc[rb][0];
+            run_sum[rb] += sacc[0][rb][0] + sacc[1][rb][0];
         } else {
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = fmaxf(tmax, lane_xor32(tmax, lane));  // v_permlane32_swap: one VALU instruction (a ds_bpermute is a trip through the LDS crossbar)
         const float new_max = fmaxf(run_max[rb], tmax);
         float prev_scale, tsum = 0.f;
-        if (interior) {  // every score is finite: exp2f(-inf) of the first tile's running maximum is the wanted 0
+        if (interior) {  // every score is finite: exp2f(-inf) of the first stage's running maximum is the wanted 0
             prev_scale = exp2_hw(run_max[rb] - new_max);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sacc[rb][r] = exp2_hw(fmaf(sacc[rb][r], scale_log2, -new_max));
-                tsum += sacc[rb][r];
-            }
+            for (int sub = 0; sub < FA_SUB; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[sub][rb][r] = exp2_hw(fmaf(sacc[sub][rb][r], scale_log2, -new_max));
+                    tsum += sacc[sub][rb][r];
+                }
         } else {
             const bool finite_row = q_valid[rb] && new_max != -INFINITY;
             prev_scale = (run_max[rb] == -INFINITY || !finite_row) ? 0.f : exp2_hw(run_max[rb] - new_max);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = (sacc[rb][r] == -INFINITY || !finite_row) ? 0.f : exp2_hw(sacc[rb][r] - new_max);
-                sacc[rb][r] = p;
-                tsum += p;
-            }
+            for (int sub = 0; sub < FA_SUB; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = (sacc[sub][rb][r] == -INFINITY || !finite_row) ? 0.f : exp2_hw(sacc[sub][rb][r] - new_max);
+                    sacc[sub][rb][r] = p;
+                    tsum += p;
+                }
         }
-        tsum += __shfl_xor(tsum, 32, 64);
+        tsum += lane_xor32(tsum, lane);
         run_max[rb] = new_max;
         run_sum[rb] = prev_scale * run_sum[rb] + tsum;
         if (!__all(prev_scale == 1.0f)) {  // once the running maxima have settled the rescale is the identity for the whole wave
@@ -727,35 +744,42 @@ __global__ __launch_bounds__(64 * NW, (QR == 1 && NW == 4) ? 2 : 1) void paged_f
         }
         }  // FA_ABL & 1
 
-        // P^T fragments (B operand), step s uses regs 8s..8s+7
+        // P^T fragments (B operand), step s uses regs 8s..8s+7; rounded to bf16 before the product like the reference
+        // (paged_attention.metal:439-444)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int sub = 0; sub < FA_SUB; ++sub)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pf[rb][s][e] = BF16::pack2(sacc[rb][8 * s + 2 * e], sacc[rb][8 * s + 2 * e + 1]);
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf[sub][rb][s][e] = BF16::pack2(sacc[sub][rb][8 * s + 2 * e], sacc[sub][rb][8 * s + 2 * e + 1]);
         }  // row block
 
         // O^T += V^T P^T: a V fragment (gathered transposed from the row-major tile) feeds every row block
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
+        for (int sub = 0; sub < FA_SUB; ++sub) {
+            if (sub == 1 && !two) continue;  // (its weights are all zero)
+            const int tb = sub * 32;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                // A fragment of V^T: lane (dim db*32 + l32, half h) needs tokens tb + 16 s + 4 h + {0..3} and + 8 + {0..3} of its dim.
-                // ds_read_b64_tr_b16: in a 16-lane group lane c hands in the address of [row c >> 2][4 dims from 4 (c & 3)] of a
-                // [4 tokens][16 dims] block and receives the block's column c (tools/lab/tr_probe.hip) -- V stays row-major.
-                const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16 *)(vtrb + (tb + 16 * s) * FA_VROW + db * 32));
-                const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16 *)(vtrb + (tb + 16 * s + 8) * FA_VROW + db * 32));
-                const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
-                const u32x4 vf = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+            for (int db = 0; db < 4; ++db) {
 #pragma unroll
-                for (int rb = 0; rb < QR; ++rb) {
-                    if constexpr (FA_ABL & 2) o[rb][db][s] += __uint_as_float((vf[0] ^ pf[rb][s][1]) & 0x3f800000u);
-                    else
-                    o[rb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
-                                                                        __builtin_bit_cast(bf16x8_t, pf[rb][s]), o[rb][db], 0, 0, 0);
+                for (int s = 0; s < 2; ++s) {
+                    // A fragment of V^T: lane (dim db*32 + l32, half h) needs tokens tb + 16 s + 4 h + {0..3} and + 8 + {0..3} of its dim.
+                    // ds_read_b64_tr_b16: in a 16-lane group lane c hands in the address of [row c >> 2][4 dims from 4 (c & 3)] of a
+                    // [4 tokens][16 dims] block and receives the block's column c (tools/lab/tr_probe.hip) -- V stays row-major.
+                    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16 *)(vtrb + (tb + 16 * s) * FA_VROW + db * 32));
+                    const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16 *)(vtrb + (tb + 16 * s + 8) * FA_VROW + db * 32));
+                    const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+                    const u32x4 vf = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+#pragma unroll
+                    for (int rb = 0; rb < QR; ++rb) {
+                        if constexpr (FA_ABL & 2) o[rb][db][s] += __uint_as_float((vf[0] ^ pf[sub][rb][s][1]) & 0x3f800000u);
+                        else
+                        o[rb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
+                                                                            __builtin_bit_cast(bf16x8_t, pf[sub][rb][s]), o[rb][db], 0, 0, 0);
+                    }
                 }
             }
         }
-        }  // sub-tile
     };
 
     if constexpr (!PIPE) {
@@ -791,19 +815,16 @@ __global__ __launch_bounds__(64 * NW, (QR == 1 && NW == 4) ? 2 : 1) void paged_f
         stage_load(stage_begin, sa, page_live(stage_begin, pg0));
         stage_store(sa, 0, 0);
         stage_load(min(stage_begin + 1, last), sa, page_live(min(stage_begin + 1, last), pg1));
-        // iteration of stage s (r = s - stage_begin): `next` holds the rows of s + 1 (requested one iteration ago), `free` takes those of s + 2
-        auto iter = [&](int stage, int r, Stg &next, Stg &free) {
+        // iteration of stage s (r = s - stage_begin): the registers hold the rows of s + 1 (requested one iteration ago): they go into the
+        // other tile, the rows of s + 2 are requested into the same registers, stage s is computed
+        for (int stage = stage_begin, r = 0; stage < stage_end; ++stage, ++r) {
             __syncthreads();  // stage s is in tile r & 1; everyone is done reading the other tile
+            if (stage + 1 < stage_end && !(FA_ABL & 8)) stage_store(sa, (r + 1) & 1, (r + 1) & 1);
             const int s2 = min(stage + 2, last);
-            if (!(FA_ABL & 16)) stage_load(s2, free, page_live(s2, pg_n));
+            if (!(FA_ABL & 16)) stage_load(s2, sa, page_live(s2, pg_n));
             fa_sload_i32(page_slot(min(stage + 3, last)), pg_n);  // waited for at the end of this iteration
             compute_stage(stage, r & 1, r & 1);
-            if (stage + 1 < stage_end && !(FA_ABL & 8)) stage_store(next, (r + 1) & 1, (r + 1) & 1);
             fa_sload_wait(pg_n);
-        };
-        for (int stage = stage_begin, r = 0; stage < stage_end; stage += 2, r += 2) {
-            iter(stage, r, sa, sb);
-            if (stage + 1 < stage_end) iter(stage + 1, r + 1, sb, sa);
         }
     }
 
@@ -981,8 +1002,8 @@ static int paged_attention_impl(const void *q, const void *key_pages, const void
         int page_shift = -1;
         for (int sh = 0; sh < 30; ++sh)
             if ((1 << sh) == page_size) page_shift = sh;
-        // 8 waves sharing a double-buffered tile (one workgroup per CU): whole groups of 8 (head, query block) items, pages of 64+ tokens
-        const bool w8 = g_fa_waves == 8 && page_shift >= 6 && L >= 64 && rep * 2 <= 8 && 8 % rep == 0;
+        // 8 waves sharing a double-buffered tile (one workgroup per CU): 8 consecutive (head, query block) items, pages of 64+ tokens
+        const bool w8 = g_fa_waves == 8 && page_shift >= 6 && L >= 64;
         const int nw = w8 ? 8 : 4;
         const int item_blocks = (items + nw - 1) / nw;
         const int max_ctx_fa = max_context_hint > 0 ? max_context_hint : max_pages * page_size;
