@@ -22,6 +22,8 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=5)
     ap.add_argument("--prefill-step", type=int, default=128)
     ap.add_argument("--max-seq-len", type=int, default=512)
+    ap.add_argument("--kv-format", default="bf16", choices=["bf16", "fp8"],
+                    help="K / V pages as bfloat16 (the reference's cache) or FP8 E4M3 codes + power-of-two row scales (extension)")
     ap.add_argument("--enable-thinking", action="store_true")
     ap.add_argument("--raw-prompts", action="store_true", help="do not wrap the prompts in the chat template")
     ap.add_argument("--prompts-file", default=None, help="one prompt per line (default: five built-in questions)")
@@ -43,7 +45,7 @@ def main(argv=None):
         limits.append(args.max_seq_len - len(ids))
     pages_per_seq = args.max_seq_len // 128 + 2
     engine = DecodeEngine(model, page_size=128, num_pages=pages_per_seq * (args.batch_size + 1) + 2,
-                          max_batch=args.batch_size + 1, max_prefill_rows=args.prefill_step)
+                          max_batch=args.batch_size + 1, max_prefill_rows=args.prefill_step, kv_format=args.kv_format)
     try:
         done = batch_generate_ids(engine, encoded, limits, batch_size=args.batch_size, prefill_step=args.prefill_step,
                                   eos_token_id=tokenizer.eos_token_id)

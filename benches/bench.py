@@ -91,6 +91,8 @@ def parse_args(argv=None) -> argparse.Namespace:
                     help="do not move live requests into the decode slots finished requests left (benches/serving.py _close_holes): the step then "
                          "decodes the prefix up to the highest live slot, as before round 5")
     ap.add_argument("--page-size", type=int, default=128)
+    ap.add_argument("--kv-format", default="bf16", choices=["bf16", "fp8"],
+                    help="--solution engine: K / V pages as bfloat16 (the reference's cache) or FP8 E4M3 codes + power-of-two row scales (extension; no reference behaviour)")
     ap.add_argument("--json-output", type=Path)
     args = ap.parse_args(argv)
     if args.num_seqs <= 0 or args.batch_size <= 0 or args.prefill_step <= 0:
@@ -175,9 +177,11 @@ def main(argv=None) -> None:
         pages_per_seq = (longest + args.page_size - 1) // args.page_size + 1
         engine = DecodeEngine(mlx_model, page_size=args.page_size, num_pages=pages_per_seq * slots + 2, max_batch=slots,
                               max_pages_per_seq=pages_per_seq,
-                              max_prefill_rows=max(args.prefill_step, (args.prefill_budget or 0) if args.staging_slots > 1 else 0, 8))
+                              max_prefill_rows=max(args.prefill_step, (args.prefill_budget or 0) if args.staging_slots > 1 else 0, 8),
+                              kv_format=args.kv_format)
 
-        kv_page_bytes = 2 * cfg["num_hidden_layers"] * cfg["num_key_value_heads"] * args.page_size * cfg["head_dim"] * 2
+        kv_row_bytes = cfg["head_dim"] * 2 if args.kv_format == "bf16" else cfg["head_dim"] + 4
+        kv_page_bytes = 2 * cfg["num_hidden_layers"] * cfg["num_key_value_heads"] * args.page_size * kv_row_bytes
 
         def run_all(reqs):
             nonlocal metrics

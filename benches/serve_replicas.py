@@ -145,6 +145,8 @@ def parse_args(argv=None) -> argparse.Namespace:
                     help="do not move live requests into the decode slots finished requests left (benches/serving.py _close_holes): the step then "
                          "decodes the prefix up to the highest live slot, as before round 5")
     ap.add_argument("--page-size", type=int, default=128)
+    ap.add_argument("--kv-format", default="bf16", choices=["bf16", "fp8"],
+                    help="K / V pages as bfloat16 (the reference's cache) or FP8 E4M3 codes + power-of-two row scales (extension; no reference behaviour)")
     ap.add_argument("--warmup-requests", type=int, default=None, help="requests of an untimed warm-up pass (default: batch size)")
     ap.add_argument("--json-output", type=Path)
     ap.add_argument("--gpus", type=int, default=None,
@@ -207,7 +209,8 @@ def main(argv=None) -> dict | None:
         model = synthetic_qwen3(cfg, seed=args.seed, sigma=0.02, device=f"cuda:{local_rank}")
         engine = DecodeEngine(model, page_size=args.page_size, num_pages=pages_per_seq * slots + 2, max_batch=slots,
                               max_pages_per_seq=pages_per_seq,
-                              max_prefill_rows=max(args.prefill_step, args.prefill_budget if args.staging_slots > 1 else 0, 8))
+                              max_prefill_rows=max(args.prefill_step, args.prefill_budget if args.staging_slots > 1 else 0, 8),
+                              kv_format=args.kv_format)
     else:
         engine = ScheduleOnlyEngine(slots)
         clock = engine.clock
