@@ -117,7 +117,7 @@ def driver_line(args, out: dict, world: int) -> dict:
         "slowest_over_fastest_wall": round(out["slowest_over_fastest_wall"], 4),
         "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                      "bytes_per_decode_step": int(out["decode_bytes_per_step"]),
-                     "bytes_rule": "W + 147,456 B x sum of live contexts per step (SURVEY.md section 8d)",
+                     "bytes_rule": "W + 147,456 B x sum of live contexts per step (SURVEY.md section 8d); with --kv-format fp8: 76,032 B (128 codes + a 4-byte scale per row)",
                      "achieved_per_gpu": [round(g, 1) for g in gbps],
                      "achieved": round(sum(gbps) / len(gbps), 1) if gbps else None,
                      "frac": round(sum(gbps) / len(gbps) / HBM_PEAK_GBPS, 4) if gbps else None,
