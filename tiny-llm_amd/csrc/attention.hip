@@ -1019,7 +1019,10 @@ static int paged_attention_impl(const void *q, const void *key_pages, const void
                            value_scales)
 #define FA_LAUNCH8(K8)                                                                                                           \
         do {                                                                                                                         \
-            static bool attr_set = false;                                                                                            \
+            static bool attr_set_dev[64] = {};  /* per HIP device: a function attribute belongs to the device's code object */      \
+            int dev_ = 0;                                                                                                            \
+            (void)hipGetDevice(&dev_);                                                                                               \
+            bool &attr_set = attr_set_dev[dev_ & 63];                                                                                \
             if (!attr_set) {                                                                                                         \
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(&paged_fa_bf16_d128_kernel<true, 1, K8, 8>),                  \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)fa_pipe_lds_bytes()) != hipSuccess)         \
