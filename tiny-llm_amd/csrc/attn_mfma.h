@@ -73,7 +73,11 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
     sload_i32(brow, first_page);
     sload_i32(brow + min(page_of(wave_base(0)), p.max_pages - 1), pg_cur);
     sload_i32(brow + min(page_of(wave_base(min(1, n_it - 1))), p.max_pages - 1), pg_nxt);
-    RawRow<VD> kraw_new, vraw_new, qraw[RQ], qw, kw;
+    // the prologue's query rows are shared out over the waves (round 6): wave w norms and rotates query head w of the group (and the new K row, which
+    // every wave needs for its head's score against the token being decoded).  Until then every wave did all RQ heads and three waves' results were
+    // dropped: 720 VALU instructions per wave in front of a walk of 170 per stage -- with two workgroups per CU the prologue WAS the launch at short contexts.
+    static_assert(RQ == 4, "one query head of the GQA group per wave");
+    RawRow<VD> kraw_new, vraw_new, qraw_w, qw, kw;
     if constexpr (!QP) {
         load_raw_act<VD>(row + (long)(Hq + kvh) * D + t * VD, kraw_new);
         load_raw_act<VD>(row + (long)(Hq + Hkv + kvh) * D + t * VD, vraw_new);
@@ -102,11 +106,8 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
                 qp_x[j][s] = *reinterpret_cast<const f32x4 *>(src + (long)min(s, p.qkv_slices - 1) * p.qkv_plane);
         }
     } else {
-#pragma unroll
-        for (int r = 0; r < RQ; ++r) {
-            const int hq = min(chunk * RQ + r, rep - 1);
-            load_raw_act<VD>(row + (long)(kvh * rep + hq) * D + t * VD, qraw[r]);
-        }
+        const int hq = min(chunk * RQ + w, rep - 1);
+        load_raw_act<VD>(row + (long)(kvh * rep + hq) * D + t * VD, qraw_w);
     }
     float cs[VD], sn[VD];
     rope_from_table<VD>(p.rope_cur + (long)b * (D / 2), t, cs, sn);
@@ -186,8 +187,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
         __syncthreads();
         load_raw<VD>(qs + 0 * D + t * VD, kraw_new);
         load_raw<VD>(qs + 1 * D + t * VD, vraw_new);
-#pragma unroll
-        for (int r = 0; r < RQ; ++r) load_raw<VD>(qs + (2 + r) * D + t * VD, qraw[r]);
+        load_raw<VD>(qs + (2 + w) * D + t * VD, qraw_w);
     }
 
     // ---- prologue math while the K/V rows are in flight ---------------------------------------------------------------
@@ -229,16 +229,16 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnDecodeA
     }
     uint16_t *qrows = reinterpret_cast<uint16_t *>(lds + AM_OFF_Q);
     const bool with_new = split == 0 && live;
-#pragma unroll
-    for (int r = 0; r < RQ; ++r) {
+    {
+        const int r = w;  // this wave's query head
         float qn[VD];
-        norm_rope(qraw[r], qw, qn);
+        norm_rope(qraw_w, qw, qn);
         // merge slot 0: the token being decoded (position ctx), straight from registers: (m, l, acc) = (score, 1, v)
         float part = 0.f;
 #pragma unroll
         for (int i = 0; i < VD; ++i) part += (qn[i] * scale_log2) * k_new[i];
         const float score = group16_allsum(part);
-        if (g16 == 0) {
+        if ((threadIdx.x & 63) < 16) {  // the wave's first 16-lane group holds the row like every other: it writes
             store_row<VD>(qrows + r * D + t * VD, qn);  // (bf16 values: exact)
             float *dst = psm + (long)r * STRIDE;
 #pragma unroll
