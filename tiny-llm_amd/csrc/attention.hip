@@ -1109,10 +1109,10 @@ extern "C" int tl_paged_attention(const void *q, const void *key_pages, const vo
 // ---- FP8 (E4M3) KV pages: the quantised twins of paged_cache_update / paged_attention (kv8.h, include/tinyllm_hip.h) ----------------
 extern "C" int tl_kv_fp8_quantize_rows(const void *values, void *codes, float *scales, long rows, int head_dim, void *stream) {
     TL_REQUIRE(values && codes && scales, "kv_fp8_quantize_rows: null pointer");
-    TL_REQUIRE(head_dim == 128 && rows >= 0, "kv_fp8_quantize_rows: rows of 128 bfloat16 values");
+    TL_REQUIRE(head_dim == 128 && rows >= 0 && rows < (1L << 30), "kv_fp8_quantize_rows: fewer than 2^30 rows of 128 bfloat16 values");
     if (rows == 0) return TL_OK;
     hipLaunchKernelGGL(kv8_quantize_rows_kernel, dim3(ceil_div(rows, 16)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)values,
-                       (uint8_t *)codes, scales, rows, (int)std::min<long>(rows, 1 << 30), (int)std::min<long>(rows, 1 << 30), 0L, 0);
+                       (uint8_t *)codes, scales, rows, (int)rows, (int)rows, 0L, 0);
     TL_CHECK_LAUNCH("kv_fp8_quantize_rows");
     return TL_OK;
 }
