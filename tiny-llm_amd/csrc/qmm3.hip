@@ -1,4 +1,6 @@
 // Launchers of the skinny batched-decode matmul (qmm3.h) and its slice-reduction / epilogue kernel.
+#include <type_traits>
+
 #include "qmm3.h"
 #include "qmm6.h"
 
@@ -32,25 +34,33 @@ __global__ __launch_bounds__(256) void qmm3_reduce_kernel(const float *__restric
             rv = *reinterpret_cast<const uint2 *>(residual + in0);
             if (out_w) nv = *reinterpret_cast<const uint2 *>(norm_out + (size_t)q * 4);  // uniform
         }
-        for (int s0 = 0; s0 < slices; s0 += 8) {
-            f32x4 x[8][IN_PER / 4];
+        // B planes in flight per round trip: 8, or -- 9 to 16 planes (w_down: 10) -- all of them at once (round 6: the second, dependent batch of two
+        // planes cost the launch ~1.5 us); the planes are added in index order either way
+        auto add_planes = [&](auto bc) __attribute__((always_inline)) {
+            constexpr int B = decltype(bc)::value;
+            for (int s0 = 0; s0 < slices; s0 += B) {
+                f32x4 x[B][IN_PER / 4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const size_t sidx = (size_t)min(s0 + j, slices - 1);
-#pragma unroll
-                for (int v = 0; v < IN_PER / 4; ++v)
-                    x[j][v] = *reinterpret_cast<const f32x4 *>(partial + sidx * slice_stride + in0 + 4 * v);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (s0 + j < slices) {  // uniform; no load inside
+                for (int j = 0; j < B; ++j) {
+                    const size_t sidx = (size_t)min(s0 + j, slices - 1);
 #pragma unroll
                     for (int v = 0; v < IN_PER / 4; ++v)
+                        x[j][v] = *reinterpret_cast<const f32x4 *>(partial + sidx * slice_stride + in0 + 4 * v);
+                }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[4 * v + e] += x[j][v][e];
+                for (int j = 0; j < B; ++j) {
+                    if (s0 + j < slices) {  // uniform; no load inside
+#pragma unroll
+                        for (int v = 0; v < IN_PER / 4; ++v)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[4 * v + e] += x[j][v][e];
+                    }
                 }
             }
-        }
+        };
+        if (slices <= 8 || slices > 16 || EPI == EPI_SWIGLU) add_planes(std::integral_constant<int, 8>{});  // uniform
+        else if (slices <= 12) add_planes(std::integral_constant<int, 12>{});
+        else add_planes(std::integral_constant<int, 16>{});
         uint16_t o[4];
         if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
