@@ -35,7 +35,8 @@ int dequant_w4_to_bf16(const uint32_t *weight, const uint16_t *scales, const uin
 // whole 64-wide reduction steps; rows and columns are ragged-safe (buffer range checks, masked stores); the byte offsets of a lane stay
 // inside 32 bits
 bool gemm8_applicable(int M, int N, int K) {
-    return M >= 1 && N >= 2 && K >= G8_BK && K % G8_BK == 0 && N % 2 == 0 && (size_t)(M + 256) * K * 2 < (1ull << 31) && (size_t)(N + 256) * K * 2 < (1ull << 31);
+    return M >= 1 && N >= 4 && K >= G8_BK && K % G8_BK == 0 && N % 4 == 0 && (size_t)(M + 256) * K * 2 < (1ull << 31) && (size_t)(N + 256) * K * 2 < (1ull << 31) &&
+           (size_t)M * N * 2 < (1ull << 31);  // (a lane stores four consecutive columns; the output's byte offsets stay inside 31 bits too)
 }
 
 int qmm3_num_cus();  // qmm3.hip

@@ -9,5 +9,5 @@ F="-O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16"
 /opt/rocm/bin/hipcc $F -c $C/qmm3.hip -o /tmp/gemm8_lab_q3.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/gemm8_lab.o /tmp/gemm8_lab_k.o /tmp/gemm8_lab_q3.o -o tools/lab/gemm8_lab
 CMD=""
-for m in ${1:-2048}; do CMD="$CMD tools/lab/gemm8_lab $m;"; done
+for m in ${1:-2048}; do for e in ${3:-0}; do CMD="$CMD echo epi $e; tools/lab/gemm8_lab $m $e;"; done; done
 timeout 1500 /usr/local/graft/bin/gpurun --timeout 600 -- "$CMD" 2>&1 | grep -vE "amdgpu.ids|sending"
