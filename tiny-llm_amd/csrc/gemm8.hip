@@ -35,7 +35,7 @@ int dequant_w4_to_bf16(const uint32_t *weight, const uint16_t *scales, const uin
 // whole 64-wide reduction steps; rows and columns are ragged-safe (buffer range checks, masked stores); the byte offsets of a lane stay
 // inside 32 bits
 bool gemm8_applicable(int M, int N, int K) {
-    return M >= 1 && N >= 4 && K >= G8_BK && K % G8_BK == 0 && N % 4 == 0 && (size_t)(M + 256) * K * 2 < (1ull << 31) && (size_t)(N + 256) * K * 2 < (1ull << 31) &&
+    return M >= 1 && N >= 4 && K >= 2 * G8_BK && K % G8_BK == 0 && N % 4 == 0 && (size_t)(M + 256) * K * 2 < (1ull << 31) && (size_t)(N + 256) * K * 2 < (1ull << 31) &&
            (size_t)M * N * 2 < (1ull << 31);  // (a lane stores four consecutive columns; the output's byte offsets stay inside 31 bits too)
 }
 
@@ -65,7 +65,10 @@ template <typename KernelT>
 static int launch8(KernelT kern, const Gemm8Args &a, const Gemm8Plan &pl, hipStream_t st) {
     const size_t lds = gemm8_lds_bytes(pl.BM, pl.BN);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(pl.tiles), dim3(G8_WAVES * 64), lds, st, a);
+    // one workgroup per CU at most: a workgroup walks tiles b, b + grid, ... with its reduction steps running on across them (gemm8_body.inc)
+    // (slots, not tiles: gemm8_body.inc deals blocks of 4 x 8 tiles to the XCDs; a ragged block's empty slots are skipped inside)
+    const int slots = (((a.M + pl.BM - 1) / pl.BM + 3) / 4 * (((a.N + pl.BN - 1) / pl.BN + 7) / 8) + 7) / 8 * 256;
+    hipLaunchKernelGGL(kern, dim3(std::min(slots, std::max(8, qmm3_num_cus() / 8 * 8))), dim3(G8_WAVES * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <int EPI>

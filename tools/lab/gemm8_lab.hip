@@ -32,7 +32,10 @@ int main(int argc, char **argv) {
     struct Shape { const char *name; int N, K; } shapes[] = {{"qkv", 6144, 2560}, {"o", 2560, 4096}, {"gate_up", 19456, 2560}, {"down", 2560, 9728}, {"square", 8192, 8192}};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     double layer_us = 0, layer_flop = 0;
-    for (auto &sh : shapes) {
+    int n_shapes = 5;
+    if (argc > 4) { shapes[0] = Shape{"custom", atoi(argv[3]), atoi(argv[4])}; n_shapes = 1; }  // gemm8_lab <rows> <epi> <N> <K>
+    for (int si = 0; si < n_shapes; ++si) {
+        auto &sh = shapes[si];
         const int N = sh.N, K = sh.K, Mx = strcmp(sh.name, "square") == 0 ? 8192 : M;
         uint16_t *A, *W, *C;
         CK(hipMalloc(&A, (size_t)Mx * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)Mx * N * 2));

@@ -14,7 +14,8 @@ import time
 
 ROOT = pathlib.Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "tiny-llm_amd"))
-sys.path.insert(0, str(ROOT / "tiny-llm_amd" / "extensions_hip"))
+import os  # noqa: E402
+sys.path.insert(0, os.environ.get("TL_EXT_ROOT") or str(ROOT / "tiny-llm_amd" / "extensions_hip"))  # (an A/B against another build of the library)
 
 
 def main() -> None:
