@@ -33,6 +33,12 @@ struct Gemm8Args {
 };
 
 constexpr int G8_BK = 64, G8_WAVES = 8;
+#ifdef G8_TRACE  // tools/lab/gemm8_lab only: wall-clock stamps of wave 0 of workgroup G8_TRACE behind every step's barrier (and around a tile's epilogue)
+__device__ unsigned long long g8_trace[2048];
+#define G8_STAMP(code) do { if (blockIdx.x == (G8_TRACE) && tid == 0 && g8_n < 2040) { g8_trace[1 + g8_n++] = (wall_clock64() << 8) | (unsigned)(code); g8_trace[0] = g8_n; } } while (0)
+#else
+#define G8_STAMP(code) do { } while (0)
+#endif
 // The tile is a parameter of the kernel body (gemm8_body.inc): WM x WN waves, TM x TN accumulator tiles (16 x 16) per wave -> BM = 16 WM TM
 // rows, BN = 16 WN TN columns.  256 x 256 = (2, 4, 8, 4);  256 x 192 = (2, 4, 8, 3) and 256 x 160 = (4, 2, 4, 5) exist because 2,048- and 4,096-row chunks against 2,560 /
 //   6,144 output columns leave a quarter to a third of the 256 CUs idle on 256 x 256 tiles (gemm8_plan picks by rounds x tile size).
@@ -103,6 +109,9 @@ Gemm8Plan gemm8_plan(int M, int N, int K);
 bool gemm8_applicable(int M, int N, int K);
 int launch_gemm8_bf16(const Gemm8Args &args, int epi, hipStream_t st);  // -1: not applicable, nothing launched
 // W4 (checkpoint layout) -> bf16 [rows, cols]: bf16(q * s + beta) per element, the reference tile GEMM's own rounding (quantized_matmul.metal:142-160)
+#ifdef G8_TRACE
+int gemm8_trace_read(unsigned long long *dst, int n);
+#endif
 int dequant_w4_to_bf16(const uint32_t *weight, const uint16_t *scales, const uint16_t *biases, uint16_t *out, int rows, int cols, hipStream_t st);
 
 }  // namespace tl

@@ -92,4 +92,8 @@ int launch_gemm8_bf16(const Gemm8Args &args, int epi, hipStream_t st) {
     return -1;
 }
 
+#ifdef G8_TRACE
+int gemm8_trace_read(unsigned long long *dst, int n) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g8_trace), (size_t)n * 8) == hipSuccess ? 0 : -1; }
+#endif
+
 }  // namespace tl

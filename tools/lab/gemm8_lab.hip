@@ -81,6 +81,26 @@ int main(int argc, char **argv) {
         { const Gemm8Plan pl = gemm8_plan(Mx, N, K); printf("[%dx%d, %d tiles] ", pl.BM, pl.BN, pl.tiles); }
         printf("%-8s M=%d N=%d K=%d: %8.1f us  %7.1f TFLOP/s   sampled outputs off: %d of %d (max err %.4g at scale %.3g)\n", sh.name, Mx, N, K, us, flop / us / 1e6, bad, ns, worst, scale);
         if (strcmp(sh.name, "square") != 0) layer_us += us, layer_flop += flop;
+#ifdef G8_TRACE  // build gemm8.hip and this file with -DG8_TRACE=<workgroup> (per-step stamps of that workgroup) or -DG8_TRACE=-1 (start / end of every workgroup)
+        {
+            launch_gemm8_bf16(g, EPI_T, 0); CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> tr(2048); gemm8_trace_read(tr.data(), 2048);
+            int rate = 0; CK(hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, 0));
+            if ((G8_TRACE) < 0) {
+                unsigned long long t0 = ~0ull; for (int b = 0; b < 256; ++b) t0 = std::min(t0, tr[2 * b]);
+                printf("   start / end of every workgroup, us since the first start:\n");
+                for (int b = 0; b < 256; ++b) printf("%s%d:%.1f-%.1f", b % 8 ? "  " : "\n   ", b, (double)(tr[2 * b] - t0) * 1000.0 / rate, (double)(tr[2 * b + 1] - t0) * 1000.0 / rate);
+                printf("\n");
+                continue;
+            }
+            const int n = (int)tr[0];
+            printf("   trace of workgroup %d (%d stamps; us since the first; code 2 = behind a step's barrier, 3 / 4 = epilogue begins / ends):\n   ", (int)(G8_TRACE), n);
+            unsigned long long t0 = tr[1] >> 8, prev = t0;
+            for (int i = 0; i < n; ++i) { const unsigned long long t = tr[1 + i] >> 8; const int code = (int)(tr[1 + i] & 0xff);
+                if (code != 2) printf("\n   [%d @%.2f] ", code, (double)(t - t0) * 1000.0 / rate); else printf("%.2f ", (double)(t - prev) * 1000.0 / rate); prev = t; }
+            printf("\n");
+        }
+#endif
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(dr)); CK(hipFree(dc)); CK(hipFree(dref));
     }
     printf("layer (qkv + o + gate_up + down) at %d rows: %.1f us  %.1f TFLOP/s\n", M, layer_us, layer_flop / layer_us / 1e6);
