@@ -900,7 +900,9 @@ static int enqueue_step(tl_engine *e, int batch, SplitPlan sp, ProfCtx *pc = nul
             // (profiles/r05_labs/batched_qkv_on_qmm6_ab.log; round 4 had measured -1 ... -2.9 % on a fast box and left 17-64 rows on the sliced
             // matmul, whose slices the attention kernel adds -- that route is now the one behind option "qmm6" = 0 only)
             const bool qkv6 = qmm6_takes(e, w.wqkv, batch);
-            const bool wo6 = wo6_ok && (batch <= 16 || batch > 32 || !sliced_leaves_weighted(w.wo));
+            // wo on the register-resident kernel at EVERY row count (round 6: its planner now deals 16-row blocks to more workgroups where the rows are long --
+            // 17-32 rows 6.9 us against 8.4-9.1 for the sliced matmul + reduction that took them until then, 33-48 rows 10.1 -> 7.1; qmm6.h, qmm6_plan)
+            const bool wo6 = wo6_ok;
             // this layer's hand-over buffers: the shared ones, or -- the AQL route's per-layer mode -- its own (written once per step)
             uint16_t *hb = e->h, *hwb = e->xn, *qkvb = e->qkv, *attnb = e->attn, *actb = e->act, *x_out = e->x, *xw_out = e->xn;
             float *sshb = e->ss_h, *ssx_out = e->ss_x;

@@ -514,18 +514,44 @@ inline Qmm6Plan qmm6_plan(int M, int N, int K, bool frag = false) {
     const int G = N / 128, tiles = K / 16;
     if ((G + QM6_WAVES - 1) / QM6_WAVES > 19) return pl;
     pl.GPW = qmm6_round_gpw((G + QM6_WAVES - 1) / QM6_WAVES);
-    // the largest row block whose fragments fit the registers; the rows beyond it go to further workgroups over the same tiles
+    // Row blocks per workgroup (MB = 1, 2 or 4 blocks of 16 rows; the rows beyond go to further workgroups over the same tiles).  Until round 6: the largest
+    // block whose fragments fit the registers.  But what a workgroup costs is what its CU pulls -- MB x 16 rows of N columns + its tiles' weights, at ~13.5 ns
+    // per KiB (the L2 -> CU path, profiles/r05_labs) -- plus its walk (a tile: the four waves' meeting and the stores, + MB x GPW x 4 MFMAs on one wave per
+    // SIMD), and long rows against few tiles (wo: 4,096 columns, 160 tiles) are cheaper in MORE, SMALLER workgroups: 64 rows as 4 x 56 workgroups of 16 rows
+    // x 3 tiles pull 227 KiB each where 2 x 80 of 32 rows x 2 tiles pull 326 (lab: 10.3 -> 9.1 us; 33-48 rows, three blocks instead of a padded four: 10.1
+    // -> 7.2).  gate|up / lm_head (many tiles per workgroup) keep the largest block by the same arithmetic.
     const int blocks16 = (M + 15) / 16;
-    pl.MB = blocks16 >= 3 ? 4 : (blocks16 >= 2 ? 2 : 1);
-    while (pl.MB > 1 && !qmm6_has_variant(pl.MB, pl.GPW)) pl.MB /= 2;
-    if (!qmm6_has_variant(pl.MB, pl.GPW)) return pl;
-    pl.row_blocks = (blocks16 + pl.MB - 1) / pl.MB;
     const int ncu = qmm3_num_cus();
-    const int wgs = std::min(tiles, std::max(1, ncu / pl.row_blocks));
-    pl.tiles_per_wg = (tiles + wgs - 1) / wgs;
-    pl.wgs = (tiles + pl.tiles_per_wg - 1) / pl.tiles_per_wg;
-    // the workgroups of one tile range sit a multiple of 8 apart in the launch order: one XCD, one L2 for the weights they share
-    if (pl.row_blocks > 1) pl.wgs = (pl.wgs + 7) / 8 * 8;
+    auto shape_for = [&](int mb, Qmm6Plan &q) {
+        q.MB = mb;
+        q.row_blocks = (blocks16 + mb - 1) / mb;
+        const int wgs = std::min(tiles, std::max(1, ncu / q.row_blocks));
+        q.tiles_per_wg = (tiles + wgs - 1) / wgs;
+        q.wgs = (tiles + q.tiles_per_wg - 1) / q.tiles_per_wg;
+        // the workgroups of one tile range sit a multiple of 8 apart in the launch order: one XCD, one L2 for the weights they share
+        if (q.row_blocks > 1) q.wgs = (q.wgs + 7) / 8 * 8;
+    };
+    const int mb_max = blocks16 >= 3 ? 4 : (blocks16 >= 2 ? 2 : 1);
+    double best = 0.0;
+    bool found = false;
+    for (int mb = mb_max; mb >= 1; mb /= 2) {
+        if (!qmm6_has_variant(mb, pl.GPW) || qmm6_lds_bytes(mb, pl.GPW, frag) > 150 * 1024) continue;
+        Qmm6Plan q = pl;
+        shape_for(mb, q);
+        // (the arithmetic below decides for LONG rows against FEW tiles only -- 8 groups per wave and more, at most two tiles per workgroup on the largest
+        // block: wo.  A projection whose workgroups walk more tiles keeps the largest block; so does qkv: the row-streaming kernel (qmm7.h) is its twin
+        // bit for bit, and the order in which a group's four k-steps are added follows the row-block count -- CH below)
+        if (found && (pl.tiles_per_wg > 2 || pl.GPW < 8)) break;
+        if ((long)q.wgs * q.row_blocks > ncu + 7) continue;  // one workgroup per CU
+        const double kib = (double)std::min(mb * 16, M) * N * 2 / 1024.0 + (double)q.tiles_per_wg * G;
+        // (plain rows come through each wave's 8-slot transposer ring: a second and third pass of the ring -- MB x GPW units -- is a dependent round trip each)
+        const double us = 0.0135 * kib + q.tiles_per_wg * (0.35 + 0.03 * mb * pl.GPW) + 1.3 * ((mb * pl.GPW - 1) / QM6_RING);
+#ifdef QMM6_PLAN_LARGEST_BLOCK  // tools/lab only: the rule of rounds 4-5
+        if (found) continue;
+#endif
+        if (!found || us < best - 1e-9) pl.MB = q.MB, pl.row_blocks = q.row_blocks, pl.tiles_per_wg = q.tiles_per_wg, pl.wgs = q.wgs, best = us, found = true;
+    }
+    if (!found) return pl;
     pl.NSETS = qmm6_pick_sets(pl.MB, pl.GPW, pl.tiles_per_wg);
     pl.lds = qmm6_lds_bytes(pl.MB, pl.GPW, frag);
     pl.ok = pl.lds <= 150 * 1024;
