@@ -553,6 +553,9 @@ inline Qmm3Plan qmm3_plan(int M, int N, int K, int mode = -1) {
     if (mode < 0) mode = qmm3_default_mode();
     if (mode < 0) mode = qmm3_prefers_persistent(pl.MB, G, tiles) ? 1 : 0;
     if (mode == 1) {
+        // 33-48 rows: THREE row blocks on the persistent grid (round 6: a 48-row slice is 96 KiB of LDS instead of 128, 12 MFMAs per k-step pair instead of
+        // 16 -- w_down at 33-48 rows cost what 64 rows cost)
+        if (M > 32 && M <= 48) pl.MB = 3;
         // slices of 8 groups (two units) where the LDS holds them, workgroups shared out in proportion to the groups of a slice
         const int ncu = qmm3_num_cus();
         int nu = qmm3_lds_bytes(pl.MB, 8) <= 150 * 1024 && G > 4 ? 2 : 1;

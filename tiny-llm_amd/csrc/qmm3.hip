@@ -157,7 +157,7 @@ int launch_qmm3_bf16(const Qmm3Args &args, hipStream_t st, int pro, int mode) {
         hipLaunchKernelGGL(kern, pgrid, block, pl.lds, st, args, pl.pgrid);                                          \
         return hipGetLastError() == hipSuccess ? 0 : -1;                                                             \
     }
-        QM3P_CASE(1, 1) QM3P_CASE(1, 2) QM3P_CASE(2, 1) QM3P_CASE(2, 2) QM3P_CASE(4, 1) QM3P_CASE(4, 2)
+        QM3P_CASE(1, 1) QM3P_CASE(1, 2) QM3P_CASE(2, 1) QM3P_CASE(2, 2) QM3P_CASE(3, 1) QM3P_CASE(3, 2) QM3P_CASE(4, 1) QM3P_CASE(4, 2)
 #undef QM3P_CASE
         return -2;
     }
