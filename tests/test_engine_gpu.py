@@ -646,6 +646,28 @@ def test_packed_prefill_of_several_slots(ckpt, err):
         eng.close()
 
 
+NORM_CFG = dict(hidden_size=2560, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=1024,
+                vocab_size=2048, rope_theta=1000000, rms_norm_eps=1e-6, max_position_embeddings=4096, tie_word_embeddings=True)
+
+
+@pytest.mark.parametrize("cfg_name", ["wide", "2304", "2560", "4096"])
+@pytest.mark.parametrize("n_prompt,rows", [(300, 128), (77, 80), (40, 64), (600, 256), (130, 128)])
+def test_prefill_reduce_norm_fusion_is_bit_identical(ckpt, monkeypatch, n_prompt, rows, cfg_name):
+    """The split-K residual reduction that also writes the RMSNorm of the rows it completes (csrc/qmm.hip splitk_reduce_residual_norm_kernel: wo -> post-attention
+    norm, w_down -> the NEXT layer's input norm) against the two launches it replaces (engine option "prefill_reduce_norm" = 0): the same expressions on the same
+    values in the same order, so every logit must be IDENTICAL -- hidden sizes of 2,304 / 2,560 / 4,096 (the range the fusion takes: tl_rms_norm's 256-thread
+    kernel, whose threads 0 .. dim / 8 - 257 add a second chunk), 1,280 (not fused: the control), three layers so that a fused input norm feeds a layer,
+    chunks that leave ragged last passes."""
+    cfg = WIDE_CFG if cfg_name == "wide" else dict(NORM_CFG, hidden_size=int(cfg_name))
+    model = to_mlx_shaped(cfg, O.make_qwen3_weights(cfg, seed=5, sigma=0.03))
+    prompt = [int(t) for t in np.random.default_rng(n_prompt).integers(1, cfg["vocab_size"], size=n_prompt)]
+    monkeypatch.setenv("TL_ENGINE_OPTIONS", "prefill_reduce_norm=0")
+    separate = _prefill_logits(model, prompt, rows)
+    monkeypatch.setenv("TL_ENGINE_OPTIONS", "prefill_reduce_norm=1")
+    fused = _prefill_logits(model, prompt, rows)
+    assert np.array_equal(separate, fused), f"{int((separate != fused).sum())} logits differ, max {np.abs(separate - fused).max()}"
+
+
 @pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("n_prompt,rows", [(300, 512), (77, 80), (40, 64), (600, 256)])
 def test_prefill_gemm_fused_epilogue_is_bit_identical(ckpt, monkeypatch, n_prompt, rows, wide):

@@ -79,6 +79,7 @@ struct tl_engine {
     std::map<const uint32_t *, uint16_t *> bf16w;
     size_t bf16w_bytes = 0;
     bool use_gemm8 = true;  // tl_engine_set_option "gemm8" = 0: every chunk through the W4 GEMM (qmm.hip), the twin
+    bool fuse_reduce_norm = true;  // "prefill_reduce_norm" = 0: the split-K residual reduction and the RMSNorm behind it as two launches, the twin
 
     int32_t *block_table = nullptr, *context_lens = nullptr, *tokens = nullptr, *live = nullptr, *produced = nullptr,
             *ring = nullptr, *scratch_ctx = nullptr, *prefill_tokens = nullptr;
@@ -371,8 +372,11 @@ static bool gemm8_wins(int M, int out_features) {
     (void)out_features;
     return M >= GEMM8_MIN_ROWS;
 }
+// norm_w / norm_out / norm_done: the RMSNorm that follows an EPI_RESIDUAL projection, taken along by its split-K reduction pass where there is one
+// (small chunks on the W4 GEMM); *norm_done says whether norm_out was written -- the caller launches tl_rms_norm otherwise
 static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t *out, int M, int epi,
-                       const uint16_t *residual) {
+                       const uint16_t *residual, const void *norm_w = nullptr, uint16_t *norm_out = nullptr, bool *norm_done = nullptr) {
+    if (norm_done) *norm_done = false;
     if (e->use_gemm8 && gemm8_wins(M, w.rows)) {
         const auto wb = e->bf16w.find(w.weight_dev);
         if (wb != e->bf16w.end() && gemm8_applicable(M, w.rows, w.cols)) {
@@ -387,7 +391,8 @@ static int engine_gemm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t
         const size_t need = tl_quantized_matmul_workspace_bytes(M, w.cols, w.rows, TL_BF16, 1, 1);
         TL_TRY(ensure_splitk(e, need));
         TL_TRY(qmm_bf16_epilogue(w.scales_dev, w.biases_dev, a, w.weight_dev, out, M, w.cols, w.rows, epi, residual, e->splitk_ws,
-                                 e->splitk_ws_bytes, e->stream));
+                                 e->splitk_ws_bytes, e->stream, e->fuse_reduce_norm ? (const uint16_t *)norm_w : nullptr, norm_out, e->cfg.rms_norm_eps,
+                                 norm_done));
         TL_CHECK_LAUNCH("engine matmul");
         return TL_OK;
     }
@@ -1609,8 +1614,9 @@ extern "C" int tl_engine_set_option(tl_engine *e, const char *name, int value) {
     else if (n == "lmhead_tile_max") e->lm_tile_max_on = on;
     else if (n == "gemm_fused_epilogue") e->gemm_fused_epilogue = on;
     else if (n == "gemm8") e->use_gemm8 = on;
+    else if (n == "prefill_reduce_norm") e->fuse_reduce_norm = on;
     else if (n == "aql_fences") e->aql_fences.inner_acquire = e->aql_fences.inner_release = on ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
-    else return fail(TL_ERR_INVALID, "engine_set_option: unknown option '" + n + "' (qmm3, qmm6, qmm7, gemm8, attn_qkv_partials, lmhead_tile_max, gemm_fused_epilogue, aql_fences)");
+    else return fail(TL_ERR_INVALID, "engine_set_option: unknown option '" + n + "' (qmm3, qmm6, qmm7, gemm8, prefill_reduce_norm, attn_qkv_partials, lmhead_tile_max, gemm_fused_epilogue, aql_fences)");
     return TL_OK;
 }
 
@@ -1877,9 +1883,11 @@ static int prefill_impl(tl_engine *e, int slot, const int32_t *tokens, int n, in
                                   n, c.hidden_size, c.vocab_size, 128, 4, TL_BF16, e->stream));
     const size_t attn_ws_need = tl_paged_attention_workspace_bytes(Hq, n, D, c.page_size, c.max_pages_per_seq, Hq, Hkv, start + n);
     TL_REQUIRE(attn_ws_need <= e->attn_ws_bytes, "engine_prefill: attention workspace too small");
+    bool x_normed = false;  // the previous layer's w_down reduction left this layer's normalised rows in xn (engine_gemm)
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
-        TL_TRY(tl_rms_norm(e->x, w.input_norm_dev, e->xn, n, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
+        if (!x_normed) TL_TRY(tl_rms_norm(e->x, w.input_norm_dev, e->xn, n, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
+        x_normed = false;
         TL_TRY(engine_gemm(e, w.wqkv, e->xn, e->qkv, n, EPI_STORE, nullptr));
         QkvPostArgs q{};
         q.qkv = e->qkv;
@@ -1904,14 +1912,16 @@ static int prefill_impl(tl_engine *e, int slot, const int32_t *tokens, int n, in
             const long total = (long)Hq * n * (D / 8);
             hipLaunchKernelGGL(heads_to_rows_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, e->stream, e->attn_t, e->attn, Hq, n, D);
         }
-        TL_TRY(engine_gemm(e, w.wo, e->attn, e->h, n, EPI_RESIDUAL, e->x));
-        TL_TRY(tl_rms_norm(e->h, w.post_norm_dev, e->xn, n, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
+        bool h_normed = false;
+        TL_TRY(engine_gemm(e, w.wo, e->attn, e->h, n, EPI_RESIDUAL, e->x, w.post_norm_dev, e->xn, &h_normed));
+        if (!h_normed) TL_TRY(tl_rms_norm(e->h, w.post_norm_dev, e->xn, n, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
         if (e->is_moe(l)) {
             TL_TRY(engine_moe_mlp(e, l, e->xn, e->h, e->x, n, nullptr));
         } else {
             TL_REQUIRE(w.wgu.weight_dev != nullptr, "engine: a layer has neither a dense MLP nor experts (tl_engine_set_moe_layer)");
             TL_TRY(engine_gemm(e, w.wgu, e->xn, e->act, n, EPI_SWIGLU, nullptr));
-            TL_TRY(engine_gemm(e, w.wdown, e->act, e->x, n, EPI_RESIDUAL, e->h));
+            TL_TRY(engine_gemm(e, w.wdown, e->act, e->x, n, EPI_RESIDUAL, e->h, l + 1 < c.num_layers ? e->layers[l + 1].input_norm_dev : nullptr, e->xn,
+                               &x_normed));
         }
         TL_CHECK_LAUNCH("engine prefill layer");
     }
@@ -2006,9 +2016,11 @@ static int prefill_packed_impl(tl_engine *e, int n_seqs, const int *slots, const
     for (int i = 0; i < n_seqs; ++i)
         TL_REQUIRE(tl_paged_attention_workspace_bytes(Hq, lens[i], D, c.page_size, c.max_pages_per_seq, Hq, Hkv, start[i] + lens[i]) <=
                        e->attn_ws_bytes, "engine_prefill_packed: attention workspace too small");
+    bool x_normed = false;  // the previous layer's w_down reduction left this layer's normalised rows in xn (engine_gemm)
     for (int l = 0; l < c.num_layers; ++l) {
         const tl_layer_weights &w = e->layers[l];
-        TL_TRY(tl_rms_norm(e->x, w.input_norm_dev, e->xn, total, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
+        if (!x_normed) TL_TRY(tl_rms_norm(e->x, w.input_norm_dev, e->xn, total, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
+        x_normed = false;
         TL_TRY(engine_gemm(e, w.wqkv, e->xn, e->qkv, total, EPI_STORE, nullptr));
         for (int i = 0; i < n_seqs; ++i) {
             const int n = lens[i];
@@ -2038,14 +2050,16 @@ static int prefill_packed_impl(tl_engine *e, int n_seqs, const int *slots, const
             hipLaunchKernelGGL(heads_to_rows_kernel, dim3(ceil_div(items, 256)), dim3(256), 0, e->stream, attn_t,
                                e->attn + (size_t)row0[i] * Hq * D, Hq, n, D);
         }
-        TL_TRY(engine_gemm(e, w.wo, e->attn, e->h, total, EPI_RESIDUAL, e->x));
-        TL_TRY(tl_rms_norm(e->h, w.post_norm_dev, e->xn, total, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
+        bool h_normed = false;
+        TL_TRY(engine_gemm(e, w.wo, e->attn, e->h, total, EPI_RESIDUAL, e->x, w.post_norm_dev, e->xn, &h_normed));
+        if (!h_normed) TL_TRY(tl_rms_norm(e->h, w.post_norm_dev, e->xn, total, c.hidden_size, c.rms_norm_eps, TL_BF16, e->stream));
         if (e->is_moe(l)) {
             TL_TRY(engine_moe_mlp(e, l, e->xn, e->h, e->x, total, nullptr));
         } else {
             TL_REQUIRE(w.wgu.weight_dev != nullptr, "engine: a layer has neither a dense MLP nor experts (tl_engine_set_moe_layer)");
             TL_TRY(engine_gemm(e, w.wgu, e->xn, e->act, total, EPI_SWIGLU, nullptr));
-            TL_TRY(engine_gemm(e, w.wdown, e->act, e->x, total, EPI_RESIDUAL, e->h));
+            TL_TRY(engine_gemm(e, w.wdown, e->act, e->x, total, EPI_RESIDUAL, e->h, l + 1 < c.num_layers ? e->layers[l + 1].input_norm_dev : nullptr, e->xn,
+                               &x_normed));
         }
         TL_CHECK_LAUNCH("engine packed prefill layer");
     }

@@ -352,6 +352,88 @@ __global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(const uint16_t *
     }
 }
 
+// The residual reduction of a split-K projection AND the RMSNorm of the row it completes, one launch (round 6, late): at small prefill chunks the reduction
+// pass (5 us) was followed by rms_norm_kernel (5 us) re-reading the rows it had just written -- 2 of a layer's 14 launches at a 128-token chunk.  One
+// workgroup per row, one thread per 8-element chunk (dim / 8 threads: 2,049 .. 4,096 features, the range in which tl_rms_norm runs rms_norm_kernel<TT, 256, 8>):
+// the row's elements are formed exactly as splitk_reduce_epi_kernel<EPI_RESIDUAL> forms them (slices added in index order, rounded, + residual, rounded),
+// stored, and kept in registers.  The sum of squares follows rms_norm_kernel's ORDER: its thread u adds the squares of chunk u, then of chunk u + 256, to one
+// accumulator -- so the threads of chunks 256 .. hand their values to thread u through LDS -- then wave_sum and the four wave partials in index order; the
+// normalised row is its expression on the same values.  Both outputs are bit-identical to the two launches.  Slices are requested 16 at a time.
+template <typename TT>
+__global__ __launch_bounds__(512) void splitk_reduce_residual_norm_kernel(const uint16_t *__restrict__ partials, uint16_t *__restrict__ out, size_t elements,
+                                                                          int split_k, const uint16_t *__restrict__ residual,
+                                                                          const uint16_t *__restrict__ norm_w, uint16_t *__restrict__ out_norm, int dim, float eps) {
+    __shared__ float hand[256][8];
+    __shared__ float partial[4];
+    const int t = threadIdx.x;
+    const int chunks = dim >> 3;  // 257 .. 512
+    const bool live = t < chunks;
+    const size_t i = (size_t)blockIdx.x * dim + (size_t)(live ? t : 0) * 8;
+    const u32x4 rv = *reinterpret_cast<const u32x4 *>(residual + i);
+    const u32x4 g = *reinterpret_cast<const u32x4 *>(norm_w + (live ? t : 0) * 8);
+    float sum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+    for (int p0 = 0; p0 < split_k; p0 += 16) {
+        u32x4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const u32x4 *>(partials + (size_t)min(p0 + j, split_k - 1) * elements + i);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (p0 + j < split_k) {  // uniform; no load inside
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sum[2 * e] += TT::to_float((uint16_t)(v[j][e] & 0xffffu));
+                    sum[2 * e + 1] += TT::to_float((uint16_t)(v[j][e] >> 16));
+                }
+            }
+        }
+    }
+    float f[8];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint16_t o0 = TT::from_float(TT::to_float((uint16_t)(rv[e] & 0xffffu)) + TT::to_float(TT::from_float(sum[2 * e])));
+        const uint16_t o1 = TT::from_float(TT::to_float((uint16_t)(rv[e] >> 16)) + TT::to_float(TT::from_float(sum[2 * e + 1])));
+        o[e] = (uint32_t)o0 | ((uint32_t)o1 << 16);
+        f[2 * e] = TT::to_float(o0);
+        f[2 * e + 1] = TT::to_float(o1);
+    }
+    if (live) *reinterpret_cast<u32x4 *>(out + i) = o;
+    if (live && t >= 256) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hand[t - 256][e] = f[e];
+    }
+    __syncthreads();
+    float sum_sq = 0.f;
+    if (t < 256) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum_sq += f[e] * f[e];
+        if (t + 256 < chunks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float h = hand[t][e];
+                sum_sq += h * h;
+            }
+        }
+        sum_sq = wave_sum(sum_sq);
+        if ((t & 63) == 0) partial[t >> 6] = sum_sq;
+    }
+    __syncthreads();
+    sum_sq = partial[0] + partial[1] + partial[2] + partial[3];
+    const float inv = rsqrtf(sum_sq / (float)dim + eps);
+    if (live) {
+        u32x4 n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint16_t o0 = TT::from_float(f[2 * e] * inv * TT::to_float((uint16_t)(g[e] & 0xffffu)));
+            const uint16_t o1 = TT::from_float(f[2 * e + 1] * inv * TT::to_float((uint16_t)(g[e] >> 16)));
+            n[e] = (uint32_t)o0 | ((uint32_t)o1 << 16);
+        }
+        *reinterpret_cast<u32x4 *>(out_norm + i) = n;
+    }
+}
+
 // XCD-aware tile order of qmm_mfma_kernel (round 3 A/B: 731 -> 752 TFLOP/s on a 2,048-row layer; the launch-order switch is gone)
 static int qmm_xcd_remap() { return 1; }
 static int mfma_mt(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : 4); }
@@ -466,7 +548,9 @@ static int run_qmm(const void *scales, const void *biases, const void *a, const 
 // bits) with the residual add or the SwiGLU of the interleaved gate|up rows folded into the kernel's store (unsplit) or into the
 // split-K reduction -- the separate elementwise launch and a round trip of the [M, K] intermediate through HBM are gone.
 int qmm_bf16_epilogue(const void *scales, const void *biases, const uint16_t *A, const uint32_t *b, uint16_t *O, int M, int N, int K,
-                      int epi, const uint16_t *residual, void *workspace, size_t workspace_bytes, hipStream_t st) {
+                      int epi, const uint16_t *residual, void *workspace, size_t workspace_bytes, hipStream_t st, const uint16_t *norm_w,
+                      uint16_t *norm_out, float norm_eps, bool *norm_done) {
+    if (norm_done) *norm_done = false;
     if (M <= 8 || epi == EPI_STORE) return fail(TL_ERR_INVALID, "qmm_bf16_epilogue: for more than 8 rows and a real epilogue");
     if (epi == EPI_RESIDUAL && !residual) return fail(TL_ERR_INVALID, "qmm_bf16_epilogue: residual rows missing");
     if (epi == EPI_SWIGLU && (K % 2) != 0) return fail(TL_ERR_INVALID, "qmm_bf16_epilogue: SwiGLU needs an even number of weight rows");
@@ -490,6 +574,12 @@ int qmm_bf16_epilogue(const void *scales, const void *biases, const uint16_t *A,
         if (elements % 8 != 0 || (((uintptr_t)O | (uintptr_t)dst | (uintptr_t)residual) & 15) != 0)
             return fail(TL_ERR_INVALID, "qmm_bf16_epilogue: rows x features must be a multiple of 8 and the rows 16-byte aligned");
         const dim3 rg(ceil_div(elements / 8, 256));
+        if (epi == EPI_RESIDUAL && norm_w && norm_out && norm_done && K % 8 == 0 && K > 2048 && K <= 4096 && (((uintptr_t)norm_w | (uintptr_t)norm_out) & 15) == 0) {
+            // the row's RMSNorm rides on its reduction (one workgroup per row): the caller skips its rms_norm launch
+            hipLaunchKernelGGL((splitk_reduce_residual_norm_kernel<BF16>), dim3(M), dim3((K / 8 + 63) / 64 * 64), 0, st, dst, O, elements, split, residual, norm_w, norm_out, K, norm_eps);
+            *norm_done = true;
+            return TL_OK;
+        }
         if (epi == EPI_SWIGLU) hipLaunchKernelGGL((splitk_reduce_epi_kernel<BF16, EPI_SWIGLU>), rg, dim3(256), 0, st, dst, O, elements, split, residual);
         else hipLaunchKernelGGL((splitk_reduce_epi_kernel<BF16, EPI_RESIDUAL>), rg, dim3(256), 0, st, dst, O, elements, split, residual);
         return TL_OK;

@@ -414,6 +414,9 @@ int launch_qmv_fused_bf16(const QmvArgs &args, int pro, int epi, hipStream_t st)
 int gather_qmv_bf16(const void *scales, const void *biases, const uint16_t *a, const uint32_t *b, const int32_t *expert_ids,
                     uint16_t *out, int M, int N, int K, int num_experts, int a_rows_div, hipStream_t st);
 // qmm.hip: the prefill W4 GEMM with the engine's epilogue folded in (rows > 8; epi = EPI_RESIDUAL / EPI_SWIGLU)
+// norm_w / norm_out / norm_done (optional, EPI_RESIDUAL): when the projection is split and its reduction pass runs, that pass also writes the RMSNorm of the
+// finished rows (weights norm_w) to norm_out and sets *norm_done -- bit-identical to tl_rms_norm on the output; otherwise *norm_done = false and nothing is written
 int qmm_bf16_epilogue(const void *scales, const void *biases, const uint16_t *a, const uint32_t *b, uint16_t *out, int M, int N, int K,
-                      int epi, const uint16_t *residual, void *workspace, size_t workspace_bytes, hipStream_t st);
+                      int epi, const uint16_t *residual, void *workspace, size_t workspace_bytes, hipStream_t st, const uint16_t *norm_w = nullptr,
+                      uint16_t *norm_out = nullptr, float norm_eps = 0.f, bool *norm_done = nullptr);
 }  // namespace tl
