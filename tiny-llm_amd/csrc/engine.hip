@@ -635,14 +635,20 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // 1.666 -> 1.540, four sequences at 1,000 tokens 1.762 -> 1.610.  Two exceptions at 257..512 tokens, both measured: one sequence
     // 128-token windows (4 instead of 8 partials for the wo GEMV: 1.018 -> 1.014), 5-8 sequences 128 (1.882 -> 1.824 at 8).
     // TL_ATTN_MIN_TOKENS pins one size (lab).
+    // Batched steps (5+ sequences) up to 1,024 tokens of context, re-measured at the end of round 6 on the round's kernels (matrix-core walk, shared prologue;
+    // tools/lab/ab_attn_splits_batched.sh, profiles/r06_labs/README.md section 9): ONE workgroup per CU at most and windows of 128+ tokens -- the merge launch
+    // and the second dependent trip of a short window cost more than a longer walk once every sequence's KV head has a workgroup: 5 / 8 / 12 / 16 / 23 sequences
+    // at ~600 tokens 1.47 / 1.52 / 1.56 / 1.59 / 2.04 -> 1.39 / 1.42 / 1.53 / 1.57 / 1.87 ms per step, 9-23 at ~300 tokens -3 ... -6 %.
+    const bool batched_short = e->attn_min_tokens_auto && batch >= 5 && bucket <= 1024;
     int min_tokens = e->attn_min_tokens;
     if (e->attn_min_tokens_auto) {
         if (bucket > 512 && batch <= 4) min_tokens = 256;
-        else if (bucket == 512 && (batch == 1 || (batch >= 5 && batch <= 8))) min_tokens = 128;
+        else if (bucket == 512 && batch == 1) min_tokens = 128;
+        else if (batched_short) min_tokens = 128;
     }
     // few sequences: split for latency (up to 2048 short-lived workgroups); many sequences: the chip is already full, longer
     // windows amortise the per-workgroup prologue and skip the merge launch (measured at 16 and 64 sequences)
-    const int wg_cap = e->attn_wg_cap > 0 ? e->attn_wg_cap : (batch <= 4 ? 2048 : 512);
+    const int wg_cap = e->attn_wg_cap > 0 ? e->attn_wg_cap : (batch <= 4 ? 2048 : (batched_short ? 256 : 512));
     // a whole GQA group per workgroup (long contexts / several sequences): at most 32 windows -- one workgroup per CU for one sequence;
     // measured at 8k 666 -> 680 tok/s against 64 windows, 32k unchanged (round 3)
     int max_splits = rq == AD_RQ ? e->attn_max_splits_gqa : e->attn_max_splits;
@@ -652,7 +658,8 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // profiles/r04_labs/README.md): 12 / 16 sequences 1.623 -> 1.603 / 1.661 -> 1.634 ms per step at ~190 tokens (at ~660 the split stays:
     // 16 sequences 1.885 against 2.000), 24 / 32 sequences 2.15 -> 2.03 / 2.215 -> 2.07 at ~190 and 32 sequences 2.56 -> 2.495 at ~660.
     // The merge launch and its boundary cost ~2.5 us per layer; the unsplit walk of a few stages costs less once every CU has a workgroup.
-    if (e->attn_min_tokens_auto && ((batch >= 24 && bucket <= 1024) || (batch >= 12 && bucket <= 256))) max_splits = 1;
+    // (from 5 sequences at up to 256 tokens since the end of round 6: 5 / 7 / 9 / 10 sequences at ~150 tokens 1.30 / 1.35 / 1.44 / 1.45 -> 1.26 / 1.28 / 1.31 / 1.33 ms per step)
+    if (e->attn_min_tokens_auto && ((batch >= 24 && bucket <= 1024) || (batch >= 5 && bucket <= 256))) max_splits = 1;
     while (s * 2 <= bucket / min_tokens && s * 2 * base <= wg_cap && s * 2 <= max_splits) s *= 2;  // >= min_tokens per workgroup
     // Windows sized to the context, not to its power-of-two bucket: a workgroup walks its whole window in 64-token stages
     // whether or not the tokens exist, so a 33k context on a 64k bucket spent half of every window on masked loads (r02:
