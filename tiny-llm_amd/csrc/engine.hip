@@ -1391,7 +1391,7 @@ extern "C" int tl_engine_create_kv(const tl_engine_config *cfg, const tl_layer_w
                              b_ws = align_up((size_t)std::min(rows * 64, std::max(4 * 64, std::min(rows * 16, 1024))) * c.num_heads * ws_row * 4, 256);
                 // slice planes of the sliced matmuls a batched step can take (wo, w_down), the largest over 5 .. rows rows
                 size_t b_pl[2] = {0, 0};
-                for (int M = 5; M <= rows; ++M) {
+                for (int M = std::min(5, e->qmm3_min_rows); M <= rows; ++M) {
                     const Qmm3Plan pw = qmm3_plan(M, q_dim, c.hidden_size, -1), pd = qmm3_plan(M, c.intermediate_size, c.hidden_size, -1);
                     if (pw.ok) b_pl[0] = std::max(b_pl[0], align_up(pw.partial_bytes, 256));
                     if (pd.ok) b_pl[1] = std::max(b_pl[1], align_up(pd.partial_bytes, 256));
