@@ -648,7 +648,10 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     }
     // few sequences: split for latency (up to 2048 short-lived workgroups); many sequences: the chip is already full, longer
     // windows amortise the per-workgroup prologue and skip the merge launch (measured at 16 and 64 sequences)
-    const int wg_cap = e->attn_wg_cap > 0 ? e->attn_wg_cap : (batch <= 4 ? 2048 : (batched_short ? 256 : 512));
+    // (5-7 sequences beyond 1,024 tokens too: 4 windows on 160-224 workgroups against 8 on 320-448 -- 5 / 6 / 7 sequences at 2,000 tokens 1.64 / 1.67 / 1.71 ->
+    // 1.57 / 1.63 / 1.70 ms per step, at 8,000 2.45 / 2.57 / 2.65 -> 2.26 / 2.43 / 2.62; 8 and 16 sequences keep 512: 8 x 4,000 2.11 against 2.19)
+    const bool few_long = e->attn_min_tokens_auto && batch >= 5 && batch <= 7 && bucket > 1024;
+    const int wg_cap = e->attn_wg_cap > 0 ? e->attn_wg_cap : (batch <= 4 ? 2048 : ((batched_short || few_long) ? 256 : 512));
     // a whole GQA group per workgroup (long contexts / several sequences): at most 32 windows -- one workgroup per CU for one sequence;
     // measured at 8k 666 -> 680 tok/s against 64 windows, 32k unchanged (round 3)
     int max_splits = rq == AD_RQ ? e->attn_max_splits_gqa : e->attn_max_splits;
