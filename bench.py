@@ -753,8 +753,9 @@ def serving64_leg(mlx_model, cfg: dict, device: str, seed: int, page: int = 128)
     """BASELINE.json configs[3] on ONE GPU as the reference runs it (benches/bench.py:351-572 -> benches/serving.py): the reference's
     serving trace scaled to 64 decode slots -- `--num-seqs 128 --batch-size 64`, 128-1,024 tokens in / 32-128 out, 128-token chunks,
     seed 0 (book/src/appendix-performance.md:22-27,528-541) -- under the reference's admission rule (one chunk of one request per turn)
-    and under the 2,048-token admission budget with 8 staging slots (one packed multi-token pass per turn).  GPU only, after the timed
-    region; one engine for both; a complete-request warm-up of 32 requests first (graph captures of every row bucket)."""
+    and under the 2,048-token admission budget with 8 staging slots (one packed multi-token pass per turn); since the end of round 6 also under a
+    4,096-token budget in chunks of up to 1,024 tokens over 16 staging slots (the plain bf16 prefill GEMM is at its best from 3,072 rows).  GPU only, after
+    the timed region; one engine for all; a complete-request warm-up of 32 requests first (graph captures of every row bucket)."""
     import torch
     from random import Random
 
@@ -762,21 +763,25 @@ def serving64_leg(mlx_model, cfg: dict, device: str, seed: int, page: int = 128)
     from benches.serving import serve_requests, nearest_rank, median
     from tiny_llm_hip.engine import DecodeEngine
 
-    B, staging = 64, 8
+    B, staging, staging_max = 64, 8, 16
     trace = build_requests(rng=Random(0), num_seqs=128, vocab_size=cfg["vocab_size"], eos_token_id=cfg["vocab_size"] - 1,
                            min_input_len=128, max_input_len=1024, min_output_len=32, max_output_len=128)
     longest = max(len(r.prompt_token_ids) + r.max_new_tokens for r in trace)
     pages_per_seq = (longest + page - 1) // page + 1
-    slots = B + staging
+    slots = B + staging_max
     kv_page_bytes = 2 * cfg["num_hidden_layers"] * cfg["num_key_value_heads"] * page * cfg["head_dim"] * 2
     out = {"requests": len(trace), "decode_slots": B, "prompt_tokens": sum(len(r.prompt_token_ids) for r in trace),
            "shape": "128-1,024 tokens in / 32-128 out, 128-token chunks, seed 0 (the reference's serving trace at 64 slots)"}
     eng = None
     try:
         eng = DecodeEngine(mlx_model, page_size=page, num_pages=pages_per_seq * slots + 2, max_batch=slots, max_pages_per_seq=pages_per_seq,
-                           max_prefill_rows=2048)
+                           max_prefill_rows=4096)
+        notes = {"reference_admission": "one 128-token chunk of one request per turn (batch.py:48-76)",
+                 "budget_2048": "up to 2,048 prompt tokens per turn over 8 staging slots, one packed pass",
+                 "budget_4096": "up to 4,096 prompt tokens per turn in chunks of up to 1,024 over 16 staging slots, one packed pass"}
         for name, kw in (("reference_admission", dict(prefill_step=128, prefill_budget=128, staging_slots=1)),
-                         ("budget_2048", dict(prefill_step=512, prefill_budget=2048, staging_slots=staging))):
+                         ("budget_2048", dict(prefill_step=512, prefill_budget=2048, staging_slots=staging)),
+                         ("budget_4096", dict(prefill_step=1024, prefill_budget=4096, staging_slots=staging_max))):
             def run(reqs):
                 return serve_requests(eng, reqs, batch_size=B, page_size=page, kv_bytes_per_page=kv_page_bytes, capacity_pages=pages_per_seq * slots + 2, **kw)
             run(trace[:32])
@@ -788,8 +793,7 @@ def serving64_leg(mlx_model, cfg: dict, device: str, seed: int, page: int = 128)
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
             steps = m.decode_step_ms
-            out[name] = {"admission": "one 128-token chunk of one request per turn (batch.py:48-76)" if name == "reference_admission"
-                                      else "up to 2,048 prompt tokens per turn over 8 staging slots, one packed pass",
+            out[name] = {"admission": notes[name],
                          "wall_s": round(wall, 3), "output_tok_s": round(m.generated_tokens / wall, 1),
                          "total_tok_s": round((out["prompt_tokens"] + m.generated_tokens) / wall, 1),
                          "decode_tok_s": round(m.decode_tokens / m.decode_time, 1) if m.decode_time else None,
