@@ -137,7 +137,8 @@ int tl_engine_set_moe_layer(tl_engine *e, int layer, const tl_moe_weights *w);
  *   register-resident batched matmul (0: the K-sliced one everywhere);  "qmm7" [1] the row-streaming matmul for gate|up / qkv (0: qmm6);
  *   "gemm8" [1] prefill chunks of 1,536 rows and more through the plain bf16 GEMM over the bf16 weight copy (0: the W4 GEMM at every size);
  *   "attn_qkv_partials" [1] the decode attention adds the qkv slice planes itself;  "lmhead_tile_max" [1] per-tile maxima from the lm_head
- *   GEMV;  "gemm_fused_epilogue" [1] residual / SwiGLU inside the prefill GEMM;  "aql_fences" [0] HIP's agent-scope fences back on every
+ *   GEMV;  "gemm_fused_epilogue" [1] residual / SwiGLU inside the prefill GEMM;  "prefill_reduce_norm" [1] the split-K residual
+ *   reduction of a small prefill chunk also writes the RMSNorm behind it;  "aql_fences" [0] HIP's agent-scope fences back on every
  *   packet of the AQL route.  Not part of the reference's surface: product code never calls it. */
 int tl_engine_set_option(tl_engine *e, const char *name, int value);
 void tl_engine_destroy(tl_engine *e);
