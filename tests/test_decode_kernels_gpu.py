@@ -555,6 +555,29 @@ def test_decode_attention_long_contexts(ext, ctxs, mode, monkeypatch):
     log_parity({"what": "decode_attention_long", "ctxs": ctxs, "mode": mode, **info})
 
 
+@pytest.mark.parametrize("ctxs,windows", [
+    ([150, 129, 64, 1, 255], 1),                                         # 5+ sequences up to 256 tokens: one window each, no merge launch
+    ([300, 511, 257, 2, 130, 400, 64, 333, 500], 2),                     # 9 sequences at 257..512: windows of 128+ tokens on at most 256 workgroups
+    ([2000, 1030, 5, 1500, 1999, 700], 4),                               # 5-7 sequences beyond 1,024 tokens: 4 windows
+    ([1500, 1100, 3000, 700, 64, 129, 2047, 2048, 1, 900] * 2, 1),       # 20 sequences up to 8,192 tokens: whole contexts, one workgroup per (sequence, KV head)
+    ([8000] + [200, 1300, 77, 4100, 640, 31, 2500] * 3 + [129, -1], 1),  # 24 slots, one at 8,000 tokens, one idle
+])
+def test_decode_attention_many_sequences_follow_the_remeasured_plan(ext, ctxs, windows, monkeypatch):
+    """The batched plans of the end of round 6 (engine.hip plan_splits; profiles/r06_labs/README.md section 9) at the kernel-level entry point, ragged
+    contexts, against the oracle: longer windows than the round-4 plan walked (up to a whole 8,000-token context in one workgroup)."""
+    for name in ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS", "TL_ATTN_MFMA"):
+        monkeypatch.delenv(name, raising=False)
+    idle = [c < 0 for c in ctxs]
+    rng = np.random.default_rng(abs(sum(ctxs)) + len(ctxs))
+    case = _attention_case(rng, ctxs)
+    got, kpa, vpa, info = _run_attention(ext, case, max(ctxs))
+    what = f"ctxs={ctxs} {info}"
+    assert info["n_splits"] == windows and info["heads_per_workgroup"] == 4, what
+    assert info["launches"] == (1 if windows == 1 else 2), what
+    _check_attention(case, got, kpa, vpa, idle, what)
+    log_parity({"what": "decode_attention_many", "ctxs": ctxs, **info})
+
+
 def test_flash_attention_2048_row_chunk_over_8k_context(ext):
     """The paged MFMA FlashAttention operator as chunked prefill uses it at BASELINE config 3: the last 2048-row chunk of an
     8,192-token prompt (context 8,192 incl. the chunk), 32/8 heads, page 128.  Sampled query rows (first / last rows,

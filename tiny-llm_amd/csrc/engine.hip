@@ -662,7 +662,10 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // 16 sequences 1.885 against 2.000), 24 / 32 sequences 2.15 -> 2.03 / 2.215 -> 2.07 at ~190 and 32 sequences 2.56 -> 2.495 at ~660.
     // The merge launch and its boundary cost ~2.5 us per layer; the unsplit walk of a few stages costs less once every CU has a workgroup.
     // (from 5 sequences at up to 256 tokens since the end of round 6: 5 / 7 / 9 / 10 sequences at ~150 tokens 1.30 / 1.35 / 1.44 / 1.45 -> 1.26 / 1.28 / 1.31 / 1.33 ms per step)
-    if (e->attn_min_tokens_auto && ((batch >= 24 && bucket <= 1024) || (batch >= 5 && bucket <= 256))) max_splits = 1;
+    // (from 20 sequences up to 8,192 tokens too, end of round 6: 160+ workgroups walking whole contexts beat twice as many on halves + a merge launch -- 20 / 23 / 24 / 32
+    // sequences at 1,500 tokens 2.49 / 2.56 / 2.63 / 2.82 -> 2.25 / 2.36 / 2.40 / 2.70 ms per step, 24 at 2,500 / 4,000 / 8,000 3.10 / 4.20 / 6.44 -> 2.91 / 3.98 / 6.12;
+    // 16 sequences at 2,000 want their 4 windows: 2.16 against 2.29)
+    if (e->attn_min_tokens_auto && ((batch >= 24 && bucket <= 1024) || (batch >= 5 && bucket <= 256) || (batch >= 20 && bucket <= 8192))) max_splits = 1;
     while (s * 2 <= bucket / min_tokens && s * 2 * base <= wg_cap && s * 2 <= max_splits) s *= 2;  // >= min_tokens per workgroup
     // Windows sized to the context, not to its power-of-two bucket: a workgroup walks its whole window in 64-token stages
     // whether or not the tokens exist, so a 33k context on a 64k bucket spent half of every window on masked loads (r02:
