@@ -78,7 +78,7 @@ typedef struct tl_engine_config {
     int num_pages;         /* physical pages per layer pool */
     int max_batch;         /* sequence slots */
     int max_pages_per_seq; /* block-table width */
-    int max_prefill_rows;  /* largest prefill chunk (rows of the activation workspace).  From 1,536 rows the engine also keeps the layer
+    int max_prefill_rows;  /* largest prefill chunk (rows of the activation workspace).  From 1,792 rows the engine also keeps the layer
                               matrices as bf16 (rows x cols x 2 bytes each: 7.3 GB at Qwen3-4B) for the plain bf16 GEMM of large chunks */
 } tl_engine_config;
 
@@ -135,7 +135,7 @@ int tl_engine_set_moe_layer(tl_engine *e, int layer, const tl_moe_weights *w);
  * steps hold the routes they were captured with).  value 0 = off, anything else = on.  Options (defaults in brackets):
  *   "qmm3" [1] rows > 8 of a decode step on the K-sliced skinny matmul (0: the prefill GEMM's op sequence);  "qmm6" [1] the
  *   register-resident batched matmul (0: the K-sliced one everywhere);  "qmm7" [1] the row-streaming matmul for gate|up / qkv (0: qmm6);
- *   "gemm8" [1] prefill chunks of 1,536 rows and more through the plain bf16 GEMM over the bf16 weight copy (0: the W4 GEMM at every size);
+ *   "gemm8" [1] prefill chunks of 1,792 rows and more through the plain bf16 GEMM over the bf16 weight copy (0: the W4 GEMM at every size);
  *   "attn_qkv_partials" [1] the decode attention adds the qkv slice planes itself;  "lmhead_tile_max" [1] per-tile maxima from the lm_head
  *   GEMV;  "gemm_fused_epilogue" [1] residual / SwiGLU inside the prefill GEMM;  "prefill_reduce_norm" [1] the split-K residual
  *   reduction of a small prefill chunk also writes the RMSNorm behind it;  "aql_fences" [0] HIP's agent-scope fences back on every
@@ -347,7 +347,7 @@ int tl_decode_linear_ex(const tl_tiled_w4 *w, const void *a_dev, void *out_dev, 
                         const void *norm_w_dev, const void *residual_dev, float eps, int kernel, void *workspace_dev,
                         size_t workspace_bytes, void *stream, const tl_linear_ex *ex, tl_linear_info *info);
 
-/* The prefill projection of LARGE chunks (csrc/gemm8.h; the engine takes it from 1,536 rows): the reference's tile GEMM rounds the dequantised
+/* The prefill projection of LARGE chunks (csrc/gemm8.h; the engine takes it from 1,792 rows): the reference's tile GEMM rounds the dequantised
  * weights to bf16 before the product (quantized_matmul.metal:96-249), so the weights are expanded ONCE --
  *   tl_prefill_weights_bf16: out_dev [rows, cols] bf16 = bf16(q * scale + bias) per element --
  * and the product is a plain bf16 GEMM with fp32 accumulation over the whole reduction (the unsplit tile kernel's arithmetic),

@@ -2,7 +2,7 @@
 
 The reference's tile GEMM (quantized_matmul_simdgroup_w4a16_g128: src/extensions_ref/src/quantized_matmul.metal:96-249) rounds every
 dequantised weight to bf16 -- T(q * scale + bias) -- before a bf16 MMA with fp32 accumulation over the whole reduction.  The engine forms
-that B operand once (tl_prefill_weights_bf16) and multiplies chunks of 1,536 rows and more against it with a 256-wide-tile GEMM whose
+that B operand once (tl_prefill_weights_bf16) and multiplies chunks of 1,792 rows and more against it (kernel-level cases from 1,536) with a 256-wide-tile GEMM whose
 operands both arrive by LDS-DMA (tl_prefill_matmul_bf16).  Held here
 
   * the expansion against the numpy oracle's dequantisation: BIT-identical;
@@ -100,7 +100,7 @@ def test_product_against_the_tile_oracle(ext, name, M):
 
 
 def test_engine_prefill_of_a_4096_token_chunk_against_the_w4_gemm_and_the_truth():
-    """One 4,096-row chunk through the bf16 GEMM (max_prefill_rows >= 1,536 makes the engine keep the bf16 copy) against the same chunk through
+    """One 4,096-row chunk through the bf16 GEMM (max_prefill_rows >= 1,792 makes the engine keep the bf16 copy) against the same chunk through
     the W4 GEMM (option "gemm8" = 0) -- two summation orders of the same rounded operands: within the band of two HIP paths -- and both
     against the float64 truth of a shorter prompt's last row (TINY model: the truth of 4,096 tokens would take minutes on the CPU, so the
     truth check runs at 3,100 tokens, still one gemm8 chunk)."""

@@ -363,11 +363,11 @@ static int engine_qmm(tl_engine *e, const tl_w4 &w, const uint16_t *a, uint16_t 
 // out = epilogue(a @ W^T) for any number of rows (chunked prefill, batches above 64): the reference's own op sequence --
 // W4 MFMA GEMM over the checkpoint layout (quantize.py:54-65 routes rows > 8 to the matmul path, whose tile kernel rounds
 // the dequantised weights to bf16 first), then SwiGLU / residual as separate launches.
-// From this many rows a chunk's projections run on the plain bf16 GEMM (gemm8.h).  A layer's four projections, W4 GEMM against gemm8, in the lab
-// (back-to-back launches on one weight matrix, which then sits in the 256-MB Infinity Cache): 4,096 rows 1,114 / 833 us, 2,048 rows 543 / 477, 1,536
-// rows 413 / 386, 1,024 rows 311 / 321.  In the engine every layer streams its own 202 MB of bf16 weights from HBM (~40 us per layer and chunk
-// whatever the rows): 4,096-row chunks keep most of the gain (8k prefill 74.1k -> 86.9k tokens/s), 2,048-row chunks are neutral (72.3k -> 72.8k).
-constexpr int GEMM8_MIN_ROWS = 1536;
+// From this many rows a chunk's projections run on the plain bf16 GEMM (gemm8.h).  In the lab (back-to-back launches on one weight matrix, which then sits in the
+// 256-MB Infinity Cache) gemm8 wins from ~1,500 rows; in the ENGINE every layer streams its own 202 MB of bf16 weights from HBM and the grid counts in
+// whole 256-row bands, measured at the end of round 6 (chunked prefill of 6,144 / 8,192 tokens, gemm8 / W4 GEMM, tokens/s): 1,536-row chunks 63.0k / 71.7k,
+// 2,048 83.8k / 75.6k, 3,072 77.7k / 78.0k, 4,096 100.5k / 75.9k -- so from 7 bands (until then the constant was 1,536: 12 % slower at exactly that size).
+constexpr int GEMM8_MIN_ROWS = 1792;
 static bool gemm8_wins(int M, int out_features) {
     (void)out_features;
     return M >= GEMM8_MIN_ROWS;
