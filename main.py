@@ -63,14 +63,14 @@ def main(argv=None) -> str:
 
     ids = tokenizer.encode(prompt, add_special_tokens=False)
     pages = (len(ids) + args.max_new_tokens) // 128 + 2
-    engine = DecodeEngine(model, page_size=128, num_pages=pages, max_batch=1, max_prefill_rows=2048)
+    engine = DecodeEngine(model, page_size=128, num_pages=pages, max_batch=1, max_prefill_rows=4096)
     eos = tokenizer.eos_token_id
     try:
         if args.draft_model:
             draft_model, draft_tok = load(args.draft_model)
             if draft_tok.get_vocab() != tokenizer.get_vocab():
                 raise ValueError("draft and target tokenizers use different token ids")
-            draft = DecodeEngine(draft_model, page_size=128, num_pages=pages, max_batch=1, max_prefill_rows=2048)
+            draft = DecodeEngine(draft_model, page_size=128, num_pages=pages, max_batch=1, max_prefill_rows=4096)
             try:
                 out = speculative_generate_ids(engine, draft, ids, args.max_new_tokens,
                                                proposal_length=min(args.proposal_length, 7), eos_token_id=eos)

