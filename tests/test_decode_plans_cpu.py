@@ -98,6 +98,7 @@ def test_the_planners_variant_predicate_is_the_instantiation_table(lib):
     (1, 5000, 32, 4, 256), (1, 20000, 32, 4, 1024), (1, 32768, 32, 4, 2048),         # above 4,096 tokens a GQA group per workgroup, 32 windows
     (2, 300, 8, 1, 64), (2, 700, 4, 1, 256), (2, 1500, 8, 4, 256), (2, 3000, 16, 4, 256),  # two sequences switch at 1,024 tokens
     (4, 256, 8, 4, 64), (4, 1000, 4, 4, 256),                                        # 3+ sequences: always the GQA-group walk
+    (4, 4500, 8, 4, 1024), (3, 8000, 8, 4, 1024), (2, 8000, 16, 4, 512), (4, 32000, 8, 4, 4096),  # ... on at most 256 workgroups (end of round 6)
     (8, 300, 4, 4, 128), (8, 1000, 4, 4, 256), (64, 300, 1, 4, 512),                 # 5+ sequences up to 1,024 tokens (end of round 6): windows of 128+ tokens,
     (5, 600, 4, 4, 256), (9, 300, 2, 4, 256), (16, 600, 2, 4, 512), (23, 600, 1, 4, 1024),   # ... at most one workgroup per CU (256),
     (5, 150, 1, 4, 256), (11, 200, 1, 4, 256), (12, 200, 1, 4, 256), (16, 200, 1, 4, 256),   # ... no split (and no merge launch) up to 256 tokens,

@@ -651,7 +651,10 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // (5-7 sequences beyond 1,024 tokens too: 4 windows on 160-224 workgroups against 8 on 320-448 -- 5 / 6 / 7 sequences at 2,000 tokens 1.64 / 1.67 / 1.71 ->
     // 1.57 / 1.63 / 1.70 ms per step, at 8,000 2.45 / 2.57 / 2.65 -> 2.26 / 2.43 / 2.62; 8 and 16 sequences keep 512: 8 x 4,000 2.11 against 2.19)
     const bool few_long = e->attn_min_tokens_auto && batch >= 5 && batch <= 7 && bucket > 1024;
-    const int wg_cap = e->attn_wg_cap > 0 ? e->attn_wg_cap : (batch <= 4 ? 2048 : ((batched_short || few_long) ? 256 : 512));
+    // (2-4 sequences on the GQA-group walk likewise, end of round 6: one workgroup per CU -- 3 / 4 sequences at 4,500 tokens 1.80 / 1.97 -> 1.66 / 1.81 ms per step,
+    // at 8,000 2.02 / 2.29 -> 1.86 / 2.10, two sequences at 4,500 / 8,000 1.42 / 1.59 -> 1.36 / 1.55, 4 x 32,000 4.55 -> 4.41; one sequence: 8 KV heads x 32 windows already)
+    const bool few_gqa = e->attn_min_tokens_auto && batch >= 2 && batch <= 4 && rq == AD_RQ;
+    const int wg_cap = e->attn_wg_cap > 0 ? e->attn_wg_cap : (batch <= 4 ? (few_gqa ? 256 : 2048) : ((batched_short || few_long) ? 256 : 512));
     // a whole GQA group per workgroup (long contexts / several sequences): at most 32 windows -- one workgroup per CU for one sequence;
     // measured at 8k 666 -> 680 tok/s against 64 windows, 32k unchanged (round 3)
     int max_splits = rq == AD_RQ ? e->attn_max_splits_gqa : e->attn_max_splits;
