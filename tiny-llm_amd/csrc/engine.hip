@@ -650,7 +650,9 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // windows amortise the per-workgroup prologue and skip the merge launch (measured at 16 and 64 sequences)
     // (5-7 sequences beyond 1,024 tokens too: 4 windows on 160-224 workgroups against 8 on 320-448 -- 5 / 6 / 7 sequences at 2,000 tokens 1.64 / 1.67 / 1.71 ->
     // 1.57 / 1.63 / 1.70 ms per step, at 8,000 2.45 / 2.57 / 2.65 -> 2.26 / 2.43 / 2.62; 8 and 16 sequences keep 512: 8 x 4,000 2.11 against 2.19)
-    const bool few_long = e->attn_min_tokens_auto && batch >= 5 && batch <= 7 && bucket > 1024;
+    // (... and 8-16 sequences, the round's last sweep at 1,500 / 3,000 / 6,000 tokens: 10 sequences 1.80 / 2.17 / 2.96 -> 1.72 / 2.03 / 2.74 ms per step, 12: 1.85 / 2.27 / 3.08 ->
+    // 1.78 / 2.15 / 3.00, 14: -2 %, 8 and 16 within 1 % either way; 17-19 sequences keep two windows)
+    const bool few_long = e->attn_min_tokens_auto && batch >= 5 && batch <= 16 && bucket > 1024;
     // (2-4 sequences on the GQA-group walk likewise, end of round 6: one workgroup per CU -- 3 / 4 sequences at 4,500 tokens 1.80 / 1.97 -> 1.66 / 1.81 ms per step,
     // at 8,000 2.02 / 2.29 -> 1.86 / 2.10, two sequences at 4,500 / 8,000 1.42 / 1.59 -> 1.36 / 1.55, 4 x 32,000 4.55 -> 4.41; one sequence: 8 KV heads x 32 windows already)
     const bool few_gqa = e->attn_min_tokens_auto && batch >= 2 && batch <= 4 && rq == AD_RQ;
