@@ -102,8 +102,8 @@ def test_the_planners_variant_predicate_is_the_instantiation_table(lib):
     (8, 300, 4, 4, 128), (8, 1000, 4, 4, 256), (64, 300, 1, 4, 512),                 # 5+ sequences up to 1,024 tokens (end of round 6): windows of 128+ tokens,
     (5, 600, 4, 4, 256), (9, 300, 2, 4, 256), (16, 600, 2, 4, 512), (23, 600, 1, 4, 1024),   # ... at most one workgroup per CU (256),
     (5, 150, 1, 4, 256), (11, 200, 1, 4, 256), (12, 200, 1, 4, 256), (16, 200, 1, 4, 256),   # ... no split (and no merge launch) up to 256 tokens,
-    (24, 200, 1, 4, 256), (32, 700, 1, 4, 768), (32, 1500, 1, 4, 2048), (20, 1500, 1, 4, 2048), (24, 8000, 1, 4, 8192), (24, 12000, 2, 4, 8192),  # from 20 sequences none up to 8,192              # ... from 24 sequences none up to 1,024; beyond 1,024 tokens the round-4 plan
-    (8, 2000, 4, 4, 512), (16, 2000, 2, 4, 1024), (10, 3000, 2, 4, 2048), (12, 6000, 2, 4, 4096), (18, 3000, 2, 4, 2048), (5, 2000, 4, 4, 512), (7, 4000, 4, 4, 1024), (6, 8000, 4, 4, 2048),  # (5-7 sequences: 4 windows there too)
+    (24, 200, 1, 4, 256), (32, 700, 1, 4, 768), (32, 1500, 1, 4, 2048), (20, 1500, 1, 4, 2048), (24, 8000, 1, 4, 8192), (24, 12000, 2, 4, 8192),  # from 17 sequences none up to 8,192              # ... from 24 sequences none up to 1,024; beyond 1,024 tokens the round-4 plan
+    (8, 2000, 4, 4, 512), (16, 2000, 2, 4, 1024), (10, 3000, 2, 4, 2048), (12, 6000, 2, 4, 4096), (18, 3000, 1, 4, 4096), (17, 1500, 1, 4, 2048), (5, 2000, 4, 4, 512), (7, 4000, 4, 4, 1024), (6, 8000, 4, 4, 2048),  # (5-7 sequences: 4 windows there too)
 ])
 def test_attention_plans_by_context_and_sequences(lib, monkeypatch, batch, ctx, windows, heads_per_wg, max_window):
     for name in ("TL_ATTN_RQ", "TL_ATTN_MAX_SPLITS", "TL_ATTN_MIN_TOKENS", "TL_ATTN_MFMA"):

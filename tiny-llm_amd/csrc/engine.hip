@@ -651,7 +651,7 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // (5-7 sequences beyond 1,024 tokens too: 4 windows on 160-224 workgroups against 8 on 320-448 -- 5 / 6 / 7 sequences at 2,000 tokens 1.64 / 1.67 / 1.71 ->
     // 1.57 / 1.63 / 1.70 ms per step, at 8,000 2.45 / 2.57 / 2.65 -> 2.26 / 2.43 / 2.62; 8 and 16 sequences keep 512: 8 x 4,000 2.11 against 2.19)
     // (... and 8-16 sequences, the round's last sweep at 1,500 / 3,000 / 6,000 tokens: 10 sequences 1.80 / 2.17 / 2.96 -> 1.72 / 2.03 / 2.74 ms per step, 12: 1.85 / 2.27 / 3.08 ->
-    // 1.78 / 2.15 / 3.00, 14: -2 %, 8 and 16 within 1 % either way; 17-19 sequences keep two windows)
+    // 1.78 / 2.15 / 3.00, 14: -2 %, 8 and 16 within 1 % either way; from 17 sequences no split at all, below)
     const bool few_long = e->attn_min_tokens_auto && batch >= 5 && batch <= 16 && bucket > 1024;
     // (2-4 sequences on the GQA-group walk likewise, end of round 6: one workgroup per CU -- 3 / 4 sequences at 4,500 tokens 1.80 / 1.97 -> 1.66 / 1.81 ms per step,
     // at 8,000 2.02 / 2.29 -> 1.86 / 2.10, two sequences at 4,500 / 8,000 1.42 / 1.59 -> 1.36 / 1.55, 4 x 32,000 4.55 -> 4.41; one sequence: 8 KV heads x 32 windows already)
@@ -667,10 +667,10 @@ static SplitPlan pick_decode_splits(const tl_engine *e, int batch, int max_ctx) 
     // 16 sequences 1.885 against 2.000), 24 / 32 sequences 2.15 -> 2.03 / 2.215 -> 2.07 at ~190 and 32 sequences 2.56 -> 2.495 at ~660.
     // The merge launch and its boundary cost ~2.5 us per layer; the unsplit walk of a few stages costs less once every CU has a workgroup.
     // (from 5 sequences at up to 256 tokens since the end of round 6: 5 / 7 / 9 / 10 sequences at ~150 tokens 1.30 / 1.35 / 1.44 / 1.45 -> 1.26 / 1.28 / 1.31 / 1.33 ms per step)
-    // (from 20 sequences up to 8,192 tokens too, end of round 6: 160+ workgroups walking whole contexts beat twice as many on halves + a merge launch -- 20 / 23 / 24 / 32
+    // (from 17 sequences up to 8,192 tokens too, end of round 6: 160+ workgroups walking whole contexts beat twice as many on halves + a merge launch -- 20 / 23 / 24 / 32
     // sequences at 1,500 tokens 2.49 / 2.56 / 2.63 / 2.82 -> 2.25 / 2.36 / 2.40 / 2.70 ms per step, 24 at 2,500 / 4,000 / 8,000 3.10 / 4.20 / 6.44 -> 2.91 / 3.98 / 6.12;
     // 16 sequences at 2,000 want their 4 windows: 2.16 against 2.29)
-    if (e->attn_min_tokens_auto && ((batch >= 24 && bucket <= 1024) || (batch >= 5 && bucket <= 256) || (batch >= 20 && bucket <= 8192))) max_splits = 1;
+    if (e->attn_min_tokens_auto && ((batch >= 24 && bucket <= 1024) || (batch >= 5 && bucket <= 256) || (batch >= 17 && bucket <= 8192))) max_splits = 1;  // (17-19 sequences measured last: 1,500 / 3,000 / 6,000 tokens 2.44 / 3.19 / 4.85 -> 2.20 / 2.87 / 4.13 ms per step)
     while (s * 2 <= bucket / min_tokens && s * 2 * base <= wg_cap && s * 2 <= max_splits) s *= 2;  // >= min_tokens per workgroup
     // Windows sized to the context, not to its power-of-two bucket: a workgroup walks its whole window in 64-token stages
     // whether or not the tokens exist, so a 33k context on a 64k bucket spent half of every window on masked loads (r02:
